@@ -1,0 +1,77 @@
+"""ctypes mirror of include/gh_raster.h (the C-ABI drop-in boundary). Pure declarations."""
+from __future__ import annotations
+
+import ctypes as C
+
+GH_TILE = 16
+GH_CAM_FLOATS = 40
+GH_FLAG_BLEND_W_PER_GAUSSIAN = 1
+
+GH_OK = 0
+GH_ERR_INVALID_ARG = -1
+GH_ERR_WORKSPACE_SMALL = -2
+GH_ERR_LAUNCH = -3
+GH_ERR_UNSUPPORTED = -4
+_STATUS = {0: "GH_OK", -1: "GH_ERR_INVALID_ARG", -2: "GH_ERR_WORKSPACE_SMALL", -3: "GH_ERR_LAUNCH",
+           -4: "GH_ERR_UNSUPPORTED"}
+
+fp = C.POINTER(C.c_float)
+
+
+class GhDims(C.Structure):
+    _fields_ = [("P", C.c_int32), ("n_views", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("sh_degree", C.c_int32), ("M", C.c_int32), ("scale_modifier", C.c_float),
+                ("flags", C.c_uint32), ("max_instances", C.c_int64)]
+
+
+class GhInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "cams", "means3D", "opacities", "scales", "rotations", "shs", "colors_precomp",
+        "blend_xyz_b", "blend_opacity_b", "blend_color_w", "blend_color_b")]
+
+
+class GhOutputs(C.Structure):
+    _fields_ = [("image", C.c_void_p), ("radii", C.c_void_p)]
+
+
+class GhCounters(C.Structure):
+    _fields_ = [("num_rendered", C.c_uint32), ("overflow", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
+class GhGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "dL_dimage", "dL_dmeans3D", "dL_dmeans2D", "dL_dopacities", "dL_dscales", "dL_drotations",
+        "dL_dshs", "dL_dcolors", "dL_dblend_xyz_b", "dL_dblend_opacity_b", "dL_dblend_color_w",
+        "dL_dblend_color_b")]
+
+
+LAYOUT_FIELDS = ("total_bytes", "counters", "geom_g0", "geom_g1", "geom_b", "depth", "rect", "clamped",
+                 "offsets", "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "slot_gid", "sorted_gid",
+                 "sort_tables", "ranges", "final_T", "n_contrib", "inst_grad", "bwd_scratch")
+
+
+class GhLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in LAYOUT_FIELDS]
+
+
+def status_name(code: int) -> str:
+    return _STATUS.get(code, f"GH_ERR({code})")
+
+
+def declare(lib: C.CDLL) -> None:
+    """Attach argtypes/restypes for every symbol include/gh_raster.h declares."""
+    lib.gh_version.restype = C.c_int
+    lib.gh_version.argtypes = []
+    lib.gh_workspace_layout.restype = C.c_int
+    lib.gh_workspace_layout.argtypes = [C.POINTER(GhDims), C.POINTER(GhLayout)]
+    lib.gh_workspace_bytes.restype = C.c_size_t
+    lib.gh_workspace_bytes.argtypes = [C.POINTER(GhDims)]
+    lib.gh_forward.restype = C.c_int
+    lib.gh_forward.argtypes = [C.POINTER(GhDims), C.POINTER(GhInputs), C.POINTER(GhOutputs),
+                               C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.gh_backward.restype = C.c_int
+    lib.gh_backward.argtypes = [C.POINTER(GhDims), C.POINTER(GhInputs), C.POINTER(GhGrads),
+                                C.c_void_p, C.c_size_t, C.c_void_p]
+
+
+EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_forward", "gh_backward")

@@ -1,0 +1,174 @@
+/*
+ * gh_raster.h — C-ABI of the MI355X-native differentiable Gaussian-splatting rasteriser.
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json `north_star`.
+ * What it replaces in the reference (XuanHuang0/GuassianHand):
+ *   - the third-party CUDA extension imported at tgs/models/renderer_one_shot.py:3
+ *     (`from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer`)
+ *     and called at tgs/models/renderer_one_shot.py:338-346 (RGB pass) and :372-379 (mask pass);
+ *   - the per-view attribute blend of tgs/models/renderer_one_shot.py:298-334, which the
+ *     kernels fuse into the per-Gaussian projection stage (optional: all blend pointers may be NULL).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / STL types.
+ *   - Every buffer (inputs, outputs, gradients, workspace) is allocated by the caller; the library
+ *     owns no device memory and keeps no global state. All functions are re-entrant.
+ *   - All device work is enqueued on the caller-supplied stream. The library never synchronises,
+ *     never allocates and never copies to the host: every entry point is HIP-graph capturable.
+ *     Data-dependent sizes (the number of tile instances D) stay on the device; the caller bounds
+ *     them with `max_instances` and reads `GhCounters` back whenever it chooses.
+ *   - Return value: 0 on success, negative GhStatus on error. Nothing throws across the boundary.
+ *   - Matrices follow the reference's row-vector convention (renderer_one_shot.py:96,106):
+ *     viewmatrix = w2c^T, projmatrix = (P * w2c)^T, both read as 16 consecutive floats, i.e.
+ *     element [4*c + r] is M[r][c] of the column-vector matrix.
+ *
+ * The CPU oracle (oracle/gh_oracle.c) implements the same structs on host pointers; it is test
+ * infrastructure only and is never linked into or called by this library.
+ */
+#ifndef GH_RASTER_H
+#define GH_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GH_VERSION_MAJOR 0
+#define GH_VERSION_MINOR 1
+
+#define GH_TILE 16           /* tile edge in pixels (binning granularity; fixes which Gaussians a pixel sees) */
+#define GH_CAM_FLOATS 40     /* floats per camera record, see GhCamera */
+#define GH_MAX_SH_COEFFS 16  /* degree 3 */
+
+typedef enum GhStatus {
+  GH_OK = 0,
+  GH_ERR_INVALID_ARG = -1,     /* NULL / inconsistent pointers, bad dims */
+  GH_ERR_WORKSPACE_SMALL = -2, /* ws_bytes < gh_workspace_bytes(dims) */
+  GH_ERR_LAUNCH = -3,          /* hipGetLastError() != hipSuccess after a launch */
+  GH_ERR_UNSUPPORTED = -4      /* e.g. image wider than 255 tiles, sh_degree > 3 */
+} GhStatus;
+
+/* Flags for GhDims.flags */
+#define GH_FLAG_NONE 0u
+#define GH_FLAG_BLEND_W_PER_GAUSSIAN 1u /* color_w is (P,48) instead of (48,) — renderer_one_shot_edit.py:489-500 */
+
+/*
+ * One camera, GH_CAM_FLOATS consecutive floats in DEVICE memory (built by the caller without a host sync):
+ *   [ 0..15] viewmatrix   (renderer_one_shot.py:288  world_view_transform, flat)
+ *   [16..31] projmatrix   (renderer_one_shot.py:289  full_proj_transform, flat)
+ *   [32..34] campos       (renderer_one_shot.py:291)
+ *   [35]     tanfovx      (renderer_one_shot.py:278)
+ *   [36]     tanfovy      (renderer_one_shot.py:279)
+ *   [37..39] bg           (renderer_one_shot.py:286)
+ */
+typedef struct GhDims {
+  int32_t P;              /* Gaussians */
+  int32_t n_views;        /* cameras rendered by this call (grid.z); the reference loops views in Python (:494) */
+  int32_t H, W;           /* image size */
+  int32_t sh_degree;      /* active SH degree 0..3 (renderer_one_shot.py:290); ignored when colors are precomputed */
+  int32_t M;              /* SH coefficients per Gaussian present in `shs` (1,4,9,16); 0 => colors_precomp path */
+  float scale_modifier;   /* renderer_one_shot.py:287 */
+  uint32_t flags;
+  int64_t max_instances;  /* capacity for tile instances D summed over views; see GhCounters.overflow */
+} GhDims;
+
+/* Inputs: row-major fp32 device arrays exactly as the reference hands them to the rasteriser. */
+typedef struct GhInputs {
+  const float* cams;            /* (n_views, GH_CAM_FLOATS) */
+  const float* means3D;         /* (P,3) */
+  const float* opacities;       /* (P,)  — reference passes (P,1) */
+  const float* scales;          /* (P,3) */
+  const float* rotations;       /* (P,4) quaternion (w,x,y,z), used as given */
+  const float* shs;             /* (P,M,3) or NULL */
+  const float* colors_precomp;  /* (P,3)   or NULL — exactly one of shs / colors_precomp */
+  /* Optional fused attribute blend (renderer_one_shot.py:298-334). NULL => that term is absent. */
+  const float* blend_xyz_b;     /* (3,)    means3D += xyz_b                       (:300-301) */
+  const float* blend_opacity_b; /* (P,)    opacity += opacity_b                   (:306-307) */
+  const float* blend_color_w;   /* (48,) or (P,48): RGB: c*w[0:3] + w[3:6] - 1    (:323-324); SH: shs*w (:331-332) */
+  const float* blend_color_b;   /* (P,48): RGB: + b[0:3] (:327-328); SH: (shs*w)*w + b (:333-334) */
+} GhInputs;
+
+typedef struct GhOutputs {
+  float* image;    /* (n_views,3,H,W) */
+  int32_t* radii;  /* (n_views,P)   0 for culled Gaussians */
+} GhOutputs;
+
+/* Device-side counters written by gh_forward (first bytes of the workspace, see GhLayout.counters). */
+typedef struct GhCounters {
+  uint32_t num_rendered; /* D: tile instances emitted (before clamping to max_instances) */
+  uint32_t overflow;     /* 1 if D > max_instances: image/gradients are invalid, re-run with a larger workspace */
+  uint32_t reserved[2];
+} GhCounters;
+
+/* Upstream gradient + outputs of gh_backward. Any output pointer may be NULL (that gradient is skipped). */
+typedef struct GhGrads {
+  const float* dL_dimage;   /* (n_views,3,H,W) */
+  float* dL_dmeans3D;       /* (P,3)   summed over views */
+  float* dL_dmeans2D;       /* (n_views,P,3)  [dL/dpx*W/2, dL/dpy*H/2, 0] — API parity with means2D.grad */
+  float* dL_dopacities;     /* (P,) */
+  float* dL_dscales;        /* (P,3) */
+  float* dL_drotations;     /* (P,4) */
+  float* dL_dshs;           /* (P,M,3) */
+  float* dL_dcolors;        /* (P,3) */
+  /* gradients of the fused blend parameters (only when the matching input pointer was given) */
+  float* dL_dblend_xyz_b;     /* (3,) */
+  float* dL_dblend_opacity_b; /* (P,) */
+  float* dL_dblend_color_w;   /* (48,) or (P,48) */
+  float* dL_dblend_color_b;   /* (P,48) */
+} GhGrads;
+
+/* Byte offsets of the internal arrays inside the workspace (public so tests can inspect every stage). */
+typedef struct GhLayout {
+  size_t total_bytes;
+  size_t counters;       /* GhCounters */
+  size_t geom_g0;        /* float4[n_views*P]  (px, py, conicA, conicB) */
+  size_t geom_g1;        /* float4[n_views*P]  (conicC, opacity, r, g) */
+  size_t geom_b;         /* float [n_views*P]  b */
+  size_t depth;          /* float [n_views*P] */
+  size_t rect;           /* uint32[n_views*P]  minx | miny<<8 | maxx<<16 | maxy<<24 (tile units) */
+  size_t clamped;        /* uint8 [n_views*P]  SH colour clamp flags (bit ch) */
+  size_t offsets;        /* uint32[n_views*P]  inclusive scan of tiles touched */
+  size_t block_sums;     /* uint32[...]        scan scratch */
+  size_t keys_a, keys_b; /* uint64[max_instances] radix sort ping-pong; result in keys_a */
+  size_t vals_a, vals_b; /* uint32[max_instances] slot index payload; result in vals_a */
+  size_t slot_gid;       /* uint32[max_instances] emit slot -> view*P + gaussian */
+  size_t sorted_gid;     /* uint32[max_instances] sorted position -> view*P + gaussian */
+  size_t sort_tables;    /* uint32[...]        per-pass digit tables */
+  size_t ranges;         /* uint2 [n_views*tiles] [start,end) into the sorted list */
+  size_t final_T;        /* float [n_views*H*W] */
+  size_t n_contrib;      /* uint32[n_views*H*W] */
+  size_t inst_grad;      /* float[max_instances][12] per-instance gradient records (backward scratch) */
+  size_t bwd_scratch;    /* blend-parameter reduction scratch */
+} GhLayout;
+
+/* Library version: major<<16 | minor. */
+int gh_version(void);
+
+/* Fills `out` with the workspace layout for `dims`; returns GH_OK or an error. Pure host arithmetic. */
+int gh_workspace_layout(const GhDims* dims, GhLayout* out);
+
+/* Convenience: total workspace bytes (0 on invalid dims). */
+size_t gh_workspace_bytes(const GhDims* dims);
+
+/*
+ * Forward: blend -> project -> conic -> bin -> sort -> composite. Replaces
+ * GaussianRasterizer.forward (call sites renderer_one_shot.py:338-346, :372-379).
+ * The workspace must be kept intact until the matching gh_backward has run.
+ */
+int gh_forward(const GhDims* dims, const GhInputs* in, const GhOutputs* out,
+               void* workspace, size_t ws_bytes, void* hip_stream);
+
+/*
+ * Backward: per-pixel reverse walk -> per-instance records -> per-Gaussian chain rule.
+ * Replaces the autograd backward of the reference's rasteriser call. Output gradient arrays are
+ * fully overwritten (not accumulated into).
+ */
+int gh_backward(const GhDims* dims, const GhInputs* in, const GhGrads* grads,
+                void* workspace, size_t ws_bytes, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GH_RASTER_H */

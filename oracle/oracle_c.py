@@ -1,0 +1,161 @@
+"""ctypes wrapper around oracle/libgh_oracle.so (Oracle B, see gh_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg. The product package never imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from guassianhand_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgh_oracle.so")
+_lib = None
+
+
+class GhoDebug(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("xy", "depth", "conic_opacity", "rgb", "rect", "offsets",
+                                          "sorted_keys", "sorted_gid", "ranges", "final_T", "n_contrib")] + \
+               [("capacity", C.c_int64), ("num_rendered", C.c_int64)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "gh_oracle.c")
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "libgh_oracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.gho_forward.restype = C.c_int
+        _lib.gho_forward.argtypes = [C.POINTER(_abi.GhDims), C.POINTER(_abi.GhInputs), C.POINTER(_abi.GhOutputs),
+                                     C.POINTER(C.c_void_p), C.POINTER(GhoDebug)]
+        _lib.gho_backward.restype = C.c_int
+        _lib.gho_backward.argtypes = [C.c_void_p, C.POINTER(_abi.GhInputs), C.POINTER(_abi.GhGrads)]
+        _lib.gho_free.restype = None
+        _lib.gho_free.argtypes = [C.c_void_p]
+        _lib.gho_exp_public.restype = C.c_float
+        _lib.gho_exp_public.argtypes = [C.c_float]
+        _lib.gho_num_threads.restype = C.c_int
+    return _lib
+
+
+def _f32(t) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    return t.detach().to("cpu", torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class OracleRender:
+    """One forward pass of the C oracle; keeps the context for backward()."""
+
+    def __init__(self, cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None,
+                 colors_precomp=None, sh_degree: int = 0, scale_modifier: float = 1.0,
+                 xyz_b=None, opacity_b=None, color_w=None, color_b=None, debug: bool = False):
+        L = lib()
+        self.t = dict(cams=_f32(cams).reshape(-1, _abi.GH_CAM_FLOATS), means3D=_f32(means3D),
+                      opacities=_f32(opacities).reshape(-1), scales=_f32(scales), rotations=_f32(rotations),
+                      shs=_f32(shs), colors_precomp=_f32(colors_precomp), xyz_b=_f32(xyz_b),
+                      opacity_b=None if opacity_b is None else _f32(opacity_b).reshape(-1),
+                      color_w=_f32(color_w), color_b=_f32(color_b))
+        t = self.t
+        self.P = P = t["means3D"].shape[0]
+        self.NV = NV = t["cams"].shape[0]
+        self.H, self.W = H, W
+        self.M = 0 if shs is None else t["shs"].shape[1]
+        flags = 0
+        if color_w is not None and t["color_w"].numel() == P * 48 and P != 1:
+            flags |= _abi.GH_FLAG_BLEND_W_PER_GAUSSIAN
+        self.dims = _abi.GhDims(P, NV, H, W, sh_degree, self.M, scale_modifier, flags, 0)
+        self.inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
+                                 _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]),
+                                 _ptr(t["xyz_b"]), _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
+        self.image = torch.zeros(NV, 3, H, W, dtype=torch.float32)
+        self.radii = torch.zeros(NV, P, dtype=torch.int32)
+        out = _abi.GhOutputs(_ptr(self.image), _ptr(self.radii))
+        self.debug: Dict[str, torch.Tensor] = {}
+        dbg = None
+        if debug:
+            tiles = ((W + 15) // 16) * ((H + 15) // 16)
+            cap = max(1, NV * P * 64)
+            d = self.debug
+            d["xy"] = torch.zeros(NV, P, 2)
+            d["depth"] = torch.zeros(NV, P)
+            d["conic_opacity"] = torch.zeros(NV, P, 4)
+            d["rgb"] = torch.zeros(NV, P, 3)
+            d["rect"] = torch.zeros(NV, P, dtype=torch.int32)
+            d["offsets"] = torch.zeros(NV, P, dtype=torch.int32)
+            d["sorted_keys"] = torch.zeros(cap, dtype=torch.int64)
+            d["sorted_gid"] = torch.zeros(cap, dtype=torch.int32)
+            d["ranges"] = torch.zeros(NV * tiles, 2, dtype=torch.int32)
+            d["final_T"] = torch.zeros(NV, H, W)
+            d["n_contrib"] = torch.zeros(NV, H, W, dtype=torch.int32)
+            dbg = GhoDebug(*[_ptr(d[k]) for k in ("xy", "depth", "conic_opacity", "rgb", "rect", "offsets",
+                                                   "sorted_keys", "sorted_gid", "ranges", "final_T", "n_contrib")],
+                           cap, 0)
+        self._ctx = C.c_void_p()
+        rc = L.gho_forward(C.byref(self.dims), C.byref(self.inp), C.byref(out), C.byref(self._ctx),
+                           C.byref(dbg) if dbg is not None else None)
+        if rc != 0:
+            raise RuntimeError(f"gho_forward failed: {_abi.status_name(rc)}")
+        if dbg is not None:
+            self.num_rendered = int(dbg.num_rendered)
+            n = min(self.num_rendered, cap)
+            self.debug["sorted_keys"] = self.debug["sorted_keys"][:n]
+            self.debug["sorted_gid"] = self.debug["sorted_gid"][:n]
+
+    def backward(self, dL_dimage) -> Dict[str, torch.Tensor]:
+        t = self.t
+        P, NV, M = self.P, self.NV, self.M
+        g = _f32(dL_dimage).reshape(NV, 3, self.H, self.W).contiguous()
+        wpg = bool(self.dims.flags & _abi.GH_FLAG_BLEND_W_PER_GAUSSIAN)
+        o = dict(means3D=torch.zeros(P, 3), means2D=torch.zeros(NV, P, 3), opacities=torch.zeros(P),
+                 scales=torch.zeros(P, 3), rotations=torch.zeros(P, 4),
+                 shs=torch.zeros(P, M, 3) if M else None,
+                 colors_precomp=torch.zeros(P, 3) if t["colors_precomp"] is not None else None,
+                 xyz_b=torch.zeros(3) if t["xyz_b"] is not None else None,
+                 opacity_b=torch.zeros(P) if t["opacity_b"] is not None else None,
+                 color_w=(torch.zeros(P, 48) if wpg else torch.zeros(48)) if t["color_w"] is not None else None,
+                 color_b=torch.zeros(P, 48) if t["color_b"] is not None else None)
+        gr = _abi.GhGrads(_ptr(g), _ptr(o["means3D"]), _ptr(o["means2D"]), _ptr(o["opacities"]), _ptr(o["scales"]),
+                          _ptr(o["rotations"]), _ptr(o["shs"]), _ptr(o["colors_precomp"]), _ptr(o["xyz_b"]),
+                          _ptr(o["opacity_b"]), _ptr(o["color_w"]), _ptr(o["color_b"]))
+        rc = lib().gho_backward(self._ctx, C.byref(self.inp), C.byref(gr))
+        if rc != 0:
+            raise RuntimeError(f"gho_backward failed: {_abi.status_name(rc)}")
+        return {k: v for k, v in o.items() if v is not None}
+
+    def close(self):
+        if self._ctx:
+            lib().gho_free(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gho_exp(x: float) -> float:
+    return float(lib().gho_exp_public(C.c_float(x)))
+
+
+def num_threads() -> int:
+    return int(lib().gho_num_threads())
