@@ -1,0 +1,111 @@
+// gh_api.hip — the C-ABI entry points of include/gh_raster.h: workspace layout + kernel sequencing.
+// No allocation, no synchronisation, no host read-back: everything is enqueued on the caller's stream.
+#include "gh_internal.h"
+
+static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+static int check_dims(const GhDims* d) {
+  if (!d) return GH_ERR_INVALID_ARG;
+  if (d->P < 0 || d->n_views < 1 || d->H < 1 || d->W < 1 || d->max_instances < 0) return GH_ERR_INVALID_ARG;
+  if (d->sh_degree < 0 || d->sh_degree > 3) return GH_ERR_UNSUPPORTED;
+  if (d->M != 0 && d->M != 1 && d->M != 4 && d->M != 9 && d->M != 16) return GH_ERR_UNSUPPORTED;
+  int gx = (d->W + GH_TILE - 1) / GH_TILE, gy = (d->H + GH_TILE - 1) / GH_TILE;
+  if (gx > 255 || gy > 255) return GH_ERR_UNSUPPORTED;                 // rect packs tile coords in 8 bits
+  if ((long long)d->n_views * d->P >= (1ll << 31)) return GH_ERR_UNSUPPORTED;
+  if (d->max_instances >= (1ll << 32)) return GH_ERR_UNSUPPORTED;      // uint32 slots
+  if ((long long)gx * gy * d->n_views >= (1ll << 31)) return GH_ERR_UNSUPPORTED;
+  return GH_OK;
+}
+
+extern "C" int gh_version(void) { return (GH_VERSION_MAJOR << 16) | GH_VERSION_MINOR; }
+
+extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
+  int rc = check_dims(d);
+  if (rc != GH_OK || !L) return rc != GH_OK ? rc : GH_ERR_INVALID_ARG;
+  GhGrid g = gh_make_grid(d);
+  size_t N = (size_t)g.N, cap = (size_t)g.cap, pix = (size_t)g.NV * g.H * g.W;
+  size_t nblk_pre = (N + GH_BLOCK - 1) / GH_BLOCK;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
+  L->counters = take(sizeof(GhCounters));
+  L->geom_g0 = take(N * 16);
+  L->geom_g1 = take(N * 16);
+  L->geom_b = take(N * 4);
+  L->depth = take(N * 4);
+  L->rect = take(N * 4);
+  L->clamped = take(N);
+  L->offsets = take(N * 4);
+  L->block_sums = take((nblk_pre + 1) * 4);
+  L->keys_a = take(cap * 8);
+  L->keys_b = take(cap * 8);
+  L->vals_a = take(cap * 4);
+  L->vals_b = take(cap * 4);
+  L->slot_gid = take(cap * 4);
+  L->sorted_gid = take(cap * 4);
+  L->sort_tables = take(((size_t)256 * g.nblk_sort + 256) * 4);
+  L->ranges = take((size_t)g.NV * g.tiles * 8);
+  L->final_T = take(pix * 4);
+  L->n_contrib = take(pix * 4);
+  L->inst_grad = take(cap * GH_REC * 4);
+  L->bwd_scratch = take((nblk_pre + 1) * 64 * 4);
+  L->total_bytes = off;
+  return GH_OK;
+}
+
+extern "C" size_t gh_workspace_bytes(const GhDims* d) {
+  GhLayout L;
+  if (gh_workspace_layout(d, &L) != GH_OK) return 0;
+  return L.total_bytes;
+}
+
+static int check_inputs(const GhDims* d, const GhInputs* in) {
+  if (!in || !in->cams) return GH_ERR_INVALID_ARG;
+  if (d->P > 0 && (!in->means3D || !in->opacities || !in->scales || !in->rotations)) return GH_ERR_INVALID_ARG;
+  if ((in->shs != nullptr) == (in->colors_precomp != nullptr)) return GH_ERR_INVALID_ARG;  // exactly one
+  if (in->shs && d->M == 0) return GH_ERR_INVALID_ARG;
+  if (in->colors_precomp && d->M != 0) return GH_ERR_INVALID_ARG;
+  if (in->blend_color_b && !in->blend_color_w && in->shs) return GH_ERR_INVALID_ARG;      // SH: b needs w (:334)
+  if (in->shs && (in->blend_color_w || in->blend_color_b) && d->M != 16) return GH_ERR_INVALID_ARG;
+  return GH_OK;
+}
+
+extern "C" int gh_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, void* workspace,
+                          size_t ws_bytes, void* hip_stream) {
+  int rc = check_dims(d);
+  if (rc != GH_OK) return rc;
+  rc = check_inputs(d, in);
+  if (rc != GH_OK) return rc;
+  if (!out || !out->image || !workspace) return GH_ERR_INVALID_ARG;
+  GhLayout L;
+  gh_workspace_layout(d, &L);
+  if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
+  hipStream_t s = (hipStream_t)hip_stream;
+  char* ws = (char*)workspace;
+  GhGrid g = gh_make_grid(d);
+  (void)hipGetLastError();
+  if (hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s) != hipSuccess) return GH_ERR_LAUNCH;
+  if (hipMemsetAsync(ws + L.ranges, 0, (size_t)g.NV * g.tiles * 8, s) != hipSuccess) return GH_ERR_LAUNCH;
+  gh_launch_preprocess_fwd(d, g, in, out->radii, ws, L, s);
+  gh_launch_binning(d, g, ws, L, s);
+  gh_launch_render_fwd(d, g, in, out->image, ws, L, s);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_backward(const GhDims* d, const GhInputs* in, const GhGrads* gr, void* workspace,
+                           size_t ws_bytes, void* hip_stream) {
+  int rc = check_dims(d);
+  if (rc != GH_OK) return rc;
+  rc = check_inputs(d, in);
+  if (rc != GH_OK) return rc;
+  if (!gr || !gr->dL_dimage || !workspace) return GH_ERR_INVALID_ARG;
+  GhLayout L;
+  gh_workspace_layout(d, &L);
+  if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
+  hipStream_t s = (hipStream_t)hip_stream;
+  char* ws = (char*)workspace;
+  GhGrid g = gh_make_grid(d);
+  (void)hipGetLastError();
+  gh_launch_render_bwd(d, g, in, gr->dL_dimage, ws, L, s);
+  gh_launch_preprocess_bwd(d, g, in, gr, ws, L, s);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}

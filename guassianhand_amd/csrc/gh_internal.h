@@ -1,0 +1,206 @@
+// gh_internal.h — shared device helpers and launcher prototypes for the gfx950 rasteriser kernels.
+// Written for CDNA4 only: 64-lane wavefronts, DPP cross-lane ops, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gh_raster.h"
+
+#define GH_WAVE 64
+#define GH_BLOCK 256                 // 4 waves: one 8x8 pixel quadrant of a 16x16 tile per wave
+#define GH_SORT_ITEMS 16             // keys per thread per radix pass
+#define GH_SORT_TILE (GH_BLOCK * GH_SORT_ITEMS)
+#define GH_REC 12                    // floats per per-instance gradient record (9 used)
+
+struct GhGrid {
+  int P, NV, H, W, gx, gy, tiles, N;  // N = NV*P
+  int tile_bits, n_pass;
+  int64_t cap;                        // max_instances
+  int nblk_sort;                      // ceil(cap / GH_SORT_TILE)
+};
+
+static inline GhGrid gh_make_grid(const GhDims* d) {
+  GhGrid g;
+  g.P = d->P; g.NV = d->n_views; g.H = d->H; g.W = d->W;
+  g.gx = (d->W + GH_TILE - 1) / GH_TILE; g.gy = (d->H + GH_TILE - 1) / GH_TILE;
+  g.tiles = g.gx * g.gy; g.N = d->n_views * d->P;
+  int tb = 1; while ((1ll << tb) < (long long)g.tiles * d->n_views) ++tb;
+  g.tile_bits = tb; g.n_pass = 4 + (tb + 7) / 8;
+  g.cap = d->max_instances;
+  g.nblk_sort = (int)((g.cap + GH_SORT_TILE - 1) / GH_SORT_TILE);
+  if (g.nblk_sort < 1) g.nblk_sort = 1;
+  return g;
+}
+
+// ---- launchers (each enqueues on `s`, never synchronises) --------------------------------------
+void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii,
+                              char* ws, const GhLayout& L, hipStream_t s);
+void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
+void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image,
+                          char* ws, const GhLayout& L, hipStream_t s);
+void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
+                          char* ws, const GhLayout& L, hipStream_t s);
+void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr,
+                              char* ws, const GhLayout& L, hipStream_t s);
+
+#if defined(__HIPCC__)
+// ---- arithmetic contract: fp32, no implicit contraction, FMAs only where written ----
+
+// exp(x), x <= 0, from IEEE primitives only so CPU oracle and GPU agree bit for bit:
+// 2^(x*log2e): n = rne(t), Taylor-6 of 2^f on [-.5,.5], v_ldexp_f32.
+__device__ __forceinline__ float gh_exp(float x) {
+  float t = x * 1.44269504088896341f;
+  if (t < -126.0f) return 0.0f;
+  float n = __builtin_rintf(t);
+  float f = t - n;
+  float p = 1.5403530393381608e-04f;
+  p = fmaf(p, f, 1.3333558146428443e-03f);
+  p = fmaf(p, f, 9.6181291076284772e-03f);
+  p = fmaf(p, f, 5.5504108664821580e-02f);
+  p = fmaf(p, f, 2.4022650695910072e-01f);
+  p = fmaf(p, f, 6.9314718055994531e-01f);
+  p = fmaf(p, f, 1.0f);
+  return ldexpf(p, (int)n);
+}
+
+struct GhGeo {
+  float mx, my, mz, tx, ty, tz, hx, hy, hw, winv;
+  float S[6], R[9], s[3], T[6];
+  float cx, cy, fx, fy, a, b, c, det;
+  bool xclamped, yclamped;
+};
+
+// View transform, Sigma3D, EWA projection — one Gaussian, one camera. cam = GH_CAM_FLOATS record.
+__device__ __forceinline__ void gh_geo_forward(const GhInputs& in, const float* __restrict__ cam, int i,
+                                               float mod, int H, int W, GhGeo& o) {
+  const float* V = cam; const float* PM = cam + 16;
+  float mx = in.means3D[3 * i], my = in.means3D[3 * i + 1], mz = in.means3D[3 * i + 2];
+  if (in.blend_xyz_b) { mx = mx + in.blend_xyz_b[0]; my = my + in.blend_xyz_b[1]; mz = mz + in.blend_xyz_b[2]; }
+  o.mx = mx; o.my = my; o.mz = mz;
+  o.tx = fmaf(V[0], mx, fmaf(V[4], my, fmaf(V[8], mz, V[12])));
+  o.ty = fmaf(V[1], mx, fmaf(V[5], my, fmaf(V[9], mz, V[13])));
+  o.tz = fmaf(V[2], mx, fmaf(V[6], my, fmaf(V[10], mz, V[14])));
+  o.hx = fmaf(PM[0], mx, fmaf(PM[4], my, fmaf(PM[8], mz, PM[12])));
+  o.hy = fmaf(PM[1], mx, fmaf(PM[5], my, fmaf(PM[9], mz, PM[13])));
+  o.hw = fmaf(PM[3], mx, fmaf(PM[7], my, fmaf(PM[11], mz, PM[15])));
+  o.winv = 1.0f / (o.hw + 1e-7f);
+  o.s[0] = mod * in.scales[3 * i]; o.s[1] = mod * in.scales[3 * i + 1]; o.s[2] = mod * in.scales[3 * i + 2];
+  float r = in.rotations[4 * i], x = in.rotations[4 * i + 1], y = in.rotations[4 * i + 2], z = in.rotations[4 * i + 3];
+  float* R = o.R;
+  R[0] = 1.0f - 2.0f * fmaf(y, y, z * z); R[1] = 2.0f * fmaf(x, y, -(r * z)); R[2] = 2.0f * fmaf(x, z, r * y);
+  R[3] = 2.0f * fmaf(x, y, r * z); R[4] = 1.0f - 2.0f * fmaf(x, x, z * z); R[5] = 2.0f * fmaf(y, z, -(r * x));
+  R[6] = 2.0f * fmaf(x, z, -(r * y)); R[7] = 2.0f * fmaf(y, z, r * x); R[8] = 1.0f - 2.0f * fmaf(x, x, y * y);
+  float M[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) M[3 * a + j] = R[3 * a + j] * o.s[j];
+  o.S[0] = fmaf(M[0], M[0], fmaf(M[1], M[1], M[2] * M[2]));
+  o.S[1] = fmaf(M[0], M[3], fmaf(M[1], M[4], M[2] * M[5]));
+  o.S[2] = fmaf(M[0], M[6], fmaf(M[1], M[7], M[2] * M[8]));
+  o.S[3] = fmaf(M[3], M[3], fmaf(M[4], M[4], M[5] * M[5]));
+  o.S[4] = fmaf(M[3], M[6], fmaf(M[4], M[7], M[5] * M[8]));
+  o.S[5] = fmaf(M[6], M[6], fmaf(M[7], M[7], M[8] * M[8]));
+  float tanx = cam[35], tany = cam[36];
+  float limx = 1.3f * tanx, limy = 1.3f * tany;
+  float txtz = o.tx / o.tz, tytz = o.ty / o.tz;
+  float cxr = fminf(limx, fmaxf(-limx, txtz)), cyr = fminf(limy, fmaxf(-limy, tytz));
+  o.xclamped = (cxr != txtz); o.yclamped = (cyr != tytz);
+  o.cx = cxr * o.tz; o.cy = cyr * o.tz;
+  o.fx = (float)W / (2.0f * tanx); o.fy = (float)H / (2.0f * tany);
+  float tz2 = o.tz * o.tz;
+  float J00 = o.fx / o.tz, J02 = -(o.fx * o.cx) / tz2, J11 = o.fy / o.tz, J12 = -(o.fy * o.cy) / tz2;
+  float* T = o.T;
+  T[0] = fmaf(J00, V[0], J02 * V[2]); T[1] = fmaf(J00, V[4], J02 * V[6]); T[2] = fmaf(J00, V[8], J02 * V[10]);
+  T[3] = fmaf(J11, V[1], J12 * V[2]); T[4] = fmaf(J11, V[5], J12 * V[6]); T[5] = fmaf(J11, V[9], J12 * V[10]);
+  const float* S = o.S;
+  float U0 = fmaf(T[0], S[0], fmaf(T[1], S[1], T[2] * S[2]));
+  float U1 = fmaf(T[0], S[1], fmaf(T[1], S[3], T[2] * S[4]));
+  float U2 = fmaf(T[0], S[2], fmaf(T[1], S[4], T[2] * S[5]));
+  float U3 = fmaf(T[3], S[0], fmaf(T[4], S[1], T[5] * S[2]));
+  float U4 = fmaf(T[3], S[1], fmaf(T[4], S[3], T[5] * S[4]));
+  float U5 = fmaf(T[3], S[2], fmaf(T[4], S[4], T[5] * S[5]));
+  float c00 = fmaf(U0, T[0], fmaf(U1, T[1], U2 * T[2]));
+  float c01 = fmaf(U0, T[3], fmaf(U1, T[4], U2 * T[5]));
+  float c11 = fmaf(U3, T[3], fmaf(U4, T[4], U5 * T[5]));
+  o.a = c00 + 0.3f; o.b = c01; o.c = c11 + 0.3f;
+  o.det = fmaf(o.a, o.c, -(o.b * o.b));
+}
+
+// ---- SH basis (real, degree <= 3) ----------------------------------------------------------------
+#define GH_SH_C0 0.28209479177387814f
+#define GH_SH_C1 0.4886025119029199f
+#define GH_SH_C2_0 1.0925484305920792f
+#define GH_SH_C2_1 -1.0925484305920792f
+#define GH_SH_C2_2 0.31539156525252005f
+#define GH_SH_C2_3 -1.0925484305920792f
+#define GH_SH_C2_4 0.5462742152960396f
+#define GH_SH_C3_0 -0.5900435899266435f
+#define GH_SH_C3_1 2.890611442640554f
+#define GH_SH_C3_2 -0.4570457994644658f
+#define GH_SH_C3_3 0.3731763325901154f
+#define GH_SH_C3_4 -0.4570457994644658f
+#define GH_SH_C3_5 1.445305721320277f
+#define GH_SH_C3_6 -0.5900435899266435f
+
+__device__ __forceinline__ int gh_sh_basis(int deg, float x, float y, float z, float* Bv) {
+  Bv[0] = GH_SH_C0;
+  if (deg < 1) return 1;
+  Bv[1] = -GH_SH_C1 * y; Bv[2] = GH_SH_C1 * z; Bv[3] = -GH_SH_C1 * x;
+  if (deg < 2) return 4;
+  float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+  Bv[4] = GH_SH_C2_0 * xy;
+  Bv[5] = GH_SH_C2_1 * yz;
+  Bv[6] = GH_SH_C2_2 * (2.0f * zz - xx - yy);
+  Bv[7] = GH_SH_C2_3 * xz;
+  Bv[8] = GH_SH_C2_4 * (xx - yy);
+  if (deg < 3) return 9;
+  Bv[9]  = GH_SH_C3_0 * y * (3.0f * xx - yy);
+  Bv[10] = GH_SH_C3_1 * xy * z;
+  Bv[11] = GH_SH_C3_2 * y * (4.0f * zz - xx - yy);
+  Bv[12] = GH_SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+  Bv[13] = GH_SH_C3_4 * x * (4.0f * zz - xx - yy);
+  Bv[14] = GH_SH_C3_5 * z * (xx - yy);
+  Bv[15] = GH_SH_C3_6 * x * (xx - 3.0f * yy);
+  return 16;
+}
+
+// blended SH coefficient (renderer_one_shot.py:330-334, incl. the double multiply when color_b is given)
+__device__ __forceinline__ float gh_blended_sh(const GhInputs& in, uint32_t flags, int M, int i, int k, int ch) {
+  float s = in.shs[((size_t)i * M + k) * 3 + ch];
+  if (in.blend_color_w) {
+    const float* w = in.blend_color_w + ((flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? (size_t)i * 48 : 0);
+    s = s * w[k * 3 + ch];
+    if (in.blend_color_b) {
+      s = s * w[k * 3 + ch];
+      s = s + in.blend_color_b[(size_t)i * 48 + k * 3 + ch];
+    }
+  }
+  return s;
+}
+
+// ---- wave64 cross-lane helpers (DPP; no LDS traffic) ------------------------------------------------
+// DPP controls (gfx9 encoding): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_ror:n 0x120+n,
+// row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ float gh_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+
+// Sum over all 64 lanes; every lane of the wave must be active. Result is valid in lane 63.
+__device__ __forceinline__ float gh_wave_sum_to63(float v) {
+  v += gh_dpp<0xB1>(v);          // quad_perm [1,0,3,2]
+  v += gh_dpp<0x4E>(v);          // quad_perm [2,3,0,1]
+  v += gh_dpp<0x141>(v);         // row_half_mirror: 8-lane sums
+  v += gh_dpp<0x140>(v);         // row_mirror: 16-lane row sums in every lane
+  v += gh_dpp<0x142, 0xA>(v);    // row_bcast15 -> rows 1,3
+  v += gh_dpp<0x143, 0xC>(v);    // row_bcast31 -> rows 2,3
+  return v;
+}
+
+__device__ __forceinline__ unsigned gh_wave_sum_u32(unsigned v) {  // all lanes get the total
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+#endif  // __HIPCC__

@@ -1,0 +1,385 @@
+// gh_preprocess.hip — per-Gaussian stages: fused attribute blend + projection + covariance->conic
+// (forward) and the per-Gaussian chain rule incl. blend-parameter gradients (backward).
+// Restates SURVEY.md App. A.1 / A.5; the blend is tgs/models/renderer_one_shot.py:298-334.
+// HBM-streaming kernels: one thread per (view, Gaussian), outputs packed as float4 records so the
+// render kernels gather each Gaussian with two 16-byte loads + one 4-byte load.
+#include "gh_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
+    GhInputs in, int P, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
+    float4* __restrict__ g0, float4* __restrict__ g1, float* __restrict__ gb, float* __restrict__ depth,
+    uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
+    uint32_t* __restrict__ block_sums, int32_t* __restrict__ radii) {
+  __shared__ unsigned s_wsum[GH_BLOCK / GH_WAVE];
+  const int n = blockIdx.x * GH_BLOCK + threadIdx.x;
+  unsigned tiles = 0;
+  if (n < N) {
+    const int v = n / P, i = n - v * P;
+    const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
+    int radius = 0;
+    GhGeo e;
+    gh_geo_forward(in, cam, i, mod, H, W, e);
+    bool ok = (e.tz > 0.2f) && (e.det != 0.0f);
+    if (ok) {
+      float dinv = 1.0f / e.det;
+      float mid = 0.5f * (e.a + e.c);
+      float sq = sqrtf(fmaxf(0.1f, fmaf(mid, mid, -e.det)));
+      float lam1 = mid + sq, lam2 = mid - sq;
+      int rad = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
+      float ndcx = e.hx * e.winv, ndcy = e.hy * e.winv;
+      float px = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
+      float py = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+      int minx = (int)((px - (float)rad) / (float)GH_TILE); minx = minx < 0 ? 0 : (minx > gx ? gx : minx);
+      int miny = (int)((py - (float)rad) / (float)GH_TILE); miny = miny < 0 ? 0 : (miny > gy ? gy : miny);
+      int maxx = (int)((px + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
+      int maxy = (int)((py + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
+      int cnt = (maxx - minx) * (maxy - miny);
+      if (cnt > 0) {
+        tiles = (unsigned)cnt;
+        radius = rad;
+        float op = in.opacities[i];
+        if (in.blend_opacity_b) op = op + in.blend_opacity_b[i];
+        float rgb[3];
+        unsigned cl = 0;
+        if (in.colors_precomp) {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            float col = in.colors_precomp[3 * i + ch];
+            if (in.blend_color_w) {
+              const float* w = in.blend_color_w + ((flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? (size_t)i * 48 : 0);
+              col = col * w[ch]; col = col + w[3 + ch]; col = col - 1.0f;
+            }
+            if (in.blend_color_b) col = col + in.blend_color_b[(size_t)i * 48 + ch];
+            rgb[ch] = col;
+          }
+        } else {
+          float dx = e.mx - cam[32], dy = e.my - cam[33], dz = e.mz - cam[34];
+          float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+          dx = dx / len; dy = dy / len; dz = dz / len;
+          float Bv[16];
+          int nb = gh_sh_basis(sh_degree, dx, dy, dz, Bv);
+          if (nb > M) nb = M;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            float acc = 0.0f;
+            for (int k = 0; k < nb; ++k) acc = fmaf(Bv[k], gh_blended_sh(in, flags, M, i, k, ch), acc);
+            acc = acc + 0.5f;
+            if (acc < 0.0f) { cl |= (1u << ch); acc = 0.0f; }
+            rgb[ch] = acc;
+          }
+        }
+        g0[n] = make_float4(px, py, e.c * dinv, -e.b * dinv);
+        g1[n] = make_float4(e.a * dinv, op, rgb[0], rgb[1]);
+        gb[n] = rgb[2];
+        depth[n] = e.tz;
+        rect[n] = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);
+        clamped[n] = (uint8_t)cl;
+      }
+    }
+    tiles_touched[n] = tiles;
+    if (radii) radii[n] = radius;
+  }
+  unsigned ws = gh_wave_sum_u32(tiles);
+  if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+}
+
+void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii, char* ws,
+                              const GhLayout& L, hipStream_t s) {
+  if (g.N == 0) return;
+  int nblk = (g.N + GH_BLOCK - 1) / GH_BLOCK;
+  hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.N, g.H, g.W, g.gx, g.gy,
+                     d->sh_degree, d->M, d->scale_modifier, d->flags, (float4*)(ws + L.geom_g0),
+                     (float4*)(ws + L.geom_g1), (float*)(ws + L.geom_b), (float*)(ws + L.depth),
+                     (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.offsets),
+                     (uint32_t*)(ws + L.block_sums), radii);
+}
+
+// ------------------------------------------------------------------------------------------------
+// d(basis_k)/d(x,y,z)
+__device__ __forceinline__ void gh_sh_basis_grad(int deg, float x, float y, float z, float (*dB)[3]) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dB[k][0] = dB[k][1] = dB[k][2] = 0.0f;
+  if (deg < 1) return;
+  dB[1][1] = -GH_SH_C1; dB[2][2] = GH_SH_C1; dB[3][0] = -GH_SH_C1;
+  if (deg < 2) return;
+  float xx = x * x, yy = y * y, zz = z * z;
+  dB[4][0] = GH_SH_C2_0 * y;  dB[4][1] = GH_SH_C2_0 * x;
+  dB[5][1] = GH_SH_C2_1 * z;  dB[5][2] = GH_SH_C2_1 * y;
+  dB[6][0] = GH_SH_C2_2 * -2.0f * x; dB[6][1] = GH_SH_C2_2 * -2.0f * y; dB[6][2] = GH_SH_C2_2 * 4.0f * z;
+  dB[7][0] = GH_SH_C2_3 * z;  dB[7][2] = GH_SH_C2_3 * x;
+  dB[8][0] = GH_SH_C2_4 * 2.0f * x; dB[8][1] = GH_SH_C2_4 * -2.0f * y;
+  if (deg < 3) return;
+  dB[9][0]  = GH_SH_C3_0 * 6.0f * x * y;  dB[9][1] = GH_SH_C3_0 * (3.0f * xx - 3.0f * yy);
+  dB[10][0] = GH_SH_C3_1 * y * z; dB[10][1] = GH_SH_C3_1 * x * z; dB[10][2] = GH_SH_C3_1 * x * y;
+  dB[11][0] = GH_SH_C3_2 * -2.0f * x * y; dB[11][1] = GH_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); dB[11][2] = GH_SH_C3_2 * 8.0f * y * z;
+  dB[12][0] = GH_SH_C3_3 * -6.0f * x * z; dB[12][1] = GH_SH_C3_3 * -6.0f * y * z; dB[12][2] = GH_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+  dB[13][0] = GH_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); dB[13][1] = GH_SH_C3_4 * -2.0f * x * y; dB[13][2] = GH_SH_C3_4 * 8.0f * x * z;
+  dB[14][0] = GH_SH_C3_5 * 2.0f * x * z; dB[14][1] = GH_SH_C3_5 * -2.0f * y * z; dB[14][2] = GH_SH_C3_5 * (xx - yy);
+  dB[15][0] = GH_SH_C3_6 * (3.0f * xx - 3.0f * yy); dB[15][1] = GH_SH_C3_6 * -6.0f * x * y;
+}
+
+// Deterministic block-level accumulation of blend-parameter gradients: wave DPP sum, lane 63 adds the
+// wave's total to its own LDS row (single writer per row), rows are combined in fixed order at the end.
+__device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, float v) {
+  float t = gh_wave_sum_to63(v);
+  if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6][slot] += t;
+}
+
+// One thread per Gaussian; loops the views so gradients w.r.t. view-independent attributes are summed
+// in registers/own memory in a fixed order (no atomics, bitwise reproducible).
+__global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
+    GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags,
+    uint32_t cap, const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ clamped,
+    const float* __restrict__ inst_grad, float* __restrict__ scratch) {
+  __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
+  const int i = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const bool live = i < P;
+  const bool rgb_mode = in.colors_precomp != nullptr;
+  const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
+  const bool red_w = in.blend_color_w && !wpg && gr.dL_dblend_color_w;   // global (48,) weights: block reduce
+  const bool red_x = in.blend_xyz_b && gr.dL_dblend_xyz_b;
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) s_part[w][threadIdx.x] = 0.0f;
+  }
+  __syncthreads();
+
+  float am[3] = {0, 0, 0}, as[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, araw[3] = {0, 0, 0}, ao = 0.0f;
+  for (int v = 0; v < NV; ++v) {
+    const size_t n = (size_t)v * P + (live ? i : 0);
+    uint32_t o1 = 0, o0 = 0;
+    if (live) {
+      o1 = offsets[n]; o0 = n > 0 ? offsets[n - 1] : 0u;
+      if (o1 > cap) o1 = cap;
+      if (o0 > o1) o0 = o1;
+    }
+    const bool vis = live && (o1 > o0);
+    // fixed-order sum of this Gaussian's per-instance records (slots are contiguous per Gaussian)
+    float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t sidx = o0; sidx < o1; ++sidx) {
+      const float4* r = (const float4*)(inst_grad + (size_t)sidx * GH_REC);
+      float4 r0 = r[0], r1 = r[1]; float r2 = inst_grad[(size_t)sidx * GH_REC + 8];
+      s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r0.w;
+      s9[4] += r1.x; s9[5] += r1.y; s9[6] += r1.z; s9[7] += r1.w; s9[8] += r2;
+    }
+    const float g_px = s9[0], g_py = s9[1], gA = s9[2], gB = s9[3], gC = s9[4], g_o = s9[5];
+    if (live && gr.dL_dmeans2D) {
+      gr.dL_dmeans2D[3 * n] = vis ? g_px * 0.5f * (float)W : 0.0f;
+      gr.dL_dmeans2D[3 * n + 1] = vis ? g_py * 0.5f * (float)H : 0.0f;
+      gr.dL_dmeans2D[3 * n + 2] = 0.0f;
+    }
+    float dm[3] = {0, 0, 0};
+    const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
+    const float* V = cam; const float* PM = cam + 16;
+    float Bv[16]; int nb = 0; unsigned cl = 0;      // SH basis of this view (kept for the global-w reduction)
+    if (vis) {
+      GhGeo e;
+      gh_geo_forward(in, cam, i, mod, H, W, e);
+      // ---- colour ----
+      if (rgb_mode) {
+        araw[0] += s9[6]; araw[1] += s9[7]; araw[2] += s9[8];
+      } else {
+        float dx = e.mx - cam[32], dy = e.my - cam[33], dz = e.mz - cam[34];
+        float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+        float ux = dx / len, uy = dy / len, uz = dz / len;
+        float dB[16][3];
+        nb = gh_sh_basis(sh_degree, ux, uy, uz, Bv); if (nb > M) nb = M;
+        gh_sh_basis_grad(sh_degree, ux, uy, uz, dB);
+        float ddir[3] = {0, 0, 0};
+        cl = clamped[n];
+        for (int k = 0; k < M; ++k) {
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const size_t oi = ((size_t)i * M + k) * 3 + ch;
+            const size_t bi = (size_t)i * 48 + k * 3 + ch;
+            float gsh = 0.0f, gk = 0.0f, gw = 0.0f;
+            if (k < nb) {
+              float gc = (cl & (1u << ch)) ? 0.0f : s9[6 + ch];
+              float shv = gh_blended_sh(in, flags, M, i, k, ch);
+              gk = Bv[k] * gc;                     // dL/d(blended coefficient)
+              ddir[0] += dB[k][0] * shv * gc; ddir[1] += dB[k][1] * shv * gc; ddir[2] += dB[k][2] * shv * gc;
+              gsh = gk;
+              if (in.blend_color_w) {
+                const float wv = in.blend_color_w[(wpg ? (size_t)i * 48 : 0) + k * 3 + ch];
+                const float raw = in.shs[oi];
+                gsh = in.blend_color_b ? gk * wv * wv : gk * wv;
+                gw = in.blend_color_b ? gk * 2.0f * raw * wv : gk * raw;
+              }
+            }
+            if (gr.dL_dshs) gr.dL_dshs[oi] = (v == 0 ? 0.0f : gr.dL_dshs[oi]) + gsh;
+            if (in.blend_color_b && gr.dL_dblend_color_b)
+              gr.dL_dblend_color_b[bi] = (v == 0 ? 0.0f : gr.dL_dblend_color_b[bi]) + gk;
+            if (in.blend_color_w && wpg && gr.dL_dblend_color_w)
+              gr.dL_dblend_color_w[bi] = (v == 0 ? 0.0f : gr.dL_dblend_color_w[bi]) + gw;
+          }
+        }
+        float dot = ux * ddir[0] + uy * ddir[1] + uz * ddir[2];
+        dm[0] += (ddir[0] - ux * dot) / len; dm[1] += (ddir[1] - uy * dot) / len; dm[2] += (ddir[2] - uz * dot) / len;
+      }
+      // ---- conic -> dilated cov2D (a,b,c) ----
+      float a = e.a, b = e.b, cc = e.c, det = e.det;
+      float det2inv = 1.0f / (det * det);
+      float dL_da = (-cc * cc * gA + b * cc * gB - b * b * gC) * det2inv;
+      float dL_dc = (-b * b * gA + a * b * gB - a * a * gC) * det2inv;
+      float dL_db = (2.0f * b * cc * gA - (a * cc + b * b) * gB + 2.0f * a * b * gC) * det2inv;
+      // G2 = [[da, db/2],[db/2, dc]];  dSigma(full) = T^T G2 T ; dT = 2 G2 T Sigma
+      float g00 = dL_da, g01 = 0.5f * dL_db, g11 = dL_dc;
+      const float* T = e.T;
+      float GT[6];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { GT[k] = g00 * T[k] + g01 * T[3 + k]; GT[3 + k] = g01 * T[k] + g11 * T[3 + k]; }
+      float dS[9];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) dS[3 * p + q] = T[p] * GT[q] + T[3 + p] * GT[3 + q];
+      float Sf[9] = {e.S[0], e.S[1], e.S[2], e.S[1], e.S[3], e.S[4], e.S[2], e.S[4], e.S[5]};
+      float dT[6];
+#pragma unroll
+      for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+          dT[3 * r2 + q] = 2.0f * (GT[3 * r2] * Sf[q] + GT[3 * r2 + 1] * Sf[3 + q] + GT[3 * r2 + 2] * Sf[6 + q]);
+      // Sigma = M M^T, M = R diag(s): dM = 2 dSigma M
+      float Mm[9];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) Mm[3 * p + j] = e.R[3 * p + j] * e.s[j];
+      float dM[9];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          dM[3 * p + j] = 2.0f * (dS[3 * p] * Mm[j] + dS[3 * p + 1] * Mm[3 + j] + dS[3 * p + 2] * Mm[6 + j]);
+      float dR[9];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float ds = dM[j] * e.R[j] + dM[3 + j] * e.R[3 + j] + dM[6 + j] * e.R[6 + j];
+        as[j] += ds * mod;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dR[3 * p + j] = dM[3 * p + j] * e.s[j];
+      }
+      {
+        float r = in.rotations[4 * i], x = in.rotations[4 * i + 1], y = in.rotations[4 * i + 2], z = in.rotations[4 * i + 3];
+        aq[0] += 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        aq[1] += 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
+        aq[2] += 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
+        aq[3] += 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+      }
+      // ---- T = J W (the 1.3*tanfov clamp freezes the clamped view-space x / y, App. A.4-3) ----
+      float dJ00 = dT[0] * V[0] + dT[1] * V[4] + dT[2] * V[8];
+      float dJ02 = dT[0] * V[2] + dT[1] * V[6] + dT[2] * V[10];
+      float dJ11 = dT[3] * V[1] + dT[4] * V[5] + dT[5] * V[9];
+      float dJ12 = dT[3] * V[2] + dT[4] * V[6] + dT[5] * V[10];
+      float tzi = 1.0f / e.tz, tz2i = tzi * tzi, tz3i = tz2i * tzi;
+      float dtx = e.xclamped ? 0.0f : -e.fx * tz2i * dJ02;
+      float dty = e.yclamped ? 0.0f : -e.fy * tz2i * dJ12;
+      float dtz = -e.fx * tz2i * dJ00 - e.fy * tz2i * dJ11 + 2.0f * e.fx * e.cx * tz3i * dJ02 + 2.0f * e.fy * e.cy * tz3i * dJ12;
+#pragma unroll
+      for (int a2 = 0; a2 < 3; ++a2) dm[a2] += dtx * V[4 * a2] + dty * V[4 * a2 + 1] + dtz * V[4 * a2 + 2];
+      // ---- projection path ----
+      float dndcx = g_px * 0.5f * (float)W, dndcy = g_py * 0.5f * (float)H;
+      float dhx = dndcx * e.winv, dhy = dndcy * e.winv;
+      float dhw = -(dndcx * e.hx + dndcy * e.hy) * e.winv * e.winv;
+#pragma unroll
+      for (int a2 = 0; a2 < 3; ++a2) dm[a2] += dhx * PM[4 * a2] + dhy * PM[4 * a2 + 1] + dhw * PM[4 * a2 + 3];
+      am[0] += dm[0]; am[1] += dm[1]; am[2] += dm[2];
+      ao += g_o;
+    } else if (live && !rgb_mode && v == 0) {
+      // invisible in the first view: per-coefficient outputs still have to start from zero
+      for (int k = 0; k < M * 3; ++k) {
+        if (gr.dL_dshs) gr.dL_dshs[(size_t)i * M * 3 + k] = 0.0f;
+        if (in.blend_color_b && gr.dL_dblend_color_b) gr.dL_dblend_color_b[(size_t)i * 48 + k] = 0.0f;
+        if (in.blend_color_w && wpg && gr.dL_dblend_color_w) gr.dL_dblend_color_w[(size_t)i * 48 + k] = 0.0f;
+      }
+    }
+    // SH mode, global (48,) color_w: every lane of the wave takes part in the DPP reduction
+    if (!rgb_mode && red_w) {
+      for (int k = 0; k < 16; ++k) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          float gw = 0.0f;
+          if (vis && k < nb) {
+            float gk = Bv[k] * ((cl & (1u << ch)) ? 0.0f : s9[6 + ch]);
+            float raw = in.shs[((size_t)i * M + k) * 3 + ch];
+            float wv = in.blend_color_w[k * 3 + ch];
+            gw = in.blend_color_b ? gk * 2.0f * raw * wv : gk * raw;
+          }
+          gh_block_acc(s_part, k * 3 + ch, gw);
+        }
+      }
+    }
+    if (red_x) { gh_block_acc(s_part, 48, dm[0]); gh_block_acc(s_part, 49, dm[1]); gh_block_acc(s_part, 50, dm[2]); }
+  }
+
+  if (live) {
+    if (gr.dL_dmeans3D) { gr.dL_dmeans3D[3 * i] = am[0]; gr.dL_dmeans3D[3 * i + 1] = am[1]; gr.dL_dmeans3D[3 * i + 2] = am[2]; }
+    if (gr.dL_dopacities) gr.dL_dopacities[i] = ao;
+    if (gr.dL_dblend_opacity_b && in.blend_opacity_b) gr.dL_dblend_opacity_b[i] = ao;
+    if (gr.dL_dscales) { gr.dL_dscales[3 * i] = as[0]; gr.dL_dscales[3 * i + 1] = as[1]; gr.dL_dscales[3 * i + 2] = as[2]; }
+    if (gr.dL_drotations) { gr.dL_drotations[4 * i] = aq[0]; gr.dL_drotations[4 * i + 1] = aq[1]; gr.dL_drotations[4 * i + 2] = aq[2]; gr.dL_drotations[4 * i + 3] = aq[3]; }
+  }
+  if (rgb_mode) {
+    // c' = ((c*w0 + w1) - 1) + b0  (renderer_one_shot.py:324,328): araw = sum over views of dL/dc'
+    const float* w = in.blend_color_w ? in.blend_color_w + (wpg ? (size_t)(live ? i : 0) * 48 : 0) : nullptr;
+    float c[3] = {0, 0, 0};
+    if (live) { c[0] = in.colors_precomp[3 * i]; c[1] = in.colors_precomp[3 * i + 1]; c[2] = in.colors_precomp[3 * i + 2]; }
+    if (live) {
+      if (gr.dL_dcolors) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) gr.dL_dcolors[3 * i + ch] = w ? araw[ch] * w[ch] : araw[ch];
+      }
+      if (in.blend_color_b && gr.dL_dblend_color_b) {
+        float* o = gr.dL_dblend_color_b + (size_t)i * 48;
+        o[0] = araw[0]; o[1] = araw[1]; o[2] = araw[2];
+        for (int k = 3; k < 48; ++k) o[k] = 0.0f;
+      }
+      if (w && wpg && gr.dL_dblend_color_w) {
+        float* o = gr.dL_dblend_color_w + (size_t)i * 48;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) { o[ch] = araw[ch] * c[ch]; o[3 + ch] = araw[ch]; }
+        for (int k = 6; k < 48; ++k) o[k] = 0.0f;
+      }
+    }
+    if (red_w) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        gh_block_acc(s_part, ch, live ? araw[ch] * c[ch] : 0.0f);
+        gh_block_acc(s_part, 3 + ch, live ? araw[ch] : 0.0f);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && (red_w || red_x))
+    scratch[(size_t)blockIdx.x * 64 + threadIdx.x] =
+        s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+}
+
+// Second stage of the blend-parameter reduction: fixed-order sum over the per-block partials.
+__global__ __launch_bounds__(64) void gh_blend_reduce_kernel(const float* __restrict__ scratch, int nblk,
+                                                             float* __restrict__ d_w, float* __restrict__ d_xyz) {
+  const int t = threadIdx.x;
+  float s = 0.0f;
+  for (int b = 0; b < nblk; ++b) s += scratch[(size_t)b * 64 + t];
+  if (d_w && t < 48) d_w[t] = s;
+  if (d_xyz && t >= 48 && t < 51) d_xyz[t - 48] = s;
+}
+
+void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
+                              const GhLayout& L, hipStream_t s) {
+  if (g.P == 0) return;
+  int nblk = (g.P + GH_BLOCK - 1) / GH_BLOCK;
+  hipLaunchKernelGGL(gh_preprocess_bwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
+                     d->sh_degree, d->M, d->scale_modifier, d->flags, (uint32_t)g.cap,
+                     (const uint32_t*)(ws + L.offsets), (const uint8_t*)(ws + L.clamped),
+                     (const float*)(ws + L.inst_grad), (float*)(ws + L.bwd_scratch));
+  const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
+  float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;
+  float* dx = in->blend_xyz_b ? gr->dL_dblend_xyz_b : nullptr;
+  if (dw || dx)
+    hipLaunchKernelGGL(gh_blend_reduce_kernel, dim3(1), dim3(64), 0, s, (const float*)(ws + L.bwd_scratch), nblk, dw, dx);
+}

@@ -1,0 +1,299 @@
+"""Drop-in replacement for `diff_gaussian_rasterization` as used by the reference.
+
+Mirrors the call protocol of tgs/models/renderer_one_shot.py:281-296, :338-346, :355-379:
+
+    raster_settings = GaussianRasterizationSettings(image_height=..., image_width=..., tanfovx=..., tanfovy=...,
+        bg=..., scale_modifier=..., viewmatrix=..., projmatrix=..., sh_degree=..., campos=...,
+        prefiltered=False, debug=False)
+    rendered_image, radii = GaussianRasterizer(raster_settings=raster_settings)(
+        means3D=..., means2D=..., shs=..., colors_precomp=..., opacities=..., scales=..., rotations=...,
+        cov3D_precomp=None)
+
+plus `rasterize_views`, the view-batched entry with the attribute blend of :298-334 fused into the
+kernels. All compute goes through the C-ABI of include/gh_raster.h (hand-written HIP for gfx950);
+there is no PyTorch/CPU fallback — a missing library or a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, NamedTuple, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _abi, _lib
+from .camera import pack_camera
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GhOverflowError(RuntimeError):
+    """The tile-instance capacity (max_instances) was too small for a sync-free call."""
+
+
+# ---------------------------------------------------------------------------------------------------
+# capacity policy for the data-dependent instance count D
+_capacity: Dict[Tuple[int, int, int, int], int] = {}
+_pending = []  # (event, pinned counters, capacity, key) of sync-free calls not yet checked
+
+
+def _initial_capacity(P: int, NV: int) -> int:
+    return max(1 << 16, 8 * P * NV)
+
+
+def check_overflow(block: bool = True) -> None:
+    """Verify every outstanding sync-free forward fitted its capacity (raises GhOverflowError)."""
+    global _pending
+    keep = []
+    for ev, host, cap, key in _pending:
+        if not block and not ev.query():
+            keep.append((ev, host, cap, key))
+            continue
+        ev.synchronize()
+        d = int(host[0].item()) & 0xFFFFFFFF
+        if d > cap:
+            _capacity[key] = max(_capacity.get(key, 0), int(d * 1.5) + 1024)
+            _pending = keep
+            raise GhOverflowError(f"tile instances D={d} exceeded max_instances={cap}; capacity raised, re-run the step")
+    _pending = keep
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.device != dev:
+        raise ValueError(f"tensor on {t.device}, expected {dev}")
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _Ctx:
+    __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "stream")
+
+
+def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None, colors_precomp=None,
+                   sh_degree: int = 0, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
+                   color_b=None, max_instances: Optional[int] = None, sync: bool = True):
+    """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx)."""
+    L = _lib.lib()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise RuntimeError("guassianhand_amd rasteriser needs tensors on a ROCm device (no CPU fallback)")
+    if (shs is None) == (colors_precomp is None):
+        raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+    t = dict(cams=_prep(cams, dev).reshape(-1, _abi.GH_CAM_FLOATS), means3D=_prep(means3D, dev),
+             opacities=_prep(opacities, dev).reshape(-1), scales=_prep(scales, dev), rotations=_prep(rotations, dev),
+             shs=_prep(shs, dev), colors_precomp=_prep(colors_precomp, dev), xyz_b=_prep(xyz_b, dev),
+             opacity_b=None if opacity_b is None else _prep(opacity_b, dev).reshape(-1),
+             color_w=_prep(color_w, dev), color_b=_prep(color_b, dev))
+    P, NV = t["means3D"].shape[0], t["cams"].shape[0]
+    M = 0 if shs is None else t["shs"].shape[1]
+    flags = 0
+    wpg = False
+    if t["color_w"] is not None:
+        if t["color_w"].numel() == 48:
+            pass
+        elif t["color_w"].numel() == P * 48:
+            flags |= _abi.GH_FLAG_BLEND_W_PER_GAUSSIAN
+            wpg = True
+        else:
+            raise ValueError("color_w must have 48 or P*48 elements")
+    key = (P, NV, H, W)
+    while True:
+        cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))
+        dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
+        nbytes = L.gh_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError("gh_workspace_bytes rejected the dimensions")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(NV, P, dtype=torch.int32, device=dev)
+        inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
+                            _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
+                            _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
+        out = _abi.GhOutputs(_ptr(image), _ptr(radii))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            rc = L.gh_forward(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes,
+                              C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(f"gh_forward failed: {_abi.status_name(rc)}")
+        counters = ws[:16].view(torch.int32)
+        if sync:
+            d = int(counters[0].item()) & 0xFFFFFFFF      # the one host read-back, as in the reference wrapper
+            if d > cap:
+                if max_instances is not None:
+                    raise GhOverflowError(f"tile instances D={d} exceed max_instances={cap}")
+                _capacity[key] = int(d * 1.5) + 1024
+                continue
+            if max_instances is None and key not in _capacity:
+                _capacity[key] = max(int(d * 1.5) + 1024, 1 << 16)
+        else:
+            host = torch.empty(4, dtype=torch.int32, pin_memory=True)
+            host.copy_(counters, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _pending.append((ev, host, cap, key))
+            if len(_pending) > 64:
+                check_overflow(block=False)
+        break
+    ctx = _Ctx()
+    ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
+    return image, radii, ctx
+
+
+def raster_backward(ctx: _Ctx, dL_dimage: torch.Tensor, want_means2D: bool = True) -> Dict[str, torch.Tensor]:
+    L = _lib.lib()
+    t = ctx.tensors
+    dev = t["means3D"].device
+    P, NV, M = ctx.P, ctx.NV, ctx.M
+    g = dL_dimage.detach().to(torch.float32).reshape(NV, 3, ctx.H, ctx.W).contiguous()
+    mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    o = dict(means3D=mk(P, 3), means2D=mk(NV, P, 3) if want_means2D else None, opacities=mk(P), scales=mk(P, 3),
+             rotations=mk(P, 4), shs=mk(P, M, 3) if M else None,
+             colors_precomp=mk(P, 3) if t["colors_precomp"] is not None else None,
+             xyz_b=mk(3) if t["xyz_b"] is not None else None,
+             opacity_b=mk(P) if t["opacity_b"] is not None else None,
+             color_w=(mk(P, 48) if ctx.wpg else mk(48)) if t["color_w"] is not None else None,
+             color_b=mk(P, 48) if t["color_b"] is not None else None)
+    gr = _abi.GhGrads(_ptr(g), _ptr(o["means3D"]), _ptr(o["means2D"]), _ptr(o["opacities"]), _ptr(o["scales"]),
+                      _ptr(o["rotations"]), _ptr(o["shs"]), _ptr(o["colors_precomp"]), _ptr(o["xyz_b"]),
+                      _ptr(o["opacity_b"]), _ptr(o["color_w"]), _ptr(o["color_b"]))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        rc = L.gh_backward(C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.ws.data_ptr()),
+                           ctx.ws.numel(), C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"gh_backward failed: {_abi.status_name(rc)}")
+    return {k: v for k, v in o.items() if v is not None}
+
+
+def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
+    """Typed views of the internal stage arrays (for tests / profiling), via gh_workspace_layout."""
+    L = _lib.lib()
+    lay = _abi.GhLayout()
+    L.gh_workspace_layout(C.byref(ctx.dims), C.byref(lay))
+    ws, N, cap = ctx.ws, ctx.NV * ctx.P, int(ctx.dims.max_instances)
+    gx, gy = (ctx.W + 15) // 16, (ctx.H + 15) // 16
+    pix = ctx.NV * ctx.H * ctx.W
+
+    def v(off, nbytes, dtype, *shape):
+        return ws[off:off + nbytes].view(dtype).reshape(*shape)
+
+    return dict(counters=v(lay.counters, 16, torch.int32, 4), g0=v(lay.geom_g0, N * 16, torch.float32, N, 4),
+                g1=v(lay.geom_g1, N * 16, torch.float32, N, 4), gb=v(lay.geom_b, N * 4, torch.float32, N),
+                depth=v(lay.depth, N * 4, torch.float32, N), rect=v(lay.rect, N * 4, torch.int32, N),
+                offsets=v(lay.offsets, N * 4, torch.int32, N),
+                sorted_keys=v(lay.keys_a, cap * 8, torch.int64, cap), sorted_slot=v(lay.vals_a, cap * 4, torch.int32, cap),
+                sorted_gid=v(lay.sorted_gid, cap * 4, torch.int32, cap),
+                ranges=v(lay.ranges, ctx.NV * gx * gy * 8, torch.int32, ctx.NV * gx * gy, 2),
+                final_T=v(lay.final_T, pix * 4, torch.float32, ctx.NV, ctx.H, ctx.W),
+                n_contrib=v(lay.n_contrib, pix * 4, torch.int32, ctx.NV, ctx.H, ctx.W))
+
+
+# ---------------------------------------------------------------------------------------------------
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, raster_settings, sync):
+        rs = raster_settings
+        cams = pack_camera(rs.viewmatrix, rs.projmatrix, rs.campos, rs.tanfovx, rs.tanfovy, rs.bg)
+        image, radii, rctx = raster_forward(
+            cams, means3D, opacities, scales, rotations, H=int(rs.image_height), W=int(rs.image_width),
+            shs=sh, colors_precomp=colors_precomp, sh_degree=int(rs.sh_degree),
+            scale_modifier=float(rs.scale_modifier), sync=sync)
+        ctx.rctx = rctx
+        ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape,
+                      None if colors_precomp is None else colors_precomp.shape, opacities.shape, scales.shape,
+                      rotations.shape)
+        ctx.mark_non_differentiable(radii)
+        return image[0], radii[0]
+
+    @staticmethod
+    def backward(ctx, grad_image, _grad_radii):
+        g = raster_backward(ctx.rctx, grad_image)
+        ctx.rctx = None
+        s = ctx.shapes
+        return (g["means3D"].reshape(s[0]), g["means2D"][0].reshape(s[1]),
+                g["shs"].reshape(s[2]) if s[2] is not None else None,
+                g["colors_precomp"].reshape(s[3]) if s[3] is not None else None,
+                g["opacities"].reshape(s[4]), g["scales"].reshape(s[5]), g["rotations"].reshape(s[6]), None, None)
+
+
+class GaussianRasterizer(nn.Module):
+    """Same constructor / call keywords / 2-tuple return as the module the reference imports at
+    tgs/models/renderer_one_shot.py:3 and calls at :338-346 and :372-379."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings, sync: bool = True):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self.sync = sync
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if cov3D_precomp is not None:
+            raise NotImplementedError("cov3D_precomp is never passed by the reference "
+                                      "(renderer_one_shot.py:313, :346) and is not supported")
+        with torch.autocast(device_type=means3D.device.type, enabled=False):
+            return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                             self.raster_settings, self.sync)
+
+
+# ---------------------------------------------------------------------------------------------------
+class _RasterizeViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, xyz, opacity, scaling,
+                rotation, shs, xyz_b, opacity_b, color_w, color_b):
+        kw = dict(colors_precomp=shs.reshape(shs.shape[0], 3)) if use_rgb else dict(shs=shs)
+        image, radii, rctx = raster_forward(cams, xyz, opacity, scaling, rotation, H=H, W=W, sh_degree=sh_degree,
+                                            scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b,
+                                            color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances, **kw)
+        ctx.rctx = rctx
+        ctx.use_rgb = use_rgb
+        ctx.shapes = [None if t is None else t.shape for t in (xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b)]
+        ctx.mark_non_differentiable(radii)
+        return image, radii
+
+    @staticmethod
+    def backward(ctx, grad_image, _gr):
+        g = raster_backward(ctx.rctx, grad_image, want_means2D=False)
+        ctx.rctx = None
+        s = ctx.shapes
+        col = g["colors_precomp"] if ctx.use_rgb else g["shs"]
+        opt = lambda k, i: g[k].reshape(s[i]) if (s[i] is not None and k in g) else None
+        return (None,) * 8 + (g["means3D"].reshape(s[0]), g["opacities"].reshape(s[1]), g["scales"].reshape(s[2]),
+                              g["rotations"].reshape(s[3]), col.reshape(s[4]), opt("xyz_b", 5), opt("opacity_b", 6),
+                              opt("color_w", 7), opt("color_b", 8))
+
+
+def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *, H: int, W: int, use_rgb: bool,
+                    sh_degree: int = 3, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
+                    color_b=None, sync: bool = True, max_instances: Optional[int] = None):
+    """View-batched render with the attribute blend of renderer_one_shot.py:298-334 fused into the kernels.
+
+    cams: (Nv, GH_CAM_FLOATS) from camera.pack_cameras_from_w2c; returns (images (Nv,3,H,W), radii (Nv,P)).
+    Differentiable w.r.t. xyz, opacity, scaling, rotation, shs and the blend parameters.
+    """
+    return _RasterizeViews.apply(cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier),
+                                 bool(use_rgb), bool(sync), max_instances, xyz, opacity, scaling, rotation, shs, xyz_b,
+                                 opacity_b, color_w, color_b)
