@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py — forward+backward renders/s of the Gaussian-splatting hot path on MI355X.
+
+Metric (BASELINE.json): fwd+bwd renders/sec @512x334, ~100k Gaussians, with the dominant kernel priced
+against the HBM roofline. One *render* = one image forward + its backward under L = mean|img - gt|
+(SURVEY.md §8d). One *step* = one pass of the hot path over one batch: `--views-per-step` cameras of the
+ring (the 8 novel views of the one-shot fit loop, BASELINE configs[3]) rendered in one view-batched launch
+sequence per rank, gradients w.r.t. all Gaussian attributes and the blend parameters, and (N>1) one RCCL
+all-reduce of the fused gradient block. Workload = BASELINE configs[2]: two interacting hands,
+P = 98,562 Gaussians, interaction-aware attribute blend on, RGB colours, 512x334.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line. Inputs are resident in HBM before the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def algorithmic_bytes(P, NV, H, W, D, C=12, M=0):
+    """SURVEY.md §8(d) per-stage algorithmic HBM bytes for one launch sequence over NV views, D instances."""
+    T = NV * ((W + 15) // 16) * ((H + 15) // 16)
+    tb = 1
+    while (1 << tb) < T:
+        tb += 1
+    n_pass = 4 + (tb + 7) // 8
+    N = P * NV
+    return {
+        "preprocess_fwd": N * (44 + C) + N * 48,
+        "binning": N * 8 + N * 20 + D * 12 + D * 24 * n_pass + D * 8 + T * 8,
+        "render_fwd": D * 40 + T * 8 + NV * H * W * 20,
+        "render_bwd": NV * H * W * 20 + T * 8 + D * 40 + D * 36,
+        "preprocess_bwd": N * (36 + 44 + C + 4) + N * (56 + C),
+    }
+
+
+def cpu_baseline(scene, seconds: float):
+    """The C oracle (oracle/gh_oracle.c, OpenMP over tiles) on the host cores: a reported baseline only."""
+    from oracle import oracle_c
+    s = scene
+    cams = s.cams()[:1]
+    kw = dict(colors_precomp=s.shs.squeeze(1)) if s.use_rgb else dict(shs=s.shs, sh_degree=s.sh_degree)
+    g = torch.Generator().manual_seed(11)
+    dimg = torch.randn(1, 3, s.H, s.W, generator=g) / (3 * s.H * s.W)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        r = oracle_c.OracleRender(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, xyz_b=s.xyz_b,
+                                  opacity_b=s.opacity_b, color_w=s.color_w, color_b=s.color_b, **kw)
+        r.backward(dimg)
+        r.close()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 3:
+            break
+    return {"value": n / dt, "unit": "renders/s", "cores": oracle_c.num_threads(), "kind": "port",
+            "sample": f"{n} fwd+bwd renders of view 0 of the same workload ({dt:.1f} s), oracle/gh_oracle.c OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--views-per-step", type=int, default=8)
+    ap.add_argument("--config", default="two_hands")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    args = ap.parse_args()
+
+    from guassianhand_amd import dist as ghdist
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.scenes import make_scene, perturbed_target_xyz
+    import torch.distributed as tdist
+
+    rank, local, world = ghdist.init_from_env()
+    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (there is no CPU fallback)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    V = args.views_per_step
+    scene_cpu = make_scene(args.config, n_views=V * world)
+    mine = [rank * V + i for i in range(V)]          # weak scaling: V views per rank
+    s = scene_cpu.to(dev)
+    cams = s.cams()[mine].contiguous()
+    H, W, P = s.H, s.W, s.P
+
+    # ground truth = render of a perturbed copy (positions + N(0, 1 mm)), forward only
+    gt_xyz = perturbed_target_xyz(scene_cpu).to(dev)
+    blend = dict(xyz_b=s.xyz_b, opacity_b=s.opacity_b, color_w=s.color_w, color_b=s.color_b)
+    with torch.no_grad():
+        gt, _ = R.rasterize_views(cams, gt_xyz, s.opacity, s.scaling, s.rotation, s.shs, H=H, W=W, use_rgb=s.use_rgb,
+                                  sh_degree=s.sh_degree, sync=True, **blend)
+    gt = gt.detach()
+
+    names = ["xyz", "opacity", "scaling", "rotation", "shs"] + [k for k, v in blend.items() if v is not None]
+    params = {"xyz": s.xyz, "opacity": s.opacity, "scaling": s.scaling, "rotation": s.rotation, "shs": s.shs}
+    params.update({k: v for k, v in blend.items() if v is not None})
+    params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+
+    def step(sync: bool):
+        for p in params.values():
+            p.grad = None
+        img, _ = R.rasterize_views(cams, params["xyz"], params["opacity"], params["scaling"], params["rotation"],
+                                   params["shs"], H=H, W=W, use_rgb=s.use_rgb, sh_degree=s.sh_degree, sync=sync,
+                                   xyz_b=params.get("xyz_b"), opacity_b=params.get("opacity_b"),
+                                   color_w=params.get("color_w"), color_b=params.get("color_b"))
+        loss = (img - gt).abs().mean()
+        loss.backward()
+        if world > 1:
+            grads = {k: params[k].grad for k in names}
+            loss, grads = ghdist.allreduce_grads(grads, loss.detach(), names)
+        return loss
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: the first step reads D back once to size the instance capacity, the rest are sync-free
+    step(sync=True)
+    for _ in range(max(0, args.warmup - 1)):
+        step(sync=False)
+    R.check_overflow()
+    if not args.no_stage_timing:
+        R.enable_stage_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(sync=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    R.check_overflow()
+    stage_ms = R.stage_timing_summary() if not args.no_stage_timing else {}
+    R.enable_stage_timing(False)
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    renders = args.steps * V * world
+    value = renders / dt
+
+    if rank == 0:
+        D = R.last_num_rendered()
+        ab = algorithmic_bytes(P, V, H, W, D, C=12 if s.use_rgb else 192)
+        roofline = None
+        stages = {}
+        if stage_ms:
+            for k, ms in stage_ms.items():
+                stages[k] = {"ms": ms, "alg_GBs": ab[k] / (ms * 1e-3) / 1e9 if ms > 0 else None}
+            single = {k: v for k, v in stage_ms.items() if k != "binning"}   # binning is a multi-kernel stage
+            dom = max(single, key=single.get)
+            ach = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "gh_" + dom + "_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "alg_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom]}
+        out = {
+            "metric": "fwd+bwd renders/sec @512x334, ~100k Gaussians", "value": value, "unit": "renders/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: P={P} Gaussians, {H}x{W}, RGB colours, attribute blend "
+                                   f"{'on' if s.color_w is not None else 'off'} (BASELINE configs[2])",
+                       "views_per_step_per_gpu": V, "instances_per_step_per_gpu": D, "parallelism": f"view-parallel x{world}",
+                       "loss": "mean|img-gt|", "final_loss": float(loss)},
+            "roofline": roofline, "stages": stages,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

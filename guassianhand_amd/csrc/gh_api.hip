@@ -71,6 +71,11 @@ static int check_inputs(const GhDims* d, const GhInputs* in) {
 
 extern "C" int gh_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, void* workspace,
                           size_t ws_bytes, void* hip_stream) {
+  return gh_forward_stages(d, in, out, workspace, ws_bytes, hip_stream, GH_FWD_ALL);
+}
+
+extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOutputs* out, void* workspace,
+                                 size_t ws_bytes, void* hip_stream, uint32_t stages) {
   int rc = check_dims(d);
   if (rc != GH_OK) return rc;
   rc = check_inputs(d, in);
@@ -83,16 +88,25 @@ extern "C" int gh_forward(const GhDims* d, const GhInputs* in, const GhOutputs* 
   char* ws = (char*)workspace;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
-  if (hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s) != hipSuccess) return GH_ERR_LAUNCH;
-  if (hipMemsetAsync(ws + L.ranges, 0, (size_t)g.NV * g.tiles * 8, s) != hipSuccess) return GH_ERR_LAUNCH;
-  gh_launch_preprocess_fwd(d, g, in, out->radii, ws, L, s);
-  gh_launch_binning(d, g, ws, L, s);
-  gh_launch_render_fwd(d, g, in, out->image, ws, L, s);
+  if (stages & GH_FWD_PREPROCESS) {
+    if (hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s) != hipSuccess) return GH_ERR_LAUNCH;
+    gh_launch_preprocess_fwd(d, g, in, out->radii, ws, L, s);
+  }
+  if (stages & GH_FWD_BINNING) {
+    if (hipMemsetAsync(ws + L.ranges, 0, (size_t)g.NV * g.tiles * 8, s) != hipSuccess) return GH_ERR_LAUNCH;
+    gh_launch_binning(d, g, ws, L, s);
+  }
+  if (stages & GH_FWD_RENDER) gh_launch_render_fwd(d, g, in, out->image, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 
 extern "C" int gh_backward(const GhDims* d, const GhInputs* in, const GhGrads* gr, void* workspace,
                            size_t ws_bytes, void* hip_stream) {
+  return gh_backward_stages(d, in, gr, workspace, ws_bytes, hip_stream, GH_BWD_ALL);
+}
+
+extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhGrads* gr, void* workspace,
+                                  size_t ws_bytes, void* hip_stream, uint32_t stages) {
   int rc = check_dims(d);
   if (rc != GH_OK) return rc;
   rc = check_inputs(d, in);
@@ -105,7 +119,7 @@ extern "C" int gh_backward(const GhDims* d, const GhInputs* in, const GhGrads* g
   char* ws = (char*)workspace;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
-  gh_launch_render_bwd(d, g, in, gr->dL_dimage, ws, L, s);
-  gh_launch_preprocess_bwd(d, g, in, gr, ws, L, s);
+  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, ws, L, s);
+  if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -50,13 +50,54 @@ _capacity: Dict[Tuple[int, int, int, int], int] = {}
 _pending = []  # (event, pinned counters, capacity, key) of sync-free calls not yet checked
 
 
+_last_D = 0
+_stage_timing = False
+_stage_events = []   # (stage name, start event, end event)
+
+
+def last_num_rendered() -> int:
+    """Tile instances D of the most recent forward whose counters have been read back."""
+    return _last_D
+
+
+def enable_stage_timing(on: bool) -> None:
+    """Bracket every pipeline stage with HIP events on the launch stream (bench.py's roofline leg)."""
+    global _stage_timing
+    _stage_timing = bool(on)
+    if on:
+        _stage_events.clear()
+
+
+def stage_timing_summary() -> Dict[str, float]:
+    """Average milliseconds per launch of each stage since enable_stage_timing(True)."""
+    torch.cuda.synchronize()
+    acc: Dict[str, list] = {}
+    for name, e0, e1 in _stage_events:
+        acc.setdefault(name, []).append(e0.elapsed_time(e1))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def _run_stages(fn, args, stages):
+    """Call a *_stages entry point once per stage with events in between (same stream, same order)."""
+    rc = 0
+    for name, bit in stages:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args, C.c_uint32(bit))
+        e1.record()
+        _stage_events.append((name, e0, e1))
+        if rc != 0:
+            break
+    return rc
+
+
 def _initial_capacity(P: int, NV: int) -> int:
     return max(1 << 16, 8 * P * NV)
 
 
 def check_overflow(block: bool = True) -> None:
     """Verify every outstanding sync-free forward fitted its capacity (raises GhOverflowError)."""
-    global _pending
+    global _pending, _last_D
     keep = []
     for ev, host, cap, key in _pending:
         if not block and not ev.query():
@@ -64,6 +105,7 @@ def check_overflow(block: bool = True) -> None:
             continue
         ev.synchronize()
         d = int(host[0].item()) & 0xFFFFFFFF
+        _last_D = d
         if d > cap:
             _capacity[key] = max(_capacity.get(key, 0), int(d * 1.5) + 1024)
             _pending = keep
@@ -91,6 +133,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                    sh_degree: int = 0, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
                    color_b=None, max_instances: Optional[int] = None, sync: bool = True):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx)."""
+    global _last_D
     L = _lib.lib()
     dev = means3D.device
     if dev.type != "cuda":
@@ -130,13 +173,19 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         out = _abi.GhOutputs(_ptr(image), _ptr(radii))
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            rc = L.gh_forward(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes,
-                              C.c_void_p(stream))
+            fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
+            if _stage_timing:
+                rc = _run_stages(L.gh_forward_stages, fargs, (("preprocess_fwd", _abi.GH_FWD_PREPROCESS),
+                                                               ("binning", _abi.GH_FWD_BINNING),
+                                                               ("render_fwd", _abi.GH_FWD_RENDER)))
+            else:
+                rc = L.gh_forward(*fargs)
         if rc != 0:
             raise RuntimeError(f"gh_forward failed: {_abi.status_name(rc)}")
         counters = ws[:16].view(torch.int32)
         if sync:
             d = int(counters[0].item()) & 0xFFFFFFFF      # the one host read-back, as in the reference wrapper
+            _last_D = d
             if d > cap:
                 if max_instances is not None:
                     raise GhOverflowError(f"tile instances D={d} exceed max_instances={cap}")
@@ -177,8 +226,13 @@ def raster_backward(ctx: _Ctx, dL_dimage: torch.Tensor, want_means2D: bool = Tru
                       _ptr(o["opacity_b"]), _ptr(o["color_w"]), _ptr(o["color_b"]))
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev):
-        rc = L.gh_backward(C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.ws.data_ptr()),
-                           ctx.ws.numel(), C.c_void_p(stream))
+        bargs = (C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(),
+                 C.c_void_p(stream))
+        if _stage_timing:
+            rc = _run_stages(L.gh_backward_stages, bargs, (("render_bwd", _abi.GH_BWD_RENDER),
+                                                            ("preprocess_bwd", _abi.GH_BWD_PREPROCESS)))
+        else:
+            rc = L.gh_backward(*bargs)
     if rc != 0:
         raise RuntimeError(f"gh_backward failed: {_abi.status_name(rc)}")
     return {k: v for k, v in o.items() if v is not None}

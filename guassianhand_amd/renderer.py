@@ -1,0 +1,142 @@
+"""Host-side mirror of the reference's per-view render path (tgs/models/renderer_one_shot.py).
+
+Same names, argument meaning and outputs as the reference for the part of `GS3DRenderer` that sits on
+the hot path: `GaussianModel` (:114-119), the GSLayer activations (:191-214), `forward_single_view`
+(:259-382: settings, attribute blend, RGB pass + mask pass) and the per-view loop of
+`forward_single_batch` (:494-510). The feature networks above it (attention, MLPs, UV lookups) are out
+of scope and stay in the reference.
+
+Two execution forms, identical results:
+  * `forward_single_view(...)`  — the reference's protocol: blend in torch, two `GaussianRasterizer` calls.
+  * `render_views(...)`         — MI355X form: all views in one launch sequence, blend fused into the kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, NamedTuple, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .camera import Camera, pack_cameras_from_w2c
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
+
+
+class GaussianModel(NamedTuple):
+    """renderer_one_shot.py:114-119."""
+    xyz: torch.Tensor
+    opacity: torch.Tensor
+    rotation: torch.Tensor
+    scaling: torch.Tensor
+    shs: torch.Tensor
+
+
+class _TruncExp(torch.autograd.Function):
+    """tgs/utils/ops.py:37-53: forward exp(x), backward g * exp(clamp(x, max=15))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float()
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(torch.clamp(x, max=15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+def gs_activations(raw: Dict[str, torch.Tensor], pts: torch.Tensor, *, use_rgb: bool = True, xyz_offset: bool = True,
+                   restrict_offset: bool = True, clip_scaling: Optional[float] = None) -> GaussianModel:
+    """The activations of GSLayer.forward (renderer_one_shot.py:191-214) applied to the raw head outputs
+    raw = {xyz, scaling, rotation, opacity, shs}; the linear heads themselves are dense GEMMs and stay in torch."""
+    v = raw["xyz"]
+    if restrict_offset:
+        v = (torch.sigmoid(v) - 0.5) * (1.2 / 32)
+    xyz = v + pts if xyz_offset else pts
+    scaling = trunc_exp(raw["scaling"])
+    if clip_scaling is not None:
+        scaling = torch.clamp(scaling, min=0, max=clip_scaling)
+    shs = raw["shs"]
+    if use_rgb:
+        shs = torch.sigmoid(shs)
+    shs = torch.reshape(shs, (shs.shape[0], -1, 3))
+    return GaussianModel(xyz=xyz, opacity=torch.sigmoid(raw["opacity"]), rotation=F.normalize(raw["rotation"]),
+                         scaling=scaling, shs=shs)
+
+
+def forward_single_view(gs: GaussianModel, viewpoint_camera: Camera, background_color: torch.Tensor, ret_mask: bool = True,
+                        color_w=None, xyz_b=None, color_b=None, opacity_b=None, *, use_rgb: bool = True,
+                        sh_degree: int = 3, scaling_modifier: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Line-for-line protocol of GS3DRenderer.forward_single_view (renderer_one_shot.py:259-382)."""
+    device = gs.xyz.device
+    screenspace_points = torch.zeros_like(gs.xyz, dtype=gs.xyz.dtype, requires_grad=True, device=device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    mk = lambda bg, deg: GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.height), image_width=int(viewpoint_camera.width), tanfovx=tanfovx,
+        tanfovy=tanfovy, bg=bg, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform.float(), sh_degree=deg, campos=viewpoint_camera.camera_center,
+        prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=mk(background_color, sh_degree))
+    means3D = gs.xyz
+    if xyz_b is not None:
+        means3D = means3D + xyz_b
+    opacity = gs.opacity
+    if opacity_b is not None:
+        opacity = opacity + opacity_b.view(-1, 1)
+    shs, colors_precomp = None, None
+    if use_rgb:
+        colors_precomp = gs.shs.squeeze(1)
+        if color_w is not None:
+            colors_precomp = colors_precomp * color_w.view(-1, 16, 3)[:, 0, :] + color_w.view(-1, 16, 3)[:, 1, :] - 1
+        if color_b is not None:
+            colors_precomp = colors_precomp + color_b.view(-1, 16, 3)[:, 0, :]
+    else:
+        shs = gs.shs
+        if color_w is not None:
+            shs = shs * color_w.view(-1, 16, 3)
+        if color_b is not None:
+            shs = shs * color_w.view(-1, 16, 3) + color_b.view(-1, 16, 3)
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs,
+                                       colors_precomp=colors_precomp, opacities=opacity, scales=gs.scaling,
+                                       rotations=gs.rotation, cov3D_precomp=None)
+    ret = {"comp_rgb": rendered_image.permute(1, 2, 0), "comp_rgb_bg": background_color}
+    if ret_mask:
+        mask_bg = torch.zeros(3, dtype=torch.float32, device=device)
+        rasterizer = GaussianRasterizer(raster_settings=mk(mask_bg, 0))
+        rendered_mask, radii = rasterizer(means3D=means3D, means2D=screenspace_points,
+                                          colors_precomp=torch.ones_like(means3D), opacities=opacity,
+                                          scales=gs.scaling, rotations=gs.rotation, cov3D_precomp=None)
+        ret["comp_mask"] = rendered_mask.permute(1, 2, 0)
+    return ret
+
+
+def render_views(gs: GaussianModel, w2cs: torch.Tensor, intrinsics: torch.Tensor, height: int, width: int,
+                 background_color: torch.Tensor, ret_mask: bool = True, color_w=None, xyz_b=None, color_b=None,
+                 opacity_b=None, *, use_rgb: bool = True, sh_degree: int = 3, scaling_modifier: float = 1.0,
+                 sync: bool = True) -> Dict[str, torch.Tensor]:
+    """The view loop of forward_single_batch (renderer_one_shot.py:494-510) as ONE batched launch sequence
+    per pass, with the attribute blend fused into the projection kernel. Returns stacked (Nv,H,W,3) maps
+    like the reference's `torch.stack(v, dim=0)`."""
+    cams = pack_cameras_from_w2c(w2cs, intrinsics, height, width, background_color)
+    img, _ = rasterize_views(cams, gs.xyz, gs.opacity, gs.scaling, gs.rotation, gs.shs, H=height, W=width,
+                             use_rgb=use_rgb, sh_degree=sh_degree, scale_modifier=scaling_modifier, xyz_b=xyz_b,
+                             opacity_b=opacity_b, color_w=color_w, color_b=color_b, sync=sync)
+    out = {"comp_rgb": img.permute(0, 2, 3, 1), "comp_rgb_bg": background_color}
+    if ret_mask:
+        mcams = pack_cameras_from_w2c(w2cs, intrinsics, height, width, torch.zeros(3, device=gs.xyz.device))
+        ones = torch.ones(gs.xyz.shape[0], 1, 3, device=gs.xyz.device)
+        mask, _ = rasterize_views(mcams, gs.xyz, gs.opacity, gs.scaling, gs.rotation, ones, H=height, W=width,
+                                  use_rgb=True, sh_degree=0, scale_modifier=scaling_modifier, xyz_b=xyz_b,
+                                  opacity_b=opacity_b, sync=sync)
+        out["comp_mask"] = mask.permute(0, 2, 3, 1)
+    out["3dgs"] = gs
+    return out

@@ -141,7 +141,7 @@ def ring_cameras(center: torch.Tensor, n_views: int, H: int, W: int, f: float, r
     """8 novel views on a ring: elevations {0,20} deg x azimuths {0,90,180,270} deg."""
     w2cs, Ks = [], []
     for v in range(n_views):
-        az = math.radians(90.0 * (v % 4))
+        az = math.radians(90.0 * (v % 4) + 11.25 * (v // 8))   # views beyond the 8 of §8d: same ring, rotated
         el = math.radians(20.0 * ((v // 4) % 2))
         eye = center + radius * torch.tensor([math.sin(az) * math.cos(el), -math.sin(el), -math.cos(az) * math.cos(el)])
         w2cs.append(look_at_w2c(eye.tolist(), center.tolist()))

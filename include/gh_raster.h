@@ -168,6 +168,24 @@ int gh_forward(const GhDims* dims, const GhInputs* in, const GhOutputs* out,
 int gh_backward(const GhDims* dims, const GhInputs* in, const GhGrads* grads,
                 void* workspace, size_t ws_bytes, void* hip_stream);
 
+/*
+ * Stage-selective variants (same contracts as above). They let a caller time, overlap or re-run single
+ * stages; gh_forward == gh_forward_stages(GH_FWD_ALL), gh_backward == gh_backward_stages(GH_BWD_ALL).
+ * Stages must be run in order on one stream for a given workspace.
+ */
+#define GH_FWD_PREPROCESS 1u /* blend + projection + conic + tile rect (per Gaussian)          */
+#define GH_FWD_BINNING    2u /* scan + emit + radix sort + ranges                               */
+#define GH_FWD_RENDER     4u /* per-tile compositing                                            */
+#define GH_FWD_ALL        7u
+#define GH_BWD_RENDER     1u /* per-pixel reverse walk -> per-instance records                  */
+#define GH_BWD_PREPROCESS 2u /* per-Gaussian record sum + chain rule + blend-parameter gradients */
+#define GH_BWD_ALL        3u
+
+int gh_forward_stages(const GhDims* dims, const GhInputs* in, const GhOutputs* out,
+                      void* workspace, size_t ws_bytes, void* hip_stream, uint32_t stages);
+int gh_backward_stages(const GhDims* dims, const GhInputs* in, const GhGrads* grads,
+                       void* workspace, size_t ws_bytes, void* hip_stream, uint32_t stages);
+
 #ifdef __cplusplus
 }
 #endif

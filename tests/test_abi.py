@@ -1,0 +1,108 @@
+"""C-ABI surface: the library loads and exports every symbol include/gh_raster.h declares; layout and
+argument validation behave as the header says. No GPU compute is launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from guassianhand_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "gh_raster.h")).read()
+    return sorted(set(re.findall(r"^\s*(?:int|size_t)\s+(gh_\w+)\s*\(", txt, flags=re.M)))
+
+
+def test_header_declares_expected_symbols():
+    assert header_symbols() == sorted(_abi.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(gh_lib_path):
+    L = C.CDLL(gh_lib_path)
+    for sym in header_symbols():
+        assert hasattr(L, sym), sym
+    _abi.declare(L)
+    assert L.gh_version() == (0 << 16) | 1
+
+
+def test_struct_sizes_match_header():
+    # GhDims: 6 int32 + float + uint32 + int64
+    assert C.sizeof(_abi.GhDims) == 40
+    assert C.sizeof(_abi.GhInputs) == 11 * 8
+    assert C.sizeof(_abi.GhGrads) == 12 * 8
+    assert C.sizeof(_abi.GhCounters) == 16
+    assert C.sizeof(_abi.GhLayout) == len(_abi.LAYOUT_FIELDS) * 8
+
+
+def test_workspace_layout(gh_lib_path):
+    L = C.CDLL(gh_lib_path)
+    _abi.declare(L)
+    d = _abi.GhDims(98562, 8, 512, 334, 0, 0, 1.0, 0, 5_000_000)
+    lay = _abi.GhLayout()
+    assert L.gh_workspace_layout(C.byref(d), C.byref(lay)) == 0
+    offs = [getattr(lay, f) for f in _abi.LAYOUT_FIELDS[1:]]
+    assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
+    assert lay.total_bytes == L.gh_workspace_bytes(C.byref(d))
+    assert lay.keys_b - lay.keys_a >= 8 * 5_000_000
+    assert lay.inst_grad + 48 * 5_000_000 <= lay.bwd_scratch
+    # monotone in capacity
+    d2 = _abi.GhDims(98562, 8, 512, 334, 0, 0, 1.0, 0, 6_000_000)
+    assert L.gh_workspace_bytes(C.byref(d2)) > lay.total_bytes
+
+
+@pytest.mark.parametrize("dims,code", [
+    ((10, 0, 64, 64, 0, 0, 1.0, 0, 100), _abi.GH_ERR_INVALID_ARG),      # n_views < 1
+    ((10, 1, 64, 64, 4, 16, 1.0, 0, 100), _abi.GH_ERR_UNSUPPORTED),     # sh_degree > 3
+    ((10, 1, 64, 64, 0, 5, 1.0, 0, 100), _abi.GH_ERR_UNSUPPORTED),      # M not in {0,1,4,9,16}
+    ((10, 1, 64, 16 * 256, 0, 0, 1.0, 0, 100), _abi.GH_ERR_UNSUPPORTED),  # > 255 tiles wide
+    ((10, 1, 64, 64, 0, 0, 1.0, 0, -1), _abi.GH_ERR_INVALID_ARG),
+])
+def test_invalid_dims_rejected(gh_lib_path, dims, code):
+    L = C.CDLL(gh_lib_path)
+    _abi.declare(L)
+    d = _abi.GhDims(*dims)
+    lay = _abi.GhLayout()
+    assert L.gh_workspace_layout(C.byref(d), C.byref(lay)) == code
+    assert L.gh_workspace_bytes(C.byref(d)) == 0
+
+
+def test_forward_rejects_bad_arguments_before_touching_the_gpu(gh_lib_path):
+    """Validation errors are returned as status codes (nothing throws across the boundary, no launch)."""
+    L = C.CDLL(gh_lib_path)
+    _abi.declare(L)
+    d = _abi.GhDims(10, 1, 64, 64, 0, 0, 1.0, 0, 100)
+    inp = _abi.GhInputs()        # all NULL
+    out = _abi.GhOutputs()
+    assert L.gh_forward(C.byref(d), C.byref(inp), C.byref(out), None, 0, None) == _abi.GH_ERR_INVALID_ARG
+    assert L.gh_forward(None, C.byref(inp), C.byref(out), None, 0, None) == _abi.GH_ERR_INVALID_ARG
+    gr = _abi.GhGrads()
+    assert L.gh_backward(C.byref(d), C.byref(inp), C.byref(gr), None, 0, None) == _abi.GH_ERR_INVALID_ARG
+    # both / neither colour source
+    one = C.c_void_p(8)
+    inp2 = _abi.GhInputs(one, one, one, one, one, one, one, None, None, None, None)
+    assert L.gh_forward(C.byref(d), C.byref(inp2), C.byref(_abi.GhOutputs(one, one)), one, 1 << 30, None) == _abi.GH_ERR_INVALID_ARG
+    # workspace too small is reported, with valid-looking pointers, before any launch
+    inp3 = _abi.GhInputs(one, one, one, one, one, None, one, None, None, None, None)
+    assert L.gh_forward(C.byref(d), C.byref(inp3), C.byref(_abi.GhOutputs(one, one)), one, 16, None) == _abi.GH_ERR_WORKSPACE_SMALL
+
+
+def test_product_has_no_cpu_fallback():
+    """CPU tensors must raise (a silent CPU path would void the parity claims)."""
+    import torch
+    from guassianhand_amd.rasterizer import raster_forward
+    z = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        raster_forward(torch.zeros(1, 40), z, torch.zeros(4), z, torch.zeros(4, 4), H=16, W=16, colors_precomp=z)
+
+
+def test_product_never_imports_oracle():
+    """No file of the product package may reference the oracle (test infrastructure only)."""
+    pkg = os.path.join(ROOT, "guassianhand_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "gh_oracle" not in txt, f

@@ -1,0 +1,117 @@
+"""Host-side half of the path pinned against the REFERENCE's own Python: tests/golden/host_fixtures.npz was
+captured by tests/golden/make_host_fixtures.py from tgs/models/renderer_one_shot.py (Camera.from_w2c,
+forward_single_view under a recording fake rasteriser). Here our counterparts must reproduce it."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from guassianhand_amd import camera as cam_mod
+from guassianhand_amd import renderer as R
+from oracle import oracle_torch as OT
+
+
+@pytest.fixture(scope="module")
+def fx(golden_dir):
+    return np.load(os.path.join(golden_dir, "host_fixtures.npz"), allow_pickle=False)
+
+
+def test_camera_matches_reference(fx):
+    for i in range(int(fx["n_cams"])):
+        K, w2c = torch.tensor(fx[f"cam{i}_K"]), torch.tensor(fx[f"cam{i}_w2c"])
+        H, W = [int(v) for v in fx[f"cam{i}_HW"]]
+        c = cam_mod.Camera.from_w2c(w2c, K, H, W, 0.71, 1.42)
+        assert np.allclose(c.world_view_transform.numpy(), fx[f"cam{i}_viewmatrix"], atol=0, rtol=0)
+        assert np.allclose(c.full_proj_transform.numpy(), fx[f"cam{i}_projmatrix"], atol=1e-6, rtol=1e-6)
+        assert np.allclose(c.camera_center.numpy(), fx[f"cam{i}_campos"], atol=1e-6)
+        assert (c.znear, c.zfar) == tuple(fx[f"cam{i}_znear_zfar"])   # forced 0.01 / 1000 (renderer_one_shot.py:99-100)
+        tan = (math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5))
+        assert np.allclose(tan, fx[f"cam{i}_tanfov"], rtol=1e-6)
+        # batched, sync-free packing used by the kernels
+        rec = cam_mod.pack_cameras_from_w2c(w2c[None], K[None], H, W, torch.zeros(3))[0].numpy()
+        assert np.allclose(rec[:16], fx[f"cam{i}_viewmatrix"].reshape(-1), atol=0)
+        assert np.allclose(rec[16:32], fx[f"cam{i}_projmatrix"].reshape(-1), atol=1e-6, rtol=1e-6)
+        assert np.allclose(rec[32:35], fx[f"cam{i}_campos"], atol=1e-6)
+        assert np.allclose(rec[35:37], fx[f"cam{i}_tanfov"], rtol=1e-6)
+
+
+def _mode_inputs(fx, name):
+    gs = {k: torch.tensor(fx[f"{name}_gs_{k}"]) for k in ("xyz", "opacity", "rotation", "scaling", "shs")}
+    bl = {k: (torch.tensor(fx[f"{name}_{k}"]) if f"{name}_{k}" in fx.files else None)
+          for k in ("color_w", "color_b", "opacity_b", "xyz_b")}
+    return gs, bl
+
+
+def test_blend_matches_what_the_reference_hands_to_the_rasteriser(fx):
+    """The tensors arriving at the (fake) rasteriser in the reference == our blend restatement, for both
+    passes, RGB and SH modes, global and per-Gaussian color_w — incl. the `-1` and the SH double multiply."""
+    for name in [str(m) for m in fx["blend_modes"]]:
+        gs, bl = _mode_inputs(fx, name)
+        use_rgb = name.startswith("rgb")
+        means, op, cols, shs = OT.blend_attributes(gs["xyz"], gs["opacity"], gs["shs"], use_rgb=use_rgb, **bl)
+        assert int(fx[f"{name}_ncalls"]) == 2
+        assert np.array_equal(means.numpy(), fx[f"{name}_call0_means3D"])
+        assert np.array_equal(op.numpy(), fx[f"{name}_call0_opacities"])
+        if use_rgb:
+            assert np.array_equal(cols.numpy(), fx[f"{name}_call0_colors_precomp"])
+            assert "shs" in list(fx[f"{name}_call0_none"])
+        else:
+            assert np.array_equal(shs.numpy(), fx[f"{name}_call0_shs"])
+            assert "colors_precomp" in list(fx[f"{name}_call0_none"])
+        # mask pass: colour = ones, same blended means / opacity, sh_degree 0, black background
+        assert np.array_equal(fx[f"{name}_call1_colors_precomp"], np.ones_like(fx[f"{name}_call1_means3D"]))
+        assert np.array_equal(means.numpy(), fx[f"{name}_call1_means3D"])
+        assert int(fx[f"{name}_call1_sh_degree"]) == 0 and int(fx[f"{name}_call0_sh_degree"]) == 3
+        assert np.array_equal(fx[f"{name}_call1_bg"], np.zeros(3, dtype=np.float32))
+
+
+def test_call_protocol(fx):
+    """Keyword names, None-ness, settings fields and return structure of the boundary."""
+    from guassianhand_amd.rasterizer import GaussianRasterizationSettings
+    name = "rgb_w48"
+    assert tuple(str(f) for f in fx[f"{name}_call0_settings_fields"]) == GaussianRasterizationSettings._fields
+    assert sorted(str(k) for k in fx[f"{name}_call0_kwnames"]) == sorted(
+        ["means3D", "means2D", "shs", "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp"])
+    # the mask call omits `shs` entirely (renderer_one_shot.py:372-379)
+    assert "shs" not in [str(k) for k in fx[f"{name}_call1_kwnames"]]
+    assert sorted(str(k) for k in fx[f"{name}_ret_keys"]) == ["comp_mask", "comp_rgb", "comp_rgb_bg"]
+    assert tuple(fx[f"{name}_ret_rgb_shape"]) == (512, 334, 3)
+    for k in ("means3D", "opacities", "scales", "rotations", "colors_precomp"):
+        assert str(fx[f"{name}_call0_{k}_dtype"]) == "torch.float32"
+    import inspect
+    from guassianhand_amd.rasterizer import GaussianRasterizer
+    sig = inspect.signature(GaussianRasterizer.forward)
+    assert list(sig.parameters)[1:] == ["means3D", "means2D", "opacities", "shs", "colors_precomp", "scales",
+                                        "rotations", "cov3D_precomp"]
+
+
+def test_rasterizer_argument_validation():
+    from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    rs = GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), 0,
+                                       torch.zeros(3), False, False)
+    r = GaussianRasterizer(raster_settings=rs)
+    z = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=z, means2D=z, opacities=torch.zeros(4, 1), scales=z, rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(means3D=z, means2D=z, opacities=torch.zeros(4, 1), shs=torch.zeros(4, 16, 3), colors_precomp=z, scales=z,
+          rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=z, means2D=z, opacities=torch.zeros(4, 1), colors_precomp=z)
+
+
+def test_gs_activations(fx):
+    x = torch.tensor(fx["trunc_exp_x"]).requires_grad_(True)
+    y = R.trunc_exp(x)
+    y.sum().backward()
+    assert np.allclose(y.detach().numpy(), fx["trunc_exp_y"], rtol=1e-6)
+    assert np.allclose(x.grad.numpy(), fx["trunc_exp_grad"], rtol=1e-6)     # clamp at 15 in the backward only
+    v, pts = torch.tensor(fx["offset_v"]), torch.tensor(fx["offset_pts"])
+    raw = dict(xyz=v, scaling=torch.zeros(11, 3), rotation=torch.randn(11, 4), opacity=torch.zeros(11, 1),
+               shs=torch.zeros(11, 3))
+    gs = R.gs_activations(raw, pts, use_rgb=True)
+    assert np.allclose(gs.xyz.numpy(), fx["offset_out"], atol=1e-7)
+    assert torch.allclose(gs.rotation.norm(dim=1), torch.ones(11), atol=1e-6)
+    assert gs.shs.shape == (11, 1, 3) and torch.all(gs.opacity == 0.5)

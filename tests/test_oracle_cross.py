@@ -1,0 +1,83 @@
+"""Oracle A (dense PyTorch, autograd-derived backward) vs Oracle B (C, hand-written backward) and float64
+finite differences of Oracle A (SURVEY.md §8c viii-ix). This is what validates the backward FORMULAS
+independently of any hand-written chain rule."""
+import pytest
+import torch
+
+from guassianhand_amd.scenes import make_scene
+from oracle import oracle_torch as OT
+from oracle.oracle_c import OracleRender
+from tests.helpers import dimg_like, rel_l2
+
+
+def dense(sc, view, tensors, dtype=torch.float32, blend=None):
+    c = sc.cams()[view].to(dtype)
+    xyz, op, sca, rot, shs = tensors
+    means, opac, cols, sh = OT.blend_attributes(xyz, op, shs, use_rgb=sc.use_rgb, **(blend or {}))
+    kw = dict(colors_precomp=cols) if sc.use_rgb else dict(shs=sh, sh_degree=sc.sh_degree)
+    return OT.rasterize_dense(means, opac, sca, rot, viewmatrix=c[:16].reshape(4, 4), projmatrix=c[16:32].reshape(4, 4),
+                              campos=c[32:35], tanfovx=float(c[35]), tanfovy=float(c[36]), bg=c[37:40], H=sc.H, W=sc.W, **kw)
+
+
+@pytest.mark.parametrize("use_rgb,blend", [(True, False), (False, False), (True, True), (False, True)])
+def test_oracle_a_vs_b_image_and_grads(use_rgb, blend):
+    sc = make_scene("random1k", n_views=2, P=400, use_rgb=use_rgb, blend=blend)
+    if blend:
+        g = torch.Generator().manual_seed(3)
+        sc.xyz_b = 0.003 * torch.randn(3, generator=g)
+    names = ["xyz", "opacity", "scaling", "rotation", "shs"]
+    leaves = [getattr(sc, n).clone().requires_grad_(True) for n in names]
+    bl = None
+    if blend:
+        bl = {k: getattr(sc, k).clone().requires_grad_(True) for k in ("color_w", "xyz_b", "color_b", "opacity_b")}
+    dimg = dimg_like(2, sc.H, sc.W)
+    imgs = []
+    loss = 0
+    for v in range(2):
+        img, radii = dense(sc, v, leaves, blend=bl)
+        imgs.append(img)
+        loss = loss + (img * dimg[v]).sum()
+    loss.backward()
+    kw = dict(colors_precomp=sc.shs.squeeze(1)) if use_rgb else dict(shs=sc.shs, sh_degree=3)
+    blc = {k: getattr(sc, k) for k in ("xyz_b", "opacity_b", "color_w", "color_b")} if blend else {}
+    orc = OracleRender(sc.cams(), sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=sc.H, W=sc.W, **kw, **blc)
+    assert (torch.stack(imgs) - orc.image).abs().max() < 5e-6
+    gb = orc.backward(dimg)
+    pairs = [("means3D", leaves[0]), ("opacities", leaves[1]), ("scales", leaves[2]), ("rotations", leaves[3]),
+             ("colors_precomp" if use_rgb else "shs", leaves[4])]
+    if blend:
+        pairs += [(k, bl[k]) for k in ("xyz_b", "opacity_b", "color_w", "color_b")]
+    for k, leaf in pairs:
+        assert rel_l2(gb[k], leaf.grad) < 2e-5, k
+
+
+def test_oracle_a_finite_differences_float64():
+    """Central differences of the float64 dense oracle on a scene without borderline decisions."""
+    sc = make_scene("random1k", n_views=1, P=60)
+    d = torch.float64
+    base = [getattr(sc, n).to(d) for n in ("xyz", "opacity", "scaling", "rotation", "shs")]
+    base[2] = base[2] * 3.0                      # fatter Gaussians -> more overlap
+    dimg = dimg_like(1, sc.H, sc.W, seed=9)[0].to(d)
+
+    def f(ts):
+        img, _ = dense(sc, 0, ts, dtype=d)
+        return (img * dimg).sum()
+
+    leaves = [t.clone().requires_grad_(True) for t in base]
+    f(leaves).backward()
+    g = torch.Generator().manual_seed(2)
+    for ti, name in enumerate(("xyz", "opacity", "scaling", "rotation", "shs")):
+        flat = base[ti].reshape(-1)
+        idx = torch.randint(0, flat.numel(), (6,), generator=g)
+        for j in idx.tolist():
+            h = 1e-6 * max(1.0, abs(float(flat[j])))
+            if name == "scaling":
+                h = 1e-7
+            vals = []
+            for sgn in (+1, -1):
+                ts = [t.clone() for t in base]
+                ts[ti].reshape(-1)[j] += sgn * h
+                vals.append(float(f(ts)))
+            fd = (vals[0] - vals[1]) / (2 * h)
+            an = float(leaves[ti].grad.reshape(-1)[j])
+            assert fd == pytest.approx(an, rel=2e-4, abs=1e-6), (name, j)
