@@ -60,6 +60,7 @@ extern "C" size_t gh_workspace_bytes(const GhDims* d) {
 
 static int check_inputs(const GhDims* d, const GhInputs* in) {
   if (!in || !in->cams) return GH_ERR_INVALID_ARG;
+  if (d->P == 0) return GH_OK;                      // nothing to read: only the background is composited
   if (d->P > 0 && (!in->means3D || !in->opacities || !in->scales || !in->rotations)) return GH_ERR_INVALID_ARG;
   if ((in->shs != nullptr) == (in->colors_precomp != nullptr)) return GH_ERR_INVALID_ARG;  // exactly one
   if (in->shs && d->M == 0) return GH_ERR_INVALID_ARG;

@@ -25,7 +25,9 @@ def _reference_style_call(sc, dev, use_shim=False):
         from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     from guassianhand_amd.camera import Camera
     s = sc.to(dev)
-    cam = Camera.from_w2c(s.w2c[0], s.K[0], sc.H, sc.W, 0.71, 1.42)
+    cam = Camera.from_w2c(sc.w2c[0], sc.K[0], sc.H, sc.W, 0.71, 1.42)   # built on the host like the oracle's record
+    for a in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, a, getattr(cam, a).to(dev))
     xyz = s.xyz.clone().requires_grad_(True)
     opacity, scales, rots = s.opacity.clone().requires_grad_(True), s.scaling.clone().requires_grad_(True), s.rotation.clone().requires_grad_(True)
     col = s.shs.clone().requires_grad_(True)
@@ -43,7 +45,9 @@ def _reference_style_call(sc, dev, use_shim=False):
         else:
             img, radii = rasterizer(means3D=xyz, means2D=screenspace_points, shs=col, colors_precomp=None,
                                     opacities=opacity, scales=scales, rotations=rots, cov3D_precomp=None)
-    return img, radii, dict(means3D=xyz, opacities=opacity, scales=scales, rotations=rots, col=col, means2D=screenspace_points)
+    from guassianhand_amd.camera import pack_camera
+    cam_rec = pack_camera(rs.viewmatrix, rs.projmatrix, rs.campos, rs.tanfovx, rs.tanfovy, rs.bg).cpu()
+    return img, radii, dict(cam_rec=cam_rec, means3D=xyz, opacities=opacity, scales=scales, rotations=rots, col=col, means2D=screenspace_points)
 
 
 @pytest.mark.parametrize("use_rgb", [True, False])
@@ -58,7 +62,7 @@ def test_reference_call_protocol_with_autograd(dev, use_rgb):
     loss = (img - gt).abs().mean()
     loss.backward()
     kw = dict(colors_precomp=sc.shs.squeeze(1)) if use_rgb else dict(shs=sc.shs, sh_degree=3)
-    o = OracleRender(sc.cams()[:1], sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=sc.H, W=sc.W, **kw)
+    o = OracleRender(leaves["cam_rec"], sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=sc.H, W=sc.W, **kw)
     assert torch.equal(img.detach().cpu(), o.image[0])
     dimg = (torch.sign(o.image[0] - gt.cpu()) / gt.numel())[None]
     og = o.backward(dimg)
@@ -75,7 +79,7 @@ def test_forward_single_view_equals_fused_batched_views(dev):
     """Reference protocol (torch blend + 2 rasteriser calls per view, renderer_one_shot.py:259-382) vs the
     MI355X form (all views in one launch sequence, blend fused into the kernels): same images, same grads."""
     from guassianhand_amd import renderer as R
-    from guassianhand_amd.camera import Camera
+    from guassianhand_amd.camera import Camera, pack_cameras_from_w2c
     from guassianhand_amd.scenes import make_scene
     for use_rgb in (True, False):
         sc = make_scene("random1k", n_views=3, P=1500, use_rgb=use_rgb, blend=True)
@@ -91,6 +95,10 @@ def test_forward_single_view_equals_fused_batched_views(dev):
         outs = []
         for v in range(3):
             cam = Camera.from_w2c(s.w2c[v], s.K[v], sc.H, sc.W, 0.71, 1.42)
+            rec = pack_cameras_from_w2c(s.w2c[v:v + 1], s.K[v:v + 1], sc.H, sc.W, s.bg)[0]   # same device maths as render_views
+            cam.world_view_transform, cam.full_proj_transform = rec[:16].reshape(4, 4), rec[16:32].reshape(4, 4)
+            cam.camera_center = rec[32:35]
+            cam.FoVx, cam.FoVy = 2 * torch.atan(rec[35]), 2 * torch.atan(rec[36])
             outs.append(R.forward_single_view(gs, cam, s.bg, color_w=a["color_w"], xyz_b=a["xyz_b"], color_b=a["color_b"],
                                               opacity_b=a["opacity_b"], use_rgb=use_rgb, sh_degree=3))
         rgb_a = torch.stack([o["comp_rgb"] for o in outs])

@@ -23,7 +23,8 @@ def gpu_render(sc, dev, sync=True, **over):
     s = sc.to(dev)
     kw, bl = scene_kwargs(s)
     kw.update(over)
-    return raster_forward(s.cams(), s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W, sync=sync, **kw, **bl)
+    cams = sc.cams().to(dev)       # same camera bytes as the oracle (tan/atan2 differ by 1 ulp between CPU and GPU libm)
+    return raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W, sync=sync, **kw, **bl)
 
 
 def oracle_render(sc, debug=True):
@@ -132,7 +133,7 @@ def test_empty_and_fully_culled(dev):
     sc = make_scene("random1k", n_views=1, P=64)
     sc.xyz = sc.xyz - torch.tensor([0.0, 0.0, 5.0])          # everything behind the camera
     s = sc.to(dev)
-    img, radii, ctx = raster_forward(s.cams(), s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W,
+    img, radii, ctx = raster_forward(sc.cams().to(dev), s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W,
                                      colors_precomp=s.shs.squeeze(1))
     assert int(radii.abs().sum()) == 0 and float(img.abs().max()) == 0.0
     g = raster_backward(ctx, torch.ones(1, 3, sc.H, sc.W, device=dev))
