@@ -42,6 +42,9 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->vals_b = take(cap * 4);
   L->slot_gid = take(cap * 4);
   L->sorted_gid = take(cap * 4);
+  L->inst_r0 = take(cap * 16);
+  L->inst_r1 = take(cap * 16);
+  L->inst_r2 = take(cap * 4);
   L->sort_tables = take(((size_t)256 * g.nblk_sort + 256) * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
   L->final_T = take(pix * 4);

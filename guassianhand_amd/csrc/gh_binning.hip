@@ -211,10 +211,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-tile ranges from the sorted keys + the sorted Gaussian ids the render kernels walk.
+// Per-tile ranges from the sorted keys + the per-instance render records in sorted order: the one gather
+// of the pipeline happens here, massively parallel, so both render kernels stream contiguous records.
 __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                               const uint32_t* __restrict__ slot_gid, const GhCounters* __restrict__ ctr,
-                                                              uint32_t cap, uint2* __restrict__ ranges, uint32_t* __restrict__ sorted_gid) {
+                                                              uint32_t cap, uint2* __restrict__ ranges, uint32_t* __restrict__ sorted_gid,
+                                                              const float4* __restrict__ g0, const float4* __restrict__ g1,
+                                                              const float* __restrict__ gb, float4* __restrict__ r0,
+                                                              float4* __restrict__ r1, float* __restrict__ r2) {
   const uint32_t n = gh_sort_n(ctr, cap);
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -225,7 +229,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint64_t* __r
     if (tp != t) { ranges[tp].y = i; ranges[t].x = i; }
   }
   if (i == n - 1) ranges[t].y = n;
-  sorted_gid[i] = slot_gid[vals[i]];
+  const uint32_t gid = slot_gid[vals[i]];
+  sorted_gid[i] = gid;
+  r0[i] = g0[gid]; r1[i] = g1[gid]; r2[i] = gb[gid];
 }
 
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
@@ -257,5 +263,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   }
   const int nblk_d = (int)((g.cap + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, (const uint32_t*)(ws + L.slot_gid), ctr, cap,
-                     (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.sorted_gid));
+                     (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.sorted_gid), (const float4*)(ws + L.geom_g0),
+                     (const float4*)(ws + L.geom_g1), (const float*)(ws + L.geom_b), (float4*)(ws + L.inst_r0),
+                     (float4*)(ws + L.inst_r1), (float*)(ws + L.inst_r2));
 }

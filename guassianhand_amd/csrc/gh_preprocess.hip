@@ -359,14 +359,22 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
         s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
 }
 
-// Second stage of the blend-parameter reduction: fixed-order sum over the per-block partials.
-__global__ __launch_bounds__(64) void gh_blend_reduce_kernel(const float* __restrict__ scratch, int nblk,
-                                                             float* __restrict__ d_w, float* __restrict__ d_xyz) {
-  const int t = threadIdx.x;
+// Second stage of the blend-parameter reduction: one block per slot, fixed-order sum over the per-block
+// partials (strided per thread, DPP per wave, 4 waves in order) => bitwise reproducible.
+__global__ __launch_bounds__(GH_BLOCK) void gh_blend_reduce_kernel(const float* __restrict__ scratch, int nblk,
+                                                                    float* __restrict__ d_w, float* __restrict__ d_xyz) {
+  __shared__ float s_w[GH_BLOCK / GH_WAVE];
+  const int t = blockIdx.x;      // slot 0..50
   float s = 0.0f;
-  for (int b = 0; b < nblk; ++b) s += scratch[(size_t)b * 64 + t];
-  if (d_w && t < 48) d_w[t] = s;
-  if (d_xyz && t >= 48 && t < 51) d_xyz[t - 48] = s;
+  for (int b = threadIdx.x; b < nblk; b += GH_BLOCK) s += scratch[(size_t)b * 64 + t];
+  s = gh_wave_sum_to63(s);
+  if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+    if (d_w && t < 48) d_w[t] = tot;
+    if (d_xyz && t >= 48) d_xyz[t - 48] = tot;
+  }
 }
 
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
@@ -381,5 +389,5 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;
   float* dx = in->blend_xyz_b ? gr->dL_dblend_xyz_b : nullptr;
   if (dw || dx)
-    hipLaunchKernelGGL(gh_blend_reduce_kernel, dim3(1), dim3(64), 0, s, (const float*)(ws + L.bwd_scratch), nblk, dw, dx);
+    hipLaunchKernelGGL(gh_blend_reduce_kernel, dim3(51), dim3(GH_BLOCK), 0, s, (const float*)(ws + L.bwd_scratch), nblk, dw, dx);
 }

@@ -1,15 +1,21 @@
 // gh_render.hip — per-tile alpha compositing and its backward (App. A.4).
 //
 // Work decomposition (wave64-native): one 256-thread workgroup per 16x16 tile, one wave per 8x8 pixel
-// quadrant. The tile's depth-sorted Gaussian list is staged through LDS in chunks; every wave walks the
-// chunk with wave-uniform control flow (ballot skip when no pixel of the quadrant is touched).
-// Backward: each pixel replays its list back to front; the 9 per-Gaussian partial gradients are summed
-// across the 64 lanes with DPP, across the 4 waves through LDS in fixed order, and written once per
-// (tile, Gaussian) instance as a 48-byte record at the instance's emit slot. The per-Gaussian kernel
-// then sums each Gaussian's contiguous records — no global atomics, bitwise reproducible gradients.
+// quadrant, one pixel per lane. Each wave walks the tile's depth-sorted list on its own:
+//   * 64 list entries at a time are staged in REGISTERS (lane l holds entry base+l; the next 64 are
+//     prefetched while the current ones are consumed),
+//   * every lane tests "its" Gaussian against the wave's quadrant with a conservative bounding box of the
+//     alpha >= 1/255 ellipse; a ballot turns that into a 64-bit hit mask (wavefront compaction),
+//   * the wave iterates the set bits only; the selected Gaussian's 9 floats are broadcast with
+//     v_readlane (SGPR operands, no LDS traffic) and the per-pixel blend is branch-free.
+// The forward pass therefore uses no LDS and no barriers, and a quadrant retires as soon as its 64 pixels
+// are saturated. Culling never changes results: the exact per-pixel tests of App. A.3 still decide.
+//
+// Backward: each pixel replays its list back to front (same staging / culling); the 9 per-Gaussian partial
+// gradients are summed over the 64 lanes with DPP, over the 4 waves through LDS in fixed order, and written
+// once per (tile, Gaussian) instance as a 48-byte record at the instance's emit slot. The per-Gaussian
+// kernel then sums each Gaussian's contiguous records — no global atomics, bitwise reproducible gradients.
 #include "gh_internal.h"
-
-#define GH_CHUNK 256
 
 __device__ __forceinline__ void gh_tile_coords(int blk, int gx, int tiles, int& v, int& tx, int& ty) {
   v = blk / tiles;
@@ -17,106 +23,144 @@ __device__ __forceinline__ void gh_tile_coords(int blk, int gx, int tiles, int& 
   ty = t / gx; tx = t - ty * gx;
 }
 
+__device__ __forceinline__ float gh_bcast(float v, int lane) {   // lane is wave-uniform
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// Conservative test: can Gaussian (g0 = px,py,A,B; g1 = C,opacity,..) reach alpha >= 1/255 anywhere in the
+// 8x8 pixel block whose first pixel is (qx0,qy0)? alpha >= 1/255  <=>  d^T Q d <= 2 ln(255 o); the axis-aligned
+// extent of that ellipse is sqrt(2 tau Q^-1_xx), sqrt(2 tau Q^-1_yy). Margins absorb the approximate log/sqrt;
+// anything non-finite answers "hit". A false "hit" only costs time, never changes a pixel.
+__device__ __forceinline__ bool gh_quadrant_hit(const float4& g0, const float4& g1, float qx0, float qy0) {
+  const float o = g1.y;
+  if (!(o >= 1.0f / 255.0f)) return false;          // alpha = min(.99, o*exp(p<=0)) <= o < 1/255 everywhere
+  const float tau = __logf(255.0f * o) * 1.0001f + 1e-3f;
+  const float det = g0.z * g1.x - g0.w * g0.w;
+  const float k = 2.0f * tau / det;
+  const float hx = __builtin_amdgcn_sqrtf(k * g1.x) * 1.001f + 0.02f;
+  const float hy = __builtin_amdgcn_sqrtf(k * g0.z) * 1.001f + 0.02f;
+  const bool miss = (g0.x + hx < qx0) || (g0.x - hx > qx0 + 7.0f) || (g0.y + hy < qy0) || (g0.y - hy > qy0 + 7.0f);
+  return !miss;                                       // NaN extents compare false -> hit
+}
+
 // ------------------------------------------------------------------------------------------------
+struct GhBatch {          // 64 list entries staged in registers: lane l holds entry base+l
+  float4 a, b;            // (px, py, A, B), (C, opacity, r, g)
+  float cb;               // b
+};
+
+__device__ __forceinline__ void gh_load_batch(GhBatch& t, const float4* __restrict__ r0, const float4* __restrict__ r1,
+                                              const float* __restrict__ r2, int idx, int total) {
+  if (idx < total) { t.a = r0[idx]; t.b = r1[idx]; t.cb = r2[idx]; }
+  else { t.a = make_float4(0, 0, 0, 0); t.b = make_float4(0, 0, 0, 0); t.cb = 0.0f; }
+}
+
+struct GhPixelFwd {
+  float T, C0, C1, C2;
+  uint32_t last;
+  bool done;
+};
+
+// Consume one staged batch front to back. Returns true when every pixel of the wave is finished.
+__device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, float fqx0, float fqy0,
+                                               float pxf, float pyf, GhPixelFwd& p) {
+  const bool hit = (base + lane < total) && gh_quadrant_hit(t.a, t.b, fqx0, fqy0);
+  uint64_t mask = __ballot(hit);
+  while (mask) {
+    const int j = __builtin_ctzll(mask);
+    mask &= mask - 1;
+    const float gpx = gh_bcast(t.a.x, j), gpy = gh_bcast(t.a.y, j), cA = gh_bcast(t.a.z, j), cB = gh_bcast(t.a.w, j);
+    const float cC = gh_bcast(t.b.x, j), op = gh_bcast(t.b.y, j), r = gh_bcast(t.b.z, j), g = gh_bcast(t.b.w, j);
+    const float bl = gh_bcast(t.cb, j);
+    const float dx = gpx - pxf, dy = gpy - pyf;
+    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+    const float alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
+    const bool valid = !p.done && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+    const float test_T = p.T * (1.0f - alpha);
+    const bool stop = valid && (test_T < 0.0001f);
+    const bool blend = valid && !stop;
+    const float w = blend ? alpha * p.T : 0.0f;     // fma(c, 0, C) == C exactly: masked lanes keep their bits
+    p.C0 = fmaf(r, w, p.C0); p.C1 = fmaf(g, w, p.C1); p.C2 = fmaf(bl, w, p.C2);
+    p.T = blend ? test_T : p.T;
+    p.last = blend ? (uint32_t)(base + j + 1) : p.last;
+    p.done = p.done || stop;
+    if (__all(p.done)) return true;
+  }
+  return false;
+}
+
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ sorted_gid, const float4* __restrict__ g0,
-    const float4* __restrict__ g1, const float* __restrict__ gb, const float* __restrict__ cams, int H, int W, int gx,
-    int tiles, float* __restrict__ image, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  __shared__ float4 s_g0[GH_CHUNK];
-  __shared__ float4 s_g1[GH_CHUNK];
-  __shared__ float s_b[GH_CHUNK];
+    const uint2* __restrict__ ranges, const float4* __restrict__ r0, const float4* __restrict__ r1,
+    const float* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx, int tiles,
+    float* __restrict__ image, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
   int v, tx, ty;
   gh_tile_coords(blockIdx.x, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int lx = (wid & 1) * 8 + (lane & 7), ly = (wid >> 1) * 8 + (lane >> 3);
-  const int x = tx * GH_TILE + lx, y = ty * GH_TILE + ly;
+  const int qx0 = tx * GH_TILE + (wid & 1) * 8, qy0 = ty * GH_TILE + (wid >> 1) * 8;
+  const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
   const bool inside = x < W && y < H;
-  const float pxf = (float)x, pyf = (float)y;
+  const float pxf = (float)x, pyf = (float)y, fqx0 = (float)qx0, fqy0 = (float)qy0;
   const uint2 range = ranges[blockIdx.x];
   const int total = (int)(range.y - range.x);
-  const int rounds = (total + GH_CHUNK - 1) / GH_CHUNK;
+  r0 += range.x; r1 += range.x; r2 += range.x;
 
-  bool done = !inside;
-  float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-  uint32_t contributor = 0, last = 0;
-  int todo = total;
-  for (int r = 0; r < rounds; ++r, todo -= GH_CHUNK) {
-    if (__syncthreads_count(done) == GH_BLOCK) break;
-    const int idx = r * GH_CHUNK + tid;
-    if (idx < total) {
-      const uint32_t gid = sorted_gid[range.x + idx];
-      s_g0[tid] = g0[gid]; s_g1[tid] = g1[gid]; s_b[tid] = gb[gid];
-    }
-    __syncthreads();
-    const int cnt = todo < GH_CHUNK ? todo : GH_CHUNK;
-    for (int j = 0; j < cnt; ++j) {
-      if (__all(done)) break;                       // wave-uniform: this quadrant is finished
-      const float4 a = s_g0[j], b4 = s_g1[j];       // LDS broadcast reads
-      if (!done) {
-        ++contributor;
-        const float dx = a.x - pxf, dy = a.y - pyf;
-        const float power = -0.5f * (a.z * dx * dx + b4.x * dy * dy) - a.w * dx * dy;
-        if (power <= 0.0f) {
-          const float alpha = fminf(0.99f, b4.y * gh_exp(power));
-          if (alpha >= 1.0f / 255.0f) {
-            const float test_T = T * (1.0f - alpha);
-            if (test_T < 0.0001f) {
-              done = true;
-            } else {
-              const float w = alpha * T;
-              C0 = fmaf(b4.z, w, C0); C1 = fmaf(b4.w, w, C1); C2 = fmaf(s_b[j], w, C2);
-              T = test_T; last = contributor;
-            }
-          }
-        }
-      }
+  GhPixelFwd p;
+  p.T = 1.0f; p.C0 = p.C1 = p.C2 = 0.0f; p.last = 0; p.done = !inside;
+  if (total > 0 && !__all(p.done)) {
+    // two register sets in flight: while one batch is consumed the next one is already being loaded
+    GhBatch A, B;
+    gh_load_batch(A, r0, r1, r2, lane, total);
+    for (int base = 0; base < total; base += 2 * GH_WAVE) {
+      gh_load_batch(B, r0, r1, r2, base + GH_WAVE + lane, total);
+      if (gh_fwd_consume(A, base, total, lane, fqx0, fqy0, pxf, pyf, p)) break;
+      if (base + GH_WAVE >= total) break;
+      gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
+      if (gh_fwd_consume(B, base + GH_WAVE, total, lane, fqx0, fqy0, pxf, pyf, p)) break;
     }
   }
   if (inside) {
     const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
     const size_t pix = ((size_t)v * H + y) * W + x;
-    final_T[pix] = T;
-    n_contrib[pix] = last;
+    final_T[pix] = p.T;
+    n_contrib[pix] = p.last;
     float* img = image + (size_t)v * 3 * H * W + (size_t)y * W + x;
-    img[0] = fmaf(T, bg[0], C0);
-    img[(size_t)H * W] = fmaf(T, bg[1], C1);
-    img[(size_t)2 * H * W] = fmaf(T, bg[2], C2);
+    img[0] = fmaf(p.T, bg[0], p.C0);
+    img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1);
+    img[(size_t)2 * H * W] = fmaf(p.T, bg[2], p.C2);
   }
 }
 
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, char* ws, const GhLayout& L,
                           hipStream_t s) {
   hipLaunchKernelGGL(gh_render_fwd_kernel, dim3(g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
-                     (const uint32_t*)(ws + L.sorted_gid), (const float4*)(ws + L.geom_g0), (const float4*)(ws + L.geom_g1),
-                     (const float*)(ws + L.geom_b), in->cams, g.H, g.W, g.gx, g.tiles, image, (float*)(ws + L.final_T),
-                     (uint32_t*)(ws + L.n_contrib));
+                     (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1), (const float*)(ws + L.inst_r2),
+                     in->cams, g.H, g.W, g.gx, g.tiles, image, (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib));
 }
 
 // ------------------------------------------------------------------------------------------------
-#define GH_BCHUNK 128   // instances per LDS chunk in the backward walk
+#define GH_BCHUNK 128                      // instances combined across the 4 waves per barrier pair
+#define GH_BSUB (GH_BCHUNK / GH_WAVE)      // 64-entry register batches per chunk
 
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ sorted_gid, const uint32_t* __restrict__ sorted_slot,
-    const float4* __restrict__ g0, const float4* __restrict__ g1, const float* __restrict__ gb, const float* __restrict__ cams,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ sorted_slot, const float4* __restrict__ r0,
+    const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams,
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimage, float* __restrict__ inst_grad) {
-  __shared__ float4 s_g0[GH_BCHUNK];
-  __shared__ float4 s_g1[GH_BCHUNK];
-  __shared__ float s_b[GH_BCHUNK];
-  __shared__ uint32_t s_slot[GH_BCHUNK];
-  __shared__ float s_part[GH_BLOCK / GH_WAVE][GH_BCHUNK][GH_REC];   // per-wave partial records
-  __shared__ uint32_t s_touched[GH_BLOCK / GH_WAVE][GH_BCHUNK / 32];  // which records a wave wrote
+  __shared__ float s_part[GH_BLOCK / GH_WAVE][GH_BCHUNK][GH_REC];     // per-wave partial records (24 KB)
+  __shared__ uint64_t s_touched[GH_BLOCK / GH_WAVE][GH_BSUB];         // which records a wave wrote
   __shared__ int s_max;
   int v, tx, ty;
   gh_tile_coords(blockIdx.x, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int lx = (wid & 1) * 8 + (lane & 7), ly = (wid >> 1) * 8 + (lane >> 3);
-  const int x = tx * GH_TILE + lx, y = ty * GH_TILE + ly;
+  const int qx0 = tx * GH_TILE + (wid & 1) * 8, qy0 = ty * GH_TILE + (wid >> 1) * 8;
+  const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
   const bool inside = x < W && y < H;
-  const float pxf = (float)x, pyf = (float)y;
+  const float pxf = (float)x, pyf = (float)y, fqx0 = (float)qx0, fqy0 = (float)qy0;
   const uint2 range = ranges[blockIdx.x];
   const int total = (int)(range.y - range.x);
   if (total == 0) return;
+  r0 += range.x; r1 += range.x; r2 += range.x;
+  const uint32_t* slots = sorted_slot + range.x;
 
   const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
   float T_final = 1.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
@@ -131,18 +175,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   const float bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
   if (tid == 0) s_max = 0;
   __syncthreads();
-  {
-    int m = last;
+  int wave_last = last;                    // max n_contrib of this quadrant
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(m, o); m = t > m ? t : m; }
-    if (lane == 0) atomicMax(&s_max, m);
-  }
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(wave_last, o); wave_last = t > wave_last ? t : wave_last; }
+  if (lane == 0) atomicMax(&s_max, wave_last);
   __syncthreads();
-  const int max_last = s_max;   // instances at list positions >= max_last were reached by no pixel
+  const int max_last = s_max;              // list positions >= max_last were reached by no pixel of the tile
 
   // zero records for the unreached tail of the list
   for (int k = max_last + tid; k < total; k += GH_BLOCK) {
-    float4* r = (float4*)(inst_grad + (size_t)sorted_slot[range.x + k] * GH_REC);
+    float4* r = (float4*)(inst_grad + (size_t)slots[k] * GH_REC);
     r[0] = make_float4(0, 0, 0, 0); r[1] = make_float4(0, 0, 0, 0); r[2] = make_float4(0, 0, 0, 0);
   }
 
@@ -151,74 +193,77 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   for (int c = nchunks - 1; c >= 0; --c) {
     const int cbase = c * GH_BCHUNK;
     const int cnt = (max_last - cbase) < GH_BCHUNK ? (max_last - cbase) : GH_BCHUNK;
-    if (tid < cnt) {
-      const uint32_t gid = sorted_gid[range.x + cbase + tid];
-      s_g0[tid] = g0[gid]; s_g1[tid] = g1[gid]; s_b[tid] = gb[gid];
-      s_slot[tid] = sorted_slot[range.x + cbase + tid];
-    }
-    if (lane < GH_BCHUNK / 32) s_touched[wid][lane] = 0;
-    __syncthreads();
-    uint64_t t_lo = 0, t_hi = 0;                 // wave-uniform: which records of the chunk this wave wrote
-    for (int j = cnt - 1; j >= 0; --j) {
-      const int pos = cbase + j;                 // 0-based list position; pixel blended it iff pos < last && tests pass
-      const float4 a = s_g0[j], b4 = s_g1[j];
-      const float cb = s_b[j];
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b4.x * dy * dy) - a.w * dx * dy;
-      const float G = gh_exp(fminf(power, 0.0f));
-      const float alpha = fminf(0.99f, b4.y * G);
-      const bool contrib = (pos < last) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-      if (!__any(contrib)) continue;             // wave-uniform skip: quadrant untouched by this Gaussian
-      float r[9];
-      if (contrib) {
-        T = T / (1.0f - alpha);
-        const float dchannel_dcolor = alpha * T;
-        ar0 = last_alpha * lc0 + (1.0f - last_alpha) * ar0;
-        ar1 = last_alpha * lc1 + (1.0f - last_alpha) * ar1;
-        ar2 = last_alpha * lc2 + (1.0f - last_alpha) * ar2;
-        lc0 = b4.z; lc1 = b4.w; lc2 = cb;
-        float dL_dalpha = (b4.z - ar0) * d0 + (b4.w - ar1) * d1 + (cb - ar2) * d2;
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
-        const float dL_dG = b4.y * dL_dalpha;    // straight-through the 0.99 clamp (App. A.4-2)
-        const float gdx = G * dx, gdy = G * dy;
-        r[0] = dL_dG * (-gdx * a.z - gdy * a.w);
-        r[1] = dL_dG * (-gdy * b4.x - gdx * a.w);
-        r[2] = -0.5f * gdx * dx * dL_dG;
-        r[3] = -gdx * dy * dL_dG;
-        r[4] = -0.5f * gdy * dy * dL_dG;
-        r[5] = G * dL_dalpha;
-        r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
-      } else {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) r[q] = 0.0f;
-      }
+    for (int sub = GH_BSUB - 1; sub >= 0; --sub) {
+      const int sbase = cbase + sub * GH_WAVE;
+      uint64_t processed = 0;
+      if (sbase < wave_last) {             // wave-uniform: nothing of this batch was blended by this quadrant otherwise
+        const int idx = sbase + lane;
+        float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
+        float cb = 0.0f;
+        const bool have = idx < wave_last;
+        if (have) { a = r0[idx]; b = r1[idx]; cb = r2[idx]; }
+        uint64_t mask = __ballot(have && gh_quadrant_hit(a, b, fqx0, fqy0));
+        while (mask) {
+          const int j = 63 - __builtin_clzll(mask);          // back to front
+          mask &= ~(1ull << j);
+          const int pos = sbase + j;
+          const float gpx = gh_bcast(a.x, j), gpy = gh_bcast(a.y, j), cA = gh_bcast(a.z, j), cB = gh_bcast(a.w, j);
+          const float cC = gh_bcast(b.x, j), op = gh_bcast(b.y, j), cr = gh_bcast(b.z, j), cg = gh_bcast(b.w, j);
+          const float cbl = gh_bcast(cb, j);
+          const float dx = gpx - pxf, dy = gpy - pyf;
+          const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+          const float G = gh_exp(fminf(power, 0.0f));
+          const float alpha = fminf(0.99f, op * G);
+          const bool contrib = (pos < last) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+          if (!__any(contrib)) continue;                      // wave-uniform
+          processed |= 1ull << j;
+          // per-lane state advances only where the pixel really blended this Gaussian
+          const float Tn = T / (1.0f - alpha);
+          const float n0 = last_alpha * lc0 + (1.0f - last_alpha) * ar0;
+          const float n1 = last_alpha * lc1 + (1.0f - last_alpha) * ar1;
+          const float n2 = last_alpha * lc2 + (1.0f - last_alpha) * ar2;
+          float dL_dalpha = (cr - n0) * d0 + (cg - n1) * d1 + (cbl - n2) * d2;
+          dL_dalpha *= Tn;
+          dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
+          const float dL_dG = op * dL_dalpha;                 // straight-through the 0.99 clamp (App. A.4-2)
+          const float gdx = G * dx, gdy = G * dy;
+          const float dchannel_dcolor = alpha * Tn;
+          float r[9];
+          r[0] = dL_dG * (-gdx * cA - gdy * cB);
+          r[1] = dL_dG * (-gdy * cC - gdx * cB);
+          r[2] = -0.5f * gdx * dx * dL_dG;
+          r[3] = -gdx * dy * dL_dG;
+          r[4] = -0.5f * gdy * dy * dL_dG;
+          r[5] = G * dL_dalpha;
+          r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) r[q] = gh_wave_sum_to63(r[q]);
-      if (lane == 63) {
-        float4* p = (float4*)&s_part[wid][j][0];
-        p[0] = make_float4(r[0], r[1], r[2], r[3]);
-        p[1] = make_float4(r[4], r[5], r[6], r[7]);
-        s_part[wid][j][8] = r[8];
+          for (int q = 0; q < 9; ++q) r[q] = gh_wave_sum_to63(contrib ? r[q] : 0.0f);
+          T = contrib ? Tn : T;
+          ar0 = contrib ? n0 : ar0; ar1 = contrib ? n1 : ar1; ar2 = contrib ? n2 : ar2;
+          lc0 = contrib ? cr : lc0; lc1 = contrib ? cg : lc1; lc2 = contrib ? cbl : lc2;
+          last_alpha = contrib ? alpha : last_alpha;
+          if (lane == 63) {
+            float4* p = (float4*)&s_part[wid][sub * GH_WAVE + j][0];
+            p[0] = make_float4(r[0], r[1], r[2], r[3]);
+            p[1] = make_float4(r[4], r[5], r[6], r[7]);
+            s_part[wid][sub * GH_WAVE + j][8] = r[8];
+          }
+        }
       }
-      if (j < 64) t_lo |= 1ull << j; else t_hi |= 1ull << (j - 64);
-    }
-    if (lane == 0) {
-      s_touched[wid][0] = (uint32_t)t_lo; s_touched[wid][1] = (uint32_t)(t_lo >> 32);
-      s_touched[wid][2] = (uint32_t)t_hi; s_touched[wid][3] = (uint32_t)(t_hi >> 32);
+      if (lane == 0) s_touched[wid][sub] = processed;
     }
     __syncthreads();
     if (tid < cnt) {
       float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) {     // fixed wave order => reproducible sums
-        if (s_touched[w][tid >> 5] & (1u << (tid & 31))) {
+      for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) {          // fixed wave order => reproducible sums
+        if ((s_touched[w][tid >> 6] >> (tid & 63)) & 1ull) {
 #pragma unroll
           for (int q = 0; q < 9; ++q) s[q] += s_part[w][tid][q];
         }
       }
-      float4* rec = (float4*)(inst_grad + (size_t)s_slot[tid] * GH_REC);
+      float4* rec = (float4*)(inst_grad + (size_t)slots[cbase + tid] * GH_REC);
       rec[0] = make_float4(s[0], s[1], s[2], s[3]);
       rec[1] = make_float4(s[4], s[5], s[6], s[7]);
       rec[2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
@@ -230,8 +275,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage, char* ws,
                           const GhLayout& L, hipStream_t s) {
   hipLaunchKernelGGL(gh_render_bwd_kernel, dim3(g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
-                     (const uint32_t*)(ws + L.sorted_gid), (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.geom_g0),
-                     (const float4*)(ws + L.geom_g1), (const float*)(ws + L.geom_b), in->cams, g.H, g.W, g.gx, g.tiles,
+                     (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
+                     (const float*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles,
                      (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimage,
                      (float*)(ws + L.inst_grad));
 }

@@ -135,6 +135,9 @@ typedef struct GhLayout {
   size_t vals_a, vals_b; /* uint32[max_instances] slot index payload; result in vals_a */
   size_t slot_gid;       /* uint32[max_instances] emit slot -> view*P + gaussian */
   size_t sorted_gid;     /* uint32[max_instances] sorted position -> view*P + gaussian */
+  size_t inst_r0;        /* float4[max_instances] sorted per-instance render record (px, py, conicA, conicB) */
+  size_t inst_r1;        /* float4[max_instances]                                   (conicC, opacity, r, g)  */
+  size_t inst_r2;        /* float [max_instances]                                   b                        */
   size_t sort_tables;    /* uint32[...]        per-pass digit tables */
   size_t ranges;         /* uint2 [n_views*tiles] [start,end) into the sorted list */
   size_t final_T;        /* float [n_views*H*W] */
