@@ -19,7 +19,8 @@ LIB_PATH = os.path.join(_HERE, "libgh_raster.so")
 SOURCES = ("gh_api.hip", "gh_preprocess.hip", "gh_binning.hip", "gh_render.hip")
 HEADERS = ("gh_internal.h", os.path.join("..", "..", "include", "gh_raster.h"))
 # -ffp-contract=off: FMAs only where the source says fmaf() (arithmetic contract)
-HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17")
+# -fno-slp-vectorize: keeps the DPP butterflies as v_add_f32_dpp instead of v_mov_dpp + v_pk_add_f32
+HIPCC_FLAGS = ("--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17")
 
 _lib: Optional[C.CDLL] = None
 

@@ -47,9 +47,11 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->inst_r2 = take(cap * 4);
   L->sort_tables = take(((size_t)256 * g.nblk_sort + 256) * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
+  L->tile_order = take((size_t)g.NV * g.tiles * 4);
   L->final_T = take(pix * 4);
   L->n_contrib = take(pix * 4);
-  L->inst_grad = take(cap * GH_REC * 4);
+  L->inst_grad = take(cap * 4 * GH_REC * 4);
+  L->inst_flag = take(cap * 4);
   L->bwd_scratch = take((nblk_pre + 1) * 64 * 4);
   L->total_bytes = off;
   return GH_OK;

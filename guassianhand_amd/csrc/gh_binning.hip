@@ -234,15 +234,60 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint64_t* __r
   r0[i] = g0[gid]; r1[i] = g1[gid]; r2[i] = gb[gid];
 }
 
+// Longest-processing-time-first launch order for the render kernels: a counting sort of the tiles by list
+// length (256 buckets of 16 entries, longest first). Workgroups are dispatched in blockIdx order, so the heavy
+// tiles start at t=0 and the light / empty ones fill in behind them instead of forming the tail.
+// One block; the order inside a bucket is arbitrary (it only affects scheduling, never results).
+__global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int ntiles,
+                                                              uint32_t* __restrict__ order) {
+  __shared__ uint32_t s_cnt[256];
+  __shared__ uint32_t s_w[4];
+  const int tid = threadIdx.x;
+  if (tid < 256) s_cnt[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < ntiles; t += 1024) {
+    const uint2 r = ranges[t];
+    uint32_t b = (r.y - r.x + 15u) >> 4; b = b > 255u ? 255u : b;
+    atomicAdd(&s_cnt[255u - b], 1u);                 // bucket 0 = longest lists
+  }
+  __syncthreads();
+  // exclusive scan of the 256 counters by the first 4 waves
+  const int lane = tid & 63, wid = tid >> 6;
+  uint32_t v = 0, x = 0;
+  if (tid < 256) {
+    v = s_cnt[tid];
+    x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wid] = x;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += s_w[w];
+    s_cnt[tid] = woff + x - v;
+  }
+  __syncthreads();
+  for (int t = tid; t < ntiles; t += 1024) {
+    const uint2 r = ranges[t];
+    uint32_t b = (r.y - r.x + 15u) >> 4; b = b > 255u ? 255u : b;
+    order[atomicAdd(&s_cnt[255u - b], 1u)] = (uint32_t)t;
+  }
+}
+
+static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
+  gh_launch_tile_order(g, ws, L, s);
+}
+
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
-  if (g.N == 0) return;
+  if (g.N == 0) { gh_launch_tile_order(g, ws, L, s); return; }   // ranges are all-empty (memset): any order
   const int nblk_pre = (g.N + GH_BLOCK - 1) / GH_BLOCK;
   GhCounters* ctr = (GhCounters*)(ws + L.counters);
   const uint32_t cap = (uint32_t)g.cap;
   uint64_t* ka = (uint64_t*)(ws + L.keys_a); uint64_t* kb = (uint64_t*)(ws + L.keys_b);
   uint32_t* va = (uint32_t*)(ws + L.vals_a); uint32_t* vb = (uint32_t*)(ws + L.vals_b);
   hipLaunchKernelGGL(gh_scan_blocksums_kernel, dim3(1), dim3(1024), 0, s, (uint32_t*)(ws + L.block_sums), nblk_pre, ctr, cap);
-  if (cap == 0) return;
+  if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }
   // an odd number of passes starts in the b buffers so the result always lands in keys_a / vals_a
   const bool start_b = (g.n_pass & 1) != 0;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap,
@@ -266,4 +311,5 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.sorted_gid), (const float4*)(ws + L.geom_g0),
                      (const float4*)(ws + L.geom_g1), (const float*)(ws + L.geom_b), (float4*)(ws + L.inst_r0),
                      (float4*)(ws + L.inst_r1), (float*)(ws + L.inst_r2));
+  gh_launch_tile_order(g, ws, L, s);
 }

@@ -133,7 +133,7 @@ __device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, floa
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags,
     uint32_t cap, const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ clamped,
-    const float* __restrict__ inst_grad, float* __restrict__ scratch) {
+    const float* __restrict__ inst_grad, const uint32_t* __restrict__ inst_flag, float* __restrict__ scratch) {
   __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
   const int i = blockIdx.x * GH_BLOCK + threadIdx.x;
   const bool live = i < P;
@@ -160,10 +160,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     // fixed-order sum of this Gaussian's per-instance records (slots are contiguous per Gaussian)
     float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t sidx = o0; sidx < o1; ++sidx) {
-      const float4* r = (const float4*)(inst_grad + (size_t)sidx * GH_REC);
-      float4 r0 = r[0], r1 = r[1]; float r2 = inst_grad[(size_t)sidx * GH_REC + 8];
-      s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r0.w;
-      s9[4] += r1.x; s9[5] += r1.y; s9[6] += r1.z; s9[7] += r1.w; s9[8] += r2;
+      const uint32_t f = inst_flag[sidx];                    // 4 quadrant flag bytes of this tile instance
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((f >> (8 * q)) & 1u) {
+          const float4* r = (const float4*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC);
+          const float4 r0 = r[0], r1 = r[1]; const float r2 = r[2].x;
+          s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r0.w;
+          s9[4] += r1.x; s9[5] += r1.y; s9[6] += r1.z; s9[7] += r1.w; s9[8] += r2;
+        }
+      }
     }
     const float g_px = s9[0], g_py = s9[1], gA = s9[2], gB = s9[3], gC = s9[4], g_o = s9[5];
     if (live && gr.dL_dmeans2D) {
@@ -384,7 +390,7 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   hipLaunchKernelGGL(gh_preprocess_bwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (uint32_t)g.cap,
                      (const uint32_t*)(ws + L.offsets), (const uint8_t*)(ws + L.clamped),
-                     (const float*)(ws + L.inst_grad), (float*)(ws + L.bwd_scratch));
+                     (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float*)(ws + L.bwd_scratch));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;
   float* dx = in->blend_xyz_b ? gr->dL_dblend_xyz_b : nullptr;

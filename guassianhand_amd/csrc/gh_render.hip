@@ -12,9 +12,10 @@
 // are saturated. Culling never changes results: the exact per-pixel tests of App. A.3 still decide.
 //
 // Backward: each pixel replays its list back to front (same staging / culling); the 9 per-Gaussian partial
-// gradients are summed over the 64 lanes with DPP, over the 4 waves through LDS in fixed order, and written
-// once per (tile, Gaussian) instance as a 48-byte record at the instance's emit slot. The per-Gaussian
-// kernel then sums each Gaussian's contiguous records — no global atomics, bitwise reproducible gradients.
+// gradients are summed over the 64 lanes with DPP and stored by the quadrant's wave as ITS sub-record of the
+// (tile, Gaussian) instance, at the instance's emit slot, plus a flag byte. No LDS, no barriers, no atomics:
+// the per-Gaussian kernel adds each Gaussian's flagged sub-records (contiguous slots) in fixed order, so the
+// gradients are bitwise reproducible.
 #include "gh_internal.h"
 
 __device__ __forceinline__ void gh_tile_coords(int blk, int gx, int tiles, int& v, int& tx, int& ty) {
@@ -61,46 +62,71 @@ struct GhPixelFwd {
   bool done;
 };
 
-// Consume one staged batch front to back. Returns true when every pixel of the wave is finished.
+struct GhHit {            // one Gaussian broadcast to the whole wave (SGPRs) + its per-pixel alpha
+  float r, g, b, alpha;
+  bool ok;                // power <= 0 && alpha >= 1/255 for this pixel
+};
+
+__device__ __forceinline__ GhHit gh_eval_hit(const GhBatch& t, int j, float pxf, float pyf) {
+  const float gpx = gh_bcast(t.a.x, j), gpy = gh_bcast(t.a.y, j), cA = gh_bcast(t.a.z, j), cB = gh_bcast(t.a.w, j);
+  const float cC = gh_bcast(t.b.x, j), op = gh_bcast(t.b.y, j);
+  GhHit h;
+  h.r = gh_bcast(t.b.z, j); h.g = gh_bcast(t.b.w, j); h.b = gh_bcast(t.cb, j);
+  const float dx = gpx - pxf, dy = gpy - pyf;
+  const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+  h.alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
+  h.ok = (power <= 0.0f) && (h.alpha >= 1.0f / 255.0f);
+  return h;
+}
+
+__device__ __forceinline__ void gh_blend_hit(const GhHit& h, uint32_t pos1, GhPixelFwd& p) {
+  const bool valid = !p.done && h.ok;
+  const float test_T = p.T * (1.0f - h.alpha);
+  const bool stop = valid && (test_T < 0.0001f);
+  const bool blend = valid && !stop;
+  const float w = blend ? h.alpha * p.T : 0.0f;     // fma(c, 0, C) == C exactly: masked lanes keep their bits
+  p.C0 = fmaf(h.r, w, p.C0); p.C1 = fmaf(h.g, w, p.C1); p.C2 = fmaf(h.b, w, p.C2);
+  p.T = blend ? test_T : p.T;
+  p.last = blend ? pos1 : p.last;
+  p.done = p.done || stop;
+}
+
+// Consume one staged batch front to back, two hits per trip: their alpha evaluations are independent
+// (ILP for a wave that is alone on its SIMD); only the T / done update is sequential.
+// Returns true when every pixel of the wave is finished.
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, float fqx0, float fqy0,
                                                float pxf, float pyf, GhPixelFwd& p) {
   const bool hit = (base + lane < total) && gh_quadrant_hit(t.a, t.b, fqx0, fqy0);
   uint64_t mask = __ballot(hit);
   while (mask) {
-    const int j = __builtin_ctzll(mask);
+    const int j0 = __builtin_ctzll(mask);
     mask &= mask - 1;
-    const float gpx = gh_bcast(t.a.x, j), gpy = gh_bcast(t.a.y, j), cA = gh_bcast(t.a.z, j), cB = gh_bcast(t.a.w, j);
-    const float cC = gh_bcast(t.b.x, j), op = gh_bcast(t.b.y, j), r = gh_bcast(t.b.z, j), g = gh_bcast(t.b.w, j);
-    const float bl = gh_bcast(t.cb, j);
-    const float dx = gpx - pxf, dy = gpy - pyf;
-    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-    const float alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
-    const bool valid = !p.done && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-    const float test_T = p.T * (1.0f - alpha);
-    const bool stop = valid && (test_T < 0.0001f);
-    const bool blend = valid && !stop;
-    const float w = blend ? alpha * p.T : 0.0f;     // fma(c, 0, C) == C exactly: masked lanes keep their bits
-    p.C0 = fmaf(r, w, p.C0); p.C1 = fmaf(g, w, p.C1); p.C2 = fmaf(bl, w, p.C2);
-    p.T = blend ? test_T : p.T;
-    p.last = blend ? (uint32_t)(base + j + 1) : p.last;
-    p.done = p.done || stop;
+    const bool two = mask != 0;                      // wave-uniform
+    const int j1 = two ? __builtin_ctzll(mask) : j0;
+    mask &= mask - 1;                                // no-op on 0
+    const GhHit h0 = gh_eval_hit(t, j0, pxf, pyf);
+    GhHit h1 = gh_eval_hit(t, j1, pxf, pyf);
+    h1.ok = h1.ok && two;
+    gh_blend_hit(h0, (uint32_t)(base + j0 + 1), p);
+    gh_blend_hit(h1, (uint32_t)(base + j1 + 1), p);
     if (__all(p.done)) return true;
   }
   return false;
 }
 
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
-    const uint2* __restrict__ ranges, const float4* __restrict__ r0, const float4* __restrict__ r1,
-    const float* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx, int tiles,
-    float* __restrict__ image, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
+    const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
+    int tiles, float* __restrict__ image, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
   int v, tx, ty;
-  gh_tile_coords(blockIdx.x, gx, tiles, v, tx, ty);
+  const int tile = (int)tile_order[blockIdx.x];      // heaviest tiles are launched first
+  gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int qx0 = tx * GH_TILE + (wid & 1) * 8, qy0 = ty * GH_TILE + (wid >> 1) * 8;
   const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
   const bool inside = x < W && y < H;
   const float pxf = (float)x, pyf = (float)y, fqx0 = (float)qx0, fqy0 = (float)qy0;
-  const uint2 range = ranges[blockIdx.x];
+  const uint2 range = ranges[tile];
   const int total = (int)(range.y - range.x);
   r0 += range.x; r1 += range.x; r2 += range.x;
 
@@ -133,32 +159,94 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, char* ws, const GhLayout& L,
                           hipStream_t s) {
   hipLaunchKernelGGL(gh_render_fwd_kernel, dim3(g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
-                     (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1), (const float*)(ws + L.inst_r2),
+                     (const uint32_t*)(ws + L.tile_order), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1), (const float*)(ws + L.inst_r2),
                      in->cams, g.H, g.W, g.gx, g.tiles, image, (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib));
 }
 
 // ------------------------------------------------------------------------------------------------
-#define GH_BCHUNK 128                      // instances combined across the 4 waves per barrier pair
-#define GH_BSUB (GH_BCHUNK / GH_WAVE)      // 64-entry register batches per chunk
+struct GhPixelBwd {
+  float T, last_alpha, lc0, lc1, lc2, ar0, ar1, ar2;
+};
 
+// Consume one staged batch back to front; for every Gaussian that at least one pixel of the quadrant
+// blended, lane 63 stores the wave-reduced 9-float partial record + its flag byte.
+__device__ __forceinline__ void gh_bwd_consume(const GhBatch& t, int sbase, int wave_last, int lane, float fqx0, float fqy0,
+                                               float pxf, float pyf, int last, float T_final, float bg_dot, float d0,
+                                               float d1, float d2, GhPixelBwd& p, const uint32_t* __restrict__ slots,
+                                               float* __restrict__ my_rec, uint8_t* __restrict__ my_flag) {
+  const int idx = sbase + lane;
+  uint64_t mask = __ballot((idx < wave_last) && gh_quadrant_hit(t.a, t.b, fqx0, fqy0));
+  if (mask == 0) return;
+  const uint32_t slot_l = (idx < wave_last) ? slots[idx] : 0u;
+  while (mask) {
+    const int j = 63 - __builtin_clzll(mask);          // back to front
+    mask &= ~(1ull << j);
+    const int pos = sbase + j;
+    const float gpx = gh_bcast(t.a.x, j), gpy = gh_bcast(t.a.y, j), cA = gh_bcast(t.a.z, j), cB = gh_bcast(t.a.w, j);
+    const float cC = gh_bcast(t.b.x, j), op = gh_bcast(t.b.y, j), cr = gh_bcast(t.b.z, j), cg = gh_bcast(t.b.w, j);
+    const float cbl = gh_bcast(t.cb, j);
+    const float dx = gpx - pxf, dy = gpy - pyf;
+    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+    const float G = gh_exp(fminf(power, 0.0f));
+    const float alpha = fminf(0.99f, op * G);
+    const bool contrib = (pos < last) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+    if (!__any(contrib)) continue;                      // wave-uniform
+    // per-lane state advances only where the pixel really blended this Gaussian
+    // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
+    const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+    const float Tn = p.T * inv1ma;
+    const float n0 = p.last_alpha * p.lc0 + (1.0f - p.last_alpha) * p.ar0;
+    const float n1 = p.last_alpha * p.lc1 + (1.0f - p.last_alpha) * p.ar1;
+    const float n2 = p.last_alpha * p.lc2 + (1.0f - p.last_alpha) * p.ar2;
+    float dL_dalpha = (cr - n0) * d0 + (cg - n1) * d1 + (cbl - n2) * d2;
+    dL_dalpha *= Tn;
+    dL_dalpha += (-T_final * inv1ma) * bg_dot;
+    const float dL_dG = op * dL_dalpha;                 // straight-through the 0.99 clamp (App. A.4-2)
+    const float gdx = G * dx, gdy = G * dy;
+    const float dchannel_dcolor = alpha * Tn;
+    float r[9];
+    r[0] = dL_dG * (-gdx * cA - gdy * cB);
+    r[1] = dL_dG * (-gdy * cC - gdx * cB);
+    r[2] = -0.5f * gdx * dx * dL_dG;
+    r[3] = -gdx * dy * dL_dG;
+    r[4] = -0.5f * gdy * dy * dL_dG;
+    r[5] = G * dL_dalpha;
+    r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) r[q] = gh_wave_sum_to63(contrib ? r[q] : 0.0f);
+    p.T = contrib ? Tn : p.T;
+    p.ar0 = contrib ? n0 : p.ar0; p.ar1 = contrib ? n1 : p.ar1; p.ar2 = contrib ? n2 : p.ar2;
+    p.lc0 = contrib ? cr : p.lc0; p.lc1 = contrib ? cg : p.lc1; p.lc2 = contrib ? cbl : p.lc2;
+    p.last_alpha = contrib ? alpha : p.last_alpha;
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)slot_l, j);
+    if (lane == 63) {
+      float4* rec = (float4*)(my_rec + (size_t)slot * (4 * GH_REC));
+      rec[0] = make_float4(r[0], r[1], r[2], r[3]);
+      rec[1] = make_float4(r[4], r[5], r[6], r[7]);
+      rec[2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
+      my_flag[(size_t)slot * 4] = 1;
+    }
+  }
+}
+
+// One wave per 8x8 quadrant, fully autonomous (no LDS, no barriers): the quadrant's partial record of
+// instance `slot` goes to inst_grad[slot][quadrant][0..8] and inst_flag[slot][quadrant] = 1 (flags are
+// zeroed per call). The per-Gaussian kernel adds the flagged sub-records in fixed (slot, quadrant) order.
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ sorted_slot, const float4* __restrict__ r0,
-    const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ sorted_slot,
+    const float4* __restrict__ r0, const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams,
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dimage, float* __restrict__ inst_grad) {
-  __shared__ float s_part[GH_BLOCK / GH_WAVE][GH_BCHUNK][GH_REC];     // per-wave partial records (24 KB)
-  __shared__ uint64_t s_touched[GH_BLOCK / GH_WAVE][GH_BSUB];         // which records a wave wrote
-  __shared__ int s_max;
+    const float* __restrict__ dL_dimage, float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag) {
   int v, tx, ty;
-  gh_tile_coords(blockIdx.x, gx, tiles, v, tx, ty);
+  const int tile = (int)tile_order[blockIdx.x];
+  gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int qx0 = tx * GH_TILE + (wid & 1) * 8, qy0 = ty * GH_TILE + (wid >> 1) * 8;
   const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
   const bool inside = x < W && y < H;
   const float pxf = (float)x, pyf = (float)y, fqx0 = (float)qx0, fqy0 = (float)qy0;
-  const uint2 range = ranges[blockIdx.x];
-  const int total = (int)(range.y - range.x);
-  if (total == 0) return;
+  const uint2 range = ranges[tile];
+  if (range.y == range.x) return;
   r0 += range.x; r1 += range.x; r2 += range.x;
   const uint32_t* slots = sorted_slot + range.x;
 
@@ -173,110 +261,35 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     d0 = dimg[0]; d1 = dimg[(size_t)H * W]; d2 = dimg[(size_t)2 * H * W];
   }
   const float bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
-  if (tid == 0) s_max = 0;
-  __syncthreads();
-  int wave_last = last;                    // max n_contrib of this quadrant
+  int wave_last = last;                    // list positions >= wave_last were blended by no pixel of this quadrant
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(wave_last, o); wave_last = t > wave_last ? t : wave_last; }
-  if (lane == 0) atomicMax(&s_max, wave_last);
-  __syncthreads();
-  const int max_last = s_max;              // list positions >= max_last were reached by no pixel of the tile
+  if (wave_last == 0) return;
 
-  // zero records for the unreached tail of the list
-  for (int k = max_last + tid; k < total; k += GH_BLOCK) {
-    float4* r = (float4*)(inst_grad + (size_t)slots[k] * GH_REC);
-    r[0] = make_float4(0, 0, 0, 0); r[1] = make_float4(0, 0, 0, 0); r[2] = make_float4(0, 0, 0, 0);
-  }
-
-  float T = T_final, last_alpha = 0.0f, lc0 = 0.0f, lc1 = 0.0f, lc2 = 0.0f, ar0 = 0.0f, ar1 = 0.0f, ar2 = 0.0f;
-  const int nchunks = (max_last + GH_BCHUNK - 1) / GH_BCHUNK;
-  for (int c = nchunks - 1; c >= 0; --c) {
-    const int cbase = c * GH_BCHUNK;
-    const int cnt = (max_last - cbase) < GH_BCHUNK ? (max_last - cbase) : GH_BCHUNK;
-#pragma unroll
-    for (int sub = GH_BSUB - 1; sub >= 0; --sub) {
-      const int sbase = cbase + sub * GH_WAVE;
-      uint64_t processed = 0;
-      if (sbase < wave_last) {             // wave-uniform: nothing of this batch was blended by this quadrant otherwise
-        const int idx = sbase + lane;
-        float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
-        float cb = 0.0f;
-        const bool have = idx < wave_last;
-        if (have) { a = r0[idx]; b = r1[idx]; cb = r2[idx]; }
-        uint64_t mask = __ballot(have && gh_quadrant_hit(a, b, fqx0, fqy0));
-        while (mask) {
-          const int j = 63 - __builtin_clzll(mask);          // back to front
-          mask &= ~(1ull << j);
-          const int pos = sbase + j;
-          const float gpx = gh_bcast(a.x, j), gpy = gh_bcast(a.y, j), cA = gh_bcast(a.z, j), cB = gh_bcast(a.w, j);
-          const float cC = gh_bcast(b.x, j), op = gh_bcast(b.y, j), cr = gh_bcast(b.z, j), cg = gh_bcast(b.w, j);
-          const float cbl = gh_bcast(cb, j);
-          const float dx = gpx - pxf, dy = gpy - pyf;
-          const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-          const float G = gh_exp(fminf(power, 0.0f));
-          const float alpha = fminf(0.99f, op * G);
-          const bool contrib = (pos < last) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-          if (!__any(contrib)) continue;                      // wave-uniform
-          processed |= 1ull << j;
-          // per-lane state advances only where the pixel really blended this Gaussian
-          const float Tn = T / (1.0f - alpha);
-          const float n0 = last_alpha * lc0 + (1.0f - last_alpha) * ar0;
-          const float n1 = last_alpha * lc1 + (1.0f - last_alpha) * ar1;
-          const float n2 = last_alpha * lc2 + (1.0f - last_alpha) * ar2;
-          float dL_dalpha = (cr - n0) * d0 + (cg - n1) * d1 + (cbl - n2) * d2;
-          dL_dalpha *= Tn;
-          dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
-          const float dL_dG = op * dL_dalpha;                 // straight-through the 0.99 clamp (App. A.4-2)
-          const float gdx = G * dx, gdy = G * dy;
-          const float dchannel_dcolor = alpha * Tn;
-          float r[9];
-          r[0] = dL_dG * (-gdx * cA - gdy * cB);
-          r[1] = dL_dG * (-gdy * cC - gdx * cB);
-          r[2] = -0.5f * gdx * dx * dL_dG;
-          r[3] = -gdx * dy * dL_dG;
-          r[4] = -0.5f * gdy * dy * dL_dG;
-          r[5] = G * dL_dalpha;
-          r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
-#pragma unroll
-          for (int q = 0; q < 9; ++q) r[q] = gh_wave_sum_to63(contrib ? r[q] : 0.0f);
-          T = contrib ? Tn : T;
-          ar0 = contrib ? n0 : ar0; ar1 = contrib ? n1 : ar1; ar2 = contrib ? n2 : ar2;
-          lc0 = contrib ? cr : lc0; lc1 = contrib ? cg : lc1; lc2 = contrib ? cbl : lc2;
-          last_alpha = contrib ? alpha : last_alpha;
-          if (lane == 63) {
-            float4* p = (float4*)&s_part[wid][sub * GH_WAVE + j][0];
-            p[0] = make_float4(r[0], r[1], r[2], r[3]);
-            p[1] = make_float4(r[4], r[5], r[6], r[7]);
-            s_part[wid][sub * GH_WAVE + j][8] = r[8];
-          }
-        }
-      }
-      if (lane == 0) s_touched[wid][sub] = processed;
-    }
-    __syncthreads();
-    if (tid < cnt) {
-      float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-      for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) {          // fixed wave order => reproducible sums
-        if ((s_touched[w][tid >> 6] >> (tid & 63)) & 1ull) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) s[q] += s_part[w][tid][q];
-        }
-      }
-      float4* rec = (float4*)(inst_grad + (size_t)slots[cbase + tid] * GH_REC);
-      rec[0] = make_float4(s[0], s[1], s[2], s[3]);
-      rec[1] = make_float4(s[4], s[5], s[6], s[7]);
-      rec[2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
-    }
-    __syncthreads();
+  GhPixelBwd p;
+  p.T = T_final; p.last_alpha = 0.0f; p.lc0 = p.lc1 = p.lc2 = 0.0f; p.ar0 = p.ar1 = p.ar2 = 0.0f;
+  float* my_rec = inst_grad + wid * GH_REC;
+  uint8_t* my_flag = inst_flag + wid;
+  // batches of 64 from the back; two register sets keep the next batch in flight
+  const int nb = (wave_last + GH_WAVE - 1) / GH_WAVE;
+  GhBatch A, B;
+  gh_load_batch(A, r0, r1, r2, (nb - 1) * GH_WAVE + lane, wave_last);
+  for (int k = nb - 1; k >= 0; k -= 2) {
+    if (k >= 1) gh_load_batch(B, r0, r1, r2, (k - 1) * GH_WAVE + lane, wave_last);
+    gh_bwd_consume(A, k * GH_WAVE, wave_last, lane, fqx0, fqy0, pxf, pyf, last, T_final, bg_dot, d0, d1, d2, p, slots, my_rec, my_flag);
+    if (k < 1) break;
+    if (k >= 2) gh_load_batch(A, r0, r1, r2, (k - 2) * GH_WAVE + lane, wave_last);
+    gh_bwd_consume(B, (k - 1) * GH_WAVE, wave_last, lane, fqx0, fqy0, pxf, pyf, last, T_final, bg_dot, d0, d1, d2, p, slots, my_rec, my_flag);
   }
 }
 
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage, char* ws,
                           const GhLayout& L, hipStream_t s) {
+  if (g.cap == 0) return;
+  (void)hipMemsetAsync(ws + L.inst_flag, 0, (size_t)g.cap * 4, s);
   hipLaunchKernelGGL(gh_render_bwd_kernel, dim3(g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
-                     (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
+                     (const uint32_t*)(ws + L.tile_order), (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
                      (const float*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles,
                      (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimage,
-                     (float*)(ws + L.inst_grad));
+                     (float*)(ws + L.inst_grad), (uint8_t*)(ws + L.inst_flag));
 }

@@ -140,9 +140,11 @@ typedef struct GhLayout {
   size_t inst_r2;        /* float [max_instances]                                   b                        */
   size_t sort_tables;    /* uint32[...]        per-pass digit tables */
   size_t ranges;         /* uint2 [n_views*tiles] [start,end) into the sorted list */
+  size_t tile_order;     /* uint32[n_views*tiles] launch order of the render blocks: longest tile lists first */
   size_t final_T;        /* float [n_views*H*W] */
   size_t n_contrib;      /* uint32[n_views*H*W] */
-  size_t inst_grad;      /* float[max_instances][12] per-instance gradient records (backward scratch) */
+  size_t inst_grad;      /* float[max_instances][4][12] per-(instance, quadrant) gradient sub-records (backward scratch) */
+  size_t inst_flag;      /* uint8[max_instances][4]     1 where the quadrant wrote its sub-record (zeroed per backward) */
   size_t bwd_scratch;    /* blend-parameter reduction scratch */
 } GhLayout;
 
