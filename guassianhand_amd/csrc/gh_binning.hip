@@ -276,7 +276,8 @@ __global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __rest
 }
 
 static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
-  gh_launch_tile_order(g, ws, L, s);
+  hipLaunchKernelGGL(gh_tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint2*)(ws + L.ranges), g.NV * g.tiles,
+                     (uint32_t*)(ws + L.tile_order));
 }
 
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
