@@ -47,7 +47,9 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->inst_r2 = take(cap * 4);
   L->sort_tables = take(((size_t)256 * g.nblk_sort + 256) * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
+  L->tile_walk = take((size_t)g.NV * g.tiles * 4);       // directly after ranges: both are cleared by one memset
   L->tile_order = take((size_t)g.NV * g.tiles * 4);
+  L->tile_order_bwd = take((size_t)g.NV * g.tiles * 4);
   L->final_T = take(pix * 4);
   L->n_contrib = take(pix * 4);
   L->inst_grad = take(cap * 4 * GH_REC * 4);
@@ -99,7 +101,7 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
     gh_launch_preprocess_fwd(d, g, in, out->radii, ws, L, s);
   }
   if (stages & GH_FWD_BINNING) {
-    if (hipMemsetAsync(ws + L.ranges, 0, (size_t)g.NV * g.tiles * 8, s) != hipSuccess) return GH_ERR_LAUNCH;
+    if (hipMemsetAsync(ws + L.ranges, 0, L.tile_order - L.ranges, s) != hipSuccess) return GH_ERR_LAUNCH;  // ranges + tile_walk
     gh_launch_binning(d, g, ws, L, s);
   }
   if (stages & GH_FWD_RENDER) gh_launch_render_fwd(d, g, in, out->image, ws, L, s);

@@ -238,16 +238,19 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint64_t* __r
 // length (256 buckets of 16 entries, longest first). Workgroups are dispatched in blockIdx order, so the heavy
 // tiles start at t=0 and the light / empty ones fill in behind them instead of forming the tail.
 // One block; the order inside a bucket is arbitrary (it only affects scheduling, never results).
-__global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int ntiles,
-                                                              uint32_t* __restrict__ order) {
+// The key is the tile's list length (forward) or, when `walk` is given, the number of list entries the forward
+// actually walked before every pixel saturated (backward: exact work proxy).
+__global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ walk,
+                                                              int ntiles, uint32_t* __restrict__ order) {
   __shared__ uint32_t s_cnt[256];
   __shared__ uint32_t s_w[4];
   const int tid = threadIdx.x;
   if (tid < 256) s_cnt[tid] = 0;
   __syncthreads();
   for (int t = tid; t < ntiles; t += 1024) {
-    const uint2 r = ranges[t];
-    uint32_t b = (r.y - r.x + 15u) >> 4; b = b > 255u ? 255u : b;
+    uint32_t len;
+    if (walk) len = walk[t]; else { const uint2 r = ranges[t]; len = r.y - r.x; }
+    uint32_t b = (len + 15u) >> 4; b = b > 255u ? 255u : b;
     atomicAdd(&s_cnt[255u - b], 1u);                 // bucket 0 = longest lists
   }
   __syncthreads();
@@ -269,15 +272,21 @@ __global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __rest
   }
   __syncthreads();
   for (int t = tid; t < ntiles; t += 1024) {
-    const uint2 r = ranges[t];
-    uint32_t b = (r.y - r.x + 15u) >> 4; b = b > 255u ? 255u : b;
+    uint32_t len;
+    if (walk) len = walk[t]; else { const uint2 r = ranges[t]; len = r.y - r.x; }
+    uint32_t b = (len + 15u) >> 4; b = b > 255u ? 255u : b;
     order[atomicAdd(&s_cnt[255u - b], 1u)] = (uint32_t)t;
   }
 }
 
 static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
-  hipLaunchKernelGGL(gh_tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint2*)(ws + L.ranges), g.NV * g.tiles,
-                     (uint32_t*)(ws + L.tile_order));
+  hipLaunchKernelGGL(gh_tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint2*)(ws + L.ranges), (const uint32_t*)nullptr,
+                     g.NV * g.tiles, (uint32_t*)(ws + L.tile_order));
+}
+
+void gh_launch_tile_order_bwd(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
+  hipLaunchKernelGGL(gh_tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint2*)(ws + L.ranges),
+                     (const uint32_t*)(ws + L.tile_walk), g.NV * g.tiles, (uint32_t*)(ws + L.tile_order_bwd));
 }
 
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {

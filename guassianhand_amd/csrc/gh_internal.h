@@ -36,6 +36,7 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
 void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii,
                               char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
+void gh_launch_tile_order_bwd(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image,
                           char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
@@ -50,7 +51,8 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
 // 2^(x*log2e): n = rne(t), Taylor-6 of 2^f on [-.5,.5], v_ldexp_f32.
 __device__ __forceinline__ float gh_exp(float x) {
   float t = x * 1.44269504088896341f;
-  if (t < -126.0f) return 0.0f;
+  const bool tiny = t < -126.0f;                 // result 0 (same as the oracle's early return), selected below
+  t = tiny ? -126.0f : t;                        // keep the straight-line code in range; no exec-mask branch
   float n = __builtin_rintf(t);
   float f = t - n;
   float p = 1.5403530393381608e-04f;
@@ -60,7 +62,8 @@ __device__ __forceinline__ float gh_exp(float x) {
   p = fmaf(p, f, 2.4022650695910072e-01f);
   p = fmaf(p, f, 6.9314718055994531e-01f);
   p = fmaf(p, f, 1.0f);
-  return ldexpf(p, (int)n);
+  const float r = ldexpf(p, (int)n);
+  return tiny ? 0.0f : r;
 }
 
 struct GhGeo {

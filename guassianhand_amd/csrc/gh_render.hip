@@ -52,8 +52,11 @@ struct GhBatch {          // 64 list entries staged in registers: lane l holds e
 
 __device__ __forceinline__ void gh_load_batch(GhBatch& t, const float4* __restrict__ r0, const float4* __restrict__ r1,
                                               const float* __restrict__ r2, int idx, int total) {
-  if (idx < total) { t.a = r0[idx]; t.b = r1[idx]; t.cb = r2[idx]; }
-  else { t.a = make_float4(0, 0, 0, 0); t.b = make_float4(0, 0, 0, 0); t.cb = 0.0f; }
+  // unconditional loads from a clamped index (total >= 1): no exec-mask branch, so the compiler can wait
+  // for exactly this batch (counted vmcnt) while the next one stays in flight. Entries >= total are
+  // masked out of the hit ballot by the callers.
+  const int i = idx < total ? idx : total - 1;
+  t.a = r0[i]; t.b = r1[i]; t.cb = r2[i];
 }
 
 struct GhPixelFwd {
@@ -117,7 +120,8 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
     const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
-    int tiles, float* __restrict__ image, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+    int tiles, float* __restrict__ image, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+    uint32_t* __restrict__ tile_walk) {
   int v, tx, ty;
   const int tile = (int)tile_order[blockIdx.x];      // heaviest tiles are launched first
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
@@ -144,6 +148,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       if (gh_fwd_consume(B, base + GH_WAVE, total, lane, fqx0, fqy0, pxf, pyf, p)) break;
     }
   }
+  if (total > 0) {                                   // walked length of the tile = max n_contrib (orders the backward)
+    uint32_t m = p.last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if (lane == 0 && m > 0) atomicMax(&tile_walk[tile], m);
+  }
   if (inside) {
     const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
     const size_t pix = ((size_t)v * H + y) * W + x;
@@ -160,7 +170,8 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                           hipStream_t s) {
   hipLaunchKernelGGL(gh_render_fwd_kernel, dim3(g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
                      (const uint32_t*)(ws + L.tile_order), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1), (const float*)(ws + L.inst_r2),
-                     in->cams, g.H, g.W, g.gx, g.tiles, image, (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib));
+                     in->cams, g.H, g.W, g.gx, g.tiles, image, (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
+                     (uint32_t*)(ws + L.tile_walk));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -168,64 +179,90 @@ struct GhPixelBwd {
   float T, last_alpha, lc0, lc1, lc2, ar0, ar1, ar2;
 };
 
-// Consume one staged batch back to front; for every Gaussian that at least one pixel of the quadrant
-// blended, lane 63 stores the wave-reduced 9-float partial record + its flag byte.
+struct GhBwdCtx {          // per-pixel constants of the reverse walk
+  float pxf, pyf, T_final, bg_dot, d0, d1, d2;
+  int last;
+};
+
+struct GhBwdEval {         // state-independent part of one (pixel, Gaussian) step
+  float cA, cB, cC, op, cr, cg, cbl, dx, dy, G, alpha, inv1ma;
+  bool contrib;
+};
+
+__device__ __forceinline__ GhBwdEval gh_bwd_eval(const GhBatch& t, int j, int pos, const GhBwdCtx& c) {
+  GhBwdEval e;
+  const float gpx = gh_bcast(t.a.x, j), gpy = gh_bcast(t.a.y, j);
+  e.cA = gh_bcast(t.a.z, j); e.cB = gh_bcast(t.a.w, j); e.cC = gh_bcast(t.b.x, j); e.op = gh_bcast(t.b.y, j);
+  e.cr = gh_bcast(t.b.z, j); e.cg = gh_bcast(t.b.w, j); e.cbl = gh_bcast(t.cb, j);
+  e.dx = gpx - c.pxf; e.dy = gpy - c.pyf;
+  const float power = -0.5f * (e.cA * e.dx * e.dx + e.cC * e.dy * e.dy) - e.cB * e.dx * e.dy;
+  e.G = gh_exp(fminf(power, 0.0f));
+  e.alpha = fminf(0.99f, e.op * e.G);
+  e.contrib = (pos < c.last) && (power <= 0.0f) && (e.alpha >= 1.0f / 255.0f);
+  // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
+  e.inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
+  return e;
+}
+
+// State-dependent part: advance the pixel's (T, colour-behind) recurrence, reduce the 9 partials over the
+// wave and let lane 63 store the quadrant's sub-record + flag byte.
+__device__ __forceinline__ void gh_bwd_apply(const GhBwdEval& e, const GhBwdCtx& c, GhPixelBwd& p, uint32_t slot, int lane,
+                                             float* __restrict__ my_rec, uint8_t* __restrict__ my_flag) {
+  const float Tn = p.T * e.inv1ma;
+  const float n0 = p.last_alpha * p.lc0 + (1.0f - p.last_alpha) * p.ar0;
+  const float n1 = p.last_alpha * p.lc1 + (1.0f - p.last_alpha) * p.ar1;
+  const float n2 = p.last_alpha * p.lc2 + (1.0f - p.last_alpha) * p.ar2;
+  float dL_dalpha = (e.cr - n0) * c.d0 + (e.cg - n1) * c.d1 + (e.cbl - n2) * c.d2;
+  dL_dalpha *= Tn;
+  dL_dalpha += (-c.T_final * e.inv1ma) * c.bg_dot;
+  const float dL_dG = e.op * dL_dalpha;                 // straight-through the 0.99 clamp (App. A.4-2)
+  const float gdx = e.G * e.dx, gdy = e.G * e.dy;
+  const float dchannel_dcolor = e.alpha * Tn;
+  float r[9];
+  r[0] = dL_dG * (-gdx * e.cA - gdy * e.cB);
+  r[1] = dL_dG * (-gdy * e.cC - gdx * e.cB);
+  r[2] = -0.5f * gdx * e.dx * dL_dG;
+  r[3] = -gdx * e.dy * dL_dG;
+  r[4] = -0.5f * gdy * e.dy * dL_dG;
+  r[5] = e.G * dL_dalpha;
+  r[6] = dchannel_dcolor * c.d0; r[7] = dchannel_dcolor * c.d1; r[8] = dchannel_dcolor * c.d2;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) r[q] = gh_wave_sum_to63(e.contrib ? r[q] : 0.0f);
+  // per-lane state advances only where the pixel really blended this Gaussian
+  p.T = e.contrib ? Tn : p.T;
+  p.ar0 = e.contrib ? n0 : p.ar0; p.ar1 = e.contrib ? n1 : p.ar1; p.ar2 = e.contrib ? n2 : p.ar2;
+  p.lc0 = e.contrib ? e.cr : p.lc0; p.lc1 = e.contrib ? e.cg : p.lc1; p.lc2 = e.contrib ? e.cbl : p.lc2;
+  p.last_alpha = e.contrib ? e.alpha : p.last_alpha;
+  if (lane == 63) {
+    float4* rec = (float4*)(my_rec + (size_t)slot * (4 * GH_REC));
+    rec[0] = make_float4(r[0], r[1], r[2], r[3]);
+    rec[1] = make_float4(r[4], r[5], r[6], r[7]);
+    rec[2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
+    my_flag[(size_t)slot * 4] = 1;
+  }
+}
+
+// Consume one staged batch back to front, two hits per trip (independent alpha evaluations overlap).
 __device__ __forceinline__ void gh_bwd_consume(const GhBatch& t, int sbase, int wave_last, int lane, float fqx0, float fqy0,
-                                               float pxf, float pyf, int last, float T_final, float bg_dot, float d0,
-                                               float d1, float d2, GhPixelBwd& p, const uint32_t* __restrict__ slots,
+                                               const GhBwdCtx& c, GhPixelBwd& p, const uint32_t* __restrict__ slots,
                                                float* __restrict__ my_rec, uint8_t* __restrict__ my_flag) {
   const int idx = sbase + lane;
   uint64_t mask = __ballot((idx < wave_last) && gh_quadrant_hit(t.a, t.b, fqx0, fqy0));
   if (mask == 0) return;
-  const uint32_t slot_l = (idx < wave_last) ? slots[idx] : 0u;
+  const uint32_t slot_l = slots[idx < wave_last ? idx : wave_last - 1];
   while (mask) {
-    const int j = 63 - __builtin_clzll(mask);          // back to front
-    mask &= ~(1ull << j);
-    const int pos = sbase + j;
-    const float gpx = gh_bcast(t.a.x, j), gpy = gh_bcast(t.a.y, j), cA = gh_bcast(t.a.z, j), cB = gh_bcast(t.a.w, j);
-    const float cC = gh_bcast(t.b.x, j), op = gh_bcast(t.b.y, j), cr = gh_bcast(t.b.z, j), cg = gh_bcast(t.b.w, j);
-    const float cbl = gh_bcast(t.cb, j);
-    const float dx = gpx - pxf, dy = gpy - pyf;
-    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-    const float G = gh_exp(fminf(power, 0.0f));
-    const float alpha = fminf(0.99f, op * G);
-    const bool contrib = (pos < last) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-    if (!__any(contrib)) continue;                      // wave-uniform
-    // per-lane state advances only where the pixel really blended this Gaussian
-    // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
-    const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
-    const float Tn = p.T * inv1ma;
-    const float n0 = p.last_alpha * p.lc0 + (1.0f - p.last_alpha) * p.ar0;
-    const float n1 = p.last_alpha * p.lc1 + (1.0f - p.last_alpha) * p.ar1;
-    const float n2 = p.last_alpha * p.lc2 + (1.0f - p.last_alpha) * p.ar2;
-    float dL_dalpha = (cr - n0) * d0 + (cg - n1) * d1 + (cbl - n2) * d2;
-    dL_dalpha *= Tn;
-    dL_dalpha += (-T_final * inv1ma) * bg_dot;
-    const float dL_dG = op * dL_dalpha;                 // straight-through the 0.99 clamp (App. A.4-2)
-    const float gdx = G * dx, gdy = G * dy;
-    const float dchannel_dcolor = alpha * Tn;
-    float r[9];
-    r[0] = dL_dG * (-gdx * cA - gdy * cB);
-    r[1] = dL_dG * (-gdy * cC - gdx * cB);
-    r[2] = -0.5f * gdx * dx * dL_dG;
-    r[3] = -gdx * dy * dL_dG;
-    r[4] = -0.5f * gdy * dy * dL_dG;
-    r[5] = G * dL_dalpha;
-    r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) r[q] = gh_wave_sum_to63(contrib ? r[q] : 0.0f);
-    p.T = contrib ? Tn : p.T;
-    p.ar0 = contrib ? n0 : p.ar0; p.ar1 = contrib ? n1 : p.ar1; p.ar2 = contrib ? n2 : p.ar2;
-    p.lc0 = contrib ? cr : p.lc0; p.lc1 = contrib ? cg : p.lc1; p.lc2 = contrib ? cbl : p.lc2;
-    p.last_alpha = contrib ? alpha : p.last_alpha;
-    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)slot_l, j);
-    if (lane == 63) {
-      float4* rec = (float4*)(my_rec + (size_t)slot * (4 * GH_REC));
-      rec[0] = make_float4(r[0], r[1], r[2], r[3]);
-      rec[1] = make_float4(r[4], r[5], r[6], r[7]);
-      rec[2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
-      my_flag[(size_t)slot * 4] = 1;
-    }
+    const int j0 = 63 - __builtin_clzll(mask);          // back to front
+    mask &= ~(1ull << j0);
+    const bool two = mask != 0;
+    const int j1 = two ? 63 - __builtin_clzll(mask) : j0;
+    if (two) mask &= ~(1ull << j1);
+    const GhBwdEval e0 = gh_bwd_eval(t, j0, sbase + j0, c);
+    GhBwdEval e1 = gh_bwd_eval(t, j1, sbase + j1, c);
+    e1.contrib = e1.contrib && two;
+    if (__any(e0.contrib))                               // wave-uniform
+      gh_bwd_apply(e0, c, p, (uint32_t)__builtin_amdgcn_readlane((int)slot_l, j0), lane, my_rec, my_flag);
+    if (__any(e1.contrib))
+      gh_bwd_apply(e1, c, p, (uint32_t)__builtin_amdgcn_readlane((int)slot_l, j1), lane, my_rec, my_flag);
   }
 }
 
@@ -260,7 +297,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const float* dimg = dL_dimage + (size_t)v * 3 * H * W + (size_t)y * W + x;
     d0 = dimg[0]; d1 = dimg[(size_t)H * W]; d2 = dimg[(size_t)2 * H * W];
   }
-  const float bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
+  GhBwdCtx c;
+  c.pxf = pxf; c.pyf = pyf; c.T_final = T_final; c.d0 = d0; c.d1 = d1; c.d2 = d2; c.last = last;
+  c.bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
   int wave_last = last;                    // list positions >= wave_last were blended by no pixel of this quadrant
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(wave_last, o); wave_last = t > wave_last ? t : wave_last; }
@@ -276,10 +315,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   gh_load_batch(A, r0, r1, r2, (nb - 1) * GH_WAVE + lane, wave_last);
   for (int k = nb - 1; k >= 0; k -= 2) {
     if (k >= 1) gh_load_batch(B, r0, r1, r2, (k - 1) * GH_WAVE + lane, wave_last);
-    gh_bwd_consume(A, k * GH_WAVE, wave_last, lane, fqx0, fqy0, pxf, pyf, last, T_final, bg_dot, d0, d1, d2, p, slots, my_rec, my_flag);
+    gh_bwd_consume(A, k * GH_WAVE, wave_last, lane, fqx0, fqy0, c, p, slots, my_rec, my_flag);
     if (k < 1) break;
     if (k >= 2) gh_load_batch(A, r0, r1, r2, (k - 2) * GH_WAVE + lane, wave_last);
-    gh_bwd_consume(B, (k - 1) * GH_WAVE, wave_last, lane, fqx0, fqy0, pxf, pyf, last, T_final, bg_dot, d0, d1, d2, p, slots, my_rec, my_flag);
+    gh_bwd_consume(B, (k - 1) * GH_WAVE, wave_last, lane, fqx0, fqy0, c, p, slots, my_rec, my_flag);
   }
 }
 
@@ -287,8 +326,9 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                           const GhLayout& L, hipStream_t s) {
   if (g.cap == 0) return;
   (void)hipMemsetAsync(ws + L.inst_flag, 0, (size_t)g.cap * 4, s);
+  gh_launch_tile_order_bwd(g, ws, L, s);
   hipLaunchKernelGGL(gh_render_bwd_kernel, dim3(g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
-                     (const uint32_t*)(ws + L.tile_order), (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
+                     (const uint32_t*)(ws + L.tile_order_bwd), (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
                      (const float*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles,
                      (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimage,
                      (float*)(ws + L.inst_grad), (uint8_t*)(ws + L.inst_flag));

@@ -140,7 +140,9 @@ typedef struct GhLayout {
   size_t inst_r2;        /* float [max_instances]                                   b                        */
   size_t sort_tables;    /* uint32[...]        per-pass digit tables */
   size_t ranges;         /* uint2 [n_views*tiles] [start,end) into the sorted list */
-  size_t tile_order;     /* uint32[n_views*tiles] launch order of the render blocks: longest tile lists first */
+  size_t tile_walk;      /* uint32[n_views*tiles] list entries actually walked by the forward (max n_contrib of the tile) */
+  size_t tile_order;     /* uint32[n_views*tiles] forward launch order of the render blocks: longest tile lists first */
+  size_t tile_order_bwd; /* uint32[n_views*tiles] backward launch order: longest walked lists first */
   size_t final_T;        /* float [n_views*H*W] */
   size_t n_contrib;      /* uint32[n_views*H*W] */
   size_t inst_grad;      /* float[max_instances][4][12] per-(instance, quadrant) gradient sub-records (backward scratch) */
