@@ -29,10 +29,10 @@ __device__ __forceinline__ float gh_bcast(float v, int lane) {   // lane is wave
 }
 
 // Conservative test: can Gaussian (g0 = px,py,A,B; g1 = C,opacity,..) reach alpha >= 1/255 anywhere in the
-// 8x8 pixel block whose first pixel is (qx0,qy0)? alpha >= 1/255  <=>  d^T Q d <= 2 ln(255 o); the axis-aligned
+// pixel block [qx0, qx0+ext] x [qy0, qy0+ext]? alpha >= 1/255  <=>  d^T Q d <= 2 ln(255 o); the axis-aligned
 // extent of that ellipse is sqrt(2 tau Q^-1_xx), sqrt(2 tau Q^-1_yy). Margins absorb the approximate log/sqrt;
 // anything non-finite answers "hit". A false "hit" only costs time, never changes a pixel.
-__device__ __forceinline__ bool gh_quadrant_hit(const float4& g0, const float4& g1, float qx0, float qy0) {
+__device__ __forceinline__ bool gh_block_hit(const float4& g0, const float4& g1, float qx0, float qy0, float ext) {
   const float o = g1.y;
   if (!(o >= 1.0f / 255.0f)) return false;          // alpha = min(.99, o*exp(p<=0)) <= o < 1/255 everywhere
   const float tau = __logf(255.0f * o) * 1.0001f + 1e-3f;
@@ -40,8 +40,11 @@ __device__ __forceinline__ bool gh_quadrant_hit(const float4& g0, const float4& 
   const float k = 2.0f * tau / det;
   const float hx = __builtin_amdgcn_sqrtf(k * g1.x) * 1.001f + 0.02f;
   const float hy = __builtin_amdgcn_sqrtf(k * g0.z) * 1.001f + 0.02f;
-  const bool miss = (g0.x + hx < qx0) || (g0.x - hx > qx0 + 7.0f) || (g0.y + hy < qy0) || (g0.y - hy > qy0 + 7.0f);
+  const bool miss = (g0.x + hx < qx0) || (g0.x - hx > qx0 + ext) || (g0.y + hy < qy0) || (g0.y - hy > qy0 + ext);
   return !miss;                                       // NaN extents compare false -> hit
+}
+__device__ __forceinline__ bool gh_quadrant_hit(const float4& g0, const float4& g1, float qx0, float qy0) {
+  return gh_block_hit(g0, g1, qx0, qy0, 7.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -59,93 +62,111 @@ __device__ __forceinline__ void gh_load_batch(GhBatch& t, const float4* __restri
   t.a = r0[i]; t.b = r1[i]; t.cb = r2[i];
 }
 
+// ---- forward: wave = 4x4 pixels x 4 depth slots ---------------------------------------------------------
+// lane = 4*pixel + slot. Per trip the wave takes the next (up to) four surviving list entries; slot s of every
+// pixel evaluates entry s (alpha evaluation is the expensive, state-independent part and runs 4-wide), then the
+// T / colour recurrence is applied in list order by walking the quad: step s computes the blend for every lane
+// and quad_perm-broadcasts slot s's result, so all four lanes of a pixel always hold the pixel's current state.
+// Arithmetic per pixel is exactly the sequential recurrence of App. A.3 (same operations, same order).
 struct GhPixelFwd {
   float T, C0, C1, C2;
   uint32_t last;
-  bool done;
+  int done;               // 0 / 1 (kept as int so it can travel through DPP)
 };
 
-struct GhHit {            // one Gaussian broadcast to the whole wave (SGPRs) + its per-pixel alpha
-  float r, g, b, alpha;
-  bool ok;                // power <= 0 && alpha >= 1/255 for this pixel
-};
-
-__device__ __forceinline__ GhHit gh_eval_hit(const GhBatch& t, int j, float pxf, float pyf) {
-  const float gpx = gh_bcast(t.a.x, j), gpy = gh_bcast(t.a.y, j), cA = gh_bcast(t.a.z, j), cB = gh_bcast(t.a.w, j);
-  const float cC = gh_bcast(t.b.x, j), op = gh_bcast(t.b.y, j);
-  GhHit h;
-  h.r = gh_bcast(t.b.z, j); h.g = gh_bcast(t.b.w, j); h.b = gh_bcast(t.cb, j);
-  const float dx = gpx - pxf, dy = gpy - pyf;
-  const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-  h.alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
-  h.ok = (power <= 0.0f) && (h.alpha >= 1.0f / 255.0f);
-  return h;
+template <int S>
+__device__ __forceinline__ float gh_quad_bcast(float v) {     // value of the quad's lane S, in all 4 lanes
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), S * 0x55, 0xF, 0xF, false));
+}
+template <int S>
+__device__ __forceinline__ int gh_quad_bcast_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xF, 0xF, false);
 }
 
-__device__ __forceinline__ void gh_blend_hit(const GhHit& h, uint32_t pos1, GhPixelFwd& p) {
-  const bool valid = !p.done && h.ok;
-  const float test_T = p.T * (1.0f - h.alpha);
+__device__ __forceinline__ float gh_lane_fetch(float v, int src_lane_x4) {   // per-lane source (LDS crossbar, no LDS memory)
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane_x4, __builtin_bit_cast(int, v)));
+}
+
+template <int S>
+__device__ __forceinline__ void gh_fwd_chain_step(GhPixelFwd& p, float alpha, bool ok, float r, float g, float b, uint32_t pos1) {
+  const bool valid = (p.done == 0) && ok;
+  const float test_T = p.T * (1.0f - alpha);
   const bool stop = valid && (test_T < 0.0001f);
   const bool blend = valid && !stop;
-  const float w = blend ? h.alpha * p.T : 0.0f;     // fma(c, 0, C) == C exactly: masked lanes keep their bits
-  p.C0 = fmaf(h.r, w, p.C0); p.C1 = fmaf(h.g, w, p.C1); p.C2 = fmaf(h.b, w, p.C2);
-  p.T = blend ? test_T : p.T;
-  p.last = blend ? pos1 : p.last;
-  p.done = p.done || stop;
+  const float w = blend ? alpha * p.T : 0.0f;       // fma(c, 0, C) == C exactly: masked lanes keep their bits
+  const float nC0 = fmaf(r, w, p.C0), nC1 = fmaf(g, w, p.C1), nC2 = fmaf(b, w, p.C2);
+  const float nT = blend ? test_T : p.T;
+  const uint32_t nlast = blend ? pos1 : p.last;
+  const int ndone = (p.done != 0 || stop) ? 1 : 0;
+  p.T = gh_quad_bcast<S>(nT);
+  p.C0 = gh_quad_bcast<S>(nC0); p.C1 = gh_quad_bcast<S>(nC1); p.C2 = gh_quad_bcast<S>(nC2);
+  p.last = (uint32_t)gh_quad_bcast_i<S>((int)nlast);
+  p.done = gh_quad_bcast_i<S>(ndone);
 }
 
-// Consume one staged batch front to back, two hits per trip: their alpha evaluations are independent
-// (ILP for a wave that is alone on its SIMD); only the T / done update is sequential.
-// Returns true when every pixel of the wave is finished.
-__device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, float fqx0, float fqy0,
+// Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
+__device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, float fbx0, float fby0,
                                                float pxf, float pyf, GhPixelFwd& p) {
-  const bool hit = (base + lane < total) && gh_quadrant_hit(t.a, t.b, fqx0, fqy0);
+  const bool hit = (base + lane < total) && gh_block_hit(t.a, t.b, fbx0, fby0, 3.0f);
   uint64_t mask = __ballot(hit);
   while (mask) {
-    const int j0 = __builtin_ctzll(mask);
-    mask &= mask - 1;
-    const bool two = mask != 0;                      // wave-uniform
-    const int j1 = two ? __builtin_ctzll(mask) : j0;
-    mask &= mask - 1;                                // no-op on 0
-    const GhHit h0 = gh_eval_hit(t, j0, pxf, pyf);
-    GhHit h1 = gh_eval_hit(t, j1, pxf, pyf);
-    h1.ok = h1.ok && two;
-    gh_blend_hit(h0, (uint32_t)(base + j0 + 1), p);
-    gh_blend_hit(h1, (uint32_t)(base + j1 + 1), p);
-    if (__all(p.done)) return true;
+    // next four set bits, ascending (wave-uniform scalar work)
+    const int j0 = __builtin_ctzll(mask); mask &= mask - 1;
+    const int n1 = mask != 0; const int j1 = n1 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
+    const int n2 = mask != 0; const int j2 = n2 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
+    const int n3 = mask != 0; const int j3 = n3 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
+    const int myj = slot == 0 ? j0 : (slot == 1 ? j1 : (slot == 2 ? j2 : j3));
+    const bool have = slot == 0 || (slot == 1 && n1) || (slot == 2 && n2) || (slot == 3 && n3);
+    const int src = myj << 2;
+    const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
+    const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src), op = gh_lane_fetch(t.b.y, src);
+    const float r = gh_lane_fetch(t.b.z, src), g = gh_lane_fetch(t.b.w, src), bl = gh_lane_fetch(t.cb, src);
+    const float dx = gpx - pxf, dy = gpy - pyf;
+    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+    const float alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
+    const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+    const uint32_t pos1 = (uint32_t)(base + myj + 1);
+    gh_fwd_chain_step<0>(p, alpha, ok, r, g, bl, pos1);
+    gh_fwd_chain_step<1>(p, alpha, ok, r, g, bl, pos1);
+    gh_fwd_chain_step<2>(p, alpha, ok, r, g, bl, pos1);
+    gh_fwd_chain_step<3>(p, alpha, ok, r, g, bl, pos1);
+    if (__all(p.done != 0)) return true;
   }
   return false;
 }
 
+// grid = 4 blocks per tile (one per 8x8 quadrant), 4 waves per block (one per 4x4 pixel block); no LDS, no barriers.
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
     const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
     int tiles, float* __restrict__ image, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
     uint32_t* __restrict__ tile_walk) {
   int v, tx, ty;
-  const int tile = (int)tile_order[blockIdx.x];      // heaviest tiles are launched first
+  const int tile = (int)tile_order[blockIdx.x >> 2];      // heaviest tiles are launched first
+  const int quad = blockIdx.x & 3;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int qx0 = tx * GH_TILE + (wid & 1) * 8, qy0 = ty * GH_TILE + (wid >> 1) * 8;
-  const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
+  const int slot = lane & 3, pi = lane >> 2;
+  const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (wid & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (wid >> 1) * 4;
+  const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
   const bool inside = x < W && y < H;
-  const float pxf = (float)x, pyf = (float)y, fqx0 = (float)qx0, fqy0 = (float)qy0;
+  const float pxf = (float)x, pyf = (float)y, fbx0 = (float)bx0, fby0 = (float)by0;
   const uint2 range = ranges[tile];
   const int total = (int)(range.y - range.x);
   r0 += range.x; r1 += range.x; r2 += range.x;
 
   GhPixelFwd p;
-  p.T = 1.0f; p.C0 = p.C1 = p.C2 = 0.0f; p.last = 0; p.done = !inside;
-  if (total > 0 && !__all(p.done)) {
+  p.T = 1.0f; p.C0 = p.C1 = p.C2 = 0.0f; p.last = 0; p.done = inside ? 0 : 1;
+  if (total > 0 && !__all(p.done != 0)) {
     // two register sets in flight: while one batch is consumed the next one is already being loaded
     GhBatch A, B;
     gh_load_batch(A, r0, r1, r2, lane, total);
     for (int base = 0; base < total; base += 2 * GH_WAVE) {
       gh_load_batch(B, r0, r1, r2, base + GH_WAVE + lane, total);
-      if (gh_fwd_consume(A, base, total, lane, fqx0, fqy0, pxf, pyf, p)) break;
+      if (gh_fwd_consume(A, base, total, lane, slot, fbx0, fby0, pxf, pyf, p)) break;
       if (base + GH_WAVE >= total) break;
       gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
-      if (gh_fwd_consume(B, base + GH_WAVE, total, lane, fqx0, fqy0, pxf, pyf, p)) break;
+      if (gh_fwd_consume(B, base + GH_WAVE, total, lane, slot, fbx0, fby0, pxf, pyf, p)) break;
     }
   }
   if (total > 0) {                                   // walked length of the tile = max n_contrib (orders the backward)
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m; }
     if (lane == 0 && m > 0) atomicMax(&tile_walk[tile], m);
   }
-  if (inside) {
+  if (inside && slot == 0) {
     const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
     const size_t pix = ((size_t)v * H + y) * W + x;
     final_T[pix] = p.T;
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
 
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, char* ws, const GhLayout& L,
                           hipStream_t s) {
-  hipLaunchKernelGGL(gh_render_fwd_kernel, dim3(g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
+  hipLaunchKernelGGL(gh_render_fwd_kernel, dim3(4 * g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
                      (const uint32_t*)(ws + L.tile_order), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1), (const float*)(ws + L.inst_r2),
                      in->cams, g.H, g.W, g.gx, g.tiles, image, (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
                      (uint32_t*)(ws + L.tile_walk));
