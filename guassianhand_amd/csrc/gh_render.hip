@@ -196,113 +196,56 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 }
 
 // ------------------------------------------------------------------------------------------------
-struct GhPixelBwd {
-  float T, last_alpha, lc0, lc1, lc2, ar0, ar1, ar2;
-};
+// ---- backward: wave = 4x4 pixels x 4 depth slots, block = one 8x8 quadrant ----------------------------------
+// Same lane mapping as the forward (lane = 4*pixel + slot); entries are taken four per trip from the back.
+// Per pixel the reverse recurrence carries only (T, colour-behind B): after blending entry k,
+// B <- alpha_k*c_k + (1-alpha_k)*B, which is the oracle's lazily evaluated `accum` computed one step earlier on
+// the same operands. The recurrence walks the quad with quad_perm broadcasts; every lane keeps the state that
+// was current at ITS slot and then evaluates its nine partial gradients once. They are summed over the 16 pixels
+// of the slot (row_shr:4, row_shr:8, then xor-16 / xor-32 through the LDS crossbar) and the four waves of the
+// quadrant are combined through a double-buffered LDS stage, one barrier per 64 list entries, in fixed wave
+// order: lane l of the flushing wave owns entry l and writes the quadrant's sub-record + flag byte.
+struct GhStateBwd { float T, B0, B1, B2; };
 
-struct GhBwdCtx {          // per-pixel constants of the reverse walk
-  float pxf, pyf, T_final, bg_dot, d0, d1, d2;
-  int last;
-};
-
-struct GhBwdEval {         // state-independent part of one (pixel, Gaussian) step
-  float cA, cB, cC, op, cr, cg, cbl, dx, dy, G, alpha, inv1ma;
-  bool contrib;
-};
-
-__device__ __forceinline__ GhBwdEval gh_bwd_eval(const GhBatch& t, int j, int pos, const GhBwdCtx& c) {
-  GhBwdEval e;
-  const float gpx = gh_bcast(t.a.x, j), gpy = gh_bcast(t.a.y, j);
-  e.cA = gh_bcast(t.a.z, j); e.cB = gh_bcast(t.a.w, j); e.cC = gh_bcast(t.b.x, j); e.op = gh_bcast(t.b.y, j);
-  e.cr = gh_bcast(t.b.z, j); e.cg = gh_bcast(t.b.w, j); e.cbl = gh_bcast(t.cb, j);
-  e.dx = gpx - c.pxf; e.dy = gpy - c.pyf;
-  const float power = -0.5f * (e.cA * e.dx * e.dx + e.cC * e.dy * e.dy) - e.cB * e.dx * e.dy;
-  e.G = gh_exp(fminf(power, 0.0f));
-  e.alpha = fminf(0.99f, e.op * e.G);
-  e.contrib = (pos < c.last) && (power <= 0.0f) && (e.alpha >= 1.0f / 255.0f);
-  // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
-  e.inv1ma = __builtin_amdgcn_rcpf(1.0f - e.alpha);
-  return e;
+template <int S>
+__device__ __forceinline__ void gh_bwd_chain_step(GhStateBwd& st, int slot, bool contrib, float alpha, float inv1ma, float cr,
+                                                  float cg, float cbl, float& mTn, float& mB0, float& mB1, float& mB2) {
+  const float Tn = st.T * inv1ma;
+  const float oma = 1.0f - alpha;
+  const float nB0 = alpha * cr + oma * st.B0, nB1 = alpha * cg + oma * st.B1, nB2 = alpha * cbl + oma * st.B2;
+  if (slot == S) { mTn = Tn; mB0 = st.B0; mB1 = st.B1; mB2 = st.B2; }      // state seen by this lane's entry
+  st.T = gh_quad_bcast<S>(contrib ? Tn : st.T);
+  st.B0 = gh_quad_bcast<S>(contrib ? nB0 : st.B0);
+  st.B1 = gh_quad_bcast<S>(contrib ? nB1 : st.B1);
+  st.B2 = gh_quad_bcast<S>(contrib ? nB2 : st.B2);
 }
 
-// State-dependent part: advance the pixel's (T, colour-behind) recurrence, reduce the 9 partials over the
-// wave and let lane 63 store the quadrant's sub-record + flag byte.
-__device__ __forceinline__ void gh_bwd_apply(const GhBwdEval& e, const GhBwdCtx& c, GhPixelBwd& p, uint32_t slot, int lane,
-                                             float* __restrict__ my_rec, uint8_t* __restrict__ my_flag) {
-  const float Tn = p.T * e.inv1ma;
-  const float n0 = p.last_alpha * p.lc0 + (1.0f - p.last_alpha) * p.ar0;
-  const float n1 = p.last_alpha * p.lc1 + (1.0f - p.last_alpha) * p.ar1;
-  const float n2 = p.last_alpha * p.lc2 + (1.0f - p.last_alpha) * p.ar2;
-  float dL_dalpha = (e.cr - n0) * c.d0 + (e.cg - n1) * c.d1 + (e.cbl - n2) * c.d2;
-  dL_dalpha *= Tn;
-  dL_dalpha += (-c.T_final * e.inv1ma) * c.bg_dot;
-  const float dL_dG = e.op * dL_dalpha;                 // straight-through the 0.99 clamp (App. A.4-2)
-  const float gdx = e.G * e.dx, gdy = e.G * e.dy;
-  const float dchannel_dcolor = e.alpha * Tn;
-  float r[9];
-  r[0] = dL_dG * (-gdx * e.cA - gdy * e.cB);
-  r[1] = dL_dG * (-gdy * e.cC - gdx * e.cB);
-  r[2] = -0.5f * gdx * e.dx * dL_dG;
-  r[3] = -gdx * e.dy * dL_dG;
-  r[4] = -0.5f * gdy * e.dy * dL_dG;
-  r[5] = e.G * dL_dalpha;
-  r[6] = dchannel_dcolor * c.d0; r[7] = dchannel_dcolor * c.d1; r[8] = dchannel_dcolor * c.d2;
-#pragma unroll
-  for (int q = 0; q < 9; ++q) r[q] = gh_wave_sum_to63(e.contrib ? r[q] : 0.0f);
-  // per-lane state advances only where the pixel really blended this Gaussian
-  p.T = e.contrib ? Tn : p.T;
-  p.ar0 = e.contrib ? n0 : p.ar0; p.ar1 = e.contrib ? n1 : p.ar1; p.ar2 = e.contrib ? n2 : p.ar2;
-  p.lc0 = e.contrib ? e.cr : p.lc0; p.lc1 = e.contrib ? e.cg : p.lc1; p.lc2 = e.contrib ? e.cbl : p.lc2;
-  p.last_alpha = e.contrib ? e.alpha : p.last_alpha;
-  if (lane == 63) {
-    float4* rec = (float4*)(my_rec + (size_t)slot * (4 * GH_REC));
-    rec[0] = make_float4(r[0], r[1], r[2], r[3]);
-    rec[1] = make_float4(r[4], r[5], r[6], r[7]);
-    rec[2] = make_float4(r[8], 0.0f, 0.0f, 0.0f);
-    my_flag[(size_t)slot * 4] = 1;
-  }
+__device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum over the 16 pixels of this lane's slot
+  v += gh_dpp<0x114>(v);                                              // row_shr:4
+  v += gh_dpp<0x118>(v);                                              // row_shr:8 -> lanes 12..15 of each row: row sums
+  v += gh_lane_fetch(v, (lane ^ 16) << 2);
+  v += gh_lane_fetch(v, (lane ^ 32) << 2);                            // lanes 12..15 (+16k): totals per slot
+  return v;
 }
 
-// Consume one staged batch back to front, two hits per trip (independent alpha evaluations overlap).
-__device__ __forceinline__ void gh_bwd_consume(const GhBatch& t, int sbase, int wave_last, int lane, float fqx0, float fqy0,
-                                               const GhBwdCtx& c, GhPixelBwd& p, const uint32_t* __restrict__ slots,
-                                               float* __restrict__ my_rec, uint8_t* __restrict__ my_flag) {
-  const int idx = sbase + lane;
-  uint64_t mask = __ballot((idx < wave_last) && gh_quadrant_hit(t.a, t.b, fqx0, fqy0));
-  if (mask == 0) return;
-  const uint32_t slot_l = slots[idx < wave_last ? idx : wave_last - 1];
-  while (mask) {
-    const int j0 = 63 - __builtin_clzll(mask);          // back to front
-    mask &= ~(1ull << j0);
-    const bool two = mask != 0;
-    const int j1 = two ? 63 - __builtin_clzll(mask) : j0;
-    if (two) mask &= ~(1ull << j1);
-    const GhBwdEval e0 = gh_bwd_eval(t, j0, sbase + j0, c);
-    GhBwdEval e1 = gh_bwd_eval(t, j1, sbase + j1, c);
-    e1.contrib = e1.contrib && two;
-    if (__any(e0.contrib))                               // wave-uniform
-      gh_bwd_apply(e0, c, p, (uint32_t)__builtin_amdgcn_readlane((int)slot_l, j0), lane, my_rec, my_flag);
-    if (__any(e1.contrib))
-      gh_bwd_apply(e1, c, p, (uint32_t)__builtin_amdgcn_readlane((int)slot_l, j1), lane, my_rec, my_flag);
-  }
-}
-
-// One wave per 8x8 quadrant, fully autonomous (no LDS, no barriers): the quadrant's partial record of
-// instance `slot` goes to inst_grad[slot][quadrant][0..8] and inst_flag[slot][quadrant] = 1 (flags are
-// zeroed per call). The per-Gaussian kernel adds the flagged sub-records in fixed (slot, quadrant) order.
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ sorted_slot,
     const float4* __restrict__ r0, const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams,
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimage, float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag) {
+  __shared__ float s_part[2][GH_BLOCK / GH_WAVE][GH_WAVE][GH_REC];    // [buffer][wave][entry][9 used]  (24 KB)
+  __shared__ uint64_t s_mask[2][GH_BLOCK / GH_WAVE];                  // entries a wave wrote
+  __shared__ int s_qlast;
   int v, tx, ty;
-  const int tile = (int)tile_order[blockIdx.x];
+  const int tile = (int)tile_order[blockIdx.x >> 2];
+  const int quad = blockIdx.x & 3;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int qx0 = tx * GH_TILE + (wid & 1) * 8, qy0 = ty * GH_TILE + (wid >> 1) * 8;
-  const int x = qx0 + (lane & 7), y = qy0 + (lane >> 3);
+  const int slot = lane & 3, pi = lane >> 2;
+  const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (wid & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (wid >> 1) * 4;
+  const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
   const bool inside = x < W && y < H;
-  const float pxf = (float)x, pyf = (float)y, fqx0 = (float)qx0, fqy0 = (float)qy0;
+  const float pxf = (float)x, pyf = (float)y, fbx0 = (float)bx0, fby0 = (float)by0;
   const uint2 range = ranges[tile];
   if (range.y == range.x) return;
   r0 += range.x; r1 += range.x; r2 += range.x;
@@ -318,28 +261,111 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const float* dimg = dL_dimage + (size_t)v * 3 * H * W + (size_t)y * W + x;
     d0 = dimg[0]; d1 = dimg[(size_t)H * W]; d2 = dimg[(size_t)2 * H * W];
   }
-  GhBwdCtx c;
-  c.pxf = pxf; c.pyf = pyf; c.T_final = T_final; c.d0 = d0; c.d1 = d1; c.d2 = d2; c.last = last;
-  c.bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
-  int wave_last = last;                    // list positions >= wave_last were blended by no pixel of this quadrant
+  const float bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
+  int wave_last = last;                    // list positions >= wave_last were blended by no pixel of this 4x4 block
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(wave_last, o); wave_last = t > wave_last ? t : wave_last; }
-  if (wave_last == 0) return;
+  if (tid == 0) s_qlast = 0;
+  __syncthreads();
+  if (lane == 0) atomicMax(&s_qlast, wave_last);
+  __syncthreads();
+  const int qlast = s_qlast;               // ... by no pixel of the quadrant
+  if (qlast == 0) return;                  // block-uniform
 
-  GhPixelBwd p;
-  p.T = T_final; p.last_alpha = 0.0f; p.lc0 = p.lc1 = p.lc2 = 0.0f; p.ar0 = p.ar1 = p.ar2 = 0.0f;
-  float* my_rec = inst_grad + wid * GH_REC;
-  uint8_t* my_flag = inst_flag + wid;
-  // batches of 64 from the back; two register sets keep the next batch in flight
-  const int nb = (wave_last + GH_WAVE - 1) / GH_WAVE;
-  GhBatch A, B;
-  gh_load_batch(A, r0, r1, r2, (nb - 1) * GH_WAVE + lane, wave_last);
-  for (int k = nb - 1; k >= 0; k -= 2) {
-    if (k >= 1) gh_load_batch(B, r0, r1, r2, (k - 1) * GH_WAVE + lane, wave_last);
-    gh_bwd_consume(A, k * GH_WAVE, wave_last, lane, fqx0, fqy0, c, p, slots, my_rec, my_flag);
-    if (k < 1) break;
-    if (k >= 2) gh_load_batch(A, r0, r1, r2, (k - 2) * GH_WAVE + lane, wave_last);
-    gh_bwd_consume(B, (k - 1) * GH_WAVE, wave_last, lane, fqx0, fqy0, c, p, slots, my_rec, my_flag);
+  GhStateBwd st;
+  st.T = T_final; st.B0 = st.B1 = st.B2 = 0.0f;
+  const int nb = (qlast + GH_WAVE - 1) / GH_WAVE;
+  GhBatch cur, nxt;
+  gh_load_batch(cur, r0, r1, r2, (nb - 1) * GH_WAVE + lane, qlast);
+  for (int k = nb - 1; k >= 0; --k) {
+    const int buf = k & 1;
+    const int sbase = k * GH_WAVE;
+    gh_load_batch(nxt, r0, r1, r2, (k > 0 ? (k - 1) * GH_WAVE : 0) + lane, qlast);   // next batch in flight
+    uint64_t processed = 0;
+    uint64_t mask = __ballot((sbase + lane < wave_last) && gh_block_hit(cur.a, cur.b, fbx0, fby0, 3.0f));
+    while (mask) {
+      // next four set bits, descending (back to front); wave-uniform scalar work
+      const int j0 = 63 - __builtin_clzll(mask); mask &= ~(1ull << j0);
+      const int n1 = mask != 0; const int j1 = n1 ? 63 - __builtin_clzll(mask) : j0; if (n1) mask &= ~(1ull << j1);
+      const int n2 = mask != 0; const int j2 = n2 ? 63 - __builtin_clzll(mask) : j0; if (n2) mask &= ~(1ull << j2);
+      const int n3 = mask != 0; const int j3 = n3 ? 63 - __builtin_clzll(mask) : j0; if (n3) mask &= ~(1ull << j3);
+      const int myj = slot == 0 ? j0 : (slot == 1 ? j1 : (slot == 2 ? j2 : j3));
+      const bool have = slot == 0 || (slot == 1 && n1) || (slot == 2 && n2) || (slot == 3 && n3);
+      const int src = myj << 2;
+      const float gpx = gh_lane_fetch(cur.a.x, src), gpy = gh_lane_fetch(cur.a.y, src), cA = gh_lane_fetch(cur.a.z, src);
+      const float cB = gh_lane_fetch(cur.a.w, src), cC = gh_lane_fetch(cur.b.x, src), op = gh_lane_fetch(cur.b.y, src);
+      const float cr = gh_lane_fetch(cur.b.z, src), cg = gh_lane_fetch(cur.b.w, src), cbl = gh_lane_fetch(cur.cb, src);
+      const float dx = gpx - pxf, dy = gpy - pyf;
+      const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+      const float G = gh_exp(fminf(power, 0.0f));
+      const float alpha = fminf(0.99f, op * G);
+      const bool contrib = have && (sbase + myj < last) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+      const uint64_t cm = __ballot(contrib);
+      if (cm == 0) continue;                                           // wave-uniform: nothing blended by this block
+      // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
+      const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
+      float mTn = 0.0f, mB0 = 0.0f, mB1 = 0.0f, mB2 = 0.0f;
+      gh_bwd_chain_step<0>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2);
+      gh_bwd_chain_step<1>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2);
+      gh_bwd_chain_step<2>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2);
+      gh_bwd_chain_step<3>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2);
+      float dL_dalpha = (cr - mB0) * d0 + (cg - mB1) * d1 + (cbl - mB2) * d2;
+      dL_dalpha *= mTn;
+      dL_dalpha += (-T_final * inv1ma) * bg_dot;
+      const float dL_dG = op * dL_dalpha;                              // straight-through the 0.99 clamp (App. A.4-2)
+      const float gdx = G * dx, gdy = G * dy;
+      const float dchannel_dcolor = alpha * mTn;
+      float r[9];
+      r[0] = dL_dG * (-gdx * cA - gdy * cB);
+      r[1] = dL_dG * (-gdy * cC - gdx * cB);
+      r[2] = -0.5f * gdx * dx * dL_dG;
+      r[3] = -gdx * dy * dL_dG;
+      r[4] = -0.5f * gdy * dy * dL_dG;
+      r[5] = G * dL_dalpha;
+      r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) r[q] = gh_slot_sum16(contrib ? r[q] : 0.0f, lane);
+      // slots in which at least one pixel blended its entry get a partial record (wave-uniform bookkeeping)
+      const bool a0 = (cm & 0x1111111111111111ull) != 0, a1 = (cm & 0x2222222222222222ull) != 0;
+      const bool a2 = (cm & 0x4444444444444444ull) != 0, a3 = (cm & 0x8888888888888888ull) != 0;
+      if (a0) processed |= 1ull << j0;
+      if (a1) processed |= 1ull << j1;
+      if (a2) processed |= 1ull << j2;
+      if (a3) processed |= 1ull << j3;
+      const bool mine = slot == 0 ? a0 : (slot == 1 ? a1 : (slot == 2 ? a2 : a3));
+      if (lane >= 60 && mine) {                                        // lanes 60..63 hold slot 0..3's totals
+        float4* pr = (float4*)&s_part[buf][wid][myj][0];
+        pr[0] = make_float4(r[0], r[1], r[2], r[3]);
+        pr[1] = make_float4(r[4], r[5], r[6], r[7]);
+        s_part[buf][wid][myj][8] = r[8];
+      }
+    }
+    if (lane == 0) s_mask[buf][wid] = processed;
+    __syncthreads();
+    if (wid == (k & 3)) {                       // flush batch k: lane l owns entry l; fixed wave order => reproducible
+      const int pos = sbase + lane;
+      if (pos < qlast) {
+        float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        bool any = false;
+#pragma unroll
+        for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) {
+          if ((s_mask[buf][w] >> lane) & 1ull) {
+            any = true;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s9[q] += s_part[buf][w][lane][q];
+          }
+        }
+        if (any) {
+          const uint32_t sl = slots[pos];
+          float4* rec = (float4*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC);
+          rec[0] = make_float4(s9[0], s9[1], s9[2], s9[3]);
+          rec[1] = make_float4(s9[4], s9[5], s9[6], s9[7]);
+          rec[2] = make_float4(s9[8], 0.0f, 0.0f, 0.0f);
+          inst_flag[(size_t)sl * 4 + quad] = 1;
+        }
+      }
+    }
+    cur = nxt;
   }
 }
 
@@ -348,7 +374,7 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   if (g.cap == 0) return;
   (void)hipMemsetAsync(ws + L.inst_flag, 0, (size_t)g.cap * 4, s);
   gh_launch_tile_order_bwd(g, ws, L, s);
-  hipLaunchKernelGGL(gh_render_bwd_kernel, dim3(g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
+  hipLaunchKernelGGL(gh_render_bwd_kernel, dim3(4 * g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
                      (const uint32_t*)(ws + L.tile_order_bwd), (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
                      (const float*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles,
                      (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimage,
