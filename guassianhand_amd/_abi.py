@@ -31,7 +31,7 @@ class GhInputs(C.Structure):
 
 
 class GhOutputs(C.Structure):
-    _fields_ = [("image", C.c_void_p), ("radii", C.c_void_p)]
+    _fields_ = [("image", C.c_void_p), ("radii", C.c_void_p), ("alpha", C.c_void_p)]
 
 
 class GhCounters(C.Structure):
@@ -40,7 +40,7 @@ class GhCounters(C.Structure):
 
 class GhGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "dL_dimage", "dL_dmeans3D", "dL_dmeans2D", "dL_dopacities", "dL_dscales", "dL_drotations",
+        "dL_dimage", "dL_dalpha", "dL_dmeans3D", "dL_dmeans2D", "dL_dopacities", "dL_dscales", "dL_drotations",
         "dL_dshs", "dL_dcolors", "dL_dblend_xyz_b", "dL_dblend_opacity_b", "dL_dblend_color_w",
         "dL_dblend_color_b")]
 

@@ -104,7 +104,7 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
     if (hipMemsetAsync(ws + L.ranges, 0, L.tile_order - L.ranges, s) != hipSuccess) return GH_ERR_LAUNCH;  // ranges + tile_walk
     gh_launch_binning(d, g, ws, L, s);
   }
-  if (stages & GH_FWD_RENDER) gh_launch_render_fwd(d, g, in, out->image, ws, L, s);
+  if (stages & GH_FWD_RENDER) gh_launch_render_fwd(d, g, in, out->image, out->alpha, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 
@@ -127,7 +127,7 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
   char* ws = (char*)workspace;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
-  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, ws, L, s);
+  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, ws, L, s);
   if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -37,10 +37,10 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                               char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_tile_order_bwd(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
-void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image,
+void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha,
                           char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
-                          char* ws, const GhLayout& L, hipStream_t s);
+                          const float* dL_dalpha, char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr,
                               char* ws, const GhLayout& L, hipStream_t s);
 

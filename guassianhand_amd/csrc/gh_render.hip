@@ -69,7 +69,7 @@ __device__ __forceinline__ void gh_load_batch(GhBatch& t, const float4* __restri
 // and quad_perm-broadcasts slot s's result, so all four lanes of a pixel always hold the pixel's current state.
 // Arithmetic per pixel is exactly the sequential recurrence of App. A.3 (same operations, same order).
 struct GhPixelFwd {
-  float T, C0, C1, C2;
+  float T, C0, C1, C2, A;  // A: accumulated alpha = the mask channel (colour 1, bg 0)
   uint32_t last;
   int done;               // 0 / 1 (kept as int so it can travel through DPP)
 };
@@ -87,7 +87,7 @@ __device__ __forceinline__ float gh_lane_fetch(float v, int src_lane_x4) {   // 
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane_x4, __builtin_bit_cast(int, v)));
 }
 
-template <int S>
+template <int S, bool ALPHA>
 __device__ __forceinline__ void gh_fwd_chain_step(GhPixelFwd& p, float alpha, bool ok, float r, float g, float b, uint32_t pos1) {
   const bool valid = (p.done == 0) && ok;
   const float test_T = p.T * (1.0f - alpha);
@@ -95,16 +95,19 @@ __device__ __forceinline__ void gh_fwd_chain_step(GhPixelFwd& p, float alpha, bo
   const bool blend = valid && !stop;
   const float w = blend ? alpha * p.T : 0.0f;       // fma(c, 0, C) == C exactly: masked lanes keep their bits
   const float nC0 = fmaf(r, w, p.C0), nC1 = fmaf(g, w, p.C1), nC2 = fmaf(b, w, p.C2);
+  const float nA = ALPHA ? fmaf(1.0f, w, p.A) : 0.0f;   // exactly what the separate mask pass accumulates
   const float nT = blend ? test_T : p.T;
   const uint32_t nlast = blend ? pos1 : p.last;
   const int ndone = (p.done != 0 || stop) ? 1 : 0;
   p.T = gh_quad_bcast<S>(nT);
   p.C0 = gh_quad_bcast<S>(nC0); p.C1 = gh_quad_bcast<S>(nC1); p.C2 = gh_quad_bcast<S>(nC2);
+  if (ALPHA) p.A = gh_quad_bcast<S>(nA);
   p.last = (uint32_t)gh_quad_bcast_i<S>((int)nlast);
   p.done = gh_quad_bcast_i<S>(ndone);
 }
 
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
+template <bool ALPHA>
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, float fbx0, float fby0,
                                                float pxf, float pyf, GhPixelFwd& p) {
   const bool hit = (base + lane < total) && gh_block_hit(t.a, t.b, fbx0, fby0, 3.0f);
@@ -126,21 +129,23 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
     const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
     const uint32_t pos1 = (uint32_t)(base + myj + 1);
-    gh_fwd_chain_step<0>(p, alpha, ok, r, g, bl, pos1);
-    gh_fwd_chain_step<1>(p, alpha, ok, r, g, bl, pos1);
-    gh_fwd_chain_step<2>(p, alpha, ok, r, g, bl, pos1);
-    gh_fwd_chain_step<3>(p, alpha, ok, r, g, bl, pos1);
+    gh_fwd_chain_step<0, ALPHA>(p, alpha, ok, r, g, bl, pos1);
+    gh_fwd_chain_step<1, ALPHA>(p, alpha, ok, r, g, bl, pos1);
+    gh_fwd_chain_step<2, ALPHA>(p, alpha, ok, r, g, bl, pos1);
+    gh_fwd_chain_step<3, ALPHA>(p, alpha, ok, r, g, bl, pos1);
     if (__all(p.done != 0)) return true;
   }
   return false;
 }
 
 // grid = 4 blocks per tile (one per 8x8 quadrant), 4 waves per block (one per 4x4 pixel block); no LDS, no barriers.
+// ALPHA: also accumulate the mask channel (colour 1, bg 0) — SURVEY §8 f-2.
+template <bool ALPHA>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
     const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
-    int tiles, float* __restrict__ image, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-    uint32_t* __restrict__ tile_walk) {
+    int tiles, float* __restrict__ image, float* __restrict__ alpha_img, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk) {
   int v, tx, ty;
   const int tile = (int)tile_order[blockIdx.x >> 2];      // heaviest tiles are launched first
   const int quad = blockIdx.x & 3;
@@ -156,17 +161,17 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   r0 += range.x; r1 += range.x; r2 += range.x;
 
   GhPixelFwd p;
-  p.T = 1.0f; p.C0 = p.C1 = p.C2 = 0.0f; p.last = 0; p.done = inside ? 0 : 1;
+  p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.done = inside ? 0 : 1;
   if (total > 0 && !__all(p.done != 0)) {
     // two register sets in flight: while one batch is consumed the next one is already being loaded
     GhBatch A, B;
     gh_load_batch(A, r0, r1, r2, lane, total);
     for (int base = 0; base < total; base += 2 * GH_WAVE) {
       gh_load_batch(B, r0, r1, r2, base + GH_WAVE + lane, total);
-      if (gh_fwd_consume(A, base, total, lane, slot, fbx0, fby0, pxf, pyf, p)) break;
+      if (gh_fwd_consume<ALPHA>(A, base, total, lane, slot, fbx0, fby0, pxf, pyf, p)) break;
       if (base + GH_WAVE >= total) break;
       gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
-      if (gh_fwd_consume(B, base + GH_WAVE, total, lane, slot, fbx0, fby0, pxf, pyf, p)) break;
+      if (gh_fwd_consume<ALPHA>(B, base + GH_WAVE, total, lane, slot, fbx0, fby0, pxf, pyf, p)) break;
     }
   }
   if (total > 0) {                                   // walked length of the tile = max n_contrib (orders the backward)
@@ -184,15 +189,24 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     img[0] = fmaf(p.T, bg[0], p.C0);
     img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1);
     img[(size_t)2 * H * W] = fmaf(p.T, bg[2], p.C2);
+    if (ALPHA) alpha_img[pix] = fmaf(p.T, 0.0f, p.A);
   }
 }
 
-void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, char* ws, const GhLayout& L,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(gh_render_fwd_kernel, dim3(4 * g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
-                     (const uint32_t*)(ws + L.tile_order), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1), (const float*)(ws + L.inst_r2),
-                     in->cams, g.H, g.W, g.gx, g.tiles, image, (float*)(ws + L.final_T), (uint32_t*)(ws + L.n_contrib),
-                     (uint32_t*)(ws + L.tile_walk));
+void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha, char* ws,
+                          const GhLayout& L, hipStream_t s) {
+  const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
+  const uint2* ranges = (const uint2*)(ws + L.ranges);
+  const uint32_t* order = (const uint32_t*)(ws + L.tile_order);
+  const float4* r0 = (const float4*)(ws + L.inst_r0); const float4* r1 = (const float4*)(ws + L.inst_r1);
+  const float* r2 = (const float*)(ws + L.inst_r2);
+  float* fT = (float*)(ws + L.final_T); uint32_t* nc = (uint32_t*)(ws + L.n_contrib); uint32_t* tw = (uint32_t*)(ws + L.tile_walk);
+  if (alpha)
+    hipLaunchKernelGGL(gh_render_fwd_kernel<true>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
+                       g.tiles, image, alpha, fT, nc, tw);
+  else
+    hipLaunchKernelGGL(gh_render_fwd_kernel<false>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
+                       g.tiles, image, alpha, fT, nc, tw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -205,19 +219,22 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 // of the slot (row_shr:4, row_shr:8, then xor-16 / xor-32 through the LDS crossbar) and the four waves of the
 // quadrant are combined through a double-buffered LDS stage, one barrier per 64 list entries, in fixed wave
 // order: lane l of the flushing wave owns entry l and writes the quadrant's sub-record + flag byte.
-struct GhStateBwd { float T, B0, B1, B2; };
+struct GhStateBwd { float T, B0, B1, B2, B3; };   // B3: alpha accumulated behind (mask channel, colour 1)
 
-template <int S>
+template <int S, bool ALPHA>
 __device__ __forceinline__ void gh_bwd_chain_step(GhStateBwd& st, int slot, bool contrib, float alpha, float inv1ma, float cr,
-                                                  float cg, float cbl, float& mTn, float& mB0, float& mB1, float& mB2) {
+                                                  float cg, float cbl, float& mTn, float& mB0, float& mB1, float& mB2,
+                                                  float& mB3) {
   const float Tn = st.T * inv1ma;
   const float oma = 1.0f - alpha;
   const float nB0 = alpha * cr + oma * st.B0, nB1 = alpha * cg + oma * st.B1, nB2 = alpha * cbl + oma * st.B2;
-  if (slot == S) { mTn = Tn; mB0 = st.B0; mB1 = st.B1; mB2 = st.B2; }      // state seen by this lane's entry
+  const float nB3 = ALPHA ? alpha + oma * st.B3 : 0.0f;
+  if (slot == S) { mTn = Tn; mB0 = st.B0; mB1 = st.B1; mB2 = st.B2; mB3 = st.B3; }   // state seen by this lane's entry
   st.T = gh_quad_bcast<S>(contrib ? Tn : st.T);
   st.B0 = gh_quad_bcast<S>(contrib ? nB0 : st.B0);
   st.B1 = gh_quad_bcast<S>(contrib ? nB1 : st.B1);
   st.B2 = gh_quad_bcast<S>(contrib ? nB2 : st.B2);
+  if (ALPHA) st.B3 = gh_quad_bcast<S>(contrib ? nB3 : st.B3);
 }
 
 __device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum over the 16 pixels of this lane's slot
@@ -228,11 +245,13 @@ __device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum ove
   return v;
 }
 
+template <bool ALPHA>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ sorted_slot,
     const float4* __restrict__ r0, const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams,
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dimage, float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag) {
+    const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, float* __restrict__ inst_grad,
+    uint8_t* __restrict__ inst_flag) {
   __shared__ float s_part[2][GH_BLOCK / GH_WAVE][GH_WAVE][GH_REC];    // [buffer][wave][entry][9 used]  (24 KB)
   __shared__ uint64_t s_mask[2][GH_BLOCK / GH_WAVE];                  // entries a wave wrote
   __shared__ int s_qlast;
@@ -252,7 +271,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   const uint32_t* slots = sorted_slot + range.x;
 
   const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
-  float T_final = 1.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f;
+  float T_final = 1.0f, d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, dM = 0.0f;
   int last = 0;
   if (inside) {
     const size_t pix = ((size_t)v * H + y) * W + x;
@@ -260,6 +279,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     last = (int)n_contrib[pix];
     const float* dimg = dL_dimage + (size_t)v * 3 * H * W + (size_t)y * W + x;
     d0 = dimg[0]; d1 = dimg[(size_t)H * W]; d2 = dimg[(size_t)2 * H * W];
+    if (ALPHA) dM = dL_dalpha_img[pix];             // fused mask channel: colour 1, background 0
   }
   const float bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
   int wave_last = last;                    // list positions >= wave_last were blended by no pixel of this 4x4 block
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   if (qlast == 0) return;                  // block-uniform
 
   GhStateBwd st;
-  st.T = T_final; st.B0 = st.B1 = st.B2 = 0.0f;
+  st.T = T_final; st.B0 = st.B1 = st.B2 = st.B3 = 0.0f;
   const int nb = (qlast + GH_WAVE - 1) / GH_WAVE;
   GhBatch cur, nxt;
   gh_load_batch(cur, r0, r1, r2, (nb - 1) * GH_WAVE + lane, qlast);
@@ -304,12 +324,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       if (cm == 0) continue;                                           // wave-uniform: nothing blended by this block
       // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
       const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
-      float mTn = 0.0f, mB0 = 0.0f, mB1 = 0.0f, mB2 = 0.0f;
-      gh_bwd_chain_step<0>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2);
-      gh_bwd_chain_step<1>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2);
-      gh_bwd_chain_step<2>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2);
-      gh_bwd_chain_step<3>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2);
+      float mTn = 0.0f, mB0 = 0.0f, mB1 = 0.0f, mB2 = 0.0f, mB3 = 0.0f;
+      gh_bwd_chain_step<0, ALPHA>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2, mB3);
+      gh_bwd_chain_step<1, ALPHA>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2, mB3);
+      gh_bwd_chain_step<2, ALPHA>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2, mB3);
+      gh_bwd_chain_step<3, ALPHA>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2, mB3);
       float dL_dalpha = (cr - mB0) * d0 + (cg - mB1) * d1 + (cbl - mB2) * d2;
+      if (ALPHA) dL_dalpha += (1.0f - mB3) * dM;
       dL_dalpha *= mTn;
       dL_dalpha += (-T_final * inv1ma) * bg_dot;
       const float dL_dG = op * dL_dalpha;                              // straight-through the 0.99 clamp (App. A.4-2)
@@ -369,14 +390,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   }
 }
 
-void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage, char* ws,
-                          const GhLayout& L, hipStream_t s) {
+void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
+                          const float* dL_dalpha, char* ws, const GhLayout& L, hipStream_t s) {
   if (g.cap == 0) return;
   (void)hipMemsetAsync(ws + L.inst_flag, 0, (size_t)g.cap * 4, s);
   gh_launch_tile_order_bwd(g, ws, L, s);
-  hipLaunchKernelGGL(gh_render_bwd_kernel, dim3(4 * g.NV * g.tiles), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges),
-                     (const uint32_t*)(ws + L.tile_order_bwd), (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
-                     (const float*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles,
-                     (const float*)(ws + L.final_T), (const uint32_t*)(ws + L.n_contrib), dL_dimage,
-                     (float*)(ws + L.inst_grad), (uint8_t*)(ws + L.inst_flag));
+  const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(ws + L.ranges), (const uint32_t*)(ws + L.tile_order_bwd),
+                       (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
+                       (const float*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
+                       (const uint32_t*)(ws + L.n_contrib), dL_dimage, dL_dalpha, (float*)(ws + L.inst_grad),
+                       (uint8_t*)(ws + L.inst_flag));
+  };
+  if (dL_dalpha) launch(gh_render_bwd_kernel<true>); else launch(gh_render_bwd_kernel<false>);
 }

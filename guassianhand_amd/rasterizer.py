@@ -126,13 +126,14 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 
 class _Ctx:
-    __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "stream")
+    __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "stream", "alpha")
 
 
 def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None, colors_precomp=None,
                    sh_degree: int = 0, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
-                   color_b=None, max_instances: Optional[int] = None, sync: bool = True):
-    """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx)."""
+                   color_b=None, max_instances: Optional[int] = None, sync: bool = True, return_alpha: bool = False):
+    """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
+    with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha."""
     global _last_D
     L = _lib.lib()
     dev = means3D.device
@@ -167,10 +168,11 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
         radii = torch.empty(NV, P, dtype=torch.int32, device=dev)
+        alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
         inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
                             _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
                             _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
-        out = _abi.GhOutputs(_ptr(image), _ptr(radii))
+        out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha))
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
@@ -204,15 +206,20 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         break
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
+    ctx.alpha = alpha
     return image, radii, ctx
 
 
-def raster_backward(ctx: _Ctx, dL_dimage: torch.Tensor, want_means2D: bool = True) -> Dict[str, torch.Tensor]:
+def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: bool = True,
+                    dL_dalpha: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     L = _lib.lib()
     t = ctx.tensors
     dev = t["means3D"].device
     P, NV, M = ctx.P, ctx.NV, ctx.M
+    if dL_dimage is None:
+        dL_dimage = torch.zeros(NV, 3, ctx.H, ctx.W, dtype=torch.float32, device=dev)
     g = dL_dimage.detach().to(torch.float32).reshape(NV, 3, ctx.H, ctx.W).contiguous()
+    ga = None if dL_dalpha is None else dL_dalpha.detach().to(torch.float32).reshape(NV, ctx.H, ctx.W).contiguous()
     mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     o = dict(means3D=mk(P, 3), means2D=mk(NV, P, 3) if want_means2D else None, opacities=mk(P), scales=mk(P, 3),
              rotations=mk(P, 4), shs=mk(P, M, 3) if M else None,
@@ -221,9 +228,11 @@ def raster_backward(ctx: _Ctx, dL_dimage: torch.Tensor, want_means2D: bool = Tru
              opacity_b=mk(P) if t["opacity_b"] is not None else None,
              color_w=(mk(P, 48) if ctx.wpg else mk(48)) if t["color_w"] is not None else None,
              color_b=mk(P, 48) if t["color_b"] is not None else None)
-    gr = _abi.GhGrads(_ptr(g), _ptr(o["means3D"]), _ptr(o["means2D"]), _ptr(o["opacities"]), _ptr(o["scales"]),
-                      _ptr(o["rotations"]), _ptr(o["shs"]), _ptr(o["colors_precomp"]), _ptr(o["xyz_b"]),
-                      _ptr(o["opacity_b"]), _ptr(o["color_w"]), _ptr(o["color_b"]))
+    gr = _abi.GhGrads(dL_dimage=_ptr(g), dL_dalpha=_ptr(ga), dL_dmeans3D=_ptr(o["means3D"]), dL_dmeans2D=_ptr(o["means2D"]),
+                      dL_dopacities=_ptr(o["opacities"]), dL_dscales=_ptr(o["scales"]), dL_drotations=_ptr(o["rotations"]),
+                      dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]), dL_dblend_xyz_b=_ptr(o["xyz_b"]),
+                      dL_dblend_opacity_b=_ptr(o["opacity_b"]), dL_dblend_color_w=_ptr(o["color_w"]),
+                      dL_dblend_color_b=_ptr(o["color_b"]))
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev):
         bargs = (C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(),
@@ -316,38 +325,47 @@ class GaussianRasterizer(nn.Module):
 # ---------------------------------------------------------------------------------------------------
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, xyz, opacity, scaling,
-                rotation, shs, xyz_b, opacity_b, color_w, color_b):
+    def forward(ctx, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, want_alpha, xyz, opacity,
+                scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b):
         kw = dict(colors_precomp=shs.reshape(shs.shape[0], 3)) if use_rgb else dict(shs=shs)
         image, radii, rctx = raster_forward(cams, xyz, opacity, scaling, rotation, H=H, W=W, sh_degree=sh_degree,
                                             scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b,
-                                            color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances, **kw)
+                                            color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances,
+                                            return_alpha=want_alpha, **kw)
         ctx.rctx = rctx
         ctx.use_rgb = use_rgb
         ctx.shapes = [None if t is None else t.shape for t in (xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b)]
         ctx.mark_non_differentiable(radii)
-        return image, radii
+        alpha = rctx.alpha if want_alpha else image.new_zeros(0)
+        if not want_alpha:
+            ctx.mark_non_differentiable(alpha)
+        return image, alpha, radii
 
     @staticmethod
-    def backward(ctx, grad_image, _gr):
-        g = raster_backward(ctx.rctx, grad_image, want_means2D=False)
+    def backward(ctx, grad_image, grad_alpha, _gr):
+        if ctx.rctx.alpha is None:
+            grad_alpha = None
+        g = raster_backward(ctx.rctx, grad_image, want_means2D=False, dL_dalpha=grad_alpha)
         ctx.rctx = None
         s = ctx.shapes
         col = g["colors_precomp"] if ctx.use_rgb else g["shs"]
         opt = lambda k, i: g[k].reshape(s[i]) if (s[i] is not None and k in g) else None
-        return (None,) * 8 + (g["means3D"].reshape(s[0]), g["opacities"].reshape(s[1]), g["scales"].reshape(s[2]),
+        return (None,) * 9 + (g["means3D"].reshape(s[0]), g["opacities"].reshape(s[1]), g["scales"].reshape(s[2]),
                               g["rotations"].reshape(s[3]), col.reshape(s[4]), opt("xyz_b", 5), opt("opacity_b", 6),
                               opt("color_w", 7), opt("color_b", 8))
 
 
 def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *, H: int, W: int, use_rgb: bool,
                     sh_degree: int = 3, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
-                    color_b=None, sync: bool = True, max_instances: Optional[int] = None):
+                    color_b=None, sync: bool = True, max_instances: Optional[int] = None, return_alpha: bool = False):
     """View-batched render with the attribute blend of renderer_one_shot.py:298-334 fused into the kernels.
 
-    cams: (Nv, GH_CAM_FLOATS) from camera.pack_cameras_from_w2c; returns (images (Nv,3,H,W), radii (Nv,P)).
-    Differentiable w.r.t. xyz, opacity, scaling, rotation, shs and the blend parameters.
+    cams: (Nv, GH_CAM_FLOATS) from camera.pack_cameras_from_w2c; returns (images (Nv,3,H,W), radii (Nv,P)) or, with
+    return_alpha, (images, alpha (Nv,H,W), radii): alpha is the reference's mask render (colour 1, bg 0,
+    renderer_one_shot.py:353-380) produced by the same pass as a 4th channel (bit-identical to a separate pass).
+    Differentiable w.r.t. xyz, opacity, scaling, rotation, shs and the blend parameters (through image and alpha).
     """
-    return _RasterizeViews.apply(cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier),
-                                 bool(use_rgb), bool(sync), max_instances, xyz, opacity, scaling, rotation, shs, xyz_b,
-                                 opacity_b, color_w, color_b)
+    image, alpha, radii = _RasterizeViews.apply(cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier),
+                                 bool(use_rgb), bool(sync), max_instances, bool(return_alpha), xyz, opacity, scaling,
+                                 rotation, shs, xyz_b, opacity_b, color_w, color_b)
+    return (image, alpha, radii) if return_alpha else (image, radii)

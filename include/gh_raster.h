@@ -93,6 +93,8 @@ typedef struct GhInputs {
 typedef struct GhOutputs {
   float* image;    /* (n_views,3,H,W) */
   int32_t* radii;  /* (n_views,P)   0 for culled Gaussians */
+  float* alpha;    /* (n_views,H,W) or NULL. Accumulated alpha = the reference's mask pass (colour 1, bg 0,
+                      renderer_one_shot.py:353-380) produced by the SAME walk as a 4th channel */
 } GhOutputs;
 
 /* Device-side counters written by gh_forward (first bytes of the workspace, see GhLayout.counters). */
@@ -105,6 +107,7 @@ typedef struct GhCounters {
 /* Upstream gradient + outputs of gh_backward. Any output pointer may be NULL (that gradient is skipped). */
 typedef struct GhGrads {
   const float* dL_dimage;   /* (n_views,3,H,W) */
+  const float* dL_dalpha;   /* (n_views,H,W) or NULL: upstream gradient of GhOutputs.alpha (fused mask pass) */
   float* dL_dmeans3D;       /* (P,3)   summed over views */
   float* dL_dmeans2D;       /* (n_views,P,3)  [dL/dpx*W/2, dL/dpy*H/2, 0] — API parity with means2D.grad */
   float* dL_dopacities;     /* (P,) */

@@ -133,9 +133,11 @@ class OracleRender:
                  opacity_b=torch.zeros(P) if t["opacity_b"] is not None else None,
                  color_w=(torch.zeros(P, 48) if wpg else torch.zeros(48)) if t["color_w"] is not None else None,
                  color_b=torch.zeros(P, 48) if t["color_b"] is not None else None)
-        gr = _abi.GhGrads(_ptr(g), _ptr(o["means3D"]), _ptr(o["means2D"]), _ptr(o["opacities"]), _ptr(o["scales"]),
-                          _ptr(o["rotations"]), _ptr(o["shs"]), _ptr(o["colors_precomp"]), _ptr(o["xyz_b"]),
-                          _ptr(o["opacity_b"]), _ptr(o["color_w"]), _ptr(o["color_b"]))
+        gr = _abi.GhGrads(dL_dimage=_ptr(g), dL_dmeans3D=_ptr(o["means3D"]), dL_dmeans2D=_ptr(o["means2D"]),
+                          dL_dopacities=_ptr(o["opacities"]), dL_dscales=_ptr(o["scales"]),
+                          dL_drotations=_ptr(o["rotations"]), dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]),
+                          dL_dblend_xyz_b=_ptr(o["xyz_b"]), dL_dblend_opacity_b=_ptr(o["opacity_b"]),
+                          dL_dblend_color_w=_ptr(o["color_w"]), dL_dblend_color_b=_ptr(o["color_b"]))
         rc = lib().gho_backward(self._ctx, C.byref(self.inp), C.byref(gr))
         if rc != 0:
             raise RuntimeError(f"gho_backward failed: {_abi.status_name(rc)}")

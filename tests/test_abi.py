@@ -32,7 +32,8 @@ def test_struct_sizes_match_header():
     # GhDims: 6 int32 + float + uint32 + int64
     assert C.sizeof(_abi.GhDims) == 40
     assert C.sizeof(_abi.GhInputs) == 11 * 8
-    assert C.sizeof(_abi.GhGrads) == 12 * 8
+    assert C.sizeof(_abi.GhGrads) == 13 * 8
+    assert C.sizeof(_abi.GhOutputs) == 3 * 8
     assert C.sizeof(_abi.GhCounters) == 16
     assert C.sizeof(_abi.GhLayout) == len(_abi.LAYOUT_FIELDS) * 8
 
@@ -83,10 +84,10 @@ def test_forward_rejects_bad_arguments_before_touching_the_gpu(gh_lib_path):
     # both / neither colour source
     one = C.c_void_p(8)
     inp2 = _abi.GhInputs(one, one, one, one, one, one, one, None, None, None, None)
-    assert L.gh_forward(C.byref(d), C.byref(inp2), C.byref(_abi.GhOutputs(one, one)), one, 1 << 30, None) == _abi.GH_ERR_INVALID_ARG
+    assert L.gh_forward(C.byref(d), C.byref(inp2), C.byref(_abi.GhOutputs(one, one, None)), one, 1 << 30, None) == _abi.GH_ERR_INVALID_ARG
     # workspace too small is reported, with valid-looking pointers, before any launch
     inp3 = _abi.GhInputs(one, one, one, one, one, None, one, None, None, None, None)
-    assert L.gh_forward(C.byref(d), C.byref(inp3), C.byref(_abi.GhOutputs(one, one)), one, 16, None) == _abi.GH_ERR_WORKSPACE_SMALL
+    assert L.gh_forward(C.byref(d), C.byref(inp3), C.byref(_abi.GhOutputs(one, one, None)), one, 16, None) == _abi.GH_ERR_WORKSPACE_SMALL
 
 
 def test_product_has_no_cpu_fallback():

@@ -116,6 +116,44 @@ def test_forward_single_view_equals_fused_batched_views(dev):
             assert max_rel(b[n].grad.cpu(), a[n].grad.cpu()) <= 1e-3 and rel_l2(b[n].grad.cpu(), a[n].grad.cpu()) <= 2e-5, n
 
 
+def test_fused_alpha_channel_equals_separate_mask_pass(dev):
+    """the mask render of renderer_one_shot.py:353-380 (colour 1, bg 0, second rasteriser call)
+    comes out of the SAME walk as a 4th channel: bit-identical forward, matching gradients through both outputs."""
+    from guassianhand_amd.rasterizer import raster_backward, raster_forward
+    from guassianhand_amd.scenes import make_scene
+    from oracle.oracle_c import OracleRender
+    for cfg, kw in (("random1k", dict(P=3000, n_views=2)), ("one_hand", dict(P=20000, n_views=1))):
+        sc = make_scene(cfg, blend=True, **kw)
+        s = sc.to(dev)
+        cams = sc.cams().to(dev)
+        bl = dict(xyz_b=s.xyz_b, opacity_b=s.opacity_b, color_w=s.color_w, color_b=s.color_b)
+        args = (cams, s.xyz, s.opacity, s.scaling, s.rotation)
+        img, _, ctx = raster_forward(*args, H=sc.H, W=sc.W, colors_precomp=s.shs.squeeze(1), return_alpha=True, **bl)
+        mcams = cams.clone(); mcams[:, 37:40] = 0
+        mask, _, mctx = raster_forward(mcams, s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W,
+                                       colors_precomp=torch.ones_like(s.xyz), xyz_b=s.xyz_b, opacity_b=s.opacity_b)
+        assert torch.equal(ctx.alpha, mask[:, 0]) and torch.equal(mask[:, 0], mask[:, 2])
+        # the oracle's separate mask render agrees bit for bit as well
+        o = OracleRender(mcams.cpu(), sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=sc.H, W=sc.W,
+                         colors_precomp=torch.ones_like(sc.xyz), xyz_b=sc.xyz_b, opacity_b=sc.opacity_b)
+        assert torch.equal(ctx.alpha.cpu(), o.image[:, 0])
+        g = torch.Generator().manual_seed(3)
+        d_img = torch.randn(img.shape, generator=g).to(dev)
+        d_a = torch.randn(ctx.alpha.shape, generator=g).to(dev)
+        fused = raster_backward(ctx, d_img, dL_dalpha=d_a)
+        g_rgb = raster_backward(ctx, d_img)
+        g_mask = raster_backward(mctx, d_a[:, None].expand(-1, 3, -1, -1).contiguous() / 1.0 * torch.tensor([1.0, 0.0, 0.0], device=dev)[None, :, None, None])
+        for k in ("means3D", "opacities", "scales", "rotations", "xyz_b", "opacity_b"):
+            want = g_rgb[k] + g_mask[k]
+            assert max_rel(fused[k].cpu(), want.cpu()) <= 1e-3 and rel_l2(fused[k].cpu(), want.cpu()) <= 1e-5, k
+        for k in ("colors_precomp", "color_w", "color_b"):      # the mask has no colour dependence
+            assert torch.equal(fused[k], g_rgb[k]), k
+        og = o.backward(d_a[:, None].cpu() * torch.tensor([1.0, 0.0, 0.0])[None, :, None, None])
+        only_alpha = raster_backward(ctx, None, dL_dalpha=d_a)
+        for k in ("means3D", "opacities", "scales", "rotations"):
+            assert max_rel(only_alpha[k].cpu(), og[k]) <= 1e-3 and rel_l2(only_alpha[k].cpu(), og[k]) <= 1e-5, k
+
+
 def test_mask_pass_is_accumulated_alpha(dev):
     """The mask render (colour = 1, bg = 0, renderer_one_shot.py:353-380) equals 1 - final_T."""
     from guassianhand_amd.rasterizer import raster_forward, workspace_views
