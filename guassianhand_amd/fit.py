@@ -1,0 +1,122 @@
+"""One-shot fit loop — counterpart of the reference's one-shot optimisation stage.
+
+What it mirrors (all in /root/reference):
+  * learnable one-shot parameters: `color_w` (48,), `color_b` (48,1024,2048), `xyz_b` (3,), `opacity_b`
+    (1,1024,2048) — infer_one_shot.py:159-163; only color_w / color_b / opacity_b (and network-side map_bias /
+    identity codes, out of scope here) are trainable (:340-343);
+  * per-Gaussian lookup of the maps at the Gaussians' UV coordinates with bilinear `grid_sample`,
+    align_corners=True — renderer_one_shot.py:420-446, :489-492;
+  * loss: 10 * L1(rgb) + 1.0 * MSE(clip(mean_c(mask), -0.001, 1), gt_mask) — utils.py:180-252, :282-291 with the
+    shipped lambdas (config/one_shot.json:121-132; the 0.1*VGG term needs torchvision weights and is out of scope)
+    — plus the regularisers 100*mean|color_b| + mean(opacity_b^2) — infer_one_shot.py:514-519;
+  * optimiser: Adam(lr 0.01) + MultiStepLR(milestones [2,5,10,20,35,50,75], gamma 0.5) per epoch — :345-349,
+    config/one_shot.json:29.
+
+MI355X form: all of a rank's cameras go through ONE fused launch sequence (RGB + alpha in one pass, blend fused
+into the projection kernel); with N ranks the cameras are sharded round-robin and the only collective is one
+all-reduce(sum) of the gradient block AT THE RASTERISER BOUNDARY (per-Gaussian blend values + color_w) before it
+is back-propagated into the 403 MB maps — instead of PL-DDP all-reducing the maps themselves (:638).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import dist as ghdist
+from .renderer import GaussianModel
+
+MILESTONES = (2, 5, 10, 20, 35, 50, 75)
+
+
+def sample_map(tex: torch.Tensor, uv: torch.Tensor) -> torch.Tensor:
+    """(C,Hm,Wm) map sampled at uv (P,2) in [-1,1] -> (P,C); renderer_one_shot.py:420-446 (query_triplane_texture
+    with radius_texture 1.0: positions pass through scale_tensor((-1,1)->(-1,1)) unchanged)."""
+    out = F.grid_sample(tex[None], uv[None, :, None, :], align_corners=True, mode="bilinear")   # (1,C,P,1)
+    return out[0, :, :, 0].transpose(0, 1)
+
+
+def fit_loss(comp_rgb, comp_mask, gt_rgb, gt_mask, bbox_mask=None, lambda_l1: float = 10.0, lambda_mloss: float = 1.0):
+    """Image part of the reference loss for a stack of views. comp_rgb (Nv,H,W,3), comp_mask (Nv,H,W,3),
+    gt_rgb (Nv,H,W,3), gt_mask (Nv,H,W). Returns the SUM over views of the per-view means (callers divide by
+    the global number of views so that sharded ranks add up to the single-process loss)."""
+    rgb = comp_rgb
+    if bbox_mask is not None:                       # infer_one_shot.py:507-510: pixels outside the bbox are zeroed
+        rgb = rgb * (bbox_mask[..., None] != 0)
+    l1 = lambda_l1 * (rgb - gt_rgb).abs().mean(dim=(1, 2, 3))                       # utils.py:290-294
+    alpha = comp_mask.float().mean(-1)                                              # infer_one_shot.py:497
+    ml = lambda_mloss * ((alpha.clip(-0.001, 1.0) - gt_mask) ** 2).mean(dim=(1, 2))  # utils.py:249-252
+    return (l1 + ml).sum()
+
+
+class OneShotFit(nn.Module):
+    def __init__(self, gs: GaussianModel, uv: torch.Tensor, *, use_rgb: bool = True, sh_degree: int = 3,
+                 map_hw: Sequence[int] = (1024, 2048), lr: float = 0.01, render_fn: Optional[Callable] = None):
+        super().__init__()
+        self.gs = GaussianModel(*[t.detach() for t in gs])          # frozen network outputs
+        self.register_buffer("uv", uv.detach().float())
+        self.use_rgb, self.sh_degree = use_rgb, sh_degree
+        dev = gs.xyz.device
+        Hm, Wm = map_hw
+        self.color_w = nn.Parameter(torch.ones(48, device=dev))                      # infer_one_shot.py:159
+        self.color_b = nn.Parameter(torch.zeros(48, Hm, Wm, device=dev))             # :160
+        self.xyz_b = nn.Parameter(torch.zeros(3, device=dev), requires_grad=False)   # :161 (not in the trainable set)
+        self.opacity_b = nn.Parameter(torch.zeros(1, Hm, Wm, device=dev))            # :163
+        self.opt = torch.optim.Adam([self.color_w, self.color_b, self.opacity_b], lr=lr)
+        self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=list(MILESTONES), gamma=0.5)
+        if render_fn is None:
+            from .renderer import render_views
+            render_fn = render_views
+        self.render_fn = render_fn
+
+    # -- pieces ----------------------------------------------------------------------------------------
+    def blend_values(self) -> Dict[str, torch.Tensor]:
+        return dict(color_w=self.color_w, color_b=sample_map(self.color_b, self.uv),
+                    opacity_b=sample_map(self.opacity_b, self.uv), xyz_b=self.xyz_b)
+
+    def regulariser(self) -> torch.Tensor:
+        return 100.0 * self.color_b.abs().mean() + self.opacity_b.pow(2.0).mean()   # infer_one_shot.py:514-518
+
+    def render(self, w2cs, Ks, H, W, bg, blend: Dict[str, torch.Tensor], sync: bool = True):
+        return self.render_fn(self.gs, w2cs, Ks, H, W, bg, color_w=blend["color_w"], xyz_b=blend["xyz_b"],
+                              color_b=blend["color_b"], opacity_b=blend["opacity_b"], use_rgb=self.use_rgb,
+                              sh_degree=self.sh_degree, sync=sync)
+
+    # -- one optimisation step over all cameras (sharded over ranks) ------------------------------------
+    def step(self, w2cs, Ks, H: int, W: int, bg, gt_rgb, gt_mask, bbox_mask=None, sync: bool = True) -> torch.Tensor:
+        """w2cs/Ks/gt_* hold ALL Nv cameras on every rank; each rank renders views v % world == rank."""
+        rank = torch.distributed.get_rank() if ghdist.dist.is_initialized() else 0
+        world = torch.distributed.get_world_size() if ghdist.dist.is_initialized() else 1
+        n_total = w2cs.shape[0]
+        mine = ghdist.shard_views(n_total, rank, world)
+        self.opt.zero_grad(set_to_none=True)
+
+        blend = self.blend_values()                                   # graph A: maps -> per-Gaussian values
+        names = [k for k in ("color_w", "color_b", "opacity_b") if blend[k].requires_grad]
+        leaves = {k: (blend[k].detach().requires_grad_(True) if k in names else blend[k]) for k in blend}
+        loss_img = torch.zeros((), device=self.color_w.device)
+        grads = {k: torch.zeros_like(leaves[k]) for k in names}
+        if mine:                                                      # graph B: rasteriser + image loss
+            out = self.render(w2cs[mine], Ks[mine], H, W, bg, leaves, sync=sync)
+            loss_img = fit_loss(out["comp_rgb"], out["comp_mask"], gt_rgb[mine], gt_mask[mine],
+                                None if bbox_mask is None else bbox_mask[mine]) / n_total
+            g = torch.autograd.grad(loss_img, [leaves[k] for k in names], allow_unused=True)
+            grads = {k: (gi if gi is not None else torch.zeros_like(leaves[k])) for k, gi in zip(names, g)}
+        if self.use_rgb and "color_b" in grads:                       # RGB mode touches color_b[:, 0:3] only (:328)
+            small = dict(grads)
+            small["color_b"] = grads["color_b"][:, :3].contiguous()
+            loss_tot, red = ghdist.allreduce_grads(small, loss_img.detach(), sorted(small))
+            full = torch.zeros_like(grads["color_b"])
+            full[:, :3] = red["color_b"]
+            red["color_b"] = full
+        else:
+            loss_tot, red = ghdist.allreduce_grads(grads, loss_img.detach(), sorted(grads))
+        reg = self.regulariser()                                      # identical on every rank: never reduced
+        torch.autograd.backward([blend[k] for k in names] + [reg], [red[k] for k in names] + [torch.ones_like(reg)])
+        self.opt.step()
+        return loss_tot + reg.detach()
+
+    def end_epoch(self) -> None:
+        self.sched.step()

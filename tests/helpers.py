@@ -25,3 +25,41 @@ def max_rel(a, b, floor=1e-3):
 def dimg_like(nv, H, W, seed=5):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(nv, 3, H, W, generator=g)
+
+
+def oracle_render_views(gs, w2cs, Ks, H, W, bg, color_w=None, xyz_b=None, color_b=None, opacity_b=None, *, use_rgb=True,
+                        sh_degree=3, scaling_modifier=1.0, sync=True):
+    """CPU stand-in for guassianhand_amd.renderer.render_views built on the dense autograd oracle (checker):
+    same signature and outputs, differentiable, used to exercise the host logic of the fit loop without a GPU."""
+    from guassianhand_amd.camera import pack_cameras_from_w2c
+    from oracle import oracle_torch as OT
+    cams = pack_cameras_from_w2c(w2cs, Ks, H, W, bg)
+    means, op, cols, shs = OT.blend_attributes(gs.xyz, gs.opacity, gs.shs, use_rgb=use_rgb, color_w=color_w, xyz_b=xyz_b,
+                                               color_b=color_b, opacity_b=opacity_b)
+    rgbs, masks = [], []
+    for c in cams:
+        kw = dict(viewmatrix=c[:16].reshape(4, 4), projmatrix=c[16:32].reshape(4, 4), campos=c[32:35],
+                  tanfovx=float(c[35]), tanfovy=float(c[36]), H=H, W=W, scale_modifier=scaling_modifier)
+        ckw = dict(colors_precomp=cols) if use_rgb else dict(shs=shs, sh_degree=sh_degree)
+        img, _ = OT.rasterize_dense(means, op, gs.scaling, gs.rotation, bg=c[37:40], **kw, **ckw)
+        m, _ = OT.rasterize_dense(means, op, gs.scaling, gs.rotation, bg=torch.zeros(3), colors_precomp=torch.ones_like(means), **kw)
+        rgbs.append(img.permute(1, 2, 0))
+        masks.append(m.permute(1, 2, 0))
+    return {"comp_rgb": torch.stack(rgbs), "comp_mask": torch.stack(masks), "comp_rgb_bg": bg, "3dgs": gs}
+
+
+def tiny_fit_problem(P=160, n_views=4, hw=(32, 32), map_hw=(16, 32), seed=0, device="cpu"):
+    """A small one-shot fit problem: frozen Gaussians + target images rendered with 'true' blend maps."""
+    from guassianhand_amd.renderer import GaussianModel
+    from guassianhand_amd.scenes import make_scene, ring_cameras
+    sc = make_scene("random1k", n_views=n_views, P=P, seed=20240610 + seed)
+    H, W = hw
+    sc.w2c, sc.K = ring_cameras(torch.zeros(3), n_views, H, W, 2.5 * W)
+    g = torch.Generator().manual_seed(seed)
+    uv = torch.rand(P, 2, generator=g) * 2 - 1
+    gs = GaussianModel(sc.xyz, sc.opacity, sc.rotation, sc.scaling * 2.0, sc.shs)
+    true = dict(color_w=1 + 0.1 * torch.randn(48, generator=g), color_b=0.1 * torch.randn(48, *map_hw, generator=g),
+                opacity_b=0.05 * torch.randn(1, *map_hw, generator=g))
+    mv = lambda t: t.to(device)
+    return dict(gs=GaussianModel(*[mv(t) for t in gs]), uv=mv(uv), w2c=mv(sc.w2c), K=mv(sc.K), H=H, W=W, bg=mv(torch.zeros(3)),
+                true={k: mv(v) for k, v in true.items()}, map_hw=map_hw)

@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
     order = sorted(grads)
     loss, grads = ghdist.allreduce_grads(grads, loss, order)
     if rank == 0:
-        q.put((float(loss), {k: v.clone() for k, v in grads.items()}))
+        q.put((float(loss), {k: v.numpy().copy() for k, v in grads.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,6 +79,7 @@ def test_two_rank_allreduce_equals_single_process():
     for p in procs:
         p.start()
     loss2, grads2 = q.get(timeout=240)
+    grads2 = {k: torch.from_numpy(v) for k, v in grads2.items()}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
