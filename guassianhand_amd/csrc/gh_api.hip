@@ -34,10 +34,15 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->depth = take(N * 4);
   L->rect = take(N * 4);
   L->clamped = take(N);
-  L->offsets = take(N * 4);
+  L->tiles_touched = take(N * 4);
+  L->slot_begin = take(N * 4);
+  L->depth_keys_a = take(N * 4);
+  L->depth_keys_b = take(N * 4);
+  L->depth_vals_a = take(N * 4);
+  L->depth_vals_b = take(N * 4);
   L->block_sums = take((nblk_pre + 1) * 4);
-  L->keys_a = take(cap * 8);
-  L->keys_b = take(cap * 8);
+  L->keys_a = take(cap * 4);
+  L->keys_b = take(cap * 4);
   L->vals_a = take(cap * 4);
   L->vals_b = take(cap * 4);
   L->slot_gid = take(cap * 4);
@@ -45,7 +50,9 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->inst_r0 = take(cap * 16);
   L->inst_r1 = take(cap * 16);
   L->inst_r2 = take(cap * 4);
-  L->sort_tables = take(((size_t)256 * g.nblk_sort + 256) * 4);
+  const size_t nblk_n = (N + GH_SORT_TILE - 1) / GH_SORT_TILE;
+  const size_t nblk_tab = (size_t)g.nblk_sort > nblk_n ? (size_t)g.nblk_sort : nblk_n;
+  L->sort_tables = take(((size_t)256 * nblk_tab + 256) * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
   L->tile_walk = take((size_t)g.NV * g.tiles * 4);       // directly after ranges: both are cleared by one memset
   L->tile_order = take((size_t)g.NV * g.tiles * 4);

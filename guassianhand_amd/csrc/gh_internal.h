@@ -25,7 +25,7 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
   g.gx = (d->W + GH_TILE - 1) / GH_TILE; g.gy = (d->H + GH_TILE - 1) / GH_TILE;
   g.tiles = g.gx * g.gy; g.N = d->n_views * d->P;
   int tb = 1; while ((1ll << tb) < (long long)g.tiles * d->n_views) ++tb;
-  g.tile_bits = tb; g.n_pass = 4 + (tb + 7) / 8;
+  g.tile_bits = tb; g.n_pass = 4 + (tb + 7) / 8;   // level-1 depth passes + level-3 tile passes
   g.cap = d->max_instances;
   g.nblk_sort = (int)((g.cap + GH_SORT_TILE - 1) / GH_SORT_TILE);
   if (g.nblk_sort < 1) g.nblk_sort = 1;

@@ -10,11 +10,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     GhInputs in, int P, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
     float4* __restrict__ g0, float4* __restrict__ g1, float* __restrict__ gb, float* __restrict__ depth,
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
-    uint32_t* __restrict__ block_sums, int32_t* __restrict__ radii) {
-  __shared__ unsigned s_wsum[GH_BLOCK / GH_WAVE];
+    uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
+    int32_t* __restrict__ radii) {
   const int n = blockIdx.x * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
+  if (n == 0) ctr->reserved[0] = (uint32_t)N;          // element count of the level-1 (depth) sort, read on device
   if (n < N) {
+    uint32_t dkey = 0xFFFFFFFFu;                        // culled Gaussians sort behind everything and emit nothing
     const int v = n / P, i = n - v * P;
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     int radius = 0;
@@ -73,17 +75,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         g1[n] = make_float4(e.a * dinv, op, rgb[0], rgb[1]);
         gb[n] = rgb[2];
         depth[n] = e.tz;
+        dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
         rect[n] = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);
         clamped[n] = (uint8_t)cl;
       }
     }
     tiles_touched[n] = tiles;
+    depth_key[n] = dkey;
+    depth_val[n] = (uint32_t)n;
     if (radii) radii[n] = radius;
   }
-  unsigned ws = gh_wave_sum_u32(tiles);
-  if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = ws;
-  __syncthreads();
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
 }
 
 void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii, char* ws,
@@ -93,8 +94,8 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.N, g.H, g.W, g.gx, g.gy,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (float4*)(ws + L.geom_g0),
                      (float4*)(ws + L.geom_g1), (float*)(ws + L.geom_b), (float*)(ws + L.depth),
-                     (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.offsets),
-                     (uint32_t*)(ws + L.block_sums), radii);
+                     (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
+                     (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -132,7 +133,8 @@ __device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, floa
 // in registers/own memory in a fixed order (no atomics, bitwise reproducible).
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags,
-    uint32_t cap, const uint32_t* __restrict__ offsets, const uint8_t* __restrict__ clamped,
+    uint32_t cap, const uint32_t* __restrict__ slot_begin, const uint32_t* __restrict__ tiles_touched,
+    const uint8_t* __restrict__ clamped,
     const float* __restrict__ inst_grad, const uint32_t* __restrict__ inst_flag, float* __restrict__ scratch) {
   __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
   const int i = blockIdx.x * GH_BLOCK + threadIdx.x;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     const size_t n = (size_t)v * P + (live ? i : 0);
     uint32_t o1 = 0, o0 = 0;
     if (live) {
-      o1 = offsets[n]; o0 = n > 0 ? offsets[n - 1] : 0u;
+      o0 = slot_begin[n]; o1 = o0 + tiles_touched[n];   // this Gaussian's instances: consecutive emit slots
       if (o1 > cap) o1 = cap;
       if (o0 > o1) o0 = o1;
     }
@@ -389,7 +391,7 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   int nblk = (g.P + GH_BLOCK - 1) / GH_BLOCK;
   hipLaunchKernelGGL(gh_preprocess_bwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (uint32_t)g.cap,
-                     (const uint32_t*)(ws + L.offsets), (const uint8_t*)(ws + L.clamped),
+                     (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched), (const uint8_t*)(ws + L.clamped),
                      (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float*)(ws + L.bwd_scratch));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;

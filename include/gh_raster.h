@@ -132,10 +132,13 @@ typedef struct GhLayout {
   size_t depth;          /* float [n_views*P] */
   size_t rect;           /* uint32[n_views*P]  minx | miny<<8 | maxx<<16 | maxy<<24 (tile units) */
   size_t clamped;        /* uint8 [n_views*P]  SH colour clamp flags (bit ch) */
-  size_t offsets;        /* uint32[n_views*P]  inclusive scan of tiles touched */
+  size_t tiles_touched;  /* uint32[n_views*P]  tiles in the rect (0 for culled Gaussians) */
+  size_t slot_begin;     /* uint32[n_views*P]  first emit slot of the Gaussian; its instances are [begin, begin+tiles) */
+  size_t depth_keys_a, depth_keys_b; /* uint32[n_views*P] level-1 sort: depth bits (0xFFFFFFFF when culled); result in _a */
+  size_t depth_vals_a, depth_vals_b; /* uint32[n_views*P] level-1 payload: view*P + gaussian; depth order in _a */
   size_t block_sums;     /* uint32[...]        scan scratch */
-  size_t keys_a, keys_b; /* uint64[max_instances] radix sort ping-pong; result in keys_a */
-  size_t vals_a, vals_b; /* uint32[max_instances] slot index payload; result in vals_a */
+  size_t keys_a, keys_b; /* uint32[max_instances] level-3 sort: global tile id; sorted result in keys_a */
+  size_t vals_a, vals_b; /* uint32[max_instances] emit slot payload; sorted result in vals_a */
   size_t slot_gid;       /* uint32[max_instances] emit slot -> view*P + gaussian */
   size_t sorted_gid;     /* uint32[max_instances] sorted position -> view*P + gaussian */
   size_t inst_r0;        /* float4[max_instances] sorted per-instance render record (px, py, conicA, conicB) */

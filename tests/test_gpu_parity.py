@@ -50,8 +50,10 @@ def compare(sc, dev, check_stages=True):
         assert torch.equal(torch.stack([g0[vis, 2], g0[vis, 3], g1[vis, 0], g1[vis, 1]], 1), orc.debug["conic_opacity"].reshape(N, 4)[vis])
         assert torch.equal(torch.stack([g1[vis, 2], g1[vis, 3], gb[vis]], 1), orc.debug["rgb"].reshape(N, 3)[vis])
         assert torch.equal(wv["rect"].cpu()[vis], orc.debug["rect"].reshape(N)[vis])
-        assert torch.equal(wv["offsets"].cpu(), orc.debug["offsets"].reshape(N))
-        assert torch.equal(wv["sorted_keys"][:D].cpu(), orc.debug["sorted_keys"])      # stable sort, ties by index
+        oo = orc.debug["offsets"].reshape(N).long()
+        assert torch.equal(wv["tiles_touched"].cpu().long(), oo - torch.cat([oo.new_zeros(1), oo[:-1]]))
+        # two-level sort (depth order of Gaussians, then stable tile partition) == stable sort by tile<<32|depth
+        assert torch.equal(wv["sorted_tile"][:D].cpu().long(), orc.debug["sorted_keys"] >> 32)
         assert torch.equal(wv["sorted_gid"][:D].cpu(), orc.debug["sorted_gid"])
         assert torch.equal(wv["ranges"].cpu(), orc.debug["ranges"])
         assert torch.equal(wv["n_contrib"].cpu(), orc.debug["n_contrib"])

@@ -35,9 +35,9 @@ def check(config, P, rgb, blend, n_views=1):
           " opac:", torch.equal(g1[vis,1], oco[vis,3]), " rgb:", torch.equal(torch.stack([g1[vis,2], g1[vis,3], gb[vis]],1), orgb[vis]),
           " rgb maxdiff:", (torch.stack([g1[vis,2], g1[vis,3], gb[vis]],1) - orgb[vis]).abs().max().item())
     print(" depth:", torch.equal(wv["depth"].cpu()[vis], orc.debug["depth"].reshape(N)[vis]), " rect:", torch.equal(wv["rect"].cpu()[vis], orc.debug["rect"].reshape(N)[vis]),
-          " offsets:", torch.equal(wv["offsets"].cpu(), orc.debug["offsets"].reshape(N)))
+          " tiles:", int(wv["tiles_touched"].sum()) == orc.num_rendered)
     if D == orc.num_rendered:
-        print(" sorted keys:", torch.equal(wv["sorted_keys"][:D].cpu(), orc.debug["sorted_keys"]), " sorted gid:", torch.equal(wv["sorted_gid"][:D].cpu(), orc.debug["sorted_gid"]),
+        print(" sorted tile:", torch.equal(wv["sorted_tile"][:D].cpu().long(), orc.debug["sorted_keys"] >> 32), " sorted gid:", torch.equal(wv["sorted_gid"][:D].cpu(), orc.debug["sorted_gid"]),
               " ranges:", torch.equal(wv["ranges"].cpu(), orc.debug["ranges"]))
     print(" final_T bit-equal:", torch.equal(wv["final_T"].cpu(), orc.debug["final_T"]), " n_contrib:", torch.equal(wv["n_contrib"].cpu(), orc.debug["n_contrib"]))
     print(" image bit-equal:", torch.equal(img.cpu(), orc.image), " L_inf:", (img.cpu() - orc.image).abs().max().item())
