@@ -61,6 +61,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->n_contrib = take(pix * 4);
   L->inst_grad = take(cap * 4 * GH_REC * 4);
   L->inst_flag = take(cap * 4);
+  L->grad_sums = take(N * 48);
   L->bwd_scratch = take((nblk_pre + 1) * 64 * 4);
   L->total_bytes = off;
   return GH_OK;

@@ -131,15 +131,47 @@ __device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, floa
 
 // One thread per Gaussian; loops the views so gradients w.r.t. view-independent attributes are summed
 // in registers/own memory in a fixed order (no atomics, bitwise reproducible).
+// Fixed-order sum of every Gaussian's per-(instance, quadrant) gradient sub-records: one thread per (view,
+// Gaussian), its instances are the consecutive emit slots [slot_begin, slot_begin + tiles). Few registers, so
+// the scattered 48-byte reads run at full occupancy; the chain-rule kernel then reads the 9 sums coalesced.
+__global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t cap, const uint32_t* __restrict__ slot_begin,
+                                                                  const uint32_t* __restrict__ tiles_touched,
+                                                                  const float* __restrict__ inst_grad,
+                                                                  const uint32_t* __restrict__ inst_flag, float4* __restrict__ gsum) {
+  const int n = blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (n >= N) return;
+  uint32_t o0 = slot_begin[n], o1 = o0 + tiles_touched[n];
+  if (o1 > cap) o1 = cap;
+  if (o0 > o1) o0 = o1;
+  float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (uint32_t sidx = o0; sidx < o1; ++sidx) {
+    const uint32_t f = inst_flag[sidx];                      // 4 quadrant flag bytes of this tile instance
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if ((f >> (8 * q)) & 1u) {
+        const float4* r = (const float4*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC);
+        const float4 r0 = r[0], r1 = r[1]; const float r2 = r[2].x;
+        s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r0.w;
+        s9[4] += r1.x; s9[5] += r1.y; s9[6] += r1.z; s9[7] += r1.w; s9[8] += r2;
+      }
+    }
+  }
+  float4* o = gsum + (size_t)n * 3;
+  o[0] = make_float4(s9[0], s9[1], s9[2], s9[3]);
+  o[1] = make_float4(s9[4], s9[5], s9[6], s9[7]);
+  o[2] = make_float4(s9[8], 0.0f, 0.0f, 0.0f);
+}
+
+// RGB_MODE is a template parameter so the colours-precomputed path does not pay the registers of the SH path.
+template <bool RGB_MODE>
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags,
-    uint32_t cap, const uint32_t* __restrict__ slot_begin, const uint32_t* __restrict__ tiles_touched,
-    const uint8_t* __restrict__ clamped,
-    const float* __restrict__ inst_grad, const uint32_t* __restrict__ inst_flag, float* __restrict__ scratch) {
+    const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float4* __restrict__ gsum,
+    float* __restrict__ scratch) {
   __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
   const int i = blockIdx.x * GH_BLOCK + threadIdx.x;
   const bool live = i < P;
-  const bool rgb_mode = in.colors_precomp != nullptr;
+  constexpr bool rgb_mode = RGB_MODE;
   const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   const bool red_w = in.blend_color_w && !wpg && gr.dL_dblend_color_w;   // global (48,) weights: block reduce
   const bool red_x = in.blend_xyz_b && gr.dL_dblend_xyz_b;
@@ -152,26 +184,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
   float am[3] = {0, 0, 0}, as[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, araw[3] = {0, 0, 0}, ao = 0.0f;
   for (int v = 0; v < NV; ++v) {
     const size_t n = (size_t)v * P + (live ? i : 0);
-    uint32_t o1 = 0, o0 = 0;
-    if (live) {
-      o0 = slot_begin[n]; o1 = o0 + tiles_touched[n];   // this Gaussian's instances: consecutive emit slots
-      if (o1 > cap) o1 = cap;
-      if (o0 > o1) o0 = o1;
-    }
-    const bool vis = live && (o1 > o0);
-    // fixed-order sum of this Gaussian's per-instance records (slots are contiguous per Gaussian)
+    const bool vis = live && tiles_touched[n] != 0;
     float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t sidx = o0; sidx < o1; ++sidx) {
-      const uint32_t f = inst_flag[sidx];                    // 4 quadrant flag bytes of this tile instance
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if ((f >> (8 * q)) & 1u) {
-          const float4* r = (const float4*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC);
-          const float4 r0 = r[0], r1 = r[1]; const float r2 = r[2].x;
-          s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r0.w;
-          s9[4] += r1.x; s9[5] += r1.y; s9[6] += r1.z; s9[7] += r1.w; s9[8] += r2;
-        }
-      }
+    if (vis) {
+      const float4* r = gsum + n * 3;
+      const float4 r0 = r[0], r1 = r[1]; const float r2 = r[2].x;
+      s9[0] = r0.x; s9[1] = r0.y; s9[2] = r0.z; s9[3] = r0.w; s9[4] = r1.x; s9[5] = r1.y; s9[6] = r1.z; s9[7] = r1.w; s9[8] = r2;
     }
     const float g_px = s9[0], g_py = s9[1], gA = s9[2], gB = s9[3], gC = s9[4], g_o = s9[5];
     if (live && gr.dL_dmeans2D) {
@@ -389,10 +407,15 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                               const GhLayout& L, hipStream_t s) {
   if (g.P == 0) return;
   int nblk = (g.P + GH_BLOCK - 1) / GH_BLOCK;
-  hipLaunchKernelGGL(gh_preprocess_bwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
-                     d->sh_degree, d->M, d->scale_modifier, d->flags, (uint32_t)g.cap,
-                     (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched), (const uint8_t*)(ws + L.clamped),
-                     (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float*)(ws + L.bwd_scratch));
+  auto kern = in->colors_precomp ? gh_preprocess_bwd_kernel<true> : gh_preprocess_bwd_kernel<false>;
+  const int nblk_n = (g.N + GH_BLOCK - 1) / GH_BLOCK;
+  hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
+                     (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched),
+                     (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
+                     d->sh_degree, d->M, d->scale_modifier, d->flags,
+                     (const uint32_t*)(ws + L.tiles_touched), (const uint8_t*)(ws + L.clamped),
+                     (const float4*)(ws + L.grad_sums), (float*)(ws + L.bwd_scratch));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;
   float* dx = in->blend_xyz_b ? gr->dL_dblend_xyz_b : nullptr;

@@ -153,6 +153,7 @@ typedef struct GhLayout {
   size_t n_contrib;      /* uint32[n_views*H*W] */
   size_t inst_grad;      /* float[max_instances][4][12] per-(instance, quadrant) gradient sub-records (backward scratch) */
   size_t inst_flag;      /* uint8[max_instances][4]     1 where the quadrant wrote its sub-record (zeroed per backward) */
+  size_t grad_sums;      /* float4[n_views*P][3] per-(view,Gaussian) sums of the sub-records: dpx dpy dA dB | dC do dr dg | db */
   size_t bwd_scratch;    /* blend-parameter reduction scratch */
 } GhLayout;
 
