@@ -45,9 +45,9 @@ class GhGrads(C.Structure):
         "dL_dblend_color_b")]
 
 
-LAYOUT_FIELDS = ("total_bytes", "counters", "geom_g0", "geom_g1", "geom_b", "depth", "rect", "clamped",
+LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "depth", "rect", "clamped",
                  "tiles_touched", "slot_begin", "depth_keys_a", "depth_keys_b", "depth_vals_a", "depth_vals_b",
-                 "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "slot_gid", "sorted_gid", "inst_r0", "inst_r1", "inst_r2",
+                 "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "sorted_slot", "inst_r0", "inst_r1", "inst_r2",
                  "sort_tables", "ranges", "tile_walk", "tile_order", "tile_order_bwd", "final_T", "n_contrib", "inst_grad", "inst_flag", "grad_sums", "bwd_scratch")
 
 

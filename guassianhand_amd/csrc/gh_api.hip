@@ -28,9 +28,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
   L->counters = take(sizeof(GhCounters));
-  L->geom_g0 = take(N * 16);
-  L->geom_g1 = take(N * 16);
-  L->geom_b = take(N * 4);
+  L->geom = take(N * 64);
   L->depth = take(N * 4);
   L->rect = take(N * 4);
   L->clamped = take(N);
@@ -45,8 +43,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->keys_b = take(cap * 4);
   L->vals_a = take(cap * 4);
   L->vals_b = take(cap * 4);
-  L->slot_gid = take(cap * 4);
-  L->sorted_gid = take(cap * 4);
+  L->sorted_slot = take(cap * 4);
   L->inst_r0 = take(cap * 16);
   L->inst_r1 = take(cap * 16);
   L->inst_r2 = take(cap * 4);

@@ -217,12 +217,12 @@ __global__ __launch_bounds__(1024) void gh_scan_blocksums_kernel(uint32_t* __res
 }
 
 // One thread per (view, Gaussian) IN DEPTH ORDER: block-local scan -> first emit slot of the Gaussian, then one
-// instance per touched tile in row-major rect order: key = global tile id, payload = slot. A Gaussian's
+// instance per touched tile in row-major rect order: key = global tile id, payload = view*P+gaussian. A Gaussian's
 // instances occupy consecutive slots [slot_begin, slot_begin + tiles): the backward sums its records there.
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_offsets, const uint32_t* __restrict__ rect, uint32_t* __restrict__ slot_begin,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ slot_gid) {
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = blockIdx.x * GH_BLOCK + tid;
@@ -246,8 +246,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     for (int tx = minx; tx < maxx; ++tx) {
       if (off < cap) {
         keys[off] = vbase + (uint32_t)(ty * gx + tx);
-        vals[off] = off;
-        slot_gid[off] = n;
+        vals[off] = n;                                   // the emit slot is recomputed from (n, tile) after the sort
       }
       ++off;
     }
@@ -257,10 +256,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
 // Per-tile ranges from the sorted tile ids + the per-instance render records in sorted order: the one gather
 // of the pipeline happens here, massively parallel, so both render kernels stream contiguous records.
 __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                              const uint32_t* __restrict__ slot_gid, const GhCounters* __restrict__ ctr,
-                                                              uint32_t cap, uint2* __restrict__ ranges, uint32_t* __restrict__ sorted_gid,
-                                                              const float4* __restrict__ g0, const float4* __restrict__ g1,
-                                                              const float* __restrict__ gb, float4* __restrict__ r0,
+                                                              const GhCounters* __restrict__ ctr, uint32_t cap, int gx, int tiles,
+                                                              const uint32_t* __restrict__ rect, const uint32_t* __restrict__ slot_begin,
+                                                              const float4* __restrict__ geom, uint2* __restrict__ ranges,
+                                                              uint32_t* __restrict__ sorted_slot, float4* __restrict__ r0,
                                                               float4* __restrict__ r1, float* __restrict__ r2) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
@@ -272,9 +271,15 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __r
     if (tp != t) { ranges[tp].y = i; ranges[t].x = i; }
   }
   if (i == n - 1) ranges[t].y = n;
-  const uint32_t gid = slot_gid[vals[i]];
-  sorted_gid[i] = gid;
-  r0[i] = g0[gid]; r1[i] = g1[gid]; r2[i] = gb[gid];
+  const uint32_t gid = vals[i];
+  // emit slot of (gid, tile): instances of a Gaussian are emitted row-major over its tile rect
+  const uint32_t r = rect[gid];
+  const uint32_t tl = t % (uint32_t)tiles, ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
+  const uint32_t minx = r & 255u, miny = (r >> 8) & 255u, maxx = (r >> 16) & 255u;
+  sorted_slot[i] = slot_begin[gid] + (ty - miny) * (maxx - minx) + (tx - minx);
+  const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line
+  const float4 a = grec[0], b = grec[1], c = grec[2];
+  r0[i] = a; r1[i] = b; r2[i] = c.x;
 }
 
 // Longest-processing-time-first launch order for the render kernels: a counting sort of the tiles by list
@@ -361,13 +366,13 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
                      (const uint32_t*)(ws + L.block_sums), (const uint32_t*)(ws + L.rect), (uint32_t*)(ws + L.slot_begin),
-                     k_in, v_in, (uint32_t*)(ws + L.slot_gid));
+                     k_in, v_in);
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, g.nblk_sort, s);
 
   const int nblk_d = (int)((g.cap + GH_BLOCK - 1) / GH_BLOCK);
-  hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, (const uint32_t*)(ws + L.slot_gid), ctr, cap,
-                     (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.sorted_gid), (const float4*)(ws + L.geom_g0),
-                     (const float4*)(ws + L.geom_g1), (const float*)(ws + L.geom_b), (float4*)(ws + L.inst_r0),
+  hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,
+                     (const uint32_t*)(ws + L.rect), (const uint32_t*)(ws + L.slot_begin), (const float4*)(ws + L.geom),
+                     (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.sorted_slot), (float4*)(ws + L.inst_r0),
                      (float4*)(ws + L.inst_r1), (float*)(ws + L.inst_r2));
   gh_launch_tile_order(g, ws, L, s);
 }

@@ -8,7 +8,7 @@
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     GhInputs in, int P, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
-    float4* __restrict__ g0, float4* __restrict__ g1, float* __restrict__ gb, float* __restrict__ depth,
+    float4* __restrict__ geom, float* __restrict__ depth,
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii) {
@@ -71,9 +71,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
             rgb[ch] = acc;
           }
         }
-        g0[n] = make_float4(px, py, e.c * dinv, -e.b * dinv);
-        g1[n] = make_float4(e.a * dinv, op, rgb[0], rgb[1]);
-        gb[n] = rgb[2];
+        float4* grec = geom + (size_t)n * 4;           // one 64-byte line per Gaussian
+        grec[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
+        grec[1] = make_float4(e.a * dinv, op, rgb[0], rgb[1]);
+        grec[2] = make_float4(rgb[2], 0.0f, 0.0f, 0.0f);
         depth[n] = e.tz;
         dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
         rect[n] = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);
@@ -92,8 +93,7 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   if (g.N == 0) return;
   int nblk = (g.N + GH_BLOCK - 1) / GH_BLOCK;
   hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.N, g.H, g.W, g.gx, g.gy,
-                     d->sh_degree, d->M, d->scale_modifier, d->flags, (float4*)(ws + L.geom_g0),
-                     (float4*)(ws + L.geom_g1), (float*)(ws + L.geom_b), (float*)(ws + L.depth),
+                     d->sh_degree, d->M, d->scale_modifier, d->flags, (float4*)(ws + L.geom), (float*)(ws + L.depth),
                      (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii);
 }

@@ -259,13 +259,13 @@ def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
     def v(off, nbytes, dtype, *shape):
         return ws[off:off + nbytes].view(dtype).reshape(*shape)
 
-    return dict(counters=v(lay.counters, 16, torch.int32, 4), g0=v(lay.geom_g0, N * 16, torch.float32, N, 4),
-                g1=v(lay.geom_g1, N * 16, torch.float32, N, 4), gb=v(lay.geom_b, N * 4, torch.float32, N),
+    geom = v(lay.geom, N * 64, torch.float32, N, 16)
+    return dict(counters=v(lay.counters, 16, torch.int32, 4), g0=geom[:, 0:4], g1=geom[:, 4:8], gb=geom[:, 8],
                 depth=v(lay.depth, N * 4, torch.float32, N), rect=v(lay.rect, N * 4, torch.int32, N),
                 tiles_touched=v(lay.tiles_touched, N * 4, torch.int32, N), slot_begin=v(lay.slot_begin, N * 4, torch.int32, N),
                 depth_order=v(lay.depth_vals_a, N * 4, torch.int32, N),
-                sorted_tile=v(lay.keys_a, cap * 4, torch.int32, cap), sorted_slot=v(lay.vals_a, cap * 4, torch.int32, cap),
-                sorted_gid=v(lay.sorted_gid, cap * 4, torch.int32, cap),
+                sorted_tile=v(lay.keys_a, cap * 4, torch.int32, cap), sorted_slot=v(lay.sorted_slot, cap * 4, torch.int32, cap),
+                sorted_gid=v(lay.vals_a, cap * 4, torch.int32, cap),
                 ranges=v(lay.ranges, ctx.NV * gx * gy * 8, torch.int32, ctx.NV * gx * gy, 2),
                 final_T=v(lay.final_T, pix * 4, torch.float32, ctx.NV, ctx.H, ctx.W),
                 n_contrib=v(lay.n_contrib, pix * 4, torch.int32, ctx.NV, ctx.H, ctx.W))

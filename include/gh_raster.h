@@ -126,9 +126,8 @@ typedef struct GhGrads {
 typedef struct GhLayout {
   size_t total_bytes;
   size_t counters;       /* GhCounters */
-  size_t geom_g0;        /* float4[n_views*P]  (px, py, conicA, conicB) */
-  size_t geom_g1;        /* float4[n_views*P]  (conicC, opacity, r, g) */
-  size_t geom_b;         /* float [n_views*P]  b */
+  size_t geom;           /* float4[n_views*P][4]: one 64-byte line per Gaussian:
+                            (px, py, conicA, conicB) (conicC, opacity, r, g) (b, 0, 0, 0) (unused) */
   size_t depth;          /* float [n_views*P] */
   size_t rect;           /* uint32[n_views*P]  minx | miny<<8 | maxx<<16 | maxy<<24 (tile units) */
   size_t clamped;        /* uint8 [n_views*P]  SH colour clamp flags (bit ch) */
@@ -138,9 +137,8 @@ typedef struct GhLayout {
   size_t depth_vals_a, depth_vals_b; /* uint32[n_views*P] level-1 payload: view*P + gaussian; depth order in _a */
   size_t block_sums;     /* uint32[...]        scan scratch */
   size_t keys_a, keys_b; /* uint32[max_instances] level-3 sort: global tile id; sorted result in keys_a */
-  size_t vals_a, vals_b; /* uint32[max_instances] emit slot payload; sorted result in vals_a */
-  size_t slot_gid;       /* uint32[max_instances] emit slot -> view*P + gaussian */
-  size_t sorted_gid;     /* uint32[max_instances] sorted position -> view*P + gaussian */
+  size_t vals_a, vals_b; /* uint32[max_instances] payload view*P + gaussian; sorted result in vals_a */
+  size_t sorted_slot;    /* uint32[max_instances] sorted position -> emit slot (where the backward puts its record) */
   size_t inst_r0;        /* float4[max_instances] sorted per-instance render record (px, py, conicA, conicB) */
   size_t inst_r1;        /* float4[max_instances]                                   (conicC, opacity, r, g)  */
   size_t inst_r2;        /* float [max_instances]                                   b                        */
