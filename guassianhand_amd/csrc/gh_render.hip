@@ -93,9 +93,9 @@ __device__ __forceinline__ void gh_fwd_chain_step(GhPixelFwd& p, float alpha, bo
   const float test_T = p.T * (1.0f - alpha);
   const bool stop = valid && (test_T < 0.0001f);
   const bool blend = valid && !stop;
-  const float w = blend ? alpha * p.T : 0.0f;       // fma(c, 0, C) == C exactly: masked lanes keep their bits
-  const float nC0 = fmaf(r, w, p.C0), nC1 = fmaf(g, w, p.C1), nC2 = fmaf(b, w, p.C2);
-  const float nA = ALPHA ? fmaf(1.0f, w, p.A) : 0.0f;   // exactly what the separate mask pass accumulates
+  const float w = blend ? alpha * p.T : 0.0f;       // C + c*0 == C exactly: masked lanes keep their bits
+  const float nC0 = p.C0 + r * w, nC1 = p.C1 + g * w, nC2 = p.C2 + b * w;   // mul then add (contract §4), in list order
+  const float nA = ALPHA ? p.A + w : 0.0f;          // exactly what the separate mask pass accumulates (1*w == w)
   const float nT = blend ? test_T : p.T;
   const uint32_t nlast = blend ? pos1 : p.last;
   const int ndone = (p.done != 0 || stop) ? 1 : 0;
@@ -129,11 +129,38 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
     const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
     const uint32_t pos1 = (uint32_t)(base + myj + 1);
-    gh_fwd_chain_step<0, ALPHA>(p, alpha, ok, r, g, bl, pos1);
-    gh_fwd_chain_step<1, ALPHA>(p, alpha, ok, r, g, bl, pos1);
-    gh_fwd_chain_step<2, ALPHA>(p, alpha, ok, r, g, bl, pos1);
-    gh_fwd_chain_step<3, ALPHA>(p, alpha, ok, r, g, bl, pos1);
-    if (__all(p.done != 0)) return true;
+    // Fast path (no pixel of the wave saturates inside this trip — true for all but <= 16 trips of a wave):
+    // the recurrence collapses to DPP-fused prefix products / sums over the quad, in exact list order.
+    const bool valid = (p.done == 0) && ok;
+    const float f = valid ? 1.0f - alpha : 1.0f;                   // x*1 == x: skipped entries leave T bit-identical
+    const float P1 = p.T * gh_quad_bcast<0>(f);                    // T before slot 1, 2, 3 and after the trip
+    const float P2 = P1 * gh_quad_bcast<1>(f);
+    const float P3 = P2 * gh_quad_bcast<2>(f);
+    const float P4 = P3 * gh_quad_bcast<3>(f);
+    const float Pm = slot == 0 ? p.T : (slot == 1 ? P1 : (slot == 2 ? P2 : P3));   // T seen by this lane's entry
+    const float Pn = slot == 0 ? P1 : (slot == 1 ? P2 : (slot == 2 ? P3 : P4));   // ... and right after it
+    if (__any(valid && Pn < 0.0001f)) {                            // wave-uniform, rare: exact step-by-step recurrence
+      gh_fwd_chain_step<0, ALPHA>(p, alpha, ok, r, g, bl, pos1);
+      gh_fwd_chain_step<1, ALPHA>(p, alpha, ok, r, g, bl, pos1);
+      gh_fwd_chain_step<2, ALPHA>(p, alpha, ok, r, g, bl, pos1);
+      gh_fwd_chain_step<3, ALPHA>(p, alpha, ok, r, g, bl, pos1);
+      if (__all(p.done != 0)) return true;
+      continue;
+    }
+    const float w = valid ? alpha * Pm : 0.0f;
+    const float m0 = r * w, m1 = g * w, m2 = bl * w;
+    p.C0 = ((((p.C0 + gh_quad_bcast<0>(m0)) + gh_quad_bcast<1>(m0)) + gh_quad_bcast<2>(m0)) + gh_quad_bcast<3>(m0));
+    p.C1 = ((((p.C1 + gh_quad_bcast<0>(m1)) + gh_quad_bcast<1>(m1)) + gh_quad_bcast<2>(m1)) + gh_quad_bcast<3>(m1));
+    p.C2 = ((((p.C2 + gh_quad_bcast<0>(m2)) + gh_quad_bcast<1>(m2)) + gh_quad_bcast<2>(m2)) + gh_quad_bcast<3>(m2));
+    if (ALPHA) p.A = ((((p.A + gh_quad_bcast<0>(w)) + gh_quad_bcast<1>(w)) + gh_quad_bcast<2>(w)) + gh_quad_bcast<3>(w));
+    p.T = P4;
+    // n_contrib: position of the last blended entry = highest valid slot of the quad (entries ascend with slot)
+    const uint32_t lp = valid ? pos1 : 0u;
+    uint32_t lm = lp > (uint32_t)gh_quad_bcast_i<0>((int)lp) ? lp : (uint32_t)gh_quad_bcast_i<0>((int)lp);
+    { const uint32_t t1 = (uint32_t)gh_quad_bcast_i<1>((int)lp); lm = t1 > lm ? t1 : lm; }
+    { const uint32_t t2 = (uint32_t)gh_quad_bcast_i<2>((int)lp); lm = t2 > lm ? t2 : lm; }
+    { const uint32_t t3 = (uint32_t)gh_quad_bcast_i<3>((int)lp); lm = t3 > lm ? t3 : lm; }
+    p.last = lm > p.last ? lm : p.last;
   }
   return false;
 }

@@ -365,7 +365,7 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
         float test_T = Tr * (1.0f - alpha);
         if (test_T < 0.0001f) break;
         float w = alpha * Tr;
-        C0 = fmaf(g->rgb[0], w, C0); C1 = fmaf(g->rgb[1], w, C1); C2 = fmaf(g->rgb[2], w, C2);
+        C0 = C0 + g->rgb[0] * w; C1 = C1 + g->rgb[1] * w; C2 = C2 + g->rgb[2] * w;   /* mul then add (contract §4) */
         Tr = test_T; last = cnt;
       }
       size_t pix = ((size_t)v * H + y) * W + x;
