@@ -351,11 +351,36 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       if (cm == 0) continue;                                           // wave-uniform: nothing blended by this block
       // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
       const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
-      float mTn = 0.0f, mB0 = 0.0f, mB1 = 0.0f, mB2 = 0.0f, mB3 = 0.0f;
-      gh_bwd_chain_step<0, ALPHA>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2, mB3);
-      gh_bwd_chain_step<1, ALPHA>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2, mB3);
-      gh_bwd_chain_step<2, ALPHA>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2, mB3);
-      gh_bwd_chain_step<3, ALPHA>(st, slot, contrib, alpha, inv1ma, cr, cg, cbl, mTn, mB0, mB1, mB2, mB3);
+      // Reverse recurrence over the quad as DPP-fused prefix products / affine updates, in exact processing order:
+      //   T <- T * f,  B <- B * m + a   with (f, m, a) = (1/(1-alpha), 1-alpha, alpha*c) where the pixel blended the
+      //   entry and (1, 1, 0) otherwise (x*1 and x+0 leave the state bit-identical).
+      const float f = contrib ? inv1ma : 1.0f;
+      const float m = contrib ? 1.0f - alpha : 1.0f;
+      const float ac0 = contrib ? alpha * cr : 0.0f, ac1 = contrib ? alpha * cg : 0.0f, ac2 = contrib ? alpha * cbl : 0.0f;
+      const float T1 = st.T * gh_quad_bcast<0>(f), T2 = T1 * gh_quad_bcast<1>(f), T3 = T2 * gh_quad_bcast<2>(f),
+                  T4 = T3 * gh_quad_bcast<3>(f);
+      const float mTn = slot == 0 ? T1 : (slot == 1 ? T2 : (slot == 2 ? T3 : T4));      // T right after this lane's entry
+#define GH_B_CHAIN(B, A, MINE)                                                              \
+      float MINE;                                                                           \
+      {                                                                                     \
+        const float b1 = B * gh_quad_bcast<0>(m) + gh_quad_bcast<0>(A);                     \
+        const float b2 = b1 * gh_quad_bcast<1>(m) + gh_quad_bcast<1>(A);                    \
+        const float b3 = b2 * gh_quad_bcast<2>(m) + gh_quad_bcast<2>(A);                    \
+        const float b4 = b3 * gh_quad_bcast<3>(m) + gh_quad_bcast<3>(A);                    \
+        MINE = slot == 0 ? B : (slot == 1 ? b1 : (slot == 2 ? b2 : b3));   /* colour behind this lane's entry */ \
+        B = b4;                                                                             \
+      }
+      GH_B_CHAIN(st.B0, ac0, mB0)
+      GH_B_CHAIN(st.B1, ac1, mB1)
+      GH_B_CHAIN(st.B2, ac2, mB2)
+      float mB3 = 0.0f;
+      if (ALPHA) {
+        const float ac3 = contrib ? alpha : 0.0f;
+        GH_B_CHAIN(st.B3, ac3, mB3x)
+        mB3 = mB3x;
+      }
+#undef GH_B_CHAIN
+      st.T = T4;
       float dL_dalpha = (cr - mB0) * d0 + (cg - mB1) * d1 + (cbl - mB2) * d2;
       if (ALPHA) dL_dalpha += (1.0f - mB3) * dM;
       dL_dalpha *= mTn;
