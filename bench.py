@@ -49,6 +49,19 @@ def algorithmic_bytes(P, NV, H, W, D, C=12, M=0):
     }
 
 
+def pmc_traffic(kernel: str, args, V: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md). Only valid for the workload
+    the counters were collected on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if args.config != "two_hands" or V != 8 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["kernels"][kernel]["traffic_bytes"]
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(scene, seconds: float):
     """The C oracle (oracle/gh_oracle.c, OpenMP over tiles) on the host cores: a reported baseline only."""
     from oracle import oracle_c
@@ -169,7 +182,7 @@ def main():
             dom = max(single, key=single.get)
             ach = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "gh_" + dom + "_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("gh_" + dom + "_kernel", args, V),
                         "alg_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom]}
         out = {
             "metric": "fwd+bwd renders/sec @512x334, ~100k Gaussians", "value": value, "unit": "renders/s",
