@@ -91,6 +91,20 @@ def _run_stages(fn, args, stages):
     return rc
 
 
+_graph_mode = False
+_graph_counters = []   # device views of GhCounters of forwards issued in graph mode (read back by check_overflow)
+
+
+def set_graph_mode(on: bool) -> None:
+    """Graph mode: sync-free forwards issue no counter read-back at all (nothing but kernel launches and async
+    memsets reaches the stream), so a whole step can be captured with torch.cuda.CUDAGraph / hipGraph.
+    check_overflow() then reads the counters of the captured workspaces directly."""
+    global _graph_mode
+    _graph_mode = bool(on)
+    if not on:
+        _graph_counters.clear()
+
+
 def _initial_capacity(P: int, NV: int) -> int:
     return max(1 << 16, 8 * P * NV)
 
@@ -98,6 +112,12 @@ def _initial_capacity(P: int, NV: int) -> int:
 def check_overflow(block: bool = True) -> None:
     """Verify every outstanding sync-free forward fitted its capacity (raises GhOverflowError)."""
     global _pending, _last_D
+    for counters, cap, key in _graph_counters:            # graph mode: workspaces are static, read them directly
+        d = int(counters[0].item()) & 0xFFFFFFFF
+        _last_D = d
+        if d > cap:
+            _capacity[key] = max(_capacity.get(key, 0), int(d * 1.5) + 1024)
+            raise GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside a captured graph")
     keep = []
     for ev, host, cap, key in _pending:
         if not block and not ev.query():
@@ -195,6 +215,9 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                 continue
             if max_instances is None and key not in _capacity:
                 _capacity[key] = max(int(d * 1.5) + 1024, 1 << 16)
+        elif _graph_mode:
+            if len(_graph_counters) < 64:
+                _graph_counters.append((counters, cap, key))
         else:
             host = torch.empty(4, dtype=torch.int32, pin_memory=True)
             host.copy_(counters, non_blocking=True)
