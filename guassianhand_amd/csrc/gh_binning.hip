@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void gh_scan_blocksums_kernel(uint32_t* __res
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_offsets, const uint32_t* __restrict__ rect, uint32_t* __restrict__ slot_begin,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    float4* __restrict__ geom, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = blockIdx.x * GH_BLOCK + tid;
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   uint32_t off = block_offsets[blockIdx.x] + woff + x - cnt;
   slot_begin[n] = off;
   if (cnt == 0) return;
+  geom[(size_t)n * 4 + 2].z = __uint_as_float(off);      // same 64-byte line the post-sort gather reads
   const uint32_t r = rect[n];
   const int minx = r & 255, miny = (r >> 8) & 255, maxx = (r >> 16) & 255, maxy = r >> 24;
   const uint32_t vbase = (n / (uint32_t)P) * (uint32_t)tiles;
@@ -257,7 +258,6 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
 // of the pipeline happens here, massively parallel, so both render kernels stream contiguous records.
 __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                               const GhCounters* __restrict__ ctr, uint32_t cap, int gx, int tiles,
-                                                              const uint32_t* __restrict__ rect, const uint32_t* __restrict__ slot_begin,
                                                               const float4* __restrict__ geom, uint2* __restrict__ ranges,
                                                               uint32_t* __restrict__ sorted_slot, float4* __restrict__ r0,
                                                               float4* __restrict__ r1, float* __restrict__ r2) {
@@ -272,13 +272,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __r
   }
   if (i == n - 1) ranges[t].y = n;
   const uint32_t gid = vals[i];
+  const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line: record, tile rect and first emit slot
+  const float4 a = grec[0], b = grec[1], c = grec[2];
   // emit slot of (gid, tile): instances of a Gaussian are emitted row-major over its tile rect
-  const uint32_t r = rect[gid];
+  const uint32_t r = __float_as_uint(c.y);
   const uint32_t tl = t % (uint32_t)tiles, ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
   const uint32_t minx = r & 255u, miny = (r >> 8) & 255u, maxx = (r >> 16) & 255u;
-  sorted_slot[i] = slot_begin[gid] + (ty - miny) * (maxx - minx) + (tx - minx);
-  const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line
-  const float4 a = grec[0], b = grec[1], c = grec[2];
+  sorted_slot[i] = __float_as_uint(c.z) + (ty - miny) * (maxx - minx) + (tx - minx);
   r0[i] = a; r1[i] = b; r2[i] = c.x;
 }
 
@@ -366,12 +366,12 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
                      (const uint32_t*)(ws + L.block_sums), (const uint32_t*)(ws + L.rect), (uint32_t*)(ws + L.slot_begin),
-                     k_in, v_in);
+                     (float4*)(ws + L.geom), k_in, v_in);
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, g.nblk_sort, s);
 
   const int nblk_d = (int)((g.cap + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,
-                     (const uint32_t*)(ws + L.rect), (const uint32_t*)(ws + L.slot_begin), (const float4*)(ws + L.geom),
+                     (const float4*)(ws + L.geom),
                      (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.sorted_slot), (float4*)(ws + L.inst_r0),
                      (float4*)(ws + L.inst_r1), (float*)(ws + L.inst_r2));
   gh_launch_tile_order(g, ws, L, s);

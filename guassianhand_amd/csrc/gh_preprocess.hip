@@ -74,7 +74,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         float4* grec = geom + (size_t)n * 4;           // one 64-byte line per Gaussian
         grec[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
         grec[1] = make_float4(e.a * dinv, op, rgb[0], rgb[1]);
-        grec[2] = make_float4(rgb[2], 0.0f, 0.0f, 0.0f);
+        // .y = packed tile rect, .z = first emit slot (filled by gh_emit_kernel): the post-sort gather reads one line
+        grec[2] = make_float4(rgb[2], __uint_as_float((unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24)), 0.0f, 0.0f);
         depth[n] = e.tz;
         dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
         rect[n] = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);
