@@ -188,8 +188,10 @@ def main():
             "metric": "fwd+bwd renders/sec @512x334, ~100k Gaussians", "value": value, "unit": "renders/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: P={P} Gaussians, {H}x{W}, RGB colours, attribute blend "
-                                   f"{'on' if s.color_w is not None else 'off'} (BASELINE configs[2])",
+            "config": {"workload": f"{args.config}: P={P} Gaussians, {H}x{W}, "
+                                   f"{'RGB colours' if s.use_rgb else 'SH degree %d colours' % s.sh_degree}, attribute blend "
+                                   f"{'on' if s.color_w is not None else 'off'}"
+                                   + (" (BASELINE configs[2])" if args.config == "two_hands" else ""),
                        "views_per_step_per_gpu": V, "instances_per_step_per_gpu": D, "parallelism": f"view-parallel x{world}",
                        "loss": "mean|img-gt|", "final_loss": float(loss)},
             "roofline": roofline, "stages": stages,

@@ -27,6 +27,7 @@ import torch.nn.functional as F
 
 from . import dist as ghdist
 from .renderer import GaussianModel
+from .uvmap import to_reference_layout, uv_sample
 
 MILESTONES = (2, 5, 10, 20, 35, 50, 75)
 
@@ -61,23 +62,34 @@ class OneShotFit(nn.Module):
         dev = gs.xyz.device
         Hm, Wm = map_hw
         self.color_w = nn.Parameter(torch.ones(48, device=dev))                      # infer_one_shot.py:159
-        self.color_b = nn.Parameter(torch.zeros(48, Hm, Wm, device=dev))             # :160
+        # the maps are stored CHANNEL-LAST (Hm,Wm,C) for the device lookup (uvmap.py); `.color_b` / `.opacity_b` are
+        # views in the reference's (C,Hm,Wm) layout (infer_one_shot.py:160,163) for loading / exporting state
+        self.color_b_map = nn.Parameter(torch.zeros(Hm, Wm, 48, device=dev))
         self.xyz_b = nn.Parameter(torch.zeros(3, device=dev), requires_grad=False)   # :161 (not in the trainable set)
-        self.opacity_b = nn.Parameter(torch.zeros(1, Hm, Wm, device=dev))            # :163
-        self.opt = torch.optim.Adam([self.color_w, self.color_b, self.opacity_b], lr=lr)
+        self.opacity_b_map = nn.Parameter(torch.zeros(Hm, Wm, 1, device=dev))
+        self.opt = torch.optim.Adam([self.color_w, self.color_b_map, self.opacity_b_map], lr=lr)
         self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=list(MILESTONES), gamma=0.5)
         if render_fn is None:
             from .renderer import render_views
             render_fn = render_views
         self.render_fn = render_fn
 
+    @property
+    def color_b(self) -> torch.Tensor:
+        return to_reference_layout(self.color_b_map)
+
+    @property
+    def opacity_b(self) -> torch.Tensor:
+        return to_reference_layout(self.opacity_b_map)
+
     # -- pieces ----------------------------------------------------------------------------------------
     def blend_values(self) -> Dict[str, torch.Tensor]:
-        return dict(color_w=self.color_w, color_b=sample_map(self.color_b, self.uv),
-                    opacity_b=sample_map(self.opacity_b, self.uv), xyz_b=self.xyz_b)
+        """Per-Gaussian blend values: the device UV lookup of renderer_one_shot.py:489-492 (gh_uv_sample_*)."""
+        return dict(color_w=self.color_w, color_b=uv_sample(self.color_b_map, self.uv),
+                    opacity_b=uv_sample(self.opacity_b_map, self.uv), xyz_b=self.xyz_b)
 
     def regulariser(self) -> torch.Tensor:
-        return 100.0 * self.color_b.abs().mean() + self.opacity_b.pow(2.0).mean()   # infer_one_shot.py:514-518
+        return 100.0 * self.color_b_map.abs().mean() + self.opacity_b_map.pow(2.0).mean()   # infer_one_shot.py:514-518
 
     def render(self, w2cs, Ks, H, W, bg, blend: Dict[str, torch.Tensor], sync: bool = True):
         return self.render_fn(self.gs, w2cs, Ks, H, W, bg, color_w=blend["color_w"], xyz_b=blend["xyz_b"],

@@ -198,6 +198,18 @@ int gh_forward_stages(const GhDims* dims, const GhInputs* in, const GhOutputs* o
 int gh_backward_stages(const GhDims* dims, const GhInputs* in, const GhGrads* grads,
                        void* workspace, size_t ws_bytes, void* hip_stream, uint32_t stages);
 
+/*
+ * Per-Gaussian bilinear lookup of a learnable UV map and its backward. Replaces
+ * F.grid_sample(..., align_corners=True, mode="bilinear") of query_triplane_texture (renderer_one_shot.py:420-446)
+ * at the call sites :489-492. `map` is CHANNEL-LAST (Hm, Wm, C) fp32 (the reference parameter (C,Hm,Wm) permuted
+ * once); `uv` is (P,2) in [-1,1] (x = u indexes Wm, y = v indexes Hm); texels outside the map read as zero.
+ * gh_uv_sample_backward ACCUMULATES into dL_dmap (the caller zeroes it): float atomics, run-to-run order noise.
+ */
+int gh_uv_sample_forward(const float* map, const float* uv, float* out /* (P,C) */, int P, int C, int Hm, int Wm,
+                         void* hip_stream);
+int gh_uv_sample_backward(const float* uv, const float* dL_dout /* (P,C) */, float* dL_dmap /* (Hm,Wm,C) */, int P, int C,
+                          int Hm, int Wm, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,7 @@ def test_fit_reduces_loss_and_schedule():
     losses = [float(f.step(pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)) for _ in range(25)]
     assert losses[-1] < 0.7 * losses[0], losses
     assert float((f.color_w - 1).abs().max()) > 0 and float(f.color_b.abs().max()) > 0 and float(f.opacity_b.abs().max()) > 0
+    assert f.color_b.shape == (48, *pb["map_hw"]) and f.opacity_b.shape == (1, *pb["map_hw"])        # reference layout views
     assert f.xyz_b.grad is None and float(f.xyz_b.abs().max()) == 0.0                  # frozen like the reference
     lrs = []
     for _ in range(6):

@@ -33,9 +33,31 @@ def test_first_step_gradients_match_oracle_driven_loop(dev):
     lc = fc.step(pb_c["w2c"], pb_c["K"], pb_c["H"], pb_c["W"], pb_c["bg"], gt_rgb, gt_mask)
     lg = fg.step(pb_g["w2c"], pb_g["K"], pb_g["H"], pb_g["W"], pb_g["bg"], gt_rgb.to(dev), gt_mask.to(dev))
     assert float(lg) == pytest.approx(float(lc), rel=2e-5)
-    for n in ("color_w", "color_b", "opacity_b"):
+    for n in ("color_w", "color_b_map", "opacity_b_map"):
         a, b = getattr(fg, n).grad.cpu(), getattr(fc, n).grad
         assert rel_l2(a, b) <= 2e-4 and max_rel(a, b, floor=1e-2) <= 5e-3, n
+
+
+def test_uv_sample_kernels_match_grid_sample(dev):
+    """the device UV lookup (channel-last map, lanes = channels) equals F.grid_sample(bilinear,
+    align_corners=True, zeros padding) of renderer_one_shot.py:435-440, forward and scatter-add backward, including
+    coordinates on and beyond the map border."""
+    import torch.nn.functional as Fn
+    from guassianhand_amd.uvmap import to_channel_last, uv_sample
+    g = torch.Generator().manual_seed(9)
+    for C_, Hm, Wm, P in ((48, 37, 53, 5000), (1, 64, 128, 3000), (5, 8, 9, 777)):
+        chw = torch.randn(C_, Hm, Wm, generator=g)
+        uv = torch.rand(P, 2, generator=g) * 2.4 - 1.2            # some samples fall outside [-1,1]
+        uv[:7] = torch.tensor([[-1, -1], [1, 1], [1, -1], [-1, 1], [0, 0], [1.0, 0.3], [-1.0, -0.7]])
+        ref_in = chw.clone().requires_grad_(True)
+        ref = Fn.grid_sample(ref_in[None], uv[None, :, None, :], align_corners=True, mode="bilinear")[0, :, :, 0].T
+        dout = torch.randn(P, C_, generator=g)
+        (ref * dout).sum().backward()
+        m = to_channel_last(chw).to(dev).requires_grad_(True)
+        out = uv_sample(m, uv.to(dev))
+        (out * dout.to(dev)).sum().backward()
+        assert torch.allclose(out.detach().cpu(), ref.detach(), atol=2e-6, rtol=1e-5)
+        assert torch.allclose(m.grad.permute(2, 0, 1).cpu(), ref_in.grad, atol=2e-5, rtol=1e-4)
 
 
 def test_fit_converges_on_eight_views(dev):
@@ -51,7 +73,7 @@ def test_fit_converges_on_eight_views(dev):
     true = F.OneShotFit(gs, uv, map_hw=map_hw)
     with torch.no_grad():
         true.color_w.copy_((1 + 0.1 * torch.randn(48, generator=g)).to(dev))
-        true.color_b.copy_((0.1 * torch.randn(48, *map_hw, generator=g)).to(dev))
+        true.color_b.copy_((0.1 * torch.randn(48, *map_hw, generator=g)).to(dev))          # writes through the layout view
         true.opacity_b.copy_((0.05 * torch.randn(1, *map_hw, generator=g)).to(dev))
         out = true.render(sc.w2c, sc.K, sc.H, sc.W, sc.bg, true.blend_values())
         gt_rgb, gt_mask = out["comp_rgb"].clone(), out["comp_mask"].mean(-1).clone()
@@ -60,4 +82,4 @@ def test_fit_converges_on_eight_views(dev):
     from guassianhand_amd import rasterizer as R
     R.check_overflow()
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
-    assert all(torch.isfinite(p).all() for p in (f.color_w, f.color_b, f.opacity_b))
+    assert all(torch.isfinite(p).all() for p in (f.color_w, f.color_b_map, f.opacity_b_map))
