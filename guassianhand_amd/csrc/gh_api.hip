@@ -58,6 +58,10 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->n_contrib = take(pix * 4);
   L->inst_grad = take(cap * 4 * GH_REC * 4);
   L->inst_flag = take(cap * 4);
+  const bool sh_mode = d->M != 0;
+  L->sh_rgb = take(sh_mode ? N * 16 : 0);
+  L->dmean_sh = take(sh_mode ? N * 16 : 0);
+  L->sh_scratch = take(sh_mode ? (((size_t)d->P * 16 + GH_BLOCK - 1) / GH_BLOCK + 1) * 64 * 4 : 0);
   L->grad_sums = take(N * 48);
   L->bwd_scratch = take((nblk_pre + 1) * 64 * 4);
   L->total_bytes = off;
@@ -103,6 +107,7 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   (void)hipGetLastError();
   if (stages & GH_FWD_PREPROCESS) {
     if (hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s) != hipSuccess) return GH_ERR_LAUNCH;
+    gh_launch_sh_colour_fwd(d, g, in, ws, L, s);
     gh_launch_preprocess_fwd(d, g, in, out->radii, ws, L, s);
   }
   if (stages & GH_FWD_BINNING) {

@@ -8,7 +8,7 @@
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     GhInputs in, int P, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
-    float4* __restrict__ geom, float* __restrict__ depth,
+    const float4* __restrict__ sh_rgb, float4* __restrict__ geom, float* __restrict__ depth,
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii) {
@@ -55,21 +55,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
             if (in.blend_color_b) col = col + in.blend_color_b[(size_t)i * 48 + ch];
             rgb[ch] = col;
           }
-        } else {
-          float dx = e.mx - cam[32], dy = e.my - cam[33], dz = e.mz - cam[34];
-          float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-          dx = dx / len; dy = dy / len; dz = dz / len;
-          float Bv[16];
-          int nb = gh_sh_basis(sh_degree, dx, dy, dz, Bv);
-          if (nb > M) nb = M;
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            float acc = 0.0f;
-            for (int k = 0; k < nb; ++k) acc = fmaf(Bv[k], gh_blended_sh(in, flags, M, i, k, ch), acc);
-            acc = acc + 0.5f;
-            if (acc < 0.0f) { cl |= (1u << ch); acc = 0.0f; }
-            rgb[ch] = acc;
-          }
+        } else {                                       // SH colours: evaluated by gh_sh_colour_fwd_kernel (gh_sh.hip)
+          const float4 c4 = sh_rgb[n];
+          rgb[0] = c4.x; rgb[1] = c4.y; rgb[2] = c4.z; cl = __float_as_uint(c4.w);
         }
         float4* grec = geom + (size_t)n * 4;           // one 64-byte line per Gaussian
         grec[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
@@ -94,35 +82,13 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   if (g.N == 0) return;
   int nblk = (g.N + GH_BLOCK - 1) / GH_BLOCK;
   hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.N, g.H, g.W, g.gx, g.gy,
-                     d->sh_degree, d->M, d->scale_modifier, d->flags, (float4*)(ws + L.geom), (float*)(ws + L.depth),
+                     d->sh_degree, d->M, d->scale_modifier, d->flags, (const float4*)(ws + L.sh_rgb), (float4*)(ws + L.geom),
+                     (float*)(ws + L.depth),
                      (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii);
 }
 
 // ------------------------------------------------------------------------------------------------
-// d(basis_k)/d(x,y,z)
-__device__ __forceinline__ void gh_sh_basis_grad(int deg, float x, float y, float z, float (*dB)[3]) {
-#pragma unroll
-  for (int k = 0; k < 16; ++k) dB[k][0] = dB[k][1] = dB[k][2] = 0.0f;
-  if (deg < 1) return;
-  dB[1][1] = -GH_SH_C1; dB[2][2] = GH_SH_C1; dB[3][0] = -GH_SH_C1;
-  if (deg < 2) return;
-  float xx = x * x, yy = y * y, zz = z * z;
-  dB[4][0] = GH_SH_C2_0 * y;  dB[4][1] = GH_SH_C2_0 * x;
-  dB[5][1] = GH_SH_C2_1 * z;  dB[5][2] = GH_SH_C2_1 * y;
-  dB[6][0] = GH_SH_C2_2 * -2.0f * x; dB[6][1] = GH_SH_C2_2 * -2.0f * y; dB[6][2] = GH_SH_C2_2 * 4.0f * z;
-  dB[7][0] = GH_SH_C2_3 * z;  dB[7][2] = GH_SH_C2_3 * x;
-  dB[8][0] = GH_SH_C2_4 * 2.0f * x; dB[8][1] = GH_SH_C2_4 * -2.0f * y;
-  if (deg < 3) return;
-  dB[9][0]  = GH_SH_C3_0 * 6.0f * x * y;  dB[9][1] = GH_SH_C3_0 * (3.0f * xx - 3.0f * yy);
-  dB[10][0] = GH_SH_C3_1 * y * z; dB[10][1] = GH_SH_C3_1 * x * z; dB[10][2] = GH_SH_C3_1 * x * y;
-  dB[11][0] = GH_SH_C3_2 * -2.0f * x * y; dB[11][1] = GH_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); dB[11][2] = GH_SH_C3_2 * 8.0f * y * z;
-  dB[12][0] = GH_SH_C3_3 * -6.0f * x * z; dB[12][1] = GH_SH_C3_3 * -6.0f * y * z; dB[12][2] = GH_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
-  dB[13][0] = GH_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); dB[13][1] = GH_SH_C3_4 * -2.0f * x * y; dB[13][2] = GH_SH_C3_4 * 8.0f * x * z;
-  dB[14][0] = GH_SH_C3_5 * 2.0f * x * z; dB[14][1] = GH_SH_C3_5 * -2.0f * y * z; dB[14][2] = GH_SH_C3_5 * (xx - yy);
-  dB[15][0] = GH_SH_C3_6 * (3.0f * xx - 3.0f * yy); dB[15][1] = GH_SH_C3_6 * -6.0f * x * y;
-}
-
 // Deterministic block-level accumulation of blend-parameter gradients: wave DPP sum, lane 63 adds the
 // wave's total to its own LDS row (single writer per row), rows are combined in fixed order at the end.
 __device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, float v) {
@@ -167,14 +133,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t
 template <bool RGB_MODE>
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags,
-    const uint32_t* __restrict__ tiles_touched, const uint8_t* __restrict__ clamped, const float4* __restrict__ gsum,
+    const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ dmean_sh, const float4* __restrict__ gsum,
     float* __restrict__ scratch) {
   __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
   const int i = blockIdx.x * GH_BLOCK + threadIdx.x;
   const bool live = i < P;
   constexpr bool rgb_mode = RGB_MODE;
   const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
-  const bool red_w = in.blend_color_w && !wpg && gr.dL_dblend_color_w;   // global (48,) weights: block reduce
+  const bool red_w = rgb_mode && in.blend_color_w && !wpg && gr.dL_dblend_color_w;   // global (48,) weights: block reduce
   const bool red_x = in.blend_xyz_b && gr.dL_dblend_xyz_b;
   if (threadIdx.x < 64) {
 #pragma unroll
@@ -201,50 +167,15 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     float dm[3] = {0, 0, 0};
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     const float* V = cam; const float* PM = cam + 16;
-    float Bv[16]; int nb = 0; unsigned cl = 0;      // SH basis of this view (kept for the global-w reduction)
     if (vis) {
       GhGeo e;
       gh_geo_forward(in, cam, i, mod, H, W, e);
       // ---- colour ----
       if (rgb_mode) {
         araw[0] += s9[6]; araw[1] += s9[7]; araw[2] += s9[8];
-      } else {
-        float dx = e.mx - cam[32], dy = e.my - cam[33], dz = e.mz - cam[34];
-        float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-        float ux = dx / len, uy = dy / len, uz = dz / len;
-        float dB[16][3];
-        nb = gh_sh_basis(sh_degree, ux, uy, uz, Bv); if (nb > M) nb = M;
-        gh_sh_basis_grad(sh_degree, ux, uy, uz, dB);
-        float ddir[3] = {0, 0, 0};
-        cl = clamped[n];
-        for (int k = 0; k < M; ++k) {
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            const size_t oi = ((size_t)i * M + k) * 3 + ch;
-            const size_t bi = (size_t)i * 48 + k * 3 + ch;
-            float gsh = 0.0f, gk = 0.0f, gw = 0.0f;
-            if (k < nb) {
-              float gc = (cl & (1u << ch)) ? 0.0f : s9[6 + ch];
-              float shv = gh_blended_sh(in, flags, M, i, k, ch);
-              gk = Bv[k] * gc;                     // dL/d(blended coefficient)
-              ddir[0] += dB[k][0] * shv * gc; ddir[1] += dB[k][1] * shv * gc; ddir[2] += dB[k][2] * shv * gc;
-              gsh = gk;
-              if (in.blend_color_w) {
-                const float wv = in.blend_color_w[(wpg ? (size_t)i * 48 : 0) + k * 3 + ch];
-                const float raw = in.shs[oi];
-                gsh = in.blend_color_b ? gk * wv * wv : gk * wv;
-                gw = in.blend_color_b ? gk * 2.0f * raw * wv : gk * raw;
-              }
-            }
-            if (gr.dL_dshs) gr.dL_dshs[oi] = (v == 0 ? 0.0f : gr.dL_dshs[oi]) + gsh;
-            if (in.blend_color_b && gr.dL_dblend_color_b)
-              gr.dL_dblend_color_b[bi] = (v == 0 ? 0.0f : gr.dL_dblend_color_b[bi]) + gk;
-            if (in.blend_color_w && wpg && gr.dL_dblend_color_w)
-              gr.dL_dblend_color_w[bi] = (v == 0 ? 0.0f : gr.dL_dblend_color_w[bi]) + gw;
-          }
-        }
-        float dot = ux * ddir[0] + uy * ddir[1] + uz * ddir[2];
-        dm[0] += (ddir[0] - ux * dot) / len; dm[1] += (ddir[1] - uy * dot) / len; dm[2] += (ddir[2] - uz * dot) / len;
+      } else {                                         // SH colours: gh_sh_colour_bwd_kernel did the colour chain
+        const float4 d4 = dmean_sh[n];
+        dm[0] = d4.x; dm[1] = d4.y; dm[2] = d4.z;
       }
       // ---- conic -> dilated cov2D (a,b,c) ----
       float a = e.a, b = e.b, cc = e.c, det = e.det;
@@ -316,29 +247,6 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
       for (int a2 = 0; a2 < 3; ++a2) dm[a2] += dhx * PM[4 * a2] + dhy * PM[4 * a2 + 1] + dhw * PM[4 * a2 + 3];
       am[0] += dm[0]; am[1] += dm[1]; am[2] += dm[2];
       ao += g_o;
-    } else if (live && !rgb_mode && v == 0) {
-      // invisible in the first view: per-coefficient outputs still have to start from zero
-      for (int k = 0; k < M * 3; ++k) {
-        if (gr.dL_dshs) gr.dL_dshs[(size_t)i * M * 3 + k] = 0.0f;
-        if (in.blend_color_b && gr.dL_dblend_color_b) gr.dL_dblend_color_b[(size_t)i * 48 + k] = 0.0f;
-        if (in.blend_color_w && wpg && gr.dL_dblend_color_w) gr.dL_dblend_color_w[(size_t)i * 48 + k] = 0.0f;
-      }
-    }
-    // SH mode, global (48,) color_w: every lane of the wave takes part in the DPP reduction
-    if (!rgb_mode && red_w) {
-      for (int k = 0; k < 16; ++k) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-          float gw = 0.0f;
-          if (vis && k < nb) {
-            float gk = Bv[k] * ((cl & (1u << ch)) ? 0.0f : s9[6 + ch]);
-            float raw = in.shs[((size_t)i * M + k) * 3 + ch];
-            float wv = in.blend_color_w[k * 3 + ch];
-            gw = in.blend_color_b ? gk * 2.0f * raw * wv : gk * raw;
-          }
-          gh_block_acc(s_part, k * 3 + ch, gw);
-        }
-      }
     }
     if (red_x) { gh_block_acc(s_part, 48, dm[0]); gh_block_acc(s_part, 49, dm[1]); gh_block_acc(s_part, 50, dm[2]); }
   }
@@ -413,13 +321,18 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
                      (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched),
                      (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
+  const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, ws, L, s);     // SH mode only; no-op with colors_precomp
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
                      d->sh_degree, d->M, d->scale_modifier, d->flags,
-                     (const uint32_t*)(ws + L.tiles_touched), (const uint8_t*)(ws + L.clamped),
+                     (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.dmean_sh),
                      (const float4*)(ws + L.grad_sums), (float*)(ws + L.bwd_scratch));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;
   float* dx = in->blend_xyz_b ? gr->dL_dblend_xyz_b : nullptr;
+  if (nblk_sh > 0) {                     // SH mode: the colour-weight partials come from the SH kernel's own scratch
+    hipLaunchKernelGGL(gh_blend_reduce_kernel, dim3(48), dim3(GH_BLOCK), 0, s, (const float*)(ws + L.sh_scratch), nblk_sh, dw, (float*)nullptr);
+    dw = nullptr;
+  }
   if (dw || dx)
     hipLaunchKernelGGL(gh_blend_reduce_kernel, dim3(51), dim3(GH_BLOCK), 0, s, (const float*)(ws + L.bwd_scratch), nblk, dw, dx);
 }

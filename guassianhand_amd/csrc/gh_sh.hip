@@ -1,0 +1,207 @@
+// gh_sh.hip — spherical-harmonics colour stage (backward A.5-5/7) incl. the SH form of the
+// attribute blend (tgs/models/renderer_one_shot.py:330-334, with its double multiply when color_b is given).
+//
+// wave64 mapping: 16 lanes per (view, Gaussian) = one DPP row, lane = SH coefficient. The 48 coefficients of a
+// Gaussian (and its 48 blend biases) are 192 contiguous bytes, so a row reads them as one coalesced segment; the
+// fma chain over the coefficients runs IN ORDER over the row with row_newbcast (bit-identical to the sequential
+// sum of the oracle). The backward keeps its per-coefficient accumulators in registers across the view loop, so
+// dL/dshs and dL/dcolor_b are written once instead of read-modify-written per view.
+#include "gh_internal.h"
+
+template <int K>
+__device__ __forceinline__ float gh_row_bcast(float v) {       // value of lane K of this lane's 16-lane row
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float gh_row_sum(float v) {          // sum over the 16 lanes of the row, in every lane
+  v += gh_dpp<0xB1>(v);           // quad_perm [1,0,3,2]
+  v += gh_dpp<0x4E>(v);           // quad_perm [2,3,0,1]
+  v += gh_dpp<0x141>(v);          // row_half_mirror
+  v += gh_dpp<0x140>(v);          // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ float gh_pick16(const float* a, int k) {   // a[k] without a runtime-indexed register array
+  float r = a[0];
+#pragma unroll
+  for (int j = 1; j < 16; ++j) {
+    r = (k == j) ? a[j] : r;
+    asm("" : "+v"(r));          // keep the v_cndmask chain: without it the compiler spills the table to scratch and indexes it
+  }
+  return r;
+}
+
+template <int K>
+__device__ __forceinline__ void gh_sh_chain_step(float bk, float s0, float s1, float s2, int nb, float& a0, float& a1, float& a2) {
+  const float b = gh_row_bcast<K>(bk);
+  const float n0 = fmaf(b, gh_row_bcast<K>(s0), a0), n1 = fmaf(b, gh_row_bcast<K>(s1), a1), n2 = fmaf(b, gh_row_bcast<K>(s2), a2);
+  if (K < nb) { a0 = n0; a1 = n1; a2 = n2; }        // nb is wave-uniform (degree / M)
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in, int P, int N, int sh_degree, int M,
+                                                                     uint32_t flags, float4* __restrict__ sh_rgb) {
+  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int n = t >> 4, k = t & 15;
+  const bool live = n < N;
+  const int nn = live ? n : 0;
+  const int v = nn / P, i = nn - v * P;
+  const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
+  float mx = in.means3D[3 * i], my = in.means3D[3 * i + 1], mz = in.means3D[3 * i + 2];
+  if (in.blend_xyz_b) { mx = mx + in.blend_xyz_b[0]; my = my + in.blend_xyz_b[1]; mz = mz + in.blend_xyz_b[2]; }
+  float dx = mx - cam[32], dy = my - cam[33], dz = mz - cam[34];
+  const float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+  dx = dx / len; dy = dy / len; dz = dz / len;
+  float Bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) Bv[j] = 0.0f;
+  int nb = gh_sh_basis(sh_degree, dx, dy, dz, Bv);
+  if (nb > M) nb = M;
+  const float bk = gh_pick16(Bv, k);
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+  if (live && k < nb) {
+    s0 = gh_blended_sh(in, flags, M, i, k, 0); s1 = gh_blended_sh(in, flags, M, i, k, 1); s2 = gh_blended_sh(in, flags, M, i, k, 2);
+  }
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;          // acc = fmaf(B_k, sh_k, acc) for k = 0 .. nb-1, in order
+  gh_sh_chain_step<0>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<1>(bk, s0, s1, s2, nb, a0, a1, a2);
+  gh_sh_chain_step<2>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<3>(bk, s0, s1, s2, nb, a0, a1, a2);
+  gh_sh_chain_step<4>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<5>(bk, s0, s1, s2, nb, a0, a1, a2);
+  gh_sh_chain_step<6>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<7>(bk, s0, s1, s2, nb, a0, a1, a2);
+  gh_sh_chain_step<8>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<9>(bk, s0, s1, s2, nb, a0, a1, a2);
+  gh_sh_chain_step<10>(bk, s0, s1, s2, nb, a0, a1, a2);  gh_sh_chain_step<11>(bk, s0, s1, s2, nb, a0, a1, a2);
+  gh_sh_chain_step<12>(bk, s0, s1, s2, nb, a0, a1, a2);  gh_sh_chain_step<13>(bk, s0, s1, s2, nb, a0, a1, a2);
+  gh_sh_chain_step<14>(bk, s0, s1, s2, nb, a0, a1, a2);  gh_sh_chain_step<15>(bk, s0, s1, s2, nb, a0, a1, a2);
+  a0 = a0 + 0.5f; a1 = a1 + 0.5f; a2 = a2 + 0.5f;
+  unsigned cl = 0;
+  if (a0 < 0.0f) { cl |= 1u; a0 = 0.0f; }
+  if (a1 < 0.0f) { cl |= 2u; a1 = 0.0f; }
+  if (a2 < 0.0f) { cl |= 4u; a2 = 0.0f; }
+  if (live && k == 0) sh_rgb[n] = make_float4(a0, a1, a2, __uint_as_float(cl));
+}
+
+// ------------------------------------------------------------------------------------------------
+// d(basis_k)/d(x,y,z)
+__device__ __forceinline__ void gh_sh_basis_grad(int deg, float x, float y, float z, float* dBx, float* dBy, float* dBz) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dBx[k] = dBy[k] = dBz[k] = 0.0f;
+  (void)deg;                    // all bands are evaluated; the caller masks coefficients k >= (deg+1)^2
+  dBy[1] = -GH_SH_C1; dBz[2] = GH_SH_C1; dBx[3] = -GH_SH_C1;
+  const float xx = x * x, yy = y * y, zz = z * z;
+  dBx[4] = GH_SH_C2_0 * y;  dBy[4] = GH_SH_C2_0 * x;
+  dBy[5] = GH_SH_C2_1 * z;  dBz[5] = GH_SH_C2_1 * y;
+  dBx[6] = GH_SH_C2_2 * -2.0f * x; dBy[6] = GH_SH_C2_2 * -2.0f * y; dBz[6] = GH_SH_C2_2 * 4.0f * z;
+  dBx[7] = GH_SH_C2_3 * z;  dBz[7] = GH_SH_C2_3 * x;
+  dBx[8] = GH_SH_C2_4 * 2.0f * x; dBy[8] = GH_SH_C2_4 * -2.0f * y;
+  dBx[9]  = GH_SH_C3_0 * 6.0f * x * y;  dBy[9] = GH_SH_C3_0 * (3.0f * xx - 3.0f * yy);
+  dBx[10] = GH_SH_C3_1 * y * z; dBy[10] = GH_SH_C3_1 * x * z; dBz[10] = GH_SH_C3_1 * x * y;
+  dBx[11] = GH_SH_C3_2 * -2.0f * x * y; dBy[11] = GH_SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); dBz[11] = GH_SH_C3_2 * 8.0f * y * z;
+  dBx[12] = GH_SH_C3_3 * -6.0f * x * z; dBy[12] = GH_SH_C3_3 * -6.0f * y * z; dBz[12] = GH_SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+  dBx[13] = GH_SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); dBy[13] = GH_SH_C3_4 * -2.0f * x * y; dBz[13] = GH_SH_C3_4 * 8.0f * x * z;
+  dBx[14] = GH_SH_C3_5 * 2.0f * x * z; dBy[14] = GH_SH_C3_5 * -2.0f * y * z; dBz[14] = GH_SH_C3_5 * (xx - yy);
+  dBx[15] = GH_SH_C3_6 * (3.0f * xx - 3.0f * yy); dBy[15] = GH_SH_C3_6 * -6.0f * x * y;
+}
+
+// One row (16 lanes) per Gaussian, lane = coefficient; loops the views with register accumulators.
+__global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd_kernel(
+    GhInputs in, GhGrads gr, int P, int NV, int sh_degree, int M, uint32_t flags, const uint32_t* __restrict__ tiles_touched,
+    const float4* __restrict__ sh_rgb, const float4* __restrict__ gsum, float4* __restrict__ dmean_sh,
+    float* __restrict__ scratch) {
+  __shared__ float s_cw[GH_BLOCK / 16][48];
+  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int i0 = t >> 4, k = t & 15;
+  const bool live = i0 < P;
+  const int i = live ? i0 : 0;
+  const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
+  const bool has_w = in.blend_color_w != nullptr, has_b = in.blend_color_b != nullptr;
+  const bool coef = live && k < M;
+  float raw[3] = {0, 0, 0}, wv[3] = {1, 1, 1}, shv[3] = {0, 0, 0};
+  if (coef) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      raw[ch] = in.shs[((size_t)i * M + k) * 3 + ch];
+      if (has_w) wv[ch] = in.blend_color_w[(wpg ? (size_t)i * 48 : 0) + k * 3 + ch];
+      shv[ch] = gh_blended_sh(in, flags, M, i, k, ch);
+    }
+  }
+  float mx = in.means3D[3 * i], my = in.means3D[3 * i + 1], mz = in.means3D[3 * i + 2];
+  if (in.blend_xyz_b) { mx = mx + in.blend_xyz_b[0]; my = my + in.blend_xyz_b[1]; mz = mz + in.blend_xyz_b[2]; }
+  float dsh[3] = {0, 0, 0}, dcb[3] = {0, 0, 0}, dcw[3] = {0, 0, 0};
+  for (int v = 0; v < NV; ++v) {
+    const size_t n = (size_t)v * P + i;
+    const bool vis = live && tiles_touched[n] != 0;                  // row-uniform
+    float g[3] = {0, 0, 0};
+    if (vis) {
+      const float4 r1 = gsum[n * 3 + 1]; const float4 r2 = gsum[n * 3 + 2];
+      const unsigned cl = __float_as_uint(sh_rgb[n].w);
+      g[0] = (cl & 1u) ? 0.0f : r1.z; g[1] = (cl & 2u) ? 0.0f : r1.w; g[2] = (cl & 4u) ? 0.0f : r2.x;
+    }
+    const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
+    const float dx = mx - cam[32], dy = my - cam[33], dz = mz - cam[34];
+    const float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+    const float ux = dx / len, uy = dy / len, uz = dz / len;
+    float Bv[16], dBx[16], dBy[16], dBz[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Bv[j] = 0.0f;
+    int nb = gh_sh_basis(sh_degree, ux, uy, uz, Bv);
+    if (nb > M) nb = M;
+    gh_sh_basis_grad(sh_degree, ux, uy, uz, dBx, dBy, dBz);
+    const bool act = vis && k < nb;
+    const float bk = act ? gh_pick16(Bv, k) : 0.0f;
+    const float sg = shv[0] * g[0] + shv[1] * g[1] + shv[2] * g[2];      // sum_ch sh'_k[ch] * dL/drgb[ch]
+    float dd0 = act ? gh_pick16(dBx, k) * sg : 0.0f, dd1 = act ? gh_pick16(dBy, k) * sg : 0.0f, dd2 = act ? gh_pick16(dBz, k) * sg : 0.0f;
+    dd0 = gh_row_sum(dd0); dd1 = gh_row_sum(dd1); dd2 = gh_row_sum(dd2);
+    if (live && k == 0) {
+      const float dot = ux * dd0 + uy * dd1 + uz * dd2;                  // backward of d / |d|
+      dmean_sh[n] = vis ? make_float4((dd0 - ux * dot) / len, (dd1 - uy * dot) / len, (dd2 - uz * dot) / len, 0.0f)
+                        : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float gk = bk * g[ch];                                       // dL/d(blended coefficient)
+      dcb[ch] += gk;
+      if (has_w) {
+        dsh[ch] += has_b ? gk * wv[ch] * wv[ch] : gk * wv[ch];
+        dcw[ch] += has_b ? gk * 2.0f * raw[ch] * wv[ch] : gk * raw[ch];
+      } else dsh[ch] += gk;
+    }
+  }
+  if (coef) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      if (gr.dL_dshs) gr.dL_dshs[((size_t)i * M + k) * 3 + ch] = dsh[ch];
+      if (has_b && gr.dL_dblend_color_b) gr.dL_dblend_color_b[(size_t)i * 48 + k * 3 + ch] = dcb[ch];
+      if (has_w && wpg && gr.dL_dblend_color_w) gr.dL_dblend_color_w[(size_t)i * 48 + k * 3 + ch] = dcw[ch];
+    }
+  }
+  if (has_w && !wpg && gr.dL_dblend_color_w) {         // global (48,) weights: fixed-order block partials
+    const int row = threadIdx.x >> 4;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) s_cw[row][k * 3 + ch] = coef ? dcw[ch] : 0.0f;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      float s = 0.0f;
+      if (threadIdx.x < 48) for (int r = 0; r < GH_BLOCK / 16; ++r) s += s_cw[r][threadIdx.x];
+      scratch[(size_t)blockIdx.x * 64 + threadIdx.x] = s;
+    }
+  }
+}
+
+void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, char* ws, const GhLayout& L, hipStream_t s) {
+  if (g.N == 0 || !in->shs) return;
+  const size_t threads = (size_t)g.N * 16;
+  hipLaunchKernelGGL(gh_sh_colour_fwd_kernel, dim3((unsigned)((threads + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0, s, *in, g.P,
+                     g.N, d->sh_degree, d->M, d->flags, (float4*)(ws + L.sh_rgb));
+}
+
+// returns the number of scratch blocks written (0 when the global colour-weight reduction is not needed)
+int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws, const GhLayout& L,
+                            hipStream_t s) {
+  if (g.P == 0 || !in->shs) return 0;
+  const size_t threads = (size_t)g.P * 16;
+  const int nblk = (int)((threads + GH_BLOCK - 1) / GH_BLOCK);
+  hipLaunchKernelGGL(gh_sh_colour_bwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, d->sh_degree, d->M, d->flags,
+                     (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.sh_rgb), (const float4*)(ws + L.grad_sums),
+                     (float4*)(ws + L.dmean_sh), (float*)(ws + L.sh_scratch));
+  const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
+  return (in->blend_color_w && !wpg && gr->dL_dblend_color_w) ? nblk : 0;
+}

@@ -151,6 +151,9 @@ typedef struct GhLayout {
   size_t n_contrib;      /* uint32[n_views*H*W] */
   size_t inst_grad;      /* float[max_instances][4][12] per-(instance, quadrant) gradient sub-records (backward scratch) */
   size_t inst_flag;      /* uint8[max_instances][4]     1 where the quadrant wrote its sub-record (zeroed per backward) */
+  size_t sh_rgb;         /* float4[n_views*P] SH colour stage output (r, g, b, clamp-flag bits); unused with colors_precomp */
+  size_t dmean_sh;       /* float4[n_views*P] d(loss)/d(mean) through the SH view direction (backward scratch) */
+  size_t sh_scratch;     /* float[ceil(P/16)][64] block partials of the global colour-weight gradient (SH mode) */
   size_t grad_sums;      /* float4[n_views*P][3] per-(view,Gaussian) sums of the sub-records: dpx dpy dA dB | dC do dr dg | db */
   size_t bwd_scratch;    /* blend-parameter reduction scratch */
 } GhLayout;
