@@ -75,3 +75,103 @@ extern "C" int gh_uv_sample_backward(const float* uv, const float* dL_dout, floa
                      (hipStream_t)hip_stream, uv, dL_dout, dL_dmap, P, C, Hm, Wm);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
+
+// ---- active-texel form ---------------------------------------------------------------------------------------------
+// The Gaussians' UV coordinates are constant during a one-shot fit, so only the <= 4P texels under their bilinear
+// footprints ever receive an image gradient; every other texel of the zero-initialised maps has gradient
+// 100*sign(0)/n = 0 and 2*0/n = 0 from the regularisers (infer_one_shot.py:514-518) and Adam leaves it at exactly 0.
+// The fit loop therefore keeps only the active texels, compacted as (U, C) rows; slot[i][0..3] are the rows of the
+// nw, ne, sw, se corners of Gaussian i (-1 = outside the map) and w[i][0..3] their bilinear weights.
+__global__ __launch_bounds__(GH_BLOCK) void gh_uv_gather_fwd_kernel(const float* __restrict__ tex, const int32_t* __restrict__ slot,
+                                                                     const float* __restrict__ w, float* __restrict__ out, int P, int C) {
+  const size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (idx >= (size_t)P * C) return;
+  const int i = (int)(idx / C), c = (int)(idx - (size_t)i * C);
+  const int4 s4 = ((const int4*)slot)[i];
+  const float4 w4 = ((const float4*)w)[i];
+  float acc = 0.0f;                                               // same corner order as gh_uv_sample_fwd_kernel
+  if (s4.x >= 0) acc += tex[(size_t)s4.x * C + c] * w4.x;
+  if (s4.y >= 0) acc += tex[(size_t)s4.y * C + c] * w4.y;
+  if (s4.z >= 0) acc += tex[(size_t)s4.z * C + c] * w4.z;
+  if (s4.w >= 0) acc += tex[(size_t)s4.w * C + c] * w4.w;
+  out[idx] = acc;
+}
+
+__global__ __launch_bounds__(GH_BLOCK) void gh_uv_gather_bwd_kernel(const int32_t* __restrict__ slot, const float* __restrict__ w,
+                                                                     const float* __restrict__ dout, float* __restrict__ dtex, int P, int C) {
+  const size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (idx >= (size_t)P * C) return;
+  const int i = (int)(idx / C), c = (int)(idx - (size_t)i * C);
+  const int4 s4 = ((const int4*)slot)[i];
+  const float4 w4 = ((const float4*)w)[i];
+  const float g = dout[idx];
+  if (s4.x >= 0) atomicAdd(&dtex[(size_t)s4.x * C + c], g * w4.x);
+  if (s4.y >= 0) atomicAdd(&dtex[(size_t)s4.y * C + c], g * w4.y);
+  if (s4.z >= 0) atomicAdd(&dtex[(size_t)s4.z * C + c], g * w4.z);
+  if (s4.w >= 0) atomicAdd(&dtex[(size_t)s4.w * C + c], g * w4.w);
+}
+
+// One pass over a parameter array: regulariser value (sum|p|, sum p^2 of the PRE-update values, block partials),
+// regulariser gradient (l1*sign(p) + l2*2p) added to the accumulated image gradient, Adam update (torch.optim.Adam
+// semantics, no amsgrad / weight decay: infer_one_shot.py:345), and the gradient buffer is cleared for the next step.
+__global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                                float* __restrict__ v, size_t n, float lr_over_bc1, float inv_sqrt_bc2,
+                                                                float beta1, float beta2, float eps, float l1, float l2,
+                                                                float* __restrict__ partials /* [gridDim][2] */) {
+  __shared__ float s_a[GH_BLOCK / GH_WAVE], s_b[GH_BLOCK / GH_WAVE];
+  float sa = 0.0f, sb = 0.0f;
+  for (size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; idx < n; idx += (size_t)gridDim.x * GH_BLOCK) {
+    const float pv = p[idx];
+    sa += fabsf(pv); sb += pv * pv;
+    const float sgn = pv > 0.0f ? 1.0f : (pv < 0.0f ? -1.0f : 0.0f);
+    const float gv = g[idx] + l1 * sgn + l2 * 2.0f * pv;
+    const float mv = beta1 * m[idx] + (1.0f - beta1) * gv;
+    const float vv = beta2 * v[idx] + (1.0f - beta2) * gv * gv;
+    m[idx] = mv; v[idx] = vv; g[idx] = 0.0f;
+    p[idx] = pv - lr_over_bc1 * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+  }
+  sa = gh_wave_sum_to63(sa); sb = gh_wave_sum_to63(sb);
+  if ((threadIdx.x & 63) == 63) { s_a[threadIdx.x >> 6] = sa; s_b[threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0 && partials) {
+    partials[2 * blockIdx.x] = ((s_a[0] + s_a[1]) + s_a[2]) + s_a[3];
+    partials[2 * blockIdx.x + 1] = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3];
+  }
+}
+
+extern "C" int gh_uv_gather_forward(const float* texels, const int32_t* slot, const float* w, float* out, int P, int C, void* hip_stream) {
+  if (P < 0 || C < 1) return GH_ERR_INVALID_ARG;
+  if (P == 0) return GH_OK;
+  if (!texels || !slot || !w || !out) return GH_ERR_INVALID_ARG;
+  (void)hipGetLastError();
+  const size_t n = (size_t)P * C;
+  hipLaunchKernelGGL(gh_uv_gather_fwd_kernel, dim3((unsigned)((n + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0,
+                     (hipStream_t)hip_stream, texels, slot, w, out, P, C);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_uv_gather_backward(const int32_t* slot, const float* w, const float* dL_dout, float* dL_dtexels, int P, int C,
+                                     void* hip_stream) {
+  if (P < 0 || C < 1) return GH_ERR_INVALID_ARG;
+  if (P == 0) return GH_OK;
+  if (!slot || !w || !dL_dout || !dL_dtexels) return GH_ERR_INVALID_ARG;
+  (void)hipGetLastError();
+  const size_t n = (size_t)P * C;
+  hipLaunchKernelGGL(gh_uv_gather_bwd_kernel, dim3((unsigned)((n + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0,
+                     (hipStream_t)hip_stream, slot, w, dL_dout, dL_dtexels, P, C);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, float lr,
+                                float beta1, float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials,
+                                void* hip_stream) {
+  if (step < 1 || n_partials < 1) return GH_ERR_INVALID_ARG;
+  if (n == 0) return GH_OK;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !partials) return GH_ERR_INVALID_ARG;
+  (void)hipGetLastError();
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(gh_adam_reg_kernel, dim3((unsigned)n_partials), dim3(GH_BLOCK), 0, (hipStream_t)hip_stream, param, grad,
+                     exp_avg, exp_avg_sq, n, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, reg_l1, reg_l2,
+                     partials);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}

@@ -16,6 +16,13 @@ MI355X form: all of a rank's cameras go through ONE fused launch sequence (RGB +
 into the projection kernel); with N ranks the cameras are sharded round-robin and the only collective is one
 all-reduce(sum) of the gradient block AT THE RASTERISER BOUNDARY (per-Gaussian blend values + color_w) before it
 is back-propagated into the 403 MB maps — instead of PL-DDP all-reducing the maps themselves (:638).
+
+Active-texel mode (default on a ROCm device): the UVs are constant during the fit, so only the <= 4P texels under the
+Gaussians' bilinear footprints ever receive an image gradient; every other texel of the zero-initialised maps has
+regulariser gradient 100*sign(0)/n = 0 resp. 2*0/n = 0 and Adam leaves it at exactly 0. The fit therefore keeps the
+active texels compacted (U,C) (76 MB instead of 403 MB + 806 MB of Adam state), looks them up with gh_uv_gather_*,
+and applies regulariser + Adam in ONE fused pass (gh_adam_reg_step). `.color_b` / `.opacity_b` still return the dense
+reference-layout maps; tests/test_gpu_fit.py checks the mode against the dense torch.optim.Adam path step by step.
 """
 from __future__ import annotations
 
@@ -27,7 +34,7 @@ import torch.nn.functional as F
 
 from . import dist as ghdist
 from .renderer import GaussianModel
-from .uvmap import to_reference_layout, uv_sample
+from .uvmap import ActiveTexels, AdamReg, to_reference_layout, uv_gather, uv_gather_backward, uv_sample
 
 MILESTONES = (2, 5, 10, 20, 35, 50, 75)
 
@@ -54,7 +61,8 @@ def fit_loss(comp_rgb, comp_mask, gt_rgb, gt_mask, bbox_mask=None, lambda_l1: fl
 
 class OneShotFit(nn.Module):
     def __init__(self, gs: GaussianModel, uv: torch.Tensor, *, use_rgb: bool = True, sh_degree: int = 3,
-                 map_hw: Sequence[int] = (1024, 2048), lr: float = 0.01, render_fn: Optional[Callable] = None):
+                 map_hw: Sequence[int] = (1024, 2048), lr: float = 0.01, render_fn: Optional[Callable] = None,
+                 active_texels: Optional[bool] = None):
         super().__init__()
         self.gs = GaussianModel(*[t.detach() for t in gs])          # frozen network outputs
         self.register_buffer("uv", uv.detach().float())
@@ -62,33 +70,70 @@ class OneShotFit(nn.Module):
         dev = gs.xyz.device
         Hm, Wm = map_hw
         self.color_w = nn.Parameter(torch.ones(48, device=dev))                      # infer_one_shot.py:159
-        # the maps are stored CHANNEL-LAST (Hm,Wm,C) for the device lookup (uvmap.py); `.color_b` / `.opacity_b` are
-        # views in the reference's (C,Hm,Wm) layout (infer_one_shot.py:160,163) for loading / exporting state
-        self.color_b_map = nn.Parameter(torch.zeros(Hm, Wm, 48, device=dev))
         self.xyz_b = nn.Parameter(torch.zeros(3, device=dev), requires_grad=False)   # :161 (not in the trainable set)
-        self.opacity_b_map = nn.Parameter(torch.zeros(Hm, Wm, 1, device=dev))
-        self.opt = torch.optim.Adam([self.color_w, self.color_b_map, self.opacity_b_map], lr=lr)
-        self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=list(MILESTONES), gamma=0.5)
+        self.map_hw = (Hm, Wm)
+        self.lr0, self.epoch = lr, 0
+        self.active = uv.is_cuda if active_texels is None else bool(active_texels)
         if render_fn is None:
             from .renderer import render_views
             render_fn = render_views
         self.render_fn = render_fn
+        if self.active:
+            # active-texel mode: compact (U,C) storage of the texels the Gaussians can reach, fused regulariser + Adam
+            self.texels = ActiveTexels(self.uv, Hm, Wm)
+            U = self.texels.U
+            self.color_b_tex = torch.zeros(U, 48, device=dev)
+            self.opacity_b_tex = torch.zeros(U, 1, device=dev)
+            self._adam = {
+                "color_w": AdamReg(self.color_w.data, lr),
+                "color_b": AdamReg(self.color_b_tex, lr, reg_l1=100.0 / (48 * Hm * Wm)),        # 100*mean|color_b|
+                "opacity_b": AdamReg(self.opacity_b_tex, lr, reg_l2=1.0 / (Hm * Wm)),          # mean(opacity_b^2)
+            }
+            return
+        # the maps are stored CHANNEL-LAST (Hm,Wm,C) for the device lookup (uvmap.py); `.color_b` / `.opacity_b` are
+        # views in the reference's (C,Hm,Wm) layout (infer_one_shot.py:160,163) for loading / exporting state
+        self.color_b_map = nn.Parameter(torch.zeros(Hm, Wm, 48, device=dev))
+        self.opacity_b_map = nn.Parameter(torch.zeros(Hm, Wm, 1, device=dev))
+        self.opt = torch.optim.Adam([self.color_w, self.color_b_map, self.opacity_b_map], lr=lr)
+        self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=list(MILESTONES), gamma=0.5)
 
     @property
     def color_b(self) -> torch.Tensor:
-        return to_reference_layout(self.color_b_map)
+        """(48,Hm,Wm), the layout of the reference parameter (infer_one_shot.py:160)."""
+        return to_reference_layout(self.texels.dense(self.color_b_tex) if self.active else self.color_b_map)
 
     @property
     def opacity_b(self) -> torch.Tensor:
-        return to_reference_layout(self.opacity_b_map)
+        """(1,Hm,Wm) (infer_one_shot.py:163)."""
+        return to_reference_layout(self.texels.dense(self.opacity_b_tex) if self.active else self.opacity_b_map)
+
+    def load_maps(self, color_b: torch.Tensor, opacity_b: torch.Tensor) -> None:
+        """Load reference-layout maps. Active-texel mode requires them to be zero outside the active texels (true for
+        the reference's zero initialisation and for anything this class exported); otherwise use active_texels=False."""
+        cb, ob = color_b.permute(1, 2, 0).contiguous(), opacity_b.permute(1, 2, 0).contiguous()
+        if not self.active:
+            with torch.no_grad():
+                self.color_b_map.copy_(cb); self.opacity_b_map.copy_(ob)
+            return
+        ct, ot = self.texels.compact(cb), self.texels.compact(ob)
+        if float((self.texels.dense(ct) - cb).abs().max()) != 0.0 or float((self.texels.dense(ot) - ob).abs().max()) != 0.0:
+            raise ValueError("maps are non-zero outside the active texels: construct OneShotFit(active_texels=False)")
+        self.color_b_tex.copy_(ct); self.opacity_b_tex.copy_(ot)
 
     # -- pieces ----------------------------------------------------------------------------------------
     def blend_values(self) -> Dict[str, torch.Tensor]:
-        """Per-Gaussian blend values: the device UV lookup of renderer_one_shot.py:489-492 (gh_uv_sample_*)."""
+        """Per-Gaussian blend values: the device UV lookup of renderer_one_shot.py:489-492 (gh_uv_sample_* /
+        gh_uv_gather_*)."""
+        if self.active:
+            return dict(color_w=self.color_w, color_b=uv_gather(self.color_b_tex, self.texels),
+                        opacity_b=uv_gather(self.opacity_b_tex, self.texels), xyz_b=self.xyz_b)
         return dict(color_w=self.color_w, color_b=uv_sample(self.color_b_map, self.uv),
                     opacity_b=uv_sample(self.opacity_b_map, self.uv), xyz_b=self.xyz_b)
 
     def regulariser(self) -> torch.Tensor:
+        if self.active:
+            Hm, Wm = self.map_hw
+            return 100.0 * self.color_b_tex.abs().sum() / (48 * Hm * Wm) + self.opacity_b_tex.pow(2.0).sum() / (Hm * Wm)
         return 100.0 * self.color_b_map.abs().mean() + self.opacity_b_map.pow(2.0).mean()   # infer_one_shot.py:514-518
 
     def render(self, w2cs, Ks, H, W, bg, blend: Dict[str, torch.Tensor], sync: bool = True):
@@ -103,10 +148,12 @@ class OneShotFit(nn.Module):
         world = torch.distributed.get_world_size() if ghdist.dist.is_initialized() else 1
         n_total = w2cs.shape[0]
         mine = ghdist.shard_views(n_total, rank, world)
-        self.opt.zero_grad(set_to_none=True)
+        if not self.active:
+            self.opt.zero_grad(set_to_none=True)
 
         blend = self.blend_values()                                   # graph A: maps -> per-Gaussian values
-        names = [k for k in ("color_w", "color_b", "opacity_b") if blend[k].requires_grad]
+        names = ["color_w", "color_b", "opacity_b"] if self.active else \
+            [k for k in ("color_w", "color_b", "opacity_b") if blend[k].requires_grad]
         leaves = {k: (blend[k].detach().requires_grad_(True) if k in names else blend[k]) for k in blend}
         loss_img = torch.zeros((), device=self.color_w.device)
         grads = {k: torch.zeros_like(leaves[k]) for k in names}
@@ -125,10 +172,24 @@ class OneShotFit(nn.Module):
             red["color_b"] = full
         else:
             loss_tot, red = ghdist.allreduce_grads(grads, loss_img.detach(), sorted(grads))
+        if self.active:                                               # maps: scatter, then regulariser + Adam in one pass
+            uv_gather_backward(red["color_b"], self.texels, self._adam["color_b"].grad)
+            uv_gather_backward(red["opacity_b"], self.texels, self._adam["opacity_b"].grad)
+            self._adam["color_w"].grad.copy_(red["color_w"])
+            lr = self.lr0 * 0.5 ** sum(1 for m in MILESTONES if m <= self.epoch)
+            sums = {}
+            for k, a in self._adam.items():
+                a.lr = lr
+                sums[k] = a.step()
+            Hm, Wm = self.map_hw
+            reg = 100.0 * sums["color_b"][0] / (48 * Hm * Wm) + sums["opacity_b"][1] / (Hm * Wm)
+            return loss_tot + reg
         reg = self.regulariser()                                      # identical on every rank: never reduced
         torch.autograd.backward([blend[k] for k in names] + [reg], [red[k] for k in names] + [torch.ones_like(reg)])
         self.opt.step()
         return loss_tot + reg.detach()
 
     def end_epoch(self) -> None:
-        self.sched.step()
+        self.epoch += 1
+        if not self.active:
+            self.sched.step()

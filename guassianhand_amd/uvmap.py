@@ -64,3 +64,118 @@ def uv_sample(map_hwc: torch.Tensor, uv: torch.Tensor) -> torch.Tensor:
         return _UvSample.apply(map_hwc, uv)
     out = F.grid_sample(map_hwc.permute(2, 0, 1)[None], uv[None, :, None, :], align_corners=True, mode="bilinear")
     return out[0, :, :, 0].transpose(0, 1)
+
+
+# ---- active-texel form (gh_uv_gather_* / gh_adam_reg_step) ------------------------------------------------------------
+class ActiveTexels:
+    """The texels of an (Hm, Wm) map that lie under the bilinear footprints of fixed UV coordinates.
+
+    During a one-shot fit the UVs never change, so these U <= 4P texels are the only ones that ever receive an image
+    gradient; all other texels of the zero-initialised maps keep gradient 0 under the regularisers
+    (infer_one_shot.py:514-518) and stay exactly 0 under Adam. `index` (U,) int64 = linear texel index y*Wm + x
+    (sorted), `slot` (P,4) int32 = compact row of the nw/ne/sw/se corner or -1 outside the map, `w` (P,4) the bilinear
+    weights — the same float32 arithmetic as gh_bilinear in csrc/gh_uv.hip, so a gather over compacted texels is
+    bit-identical to gh_uv_sample_forward over the dense map."""
+
+    def __init__(self, uv: torch.Tensor, Hm: int, Wm: int):
+        uv = uv.detach().float()
+        ix = ((uv[:, 0] + 1.0) * 0.5) * float(Wm - 1)
+        iy = ((uv[:, 1] + 1.0) * 0.5) * float(Hm - 1)
+        fx, fy = torch.floor(ix), torch.floor(iy)
+        x0, y0 = fx.long(), fy.long()
+        wx1, wy1 = ix - fx, iy - fy
+        wx0, wy0 = 1.0 - wx1, 1.0 - wy1
+        xs = torch.stack([x0, x0 + 1, x0, x0 + 1], 1)
+        ys = torch.stack([y0, y0, y0 + 1, y0 + 1], 1)
+        valid = (xs >= 0) & (xs < Wm) & (ys >= 0) & (ys < Hm)
+        lin = ys * Wm + xs
+        self.index = torch.unique(lin[valid])
+        slot = torch.searchsorted(self.index, lin.clamp(0, Hm * Wm - 1))
+        self.slot = torch.where(valid, slot, torch.full_like(slot, -1)).to(torch.int32).contiguous()
+        self.w = torch.stack([wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1], 1).contiguous()
+        self.Hm, self.Wm, self.P = Hm, Wm, uv.shape[0]
+
+    @property
+    def U(self) -> int:
+        return int(self.index.numel())
+
+    def compact(self, map_hwc: torch.Tensor) -> torch.Tensor:
+        """(Hm,Wm,C) dense map -> (U,C) active texels."""
+        return map_hwc.reshape(self.Hm * self.Wm, -1)[self.index].contiguous()
+
+    def dense(self, texels: torch.Tensor) -> torch.Tensor:
+        """(U,C) active texels -> (Hm,Wm,C) dense map (zeros elsewhere)."""
+        out = torch.zeros(self.Hm * self.Wm, texels.shape[1], dtype=texels.dtype, device=texels.device)
+        out[self.index] = texels
+        return out.view(self.Hm, self.Wm, -1)
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_device(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("the active-texel kernels run on a ROCm device only (there is no CPU path)")
+        if t.dtype not in (torch.float32, torch.int32) or not t.is_contiguous():
+            raise ValueError("active-texel kernels take contiguous float32 / int32 tensors")
+
+
+def uv_gather(texels: torch.Tensor, at: ActiveTexels) -> torch.Tensor:
+    """(U,C) active texels -> per-Gaussian values (P,C); no autograd (the fit loop calls uv_gather_backward itself)."""
+    _need_device(texels, at.slot, at.w)
+    L = _lib.lib()
+    Cc = texels.shape[1]
+    out = torch.empty(at.P, Cc, dtype=torch.float32, device=texels.device)
+    with torch.cuda.device(texels.device):
+        rc = L.gh_uv_gather_forward(C.c_void_p(texels.data_ptr()), C.c_void_p(at.slot.data_ptr()), C.c_void_p(at.w.data_ptr()),
+                                    C.c_void_p(out.data_ptr()), at.P, Cc, _stream(texels))
+    if rc != 0:
+        raise RuntimeError(f"gh_uv_gather_forward failed: {_abi.status_name(rc)}")
+    return out
+
+
+def uv_gather_backward(grad_out: torch.Tensor, at: ActiveTexels, grad_texels: torch.Tensor) -> None:
+    """Accumulates d(loss)/d(texels) (U,C) from d(loss)/d(per-Gaussian values) (P,C)."""
+    g = grad_out.detach().float().contiguous()
+    _need_device(g, grad_texels, at.slot, at.w)
+    assert g.shape == (at.P, grad_texels.shape[1]) and grad_texels.shape[0] == at.U
+    L = _lib.lib()
+    with torch.cuda.device(g.device):
+        rc = L.gh_uv_gather_backward(C.c_void_p(at.slot.data_ptr()), C.c_void_p(at.w.data_ptr()), C.c_void_p(g.data_ptr()),
+                                     C.c_void_p(grad_texels.data_ptr()), at.P, g.shape[1], _stream(g))
+    if rc != 0:
+        raise RuntimeError(f"gh_uv_gather_backward failed: {_abi.status_name(rc)}")
+
+
+class AdamReg:
+    """State of gh_adam_reg_step for one parameter tensor: torch.optim.Adam's update with the gradient of
+    reg_l1*sum|p| + reg_l2*sum(p^2) folded in; `step()` returns (sum|p|, sum p^2) of the pre-update values as a
+    2-element device tensor (no host sync)."""
+    N_PARTIALS = 1024
+
+    def __init__(self, param: torch.Tensor, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, reg_l1: float = 0.0,
+                 reg_l2: float = 0.0):
+        _need_device(param)
+        self.param, self.lr, self.betas, self.eps, self.reg_l1, self.reg_l2 = param, lr, betas, eps, reg_l1, reg_l2
+        self.grad = torch.zeros_like(param)
+        self.exp_avg = torch.zeros_like(param)
+        self.exp_avg_sq = torch.zeros_like(param)
+        self.t = 0
+        n = param.numel()
+        self.n_partials = max(1, min(self.N_PARTIALS, (n + 255) // 256))
+        self.partials = torch.zeros(self.n_partials, 2, dtype=torch.float32, device=param.device)
+
+    def step(self) -> torch.Tensor:
+        self.t += 1
+        L = _lib.lib()
+        p = self.param
+        with torch.cuda.device(p.device):
+            rc = L.gh_adam_reg_step(C.c_void_p(p.data_ptr()), C.c_void_p(self.grad.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
+                                    C.c_void_p(self.exp_avg_sq.data_ptr()), p.numel(), self.t, self.lr, self.betas[0], self.betas[1],
+                                    self.eps, self.reg_l1, self.reg_l2, C.c_void_p(self.partials.data_ptr()), self.n_partials,
+                                    _stream(p))
+        if rc != 0:
+            raise RuntimeError(f"gh_adam_reg_step failed: {_abi.status_name(rc)}")
+        return self.partials.sum(0)

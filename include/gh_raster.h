@@ -213,6 +213,28 @@ int gh_uv_sample_forward(const float* map, const float* uv, float* out /* (P,C) 
 int gh_uv_sample_backward(const float* uv, const float* dL_dout /* (P,C) */, float* dL_dmap /* (Hm,Wm,C) */, int P, int C,
                           int Hm, int Wm, void* hip_stream);
 
+/*
+ * Active-texel form of the same lookup for the one-shot fit loop (infer_one_shot.py:489-524). The Gaussians' UVs are
+ * fixed during the fit, so only the texels under their bilinear footprints ever change (all others keep gradient 0
+ * under the regularisers of :514-518 and stay 0 under Adam). `texels` holds those U texels compacted as (U, C);
+ * slot (P,4) int32 = compact row of the nw, ne, sw, se corner (-1 = outside the map, reads as zero), w (P,4) = the
+ * bilinear weights. gh_uv_gather_backward ACCUMULATES into dL_dtexels (float atomics).
+ */
+int gh_uv_gather_forward(const float* texels, const int32_t* slot, const float* w, float* out /* (P,C) */, int P, int C,
+                         void* hip_stream);
+int gh_uv_gather_backward(const int32_t* slot, const float* w, const float* dL_dout /* (P,C) */, float* dL_dtexels /* (U,C) */,
+                          int P, int C, void* hip_stream);
+
+/*
+ * One fused pass over a parameter array of n floats: torch.optim.Adam's update (infer_one_shot.py:345; step >= 1 is
+ * the 1-based step count, no weight decay / amsgrad) on grad + reg_l1*sign(param) + reg_l2*2*param, i.e. with the
+ * gradient of reg_l1*sum|param| + reg_l2*sum(param^2) (the regularisers of :514-518) folded in. `grad` is cleared
+ * for the next accumulation. partials (n_partials,2) receives per-block sums of |param| and param^2 of the
+ * PRE-update values (the regulariser value the loss of this step reports); n_partials is also the grid size.
+ */
+int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, float lr, float beta1,
+                     float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

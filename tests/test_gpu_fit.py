@@ -21,7 +21,7 @@ def test_first_step_gradients_match_oracle_driven_loop(dev):
     pb_c = tiny_fit_problem()
     pb_g = tiny_fit_problem(device=dev)
     fc = F.OneShotFit(pb_c["gs"], pb_c["uv"], map_hw=pb_c["map_hw"], render_fn=oracle_render_views)
-    fg = F.OneShotFit(pb_g["gs"], pb_g["uv"], map_hw=pb_g["map_hw"])
+    fg = F.OneShotFit(pb_g["gs"], pb_g["uv"], map_hw=pb_g["map_hw"], active_texels=False)   # dense maps: arbitrary start values
     with torch.no_grad():
         for f, pb in ((fc, pb_c), (fg, pb_g)):
             f.color_w.copy_(1 + 0.5 * (pb["true"]["color_w"] - 1)); f.color_b.copy_(0.5 * pb["true"]["color_b"])
@@ -70,7 +70,7 @@ def test_fit_converges_on_eight_views(dev):
     uv = (torch.rand(sc.P, 2, generator=g) * 2 - 1).to(dev)
     gs = GaussianModel(sc.xyz, sc.opacity, sc.rotation, sc.scaling, sc.shs)
     map_hw = (64, 128)
-    true = F.OneShotFit(gs, uv, map_hw=map_hw)
+    true = F.OneShotFit(gs, uv, map_hw=map_hw, active_texels=False)
     with torch.no_grad():
         true.color_w.copy_((1 + 0.1 * torch.randn(48, generator=g)).to(dev))
         true.color_b.copy_((0.1 * torch.randn(48, *map_hw, generator=g)).to(dev))          # writes through the layout view
@@ -82,4 +82,97 @@ def test_fit_converges_on_eight_views(dev):
     from guassianhand_amd import rasterizer as R
     R.check_overflow()
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
-    assert all(torch.isfinite(p).all() for p in (f.color_w, f.color_b_map, f.opacity_b_map))
+    assert f.active and all(torch.isfinite(p).all() for p in (f.color_w, f.color_b_tex, f.opacity_b_tex))
+
+
+def test_active_texel_gather_is_bit_identical_to_dense_lookup(dev):
+    """gh_uv_gather_forward over the compacted active texels == gh_uv_sample_forward over the dense map, bit for bit,
+    including UVs on / outside the border; compact() / dense() round-trip; the backward scatters the same sums."""
+    from guassianhand_amd.uvmap import ActiveTexels, uv_gather, uv_gather_backward, uv_sample
+    g = torch.Generator().manual_seed(21)
+    for C_, Hm, Wm, P in ((48, 37, 53, 4000), (1, 64, 128, 3000)):
+        uv = torch.rand(P, 2, generator=g) * 2.4 - 1.2
+        uv[:6] = torch.tensor([[-1, -1], [1, 1], [1, -1], [-1, 1], [0, 0], [1.0, 0.3]])
+        uv = uv.to(dev)
+        at = ActiveTexels(uv, Hm, Wm)
+        assert 0 < at.U <= 4 * P and at.slot.shape == (P, 4) and int(at.slot.max()) == at.U - 1
+        dense = torch.randn(Hm, Wm, C_, generator=g).to(dev)
+        tex = at.compact(dense)
+        masked = at.dense(tex)                                     # dense map with the inactive texels zeroed
+        assert torch.equal(at.compact(masked), tex)
+        assert torch.equal(uv_gather(tex, at), uv_sample(dense, uv))           # inactive texels are never read
+        dout = torch.randn(P, C_, generator=g).to(dev)
+        gt = torch.zeros_like(tex)
+        uv_gather_backward(dout, at, gt)
+        m = dense.clone().requires_grad_(True)
+        (uv_sample(m, uv) * dout).sum().backward()
+        assert torch.allclose(at.dense(gt), m.grad, atol=2e-5, rtol=1e-4)
+        assert float((m.grad - at.dense(at.compact(m.grad))).abs().max()) == 0.0    # no gradient outside the active set
+
+
+def test_fused_adam_regulariser_step_matches_torch_adam(dev):
+    """gh_adam_reg_step == torch.optim.Adam on grad + d/dp (l1*sum|p| + l2*sum p^2), several steps, with an lr change;
+    returns the regulariser sums of the pre-update values and clears the gradient buffer."""
+    from guassianhand_amd.uvmap import AdamReg
+    g = torch.Generator().manual_seed(3)
+    n, l1, l2 = 100_003, 3e-4, 2e-3
+    p0 = (0.1 * torch.randn(n, generator=g)).to(dev)
+    p0[:100] = 0.0
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=0.01)
+    mine = AdamReg(p0.clone(), 0.01, reg_l1=l1, reg_l2=l2)
+    for it in range(6):
+        gimg = (0.01 * torch.randn(n, generator=g)).to(dev)
+        gimg[:50] = 0.0                                             # zero parameter + zero gradient must stay exactly 0
+        lr = 0.01 if it < 3 else 0.005
+        opt.param_groups[0]["lr"] = lr
+        opt.zero_grad()
+        reg = l1 * ref.abs().sum() + l2 * ref.pow(2).sum()
+        reg.backward()
+        ref.grad += gimg
+        want_sums = torch.stack([ref.detach().abs().sum(), ref.detach().pow(2).sum()])
+        opt.step()
+        mine.lr = lr
+        mine.grad += gimg
+        sums = mine.step()
+        assert torch.allclose(sums, want_sums, rtol=1e-5)
+        assert float(mine.grad.abs().max()) == 0.0
+        assert torch.allclose(mine.param, ref.detach(), rtol=2e-5, atol=2e-7), it
+        assert float(mine.param[:50].abs().max()) == 0.0
+
+
+def test_active_texel_fit_equals_dense_fit(dev):
+    """The active-texel fit (compact texels, fused regulariser + Adam) follows the dense torch.optim.Adam fit of the
+    reference (infer_one_shot.py:345-349, :489-524) step by step, across an lr milestone, and leaves every inactive
+    texel at exactly zero."""
+    from guassianhand_amd import fit as F
+    pb = tiny_fit_problem(device=dev)
+    tgt = F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"], active_texels=False)
+    with torch.no_grad():
+        tgt.color_w.copy_(pb["true"]["color_w"]); tgt.color_b.copy_(pb["true"]["color_b"]); tgt.opacity_b.copy_(pb["true"]["opacity_b"])
+        out = tgt.render(pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], tgt.blend_values())
+        gt_rgb, gt_mask = out["comp_rgb"].clone(), out["comp_mask"].mean(-1).clone()
+    fd = F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"], active_texels=False)
+    fa = F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"])
+    assert fa.active and not fd.active
+    for epoch in range(3):
+        for it in range(3):
+            ld = fd.step(pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
+            la = fa.step(pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
+            assert float(la) == pytest.approx(float(ld), rel=1e-4)
+        fd.end_epoch(); fa.end_epoch()
+    assert fd.opt.param_groups[0]["lr"] == pytest.approx(0.005)     # milestone 2 passed
+    # Adam normalises by sqrt(v): early steps amplify rounding differences of tiny gradients, hence the absolute floor
+    assert torch.allclose(fa.color_w, fd.color_w, rtol=1e-3, atol=2e-4)
+    assert torch.allclose(fa.color_b, fd.color_b, rtol=1e-3, atol=5e-4)
+    assert torch.allclose(fa.opacity_b, fd.opacity_b, rtol=1e-3, atol=5e-4)
+    inactive = torch.ones(pb["map_hw"][0] * pb["map_hw"][1], dtype=torch.bool, device=dev)
+    inactive[fa.texels.index] = False
+    assert float(fd.color_b_map.view(-1, 48)[inactive].abs().max()) == 0.0      # the premise of the active-texel mode
+    assert float(fd.opacity_b_map.view(-1, 1)[inactive].abs().max()) == 0.0
+    # export / import round trip through the reference layout
+    fb = F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"])
+    fb.load_maps(fa.color_b, fa.opacity_b)
+    assert torch.equal(fb.color_b_tex, fa.color_b_tex) and torch.equal(fb.opacity_b_tex, fa.opacity_b_tex)
+    with pytest.raises(ValueError):
+        fb.load_maps(torch.ones_like(fa.color_b), fa.opacity_b)
