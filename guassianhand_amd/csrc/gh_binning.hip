@@ -153,7 +153,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
 
 // Sorts (keys, vals) on bits [0, nbits) with ceil(nbits/8) digits; in/out ping-pong (pointers are swapped so that
 // on return k_in / v_in hold the result).
-static void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
+void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                           int nbits, uint32_t* table, int nblk, hipStream_t s) {
   const int passes = (nbits + 7) / 8;
   uint32_t* tot = table + (size_t)256 * nblk;

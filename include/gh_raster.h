@@ -235,6 +235,24 @@ int gh_uv_gather_backward(const int32_t* slot, const float* w, const float* dL_d
 int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, float lr, float beta1,
                      float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials, void* hip_stream);
 
+/*
+ * Interaction mask of the interaction-aware step (infer_one_shot.py:247-250):
+ *     _, idx_world, _ = knn_points(pointclouds, pointclouds, K=100)
+ *     _, idx_tpose, _ = knn_points(t_point, t_point, K=100)
+ *     mask = (idx_world == idx_tpose).sum(-1) < 10
+ * knn_points is pytorch3d.ops (third-party, not in the reference tree; environment.yml pins pytorch3d 0.7.x): exact
+ * brute-force K nearest neighbours under squared L2 distance, returned sorted by ascending distance. gh_knn_indices
+ * computes the same lists for one point set against itself (points (N,3) fp32, idx_out (N,K) int32, optional
+ * dist_out (N,K) squared distances); equal distances are ordered by ascending index. 1 <= K <= 128, K <= N.
+ * `workspace` must hold gh_knn_workspace_bytes(N) bytes. gh_knn_mismatch_mask writes mask_out[i] = 1 when fewer than
+ * `min_same` ranks of the two lists of point i hold the same index. All work is enqueued on `hip_stream`.
+ */
+size_t gh_knn_workspace_bytes(int N);
+int gh_knn_indices(const float* points, int N, int K, int32_t* idx_out, float* dist_out, void* workspace, size_t ws_bytes,
+                   void* hip_stream);
+int gh_knn_mismatch_mask(const int32_t* idx_a, const int32_t* idx_b, int N, int K, int min_same, uint8_t* mask_out,
+                         void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

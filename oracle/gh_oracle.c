@@ -621,3 +621,68 @@ int gho_num_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * kNN oracle for the interaction mask (infer_one_shot.py:247-250). knn_points is pytorch3d.ops (third-party, not in
+ * /root/reference; "parity unpinned"): brute force over all points, squared distance accumulated in x, y, z order as
+ * `dist += diff * diff` — which its compiler contracts to fma(dz,dz, fma(dy,dy, dx*dx)) —, the K smallest returned
+ * sorted by distance. Ties are ordered by ascending index (the library leaves them unspecified).
+ * queries: indices of the nq query points (NULL = all N points, nq ignored). idx_out (nq,K), dist_out (nq,K) or NULL.
+ */
+static void gho_sift_down(uint64_t* heap, int n, int i) {          /* max-heap on the u64 keys */
+  for (;;) {
+    int l = 2 * i + 1, r = l + 1, m = i;
+    if (l < n && heap[l] > heap[m]) m = l;
+    if (r < n && heap[r] > heap[m]) m = r;
+    if (m == i) return;
+    uint64_t t = heap[i]; heap[i] = heap[m]; heap[m] = t;
+    i = m;
+  }
+}
+
+static int gho_cmp_u64(const void* a, const void* b) {
+  uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+int gho_knn(const float* points, int N, const int32_t* queries, int nq, int K, int32_t* idx_out, float* dist_out) {
+  if (N < 1 || K < 1 || K > N || !points || !idx_out) return -1;
+  if (!queries) nq = N;
+  int status = 0;
+#pragma omp parallel
+  {
+    uint64_t* heap = (uint64_t*)malloc((size_t)K * sizeof(uint64_t));
+    if (!heap) {
+#pragma omp atomic write
+      status = -2;
+    }
+#pragma omp for schedule(dynamic, 16)
+    for (int qi = 0; qi < nq; ++qi) {
+      if (!heap) continue;
+      const int q = queries ? queries[qi] : qi;
+      const float qx = points[3 * q], qy = points[3 * q + 1], qz = points[3 * q + 2];
+      int n = 0;
+      for (int j = 0; j < N; ++j) {
+        const float dx = qx - points[3 * j], dy = qy - points[3 * j + 1], dz = qz - points[3 * j + 2];
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        uint32_t bits;
+        memcpy(&bits, &d2, 4);
+        const uint64_t key = ((uint64_t)bits << 32) | (uint32_t)j;      /* (distance, index) lexicographic */
+        if (n < K) {
+          heap[n++] = key;
+          if (n == K) for (int i = K / 2 - 1; i >= 0; --i) gho_sift_down(heap, K, i);
+        } else if (key < heap[0]) {
+          heap[0] = key;
+          gho_sift_down(heap, K, 0);
+        }
+      }
+      qsort(heap, (size_t)K, sizeof(uint64_t), gho_cmp_u64);
+      for (int k = 0; k < K; ++k) {
+        idx_out[(size_t)qi * K + k] = (int32_t)(uint32_t)heap[k];
+        if (dist_out) { uint32_t b = (uint32_t)(heap[k] >> 32); memcpy(&dist_out[(size_t)qi * K + k], &b, 4); }
+      }
+    }
+    free(heap);
+  }
+  return status;
+}

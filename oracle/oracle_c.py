@@ -49,6 +49,8 @@ def lib() -> C.CDLL:
         _lib.gho_exp_public.restype = C.c_float
         _lib.gho_exp_public.argtypes = [C.c_float]
         _lib.gho_num_threads.restype = C.c_int
+        _lib.gho_knn.restype = C.c_int
+        _lib.gho_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -161,3 +163,26 @@ def gho_exp(x: float) -> float:
 
 def num_threads() -> int:
     return int(lib().gho_num_threads())
+
+
+def knn(points: torch.Tensor, K: int, queries: Optional[torch.Tensor] = None):
+    """Brute-force kNN oracle (gho_knn): points (N,3) -> (idx (nq,K) int32, squared dists (nq,K)), rows sorted by
+    (distance, index); `queries` = optional int32 indices of the query points (default: all)."""
+    p = points.detach().float().contiguous().cpu()
+    N = p.shape[0]
+    qs = None if queries is None else queries.detach().to(torch.int32).contiguous().cpu()
+    nq = N if qs is None else qs.numel()
+    idx = torch.empty(nq, K, dtype=torch.int32)
+    d = torch.empty(nq, K, dtype=torch.float32)
+    rc = lib().gho_knn(C.c_void_p(p.data_ptr()), N, None if qs is None else C.c_void_p(qs.data_ptr()), nq, K,
+                       C.c_void_p(idx.data_ptr()), C.c_void_p(d.data_ptr()))
+    if rc != 0:
+        raise RuntimeError(f"gho_knn failed: {rc}")
+    return idx, d
+
+
+def interaction_mask(pointclouds: torch.Tensor, t_point: torch.Tensor, K: int = 100, min_same: int = 10) -> torch.Tensor:
+    """infer_one_shot.py:247-250 on the oracle kNN: (N,3),(N,3) -> (N,) bool."""
+    a, _ = knn(pointclouds, K)
+    b, _ = knn(t_point, K)
+    return (a == b).sum(-1) < min_same
