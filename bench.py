@@ -157,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(sync=False)
+    t_enq = time.perf_counter() - t0                 # host time to enqueue the timed steps (GPU-bound if << dt)
     barrier()
     dt = time.perf_counter() - t0
     R.check_overflow()
@@ -193,7 +194,8 @@ def main():
                                    f"{'on' if s.color_w is not None else 'off'}"
                                    + (" (BASELINE configs[2])" if args.config == "two_hands" else ""),
                        "views_per_step_per_gpu": V, "instances_per_step_per_gpu": D, "parallelism": f"view-parallel x{world}",
-                       "loss": "mean|img-gt|", "final_loss": float(loss)},
+                       "loss": "mean|img-gt|", "final_loss": float(loss),
+                       "host_enqueue_ms_per_step": t_enq / args.steps * 1e3},
             "roofline": roofline, "stages": stages,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -101,12 +101,16 @@ __device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, floa
 // Fixed-order sum of every Gaussian's per-(instance, quadrant) gradient sub-records: one thread per (view,
 // Gaussian), its instances are the consecutive emit slots [slot_begin, slot_begin + tiles). Few registers, so
 // the scattered 48-byte reads run at full occupancy; the chain-rule kernel then reads the 9 sums coalesced.
-__global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t cap, const uint32_t* __restrict__ slot_begin,
+// Threads are assigned in DEPTH order (perm = the level-1 sort result): emit slots were handed out in that order, so
+// the threads of a wave read one contiguous stretch of sub-records.
+__global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t cap, const uint32_t* __restrict__ perm,
+                                                                  const uint32_t* __restrict__ slot_begin,
                                                                   const uint32_t* __restrict__ tiles_touched,
                                                                   const float* __restrict__ inst_grad,
                                                                   const uint32_t* __restrict__ inst_flag, float4* __restrict__ gsum) {
-  const int n = blockIdx.x * GH_BLOCK + threadIdx.x;
-  if (n >= N) return;
+  const int j = blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (j >= N) return;
+  const uint32_t n = perm[j];
   uint32_t o0 = slot_begin[n], o1 = o0 + tiles_touched[n];
   if (o1 > cap) o1 = cap;
   if (o0 > o1) o0 = o1;
@@ -319,7 +323,7 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   auto kern = in->colors_precomp ? gh_preprocess_bwd_kernel<true> : gh_preprocess_bwd_kernel<false>;
   const int nblk_n = (g.N + GH_BLOCK - 1) / GH_BLOCK;
   hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
-                     (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched),
+                     (const uint32_t*)(ws + L.depth_vals_a), (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched),
                      (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
   const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, ws, L, s);     // SH mode only; no-op with colors_precomp
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
