@@ -98,6 +98,7 @@ def main():
 
     from guassianhand_amd import dist as ghdist
     from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.loss import l1_mean_loss
     from guassianhand_amd.scenes import make_scene, perturbed_target_xyz
     import torch.distributed as tdist
 
@@ -134,7 +135,7 @@ def main():
                                    params["shs"], H=H, W=W, use_rgb=s.use_rgb, sh_degree=s.sh_degree, sync=sync,
                                    xyz_b=params.get("xyz_b"), opacity_b=params.get("opacity_b"),
                                    color_w=params.get("color_w"), color_b=params.get("color_b"))
-        loss = (img - gt).abs().mean()
+        loss = l1_mean_loss(img, gt)                 # mean|img - gt| and dL/dimg in one fused pass (gh_l1_loss)
         loss.backward()
         if world > 1:
             grads = {k: params[k].grad for k in names}

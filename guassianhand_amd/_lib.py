@@ -16,7 +16,7 @@ from . import _abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libgh_raster.so")
-SOURCES = ("gh_api.hip", "gh_preprocess.hip", "gh_binning.hip", "gh_render.hip", "gh_uv.hip", "gh_sh.hip", "gh_knn.hip")
+SOURCES = ("gh_api.hip", "gh_preprocess.hip", "gh_binning.hip", "gh_render.hip", "gh_uv.hip", "gh_sh.hip", "gh_knn.hip", "gh_loss.hip")
 HEADERS = ("gh_internal.h", os.path.join("..", "..", "include", "gh_raster.h"))
 # -ffp-contract=off: FMAs only where the source says fmaf() (arithmetic contract)
 # -fno-slp-vectorize: keeps the DPP butterflies as v_add_f32_dpp instead of v_mov_dpp + v_pk_add_f32

@@ -106,12 +106,11 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
   if (stages & GH_FWD_PREPROCESS) {
-    if (hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s) != hipSuccess) return GH_ERR_LAUNCH;
+    // the projection kernel also resets the counters and the per-tile state (ranges, tile_walk) of the later stages
     gh_launch_sh_colour_fwd(d, g, in, ws, L, s);
     gh_launch_preprocess_fwd(d, g, in, out->radii, ws, L, s);
   }
   if (stages & GH_FWD_BINNING) {
-    if (hipMemsetAsync(ws + L.ranges, 0, L.tile_order - L.ranges, s) != hipSuccess) return GH_ERR_LAUNCH;  // ranges + tile_walk
     gh_launch_binning(d, g, ws, L, s);
   }
   if (stages & GH_FWD_RENDER) gh_launch_render_fwd(d, g, in, out->image, out->alpha, ws, L, s);

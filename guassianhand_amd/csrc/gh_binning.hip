@@ -260,10 +260,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __r
                                                               const GhCounters* __restrict__ ctr, uint32_t cap, int gx, int tiles,
                                                               const float4* __restrict__ geom, uint2* __restrict__ ranges,
                                                               uint32_t* __restrict__ sorted_slot, float4* __restrict__ r0,
-                                                              float4* __restrict__ r1, float* __restrict__ r2) {
+                                                              float4* __restrict__ r1, float* __restrict__ r2,
+                                                              uint32_t* __restrict__ inst_flag) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   if (i >= n) return;
+  inst_flag[i] = 0;                                    // quadrant flags of the backward's sub-records (emit slots 0 .. D-1)
   const uint32_t t = keys[i];
   if (i == 0) ranges[t].x = 0;
   else {
@@ -373,6 +375,6 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,
                      (const float4*)(ws + L.geom),
                      (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.sorted_slot), (float4*)(ws + L.inst_r0),
-                     (float4*)(ws + L.inst_r1), (float*)(ws + L.inst_r2));
+                     (float4*)(ws + L.inst_r1), (float*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag));
   gh_launch_tile_order(g, ws, L, s);
 }

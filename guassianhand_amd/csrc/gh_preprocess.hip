@@ -11,10 +11,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     const float4* __restrict__ sh_rgb, float4* __restrict__ geom, float* __restrict__ depth,
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
-    int32_t* __restrict__ radii) {
+    int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk) {
   const int n = blockIdx.x * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
-  if (n == 0) ctr->reserved[0] = (uint32_t)N;          // element count of the level-1 (depth) sort, read on device
+  if (n == 0) {                                        // counters: reserved[0] = element count of the level-1 (depth) sort
+    ctr->num_rendered = 0; ctr->overflow = 0; ctr->reserved[0] = (uint32_t)N; ctr->reserved[1] = 0;
+  }
+  if (n < T) { ranges[n] = make_uint2(0u, 0u); tile_walk[n] = 0u; }   // per-tile state of the binning / render stages
   if (n < N) {
     uint32_t dkey = 0xFFFFFFFFu;                        // culled Gaussians sort behind everything and emit nothing
     const int v = n / P, i = n - v * P;
@@ -79,13 +82,19 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
 
 void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii, char* ws,
                               const GhLayout& L, hipStream_t s) {
-  if (g.N == 0) return;
-  int nblk = (g.N + GH_BLOCK - 1) / GH_BLOCK;
+  const int T = g.NV * g.tiles;
+  if (g.N == 0) {                                      // nothing to project: only the counters and per-tile state
+    (void)hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s);
+    (void)hipMemsetAsync(ws + L.ranges, 0, L.tile_order - L.ranges, s);
+    return;
+  }
+  int nblk = ((g.N > T ? g.N : T) + GH_BLOCK - 1) / GH_BLOCK;
   hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.N, g.H, g.W, g.gx, g.gy,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (const float4*)(ws + L.sh_rgb), (float4*)(ws + L.geom),
                      (float*)(ws + L.depth),
                      (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
-                     (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii);
+                     (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii,
+                     T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk));
 }
 
 // ------------------------------------------------------------------------------------------------

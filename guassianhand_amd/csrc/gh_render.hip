@@ -455,7 +455,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, char* ws, const GhLayout& L, hipStream_t s) {
   if (g.cap == 0) return;
-  (void)hipMemsetAsync(ws + L.inst_flag, 0, (size_t)g.cap * 4, s);
+  // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (same n_contrib)
   gh_launch_tile_order_bwd(g, ws, L, s);
   const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
   auto launch = [&](auto kern) {

@@ -236,6 +236,15 @@ int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_s
                      float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials, void* hip_stream);
 
 /*
+ * Image-loss consumer (the L1 term of utils.py:282-294 as bench.py / the fit loop use it):
+ * loss_out[0] = mean|image - target| over n floats and dL_dimage = sign(image - target) / n (sign(0) = 0, as
+ * torch.abs' backward) in one pass. image / target / dL_dimage must be 16-byte aligned; partials holds n_partials
+ * floats of scratch (n_partials = grid size, e.g. 1024). Fixed-order sums: bitwise reproducible.
+ */
+int gh_l1_loss(const float* image, const float* target, size_t n, float* loss_out, float* dL_dimage, float* partials,
+               int n_partials, void* hip_stream);
+
+/*
  * Interaction mask of the interaction-aware step (infer_one_shot.py:247-250):
  *     _, idx_world, _ = knn_points(pointclouds, pointclouds, K=100)
  *     _, idx_tpose, _ = knn_points(t_point, t_point, K=100)

@@ -176,3 +176,23 @@ def test_active_texel_fit_equals_dense_fit(dev):
     assert torch.equal(fb.color_b_tex, fa.color_b_tex) and torch.equal(fb.opacity_b_tex, fa.opacity_b_tex)
     with pytest.raises(ValueError):
         fb.load_maps(torch.ones_like(fa.color_b), fa.opacity_b)
+
+
+def test_fused_l1_loss_matches_torch(dev):
+    """gh_l1_loss == (img - gt).abs().mean() and its autograd gradient, incl. exact zeros (sign(0) = 0), odd sizes and
+    an upstream gradient factor."""
+    from guassianhand_amd.loss import l1_mean_loss
+    g = torch.Generator().manual_seed(8)
+    for shape in ((8, 3, 512, 334), (1, 3, 7, 5), (3,), (2, 1025)):
+        img = torch.randn(*shape, generator=g).to(dev)
+        gt = torch.randn(*shape, generator=g).to(dev)
+        flat = img.view(-1)
+        flat[:: 7] = gt.view(-1)[:: 7]                         # exact ties
+        a = img.clone().requires_grad_(True)
+        b = img.clone().requires_grad_(True)
+        la = l1_mean_loss(a, gt)
+        lb = (b - gt).abs().mean()
+        (2.5 * la).backward(); (2.5 * lb).backward()
+        assert float(la) == pytest.approx(float(lb), rel=1e-5)
+        assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
+        assert float(a.grad.view(-1)[0]) == 0.0
