@@ -47,9 +47,8 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->inst_r0 = take(cap * 16);
   L->inst_r1 = take(cap * 16);
   L->inst_r2 = take(cap * 4);
-  const size_t nblk_n = (N + GH_SORT_TILE - 1) / GH_SORT_TILE;
-  const size_t nblk_tab = (size_t)g.nblk_sort > nblk_n ? (size_t)g.nblk_sort : nblk_n;
-  L->sort_tables = take(((size_t)256 * nblk_tab + 256) * 4);
+  const size_t tab_n = gh_radix_table_words(N), tab_d = gh_radix_table_words((size_t)g.cap);
+  L->sort_tables = take((tab_n > tab_d ? tab_n : tab_d) * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
   L->tile_walk = take((size_t)g.NV * g.tiles * 4);       // directly after ranges: both are cleared by one memset
   L->tile_order = take((size_t)g.NV * g.tiles * 4);

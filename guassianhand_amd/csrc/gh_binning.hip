@@ -15,24 +15,25 @@
 
 // ------------------------------------------------------------------------------------------------
 // LSD radix sort engine: 32-bit keys + 32-bit payload, <= 8-bit digits, element count read from device memory.
-// Each block owns GH_SORT_TILE consecutive keys.
+// Each block owns GH_BLOCK * ITEMS consecutive keys.
 __device__ __forceinline__ uint32_t gh_clamp_n(const uint32_t* n_ptr, uint32_t cap) {
   const uint32_t n = *n_ptr;
   return n < cap ? n : cap;
 }
 
 // Pass part 1: per-block digit histogram -> table[digit][block].
+template <int ITEMS>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
                                                                   uint32_t cap, int shift, uint32_t dmask,
                                                                   uint32_t* __restrict__ table, int nblk_cap) {
   __shared__ uint32_t s_hist[256];
   const uint32_t n = gh_clamp_n(n_ptr, cap);
-  const uint32_t base = blockIdx.x * (uint32_t)GH_SORT_TILE;
+  const uint32_t base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
   if (base >= n) return;
   s_hist[threadIdx.x] = 0;
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < GH_SORT_ITEMS; ++j) {
+  for (int j = 0; j < ITEMS; ++j) {
     const uint32_t idx = base + j * GH_BLOCK + threadIdx.x;
     if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & dmask], 1u);
   }
@@ -41,12 +42,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t*
 }
 
 // Pass part 2: one block per digit: exclusive scan of its row over the active blocks, row total -> tot[digit].
+template <int ITEMS>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ tot,
                                                                   const uint32_t* __restrict__ n_ptr, uint32_t cap, int nblk_cap) {
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   __shared__ uint32_t s_carry;
   const uint32_t n = gh_clamp_n(n_ptr, cap);
-  const int nblk = (int)((n + GH_SORT_TILE - 1) / GH_SORT_TILE);
+  const int nblk = (int)((n + (GH_BLOCK * ITEMS) - 1) / (GH_BLOCK * ITEMS));
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   uint32_t* row = table + (size_t)blockIdx.x * nblk_cap;
   if (tid == 0) s_carry = 0;
@@ -71,7 +73,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __res
 }
 
 // Pass part 3: stable scatter. Ranking is per wave with ballot matching (one ballot per digit bit), waves are
-// ordered through an LDS prefix over their digit counts, so equal digits keep their input order.
+// ordered through an LDS prefix over their digit counts, so equal digits keep their input order. The tile is first
+// sorted into LDS and then written out, so that each digit run leaves as contiguous global segments.
+template <int ITEMS>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t dmask,
@@ -79,8 +83,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   __shared__ uint32_t s_base[256];                         // global base of (digit, this block)
   __shared__ uint32_t s_cnt[GH_BLOCK / GH_WAVE][256];      // per-wave digit counters -> per-wave bases
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
+  __shared__ uint32_t s_lbase[256];                        // first position of each digit in the locally sorted tile
+  __shared__ uint32_t s_key[(GH_BLOCK * ITEMS)], s_val[(GH_BLOCK * ITEMS)];
   const uint32_t n = gh_clamp_n(n_ptr, cap);
-  const uint32_t blk_base = blockIdx.x * (uint32_t)GH_SORT_TILE;
+  const uint32_t blk_base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
   if (blk_base >= n) return;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
@@ -102,13 +108,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
 
   // Phase A: rank keys inside the wave. Wave w owns keys [w*1024, (w+1)*1024) of the block's tile,
   // visited as 16 rounds of 64 consecutive keys, so (round, lane) order == memory order.
-  uint32_t key[GH_SORT_ITEMS];
-  uint32_t rank[GH_SORT_ITEMS];
-  const uint32_t wave_base = blk_base + wid * (GH_SORT_ITEMS * GH_WAVE);
+  uint32_t key[ITEMS];
+  uint32_t rank[ITEMS];
+  const uint32_t wave_base = blk_base + wid * (ITEMS * GH_WAVE);
   volatile uint32_t* cnt = s_cnt[wid];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int r = 0; r < GH_SORT_ITEMS; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const uint32_t idx = wave_base + r * GH_WAVE + lane;
     const bool valid = idx < n;
     key[r] = valid ? keys_in[idx] : ~0u;
@@ -131,43 +137,86 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     rank[r] = prev + before;
   }
   __syncthreads();
-  // Phase B: turn per-wave counts into per-wave bases (digit = tid), in wave order.
+  // Phase B: per-wave bases inside the block's LOCALLY sorted tile (digit = tid): block count per digit, exclusive
+  // scan over the digits, waves in order.
   {
-    uint32_t run = s_base[tid];
+    uint32_t c[GH_BLOCK / GH_WAVE];
+    uint32_t tot_d = 0;
 #pragma unroll
-    for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+    for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { c[w] = s_cnt[w][tid]; tot_d += c[w]; }
+    uint32_t x = tot_d;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wid] = x;
+    __syncthreads();
+    uint32_t run = x - tot_d;
+    for (int w = 0; w < wid; ++w) run += s_w[w];
+    s_lbase[tid] = run;
+#pragma unroll
+    for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { s_cnt[w][tid] = run; run += c[w]; }
   }
   __syncthreads();
-  // Phase C: scatter.
+  // Phase C: stage the tile in LDS in sorted order ...
 #pragma unroll
-  for (int r = 0; r < GH_SORT_ITEMS; ++r) {
+  for (int r = 0; r < ITEMS; ++r) {
     const uint32_t idx = wave_base + r * GH_WAVE + lane;
     if (idx < n) {
       const uint32_t dg = (key[r] >> shift) & dmask;
-      const uint32_t dst = s_cnt[wid][dg] + rank[r];
-      keys_out[dst] = key[r];
-      vals_out[dst] = vals_in[idx];
+      const uint32_t lpos = s_cnt[wid][dg] + rank[r];
+      s_key[lpos] = key[r];
+      s_val[lpos] = vals_in[idx];
+    }
+  }
+  __syncthreads();
+  // ... and write it out: consecutive threads hold consecutive elements of a digit run -> contiguous global segments
+  const uint32_t nvalid = n - blk_base < (uint32_t)(GH_BLOCK * ITEMS) ? n - blk_base : (uint32_t)(GH_BLOCK * ITEMS);
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const uint32_t e = r * GH_BLOCK + tid;
+    if (e < nvalid) {
+      const uint32_t k = s_key[e];
+      const uint32_t dg = (k >> shift) & dmask;
+      const uint32_t dst = s_base[dg] + (e - s_lbase[dg]);
+      keys_out[dst] = k;
+      vals_out[dst] = s_val[e];
     }
   }
 }
 
 // Sorts (keys, vals) on bits [0, nbits) with ceil(nbits/8) digits; in/out ping-pong (pointers are swapped so that
-// on return k_in / v_in hold the result).
-void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
-                          int nbits, uint32_t* table, int nblk, hipStream_t s) {
+// on return k_in / v_in hold the result). ITEMS keys per thread: 16 for large inputs (bandwidth), 4 for small ones
+// (more, shorter blocks: the pass is latency-bound when it cannot fill the 256 CUs).
+template <int ITEMS>
+static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr,
+                            uint32_t cap, int nbits, uint32_t* table, hipStream_t s) {
   const int passes = (nbits + 7) / 8;
+  const int nblk = (int)(((size_t)cap + GH_BLOCK * ITEMS - 1) / (GH_BLOCK * ITEMS));
+  if (nblk == 0) return;
   uint32_t* tot = table + (size_t)256 * nblk;
   for (int p = 0; p < passes; ++p) {
     // spread the bits evenly over the passes (e.g. 13 bits -> 6 + 7)
     const int lo = (nbits * p) / passes, hi = (nbits * (p + 1)) / passes;
     const uint32_t dmask = (1u << (hi - lo)) - 1u;
-    hipLaunchKernelGGL(gh_radix_hist_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, k_in, n_ptr, cap, lo, dmask, table, nblk);
-    hipLaunchKernelGGL(gh_radix_scan_kernel, dim3(dmask + 1), dim3(GH_BLOCK), 0, s, table, tot, n_ptr, cap, nblk);
-    hipLaunchKernelGGL(gh_radix_scatter_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, lo,
+    hipLaunchKernelGGL(gh_radix_hist_kernel<ITEMS>, dim3(nblk), dim3(GH_BLOCK), 0, s, k_in, n_ptr, cap, lo, dmask, table, nblk);
+    hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, dim3(dmask + 1), dim3(GH_BLOCK), 0, s, table, tot, n_ptr, cap, nblk);
+    hipLaunchKernelGGL(gh_radix_scatter_kernel<ITEMS>, dim3(nblk), dim3(GH_BLOCK), 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, lo,
                        dmask, table, tot, nblk);
     uint32_t* t = k_in; k_in = k_out; k_out = t;
     t = v_in; v_in = v_out; v_out = t;
   }
+}
+
+int gh_radix_items(size_t cap) { return cap <= ((size_t)1 << 21) ? 4 : 16; }
+
+size_t gh_radix_table_words(size_t cap) {
+  const size_t tile = (size_t)GH_BLOCK * gh_radix_items(cap);
+  return 256 * ((cap + tile - 1) / tile) + 256;
+}
+
+void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
+                   int nbits, uint32_t* table, hipStream_t s) {
+  if (gh_radix_items(cap) == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, table, s);
+  else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, table, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -349,8 +398,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   // level 1: depth order of the Gaussians (keys / payload written by the preprocess kernel; reserved[0] = N)
   uint32_t* dk_in = (uint32_t*)(ws + L.depth_keys_a); uint32_t* dk_out = (uint32_t*)(ws + L.depth_keys_b);
   uint32_t* dv_in = (uint32_t*)(ws + L.depth_vals_a); uint32_t* dv_out = (uint32_t*)(ws + L.depth_vals_b);
-  const int nblk_n = (g.N + GH_SORT_TILE - 1) / GH_SORT_TILE;
-  gh_radix_sort(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, 32, table, nblk_n, s);
+  gh_radix_sort(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, 32, table, s);
   const uint32_t* perm = dv_in;                       // 4 passes: the result is back in the *_a buffers
 
   // level 2: emit in depth order
@@ -369,7 +417,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
                      (const uint32_t*)(ws + L.block_sums), (const uint32_t*)(ws + L.rect), (uint32_t*)(ws + L.slot_begin),
                      (float4*)(ws + L.geom), k_in, v_in);
-  gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, g.nblk_sort, s);
+  gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
   const int nblk_d = (int)((g.cap + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,

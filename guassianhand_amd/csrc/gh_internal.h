@@ -42,9 +42,10 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, char* ws, const GhLayout& L, hipStream_t s);
 // LSD radix sort of (keys, vals) on bits [0, nbits): ceil(nbits/8) stable passes, element count read from device memory
-// (*n_ptr <= cap); pointers are swapped so that on return k_in / v_in hold the result. table: 256*nblk + 256 words.
+// (*n_ptr <= cap); pointers are swapped so that on return k_in / v_in hold the result. table: gh_radix_table_words(cap).
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
-                   int nbits, uint32_t* table, int nblk, hipStream_t s);
+                   int nbits, uint32_t* table, hipStream_t s);
+size_t gh_radix_table_words(size_t cap);
 void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, char* ws, const GhLayout& L, hipStream_t s);
 int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
                             const GhLayout& L, hipStream_t s);

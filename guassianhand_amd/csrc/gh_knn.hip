@@ -37,10 +37,9 @@ static void gh_knn_layout(int N, GhKnnLayout* L) {
   auto take = [&](size_t b) { size_t o = off; off += (b + 255) & ~(size_t)255; return o; };
   const size_t n = (size_t)(N > 0 ? N : 1);
   const int G = gh_knn_grid(N);
-  const size_t nblk = (n + GH_SORT_TILE - 1) / GH_SORT_TILE;
   L->header = take(sizeof(GhKnnHeader));
   L->keys_a = take(n * 4); L->keys_b = take(n * 4); L->vals_a = take(n * 4); L->vals_b = take(n * 4);
-  L->table = take((256 * nblk + 256) * 4);
+  L->table = take(gh_radix_table_words(n) * 4);
   L->cell_start = take(((size_t)G * G * G + 1) * 4);
   L->pts = take(n * 16);
   L->total = off;
@@ -239,10 +238,10 @@ extern "C" int gh_knn_indices(const float* points, int N, int K, int32_t* idx_ou
   GhKnnHeader* hdr = (GhKnnHeader*)(ws + L.header);
   uint32_t* ka = (uint32_t*)(ws + L.keys_a); uint32_t* kb = (uint32_t*)(ws + L.keys_b);
   uint32_t* va = (uint32_t*)(ws + L.vals_a); uint32_t* vb = (uint32_t*)(ws + L.vals_b);
-  const int nblk = (N + GH_BLOCK - 1) / GH_BLOCK, nblk_sort = (N + GH_SORT_TILE - 1) / GH_SORT_TILE;
+  const int nblk = (N + GH_BLOCK - 1) / GH_BLOCK;
   hipLaunchKernelGGL(gh_knn_bbox_kernel, dim3(1), dim3(1024), 0, s, points, N, G, hdr);
   hipLaunchKernelGGL(gh_knn_cell_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, points, N, G, hdr, ka, va);
-  gh_radix_sort(ka, va, kb, vb, &hdr->n, (uint32_t)N, bits, (uint32_t*)(ws + L.table), nblk_sort, s);   // result in ka / va
+  gh_radix_sort(ka, va, kb, vb, &hdr->n, (uint32_t)N, bits, (uint32_t*)(ws + L.table), s);   // result in ka / va
   hipLaunchKernelGGL(gh_knn_cell_start_kernel, dim3((ncell + 1 + GH_BLOCK - 1) / GH_BLOCK), dim3(GH_BLOCK), 0, s, ka, N, ncell,
                      (uint32_t*)(ws + L.cell_start));
   hipLaunchKernelGGL(gh_knn_gather_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, points, va, N, (float4*)(ws + L.pts));
