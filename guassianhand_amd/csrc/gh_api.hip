@@ -43,10 +43,10 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->keys_b = take(cap * 4);
   L->vals_a = take(cap * 4);
   L->vals_b = take(cap * 4);
-  L->sorted_slot = take(cap * 4);
+  L->slot_gid = take(cap * 4);
   L->inst_r0 = take(cap * 16);
   L->inst_r1 = take(cap * 16);
-  L->inst_r2 = take(cap * 4);
+  L->inst_r2 = take(cap * 8);
   const size_t tab_n = gh_radix_table_words(N), tab_d = gh_radix_table_words((size_t)g.cap);
   L->sort_tables = take((tab_n > tab_d ? tab_n : tab_d) * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);

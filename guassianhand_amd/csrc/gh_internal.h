@@ -190,6 +190,45 @@ __device__ __forceinline__ float gh_blended_sh(const GhInputs& in, uint32_t flag
   return s;
 }
 
+// Culling test: can Gaussian (g0 = px,py,A,B; g1 = C,opacity,..) reach alpha >= 1/255 at any pixel centre of the
+// block [qx0, qx0+ext] x [qy0, qy0+ext]?  alpha >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o).
+// q is convex, so its minimum over the rectangle is 0 if the centre is inside, otherwise it lies on one of the
+// four edges (a clamped 1-D parabola each): an exact ellipse/rectangle intersection up to rounding. The threshold
+// carries a margin for the approximate log / rcp; anything non-finite answers "hit". A false "hit" only costs
+// time and a false "miss" is impossible within the margin: the exact per-pixel tests of App. A.3 still decide.
+__device__ __forceinline__ bool gh_block_hit(const float4& g0, const float4& g1, float qx0, float qy0, float ext) {
+  const float o = g1.y;
+  if (!(o >= 1.0f / 255.0f)) return false;          // alpha = min(.99, o*exp(p<=0)) <= o < 1/255 everywhere
+  const float thr = 2.0f * (__logf(255.0f * o) * 1.0001f + 1e-3f);
+  const float A = g0.z, B = g0.w, C = g1.x;
+  const float lx = qx0 - g0.x, ux = lx + ext, ly = qy0 - g0.y, uy = ly + ext;   // offset ranges of the block
+  const bool inside = (lx <= 0.0f) && (ux >= 0.0f) && (ly <= 0.0f) && (uy >= 0.0f);
+  const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+  // vertical edges dx = lx / ux: best dy = clamp(-B dx / C); horizontal edges dy = ly / uy: best dx = clamp(-B dy / A)
+  const float dy0 = fminf(fmaxf(-B * lx * rC, ly), uy), dy1 = fminf(fmaxf(-B * ux * rC, ly), uy);
+  const float dx0 = fminf(fmaxf(-B * ly * rA, lx), ux), dx1 = fminf(fmaxf(-B * uy * rA, lx), ux);
+  const float q0 = A * lx * lx + 2.0f * B * lx * dy0 + C * dy0 * dy0;
+  const float q1 = A * ux * ux + 2.0f * B * ux * dy1 + C * dy1 * dy1;
+  const float q2 = A * dx0 * dx0 + 2.0f * B * dx0 * ly + C * ly * ly;
+  const float q3 = A * dx1 * dx1 + 2.0f * B * dx1 * uy + C * uy * uy;
+  const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
+  const bool miss = !inside && (qmin * 0.9999f > thr);
+  return !miss;                                       // NaN compares false -> hit
+}
+// Exact tile culling (binning) and the per-instance 4x4-block mask (render kernels) are both this test:
+//   tile (tx, ty):            gh_block_hit(g0, g1, 16 tx, 16 ty, 15)
+//   block (bx, by) of a tile: gh_block_hit(g0, g1, 16 tx + 4 bx, 16 ty + 4 by, 3)   -> bit by*4 + bx
+__device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const float4& g1, float tx0, float ty0) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int by = 0; by < 4; ++by)
+#pragma unroll
+    for (int bx = 0; bx < 4; ++bx)
+      m |= gh_block_hit(g0, g1, tx0 + (float)(4 * bx), ty0 + (float)(4 * by), 3.0f) ? (1u << (by * 4 + bx)) : 0u;
+  return m;
+}
+
+
 // ---- wave64 cross-lane helpers (DPP; no LDS traffic) ------------------------------------------------
 // DPP controls (gfx9 encoding): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_ror:n 0x120+n,
 // row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143.

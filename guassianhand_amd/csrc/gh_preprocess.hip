@@ -40,11 +40,20 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
       int maxx = (int)((px + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
       int maxy = (int)((py + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
       int cnt = (maxx - minx) * (maxy - miny);
+      float op = 0.0f;
       if (cnt > 0) {
-        tiles = (unsigned)cnt;
-        radius = rad;
-        float op = in.opacities[i];
+        radius = rad;                                   // API output: the reference's 3-sigma radius (App. A.1-6)
+        op = in.opacities[i];
         if (in.blend_opacity_b) op = op + in.blend_opacity_b[i];
+        // Exact tile culling: of the tiles in the 3-sigma rect only those are instanced in which the alpha >= 1/255
+        // ellipse reaches a pixel centre (gh_block_hit, conservative within its margin). A dropped tile holds no pixel
+        // that would blend this Gaussian, so images and gradients are unchanged; gh_emit_kernel repeats this test.
+        const float4 g0 = make_float4(px, py, e.c * dinv, -e.b * dinv), g1 = make_float4(e.a * dinv, op, 0.0f, 0.0f);
+        for (int ty = miny; ty < maxy; ++ty)
+          for (int tx = minx; tx < maxx; ++tx)
+            tiles += gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
+      }
+      if (tiles > 0) {
         float rgb[3];
         unsigned cl = 0;
         if (in.colors_precomp) {

@@ -28,48 +28,22 @@ __device__ __forceinline__ float gh_bcast(float v, int lane) {   // lane is wave
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
-// Culling test: can Gaussian (g0 = px,py,A,B; g1 = C,opacity,..) reach alpha >= 1/255 at any pixel centre of the
-// block [qx0, qx0+ext] x [qy0, qy0+ext]?  alpha >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o).
-// q is convex, so its minimum over the rectangle is 0 if the centre is inside, otherwise it lies on one of the
-// four edges (a clamped 1-D parabola each): an exact ellipse/rectangle intersection up to rounding. The threshold
-// carries a margin for the approximate log / rcp; anything non-finite answers "hit". A false "hit" only costs
-// time and a false "miss" is impossible within the margin: the exact per-pixel tests of App. A.3 still decide.
-__device__ __forceinline__ bool gh_block_hit(const float4& g0, const float4& g1, float qx0, float qy0, float ext) {
-  const float o = g1.y;
-  if (!(o >= 1.0f / 255.0f)) return false;          // alpha = min(.99, o*exp(p<=0)) <= o < 1/255 everywhere
-  const float thr = 2.0f * (__logf(255.0f * o) * 1.0001f + 1e-3f);
-  const float A = g0.z, B = g0.w, C = g1.x;
-  const float lx = qx0 - g0.x, ux = lx + ext, ly = qy0 - g0.y, uy = ly + ext;   // offset ranges of the block
-  const bool inside = (lx <= 0.0f) && (ux >= 0.0f) && (ly <= 0.0f) && (uy >= 0.0f);
-  const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
-  // vertical edges dx = lx / ux: best dy = clamp(-B dx / C); horizontal edges dy = ly / uy: best dx = clamp(-B dy / A)
-  const float dy0 = fminf(fmaxf(-B * lx * rC, ly), uy), dy1 = fminf(fmaxf(-B * ux * rC, ly), uy);
-  const float dx0 = fminf(fmaxf(-B * ly * rA, lx), ux), dx1 = fminf(fmaxf(-B * uy * rA, lx), ux);
-  const float q0 = A * lx * lx + 2.0f * B * lx * dy0 + C * dy0 * dy0;
-  const float q1 = A * ux * ux + 2.0f * B * ux * dy1 + C * dy1 * dy1;
-  const float q2 = A * dx0 * dx0 + 2.0f * B * dx0 * ly + C * ly * ly;
-  const float q3 = A * dx1 * dx1 + 2.0f * B * dx1 * uy + C * uy * uy;
-  const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
-  const bool miss = !inside && (qmin * 0.9999f > thr);
-  return !miss;                                       // NaN compares false -> hit
-}
-__device__ __forceinline__ bool gh_quadrant_hit(const float4& g0, const float4& g1, float qx0, float qy0) {
-  return gh_block_hit(g0, g1, qx0, qy0, 7.0f);
-}
-
 // ------------------------------------------------------------------------------------------------
 struct GhBatch {          // 64 list entries staged in registers: lane l holds entry base+l
   float4 a, b;            // (px, py, A, B), (C, opacity, r, g)
   float cb;               // b
+  uint32_t blocks;        // 16-bit mask: 4x4-pixel blocks of the tile the entry can reach (gh_ranges_kernel)
 };
 
 __device__ __forceinline__ void gh_load_batch(GhBatch& t, const float4* __restrict__ r0, const float4* __restrict__ r1,
-                                              const float* __restrict__ r2, int idx, int total) {
+                                              const float2* __restrict__ r2, int idx, int total) {
   // unconditional loads from a clamped index (total >= 1): no exec-mask branch, so the compiler can wait
   // for exactly this batch (counted vmcnt) while the next one stays in flight. Entries >= total are
   // masked out of the hit ballot by the callers.
   const int i = idx < total ? idx : total - 1;
-  t.a = r0[i]; t.b = r1[i]; t.cb = r2[i];
+  t.a = r0[i]; t.b = r1[i];
+  const float2 c = r2[i];
+  t.cb = c.x; t.blocks = __float_as_uint(c.y);
 }
 
 // ---- forward: wave = 4x4 pixels x 4 depth slots ---------------------------------------------------------
@@ -118,9 +92,9 @@ __device__ __forceinline__ void gh_fwd_chain_step(GhPixelFwd& p, float alpha, bo
 
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
 template <bool ALPHA>
-__device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, float fbx0, float fby0,
+__device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, int blk,
                                                float pxf, float pyf, GhPixelFwd& p) {
-  const bool hit = (base + lane < total) && gh_block_hit(t.a, t.b, fbx0, fby0, 3.0f);
+  const bool hit = (base + lane < total) && ((t.blocks >> blk) & 1u);
   uint64_t mask = __ballot(hit);
   while (mask) {
     // next four set bits, ascending (wave-uniform scalar work)
@@ -180,7 +154,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
 template <bool ALPHA>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
-    const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
+    const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
     int tiles, float* __restrict__ image, float* __restrict__ alpha_img, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk) {
   int v, tx, ty;
@@ -192,7 +166,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (wid & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (wid >> 1) * 4;
   const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
   const bool inside = x < W && y < H;
-  const float pxf = (float)x, pyf = (float)y, fbx0 = (float)bx0, fby0 = (float)by0;
+  const float pxf = (float)x, pyf = (float)y;
+  const int blk = ((quad >> 1) * 2 + (wid >> 1)) * 4 + (quad & 1) * 2 + (wid & 1);      // this wave's bit in the block masks
   const uint2 range = ranges[tile];
   const int total = (int)(range.y - range.x);
   r0 += range.x; r1 += range.x; r2 += range.x;
@@ -205,10 +180,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     gh_load_batch(A, r0, r1, r2, lane, total);
     for (int base = 0; base < total; base += 2 * GH_WAVE) {
       gh_load_batch(B, r0, r1, r2, base + GH_WAVE + lane, total);
-      if (gh_fwd_consume<ALPHA>(A, base, total, lane, slot, fbx0, fby0, pxf, pyf, p)) break;
+      if (gh_fwd_consume<ALPHA>(A, base, total, lane, slot, blk, pxf, pyf, p)) break;
       if (base + GH_WAVE >= total) break;
       gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
-      if (gh_fwd_consume<ALPHA>(B, base + GH_WAVE, total, lane, slot, fbx0, fby0, pxf, pyf, p)) break;
+      if (gh_fwd_consume<ALPHA>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p)) break;
     }
   }
   if (total > 0) {                                   // walked length of the tile = max n_contrib (orders the backward)
@@ -236,7 +211,7 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   const uint2* ranges = (const uint2*)(ws + L.ranges);
   const uint32_t* order = (const uint32_t*)(ws + L.tile_order);
   const float4* r0 = (const float4*)(ws + L.inst_r0); const float4* r1 = (const float4*)(ws + L.inst_r1);
-  const float* r2 = (const float*)(ws + L.inst_r2);
+  const float2* r2 = (const float2*)(ws + L.inst_r2);
   float* fT = (float*)(ws + L.final_T); uint32_t* nc = (uint32_t*)(ws + L.n_contrib); uint32_t* tw = (uint32_t*)(ws + L.tile_walk);
   if (alpha)
     hipLaunchKernelGGL(gh_render_fwd_kernel<true>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
@@ -285,7 +260,7 @@ __device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum ove
 template <bool ALPHA>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ sorted_slot,
-    const float4* __restrict__ r0, const float4* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ cams,
+    const float4* __restrict__ r0, const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams,
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, float* __restrict__ inst_grad,
     uint8_t* __restrict__ inst_flag) {
@@ -301,7 +276,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (wid & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (wid >> 1) * 4;
   const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
   const bool inside = x < W && y < H;
-  const float pxf = (float)x, pyf = (float)y, fbx0 = (float)bx0, fby0 = (float)by0;
+  const float pxf = (float)x, pyf = (float)y;
+  const int blk = ((quad >> 1) * 2 + (wid >> 1)) * 4 + (quad & 1) * 2 + (wid & 1);
   const uint2 range = ranges[tile];
   if (range.y == range.x) return;
   r0 += range.x; r1 += range.x; r2 += range.x;
@@ -339,7 +315,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const int sbase = k * GH_WAVE;
     gh_load_batch(nxt, r0, r1, r2, (k > 0 ? (k - 1) * GH_WAVE : 0) + lane, qlast);   // next batch in flight
     uint64_t processed = 0;
-    uint64_t mask = __ballot((sbase + lane < wave_last) && gh_block_hit(cur.a, cur.b, fbx0, fby0, 3.0f));
+    uint64_t mask = __ballot((sbase + lane < wave_last) && ((cur.blocks >> blk) & 1u));
     while (mask) {
       // next four set bits, descending (back to front); wave-uniform scalar work
       const int j0 = 63 - __builtin_clzll(mask); mask &= ~(1ull << j0);
@@ -460,8 +436,8 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(ws + L.ranges), (const uint32_t*)(ws + L.tile_order_bwd),
-                       (const uint32_t*)(ws + L.sorted_slot), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
-                       (const float*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
+                       (const uint32_t*)(ws + L.vals_a), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
+                       (const float2*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
                        (const uint32_t*)(ws + L.n_contrib), dL_dimage, dL_dalpha, (float*)(ws + L.inst_grad),
                        (uint8_t*)(ws + L.inst_flag));
   };

@@ -40,24 +40,58 @@ def compare(sc, dev, check_stages=True, grad_l2=1e-5, grad_rtol=GRAD_RTOL):
     torch.cuda.synchronize()
     wv = workspace_views(ctx)
     D = int(wv["counters"][0].item())
-    assert D == orc.num_rendered
+    # exact tile culling: the instance list is the oracle's (3-sigma rect) list minus tiles the alpha >= 1/255 ellipse
+    # cannot reach; what is dropped blends nowhere, so everything downstream of the lists must still be bit-equal
+    assert 0 <= D <= orc.num_rendered
+    if bool((orc.debug["n_contrib"] > 0).any()):
+        assert D > 0
     assert torch.equal(radii.cpu(), orc.radii)
     if check_stages:
         N = sc.P * sc.w2c.shape[0]
         vis = orc.radii.reshape(-1) > 0
         g0, g1, gb = wv["g0"].cpu(), wv["g1"].cpu(), wv["gb"].cpu()
-        assert torch.equal(g0[vis, :2], orc.debug["xy"].reshape(N, 2)[vis])
-        assert torch.equal(torch.stack([g0[vis, 2], g0[vis, 3], g1[vis, 0], g1[vis, 1]], 1), orc.debug["conic_opacity"].reshape(N, 4)[vis])
-        assert torch.equal(torch.stack([g1[vis, 2], g1[vis, 3], gb[vis]], 1), orc.debug["rgb"].reshape(N, 3)[vis])
-        assert torch.equal(wv["rect"].cpu()[vis], orc.debug["rect"].reshape(N)[vis])
+        tt = wv["tiles_touched"].cpu().long()
         oo = orc.debug["offsets"].reshape(N).long()
-        assert torch.equal(wv["tiles_touched"].cpu().long(), oo - torch.cat([oo.new_zeros(1), oo[:-1]]))
-        # two-level sort (depth order of Gaussians, then stable tile partition) == stable sort by tile<<32|depth
-        assert torch.equal(wv["sorted_tile"][:D].cpu().long(), orc.debug["sorted_keys"] >> 32)
-        assert torch.equal(wv["sorted_gid"][:D].cpu(), orc.debug["sorted_gid"])
-        assert torch.equal(wv["ranges"].cpu(), orc.debug["ranges"])
-        assert torch.equal(wv["n_contrib"].cpu(), orc.debug["n_contrib"])
+        rect_tiles = oo - torch.cat([oo.new_zeros(1), oo[:-1]])
+        assert bool((tt <= rect_tiles).all()) and int(tt.sum()) == D
+        inst = tt > 0                                    # Gaussians with at least one instance carry the full record
+        assert torch.equal(g0[inst, :2], orc.debug["xy"].reshape(N, 2)[inst])
+        assert torch.equal(torch.stack([g0[inst, 2], g0[inst, 3], g1[inst, 0], g1[inst, 1]], 1), orc.debug["conic_opacity"].reshape(N, 4)[inst])
+        assert torch.equal(torch.stack([g1[inst, 2], g1[inst, 3], gb[inst]], 1), orc.debug["rgb"].reshape(N, 3)[inst])
+        assert torch.equal(wv["rect"].cpu()[inst], orc.debug["rect"].reshape(N)[inst])
+        # two-level sort (depth order of Gaussians, then stable tile partition): the (tile, gaussian) sequence is a
+        # subsequence, in order, of the oracle's stable sort by tile<<32|depth
+        g_tile = wv["sorted_tile"][:D].cpu().long()
+        g_slot = wv["sorted_slot"][:D].cpu().long()
+        g_gid = wv["slot_gid"].cpu().long()[g_slot]
+        assert torch.equal(g_slot.sort().values, torch.arange(D))               # emit slots are a permutation of 0..D-1
+        o_tile, o_gid = (orc.debug["sorted_keys"] >> 32).long(), orc.debug["sorted_gid"].long()
+        o_pair, g_pair = o_tile * N + o_gid, g_tile * N + g_gid
+        order = torch.argsort(o_pair)                                            # pairs are unique
+        so = o_pair[order]
+        idx = torch.searchsorted(so, g_pair).clamp(max=max(so.numel() - 1, 0))
+        assert torch.equal(so[idx], g_pair)                                      # every GPU instance is an oracle instance ...
+        where = order[idx]
+        assert bool((where[1:] > where[:-1]).all())                              # ... and they come in the oracle's order
+        # ranges index the culled list consistently
+        rng = wv["ranges"].cpu().long()
+        cnt = torch.bincount(g_tile, minlength=rng.shape[0])
+        assert torch.equal(rng[:, 1] - rng[:, 0], cnt) and bool((g_tile[1:] >= g_tile[:-1]).all())
+        nz = cnt > 0
+        assert torch.equal(rng[nz, 0], (torch.cumsum(cnt, 0) - cnt)[nz])
+        # per pixel: same transmittance, and the last blended entry is the same Gaussian as in the oracle's list
         assert torch.equal(wv["final_T"].cpu(), orc.debug["final_T"])
+        NV, H, W = sc.w2c.shape[0], sc.H, sc.W
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        tile_of = (torch.arange(NV)[:, None, None] * (gx * gy) + (yy // 16 * gx + xx // 16)[None]).reshape(-1)
+        nc_g, nc_o = wv["n_contrib"].cpu().long().reshape(-1), orc.debug["n_contrib"].long().reshape(-1)
+        assert torch.equal(nc_g > 0, nc_o > 0)
+        o_rng = orc.debug["ranges"].long()
+        sel = nc_g > 0
+        last_g = g_gid[(rng[tile_of, 0] + nc_g - 1)[sel]]
+        last_o = o_gid[(o_rng[tile_of, 0] + nc_o - 1)[sel]]
+        assert torch.equal(last_g, last_o)
     assert (img.cpu() - orc.image).abs().max().item() <= IMG_LINF
     assert torch.equal(img.cpu(), orc.image), "forward is expected to be bit-exact under the arithmetic contract"
     dimg = dimg_like(sc.w2c.shape[0], sc.H, sc.W)
@@ -67,6 +101,7 @@ def compare(sc, dev, check_stages=True, grad_l2=1e-5, grad_rtol=GRAD_RTOL):
     for k in og:
         assert rel_l2(g[k].cpu(), og[k]) <= grad_l2, k
         assert max_rel(g[k].cpu(), og[k]) <= grad_rtol, k
+    print(f"instances: {D} after exact tile culling, {orc.num_rendered} in the 3-sigma rects")
     orc.close()
     return D
 
@@ -213,14 +248,14 @@ def test_config1_one_hand(dev):
     """BASELINE configs[1]: single right hand, 49,281 Gaussians, 512x334, forward + backward."""
     from guassianhand_amd.scenes import make_scene
     D = compare(make_scene("one_hand", n_views=1), dev)
-    assert D > 49281
+    assert D > 20000
 
 
 def test_config2_two_hands_blend(dev):
     """BASELINE configs[2] (the headline workload): 98,562 Gaussians, interaction-aware blend, 512x334."""
     from guassianhand_amd.scenes import make_scene
     D = compare(make_scene("two_hands", n_views=2), dev)
-    assert D > 2 * 98562
+    assert D > 98562
 
 
 def test_reference_init_scale(dev):

@@ -101,7 +101,7 @@ def test_sync_free_mode_matches_sync_mode(full, dev):
     img_a, _, _ = render(full, sync=False)
     R.check_overflow()
     assert torch.equal(img_s, img_a)
-    assert R.last_num_rendered() > 4 * 98562
+    assert R.last_num_rendered() > 98562
 
 
 def test_config4_hd_sh3_smoke_properties(dev):
