@@ -71,25 +71,6 @@ __device__ __forceinline__ float gh_lane_fetch(float v, int src_lane_x4) {   // 
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane_x4, __builtin_bit_cast(int, v)));
 }
 
-template <int S, bool ALPHA>
-__device__ __forceinline__ void gh_fwd_chain_step(GhPixelFwd& p, float alpha, bool ok, float r, float g, float b, uint32_t pos1) {
-  const bool valid = (p.done == 0) && ok;
-  const float test_T = p.T * (1.0f - alpha);
-  const bool stop = valid && (test_T < 0.0001f);
-  const bool blend = valid && !stop;
-  const float w = blend ? alpha * p.T : 0.0f;       // C + c*0 == C exactly: masked lanes keep their bits
-  const float nC0 = p.C0 + r * w, nC1 = p.C1 + g * w, nC2 = p.C2 + b * w;   // mul then add (contract §4), in list order
-  const float nA = ALPHA ? p.A + w : 0.0f;          // exactly what the separate mask pass accumulates (1*w == w)
-  const float nT = blend ? test_T : p.T;
-  const uint32_t nlast = blend ? pos1 : p.last;
-  const int ndone = (p.done != 0 || stop) ? 1 : 0;
-  p.T = gh_quad_bcast<S>(nT);
-  p.C0 = gh_quad_bcast<S>(nC0); p.C1 = gh_quad_bcast<S>(nC1); p.C2 = gh_quad_bcast<S>(nC2);
-  if (ALPHA) p.A = gh_quad_bcast<S>(nA);
-  p.last = (uint32_t)gh_quad_bcast_i<S>((int)nlast);
-  p.done = gh_quad_bcast_i<S>(ndone);
-}
-
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
 template <bool ALPHA>
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, int blk,
@@ -112,9 +93,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
     const float alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
     const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-    const uint32_t pos1 = (uint32_t)(base + myj + 1);
-    // Fast path (no pixel of the wave saturates inside this trip — true for all but <= 16 trips of a wave):
-    // the recurrence collapses to DPP-fused prefix products / sums over the quad, in exact list order.
+    // The recurrence collapses to DPP-fused prefix products / sums over the quad, in exact list order.
     const bool valid = (p.done == 0) && ok;
     const float f = valid ? 1.0f - alpha : 1.0f;                   // x*1 == x: skipped entries leave T bit-identical
     const float P1 = p.T * gh_quad_bcast<0>(f);                    // T before slot 1, 2, 3 and after the trip
@@ -123,28 +102,33 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float P4 = P3 * gh_quad_bcast<3>(f);
     const float Pm = slot == 0 ? p.T : (slot == 1 ? P1 : (slot == 2 ? P2 : P3));   // T seen by this lane's entry
     const float Pn = slot == 0 ? P1 : (slot == 1 ? P2 : (slot == 2 ? P3 : P4));   // ... and right after it
-    if (__any(valid && Pn < 0.0001f)) {                            // wave-uniform, rare: exact step-by-step recurrence
-      gh_fwd_chain_step<0, ALPHA>(p, alpha, ok, r, g, bl, pos1);
-      gh_fwd_chain_step<1, ALPHA>(p, alpha, ok, r, g, bl, pos1);
-      gh_fwd_chain_step<2, ALPHA>(p, alpha, ok, r, g, bl, pos1);
-      gh_fwd_chain_step<3, ALPHA>(p, alpha, ok, r, g, bl, pos1);
-      if (__all(p.done != 0)) return true;
-      continue;
+    // Early stop (App. A.3): the FIRST entry of a pixel with T(1-alpha) < 1e-4 is not blended and ends the pixel.
+    // Up to and including that entry the prefix products above are exactly the sequential ones, so the stop slot, the
+    // entries blended before it and the T they leave behind are all read off the same values; flags of later slots
+    // (computed from products that never happen) are masked by the first one.
+    bool blend = valid;
+    float Tn = P4;
+    const uint64_t sb = __ballot(valid && Pn < 0.0001f);
+    if (sb) {                                                      // wave-uniform, rare
+      const uint32_t qb = (uint32_t)(sb >> (lane & 60)) & 0xFu;   // stop flags of this pixel's four slots
+      blend = valid && ((qb & ((2u << slot) - 1u)) == 0u);         // no stop at or before this slot
+      Tn = (qb & 1u) ? p.T : ((qb & 2u) ? P1 : ((qb & 4u) ? P2 : ((qb & 8u) ? P3 : P4)));   // T right before the stop
+      if (qb) p.done = 1;
     }
-    const float w = valid ? alpha * Pm : 0.0f;
+    const float w = blend ? alpha * Pm : 0.0f;                     // C + c*0 == C exactly
     const float m0 = r * w, m1 = g * w, m2 = bl * w;
     p.C0 = ((((p.C0 + gh_quad_bcast<0>(m0)) + gh_quad_bcast<1>(m0)) + gh_quad_bcast<2>(m0)) + gh_quad_bcast<3>(m0));
     p.C1 = ((((p.C1 + gh_quad_bcast<0>(m1)) + gh_quad_bcast<1>(m1)) + gh_quad_bcast<2>(m1)) + gh_quad_bcast<3>(m1));
     p.C2 = ((((p.C2 + gh_quad_bcast<0>(m2)) + gh_quad_bcast<1>(m2)) + gh_quad_bcast<2>(m2)) + gh_quad_bcast<3>(m2));
     if (ALPHA) p.A = ((((p.A + gh_quad_bcast<0>(w)) + gh_quad_bcast<1>(w)) + gh_quad_bcast<2>(w)) + gh_quad_bcast<3>(w));
-    p.T = P4;
-    // n_contrib: position of the last blended entry = highest valid slot of the quad (entries ascend with slot)
-    const uint32_t lp = valid ? pos1 : 0u;
-    uint32_t lm = lp > (uint32_t)gh_quad_bcast_i<0>((int)lp) ? lp : (uint32_t)gh_quad_bcast_i<0>((int)lp);
-    { const uint32_t t1 = (uint32_t)gh_quad_bcast_i<1>((int)lp); lm = t1 > lm ? t1 : lm; }
-    { const uint32_t t2 = (uint32_t)gh_quad_bcast_i<2>((int)lp); lm = t2 > lm ? t2 : lm; }
-    { const uint32_t t3 = (uint32_t)gh_quad_bcast_i<3>((int)lp); lm = t3 > lm ? t3 : lm; }
+    p.T = Tn;
+    // n_contrib: position of the last blended entry = highest blended slot of the pixel (entries ascend with slot; the
+    // four positions are wave-uniform scalars)
+    const uint32_t qbl = (uint32_t)(__ballot(blend) >> (lane & 60)) & 0xFu;
+    const uint32_t lm = (qbl & 8u) ? (uint32_t)(base + j3 + 1) : ((qbl & 4u) ? (uint32_t)(base + j2 + 1)
+                      : ((qbl & 2u) ? (uint32_t)(base + j1 + 1) : ((qbl & 1u) ? (uint32_t)(base + j0 + 1) : 0u)));
     p.last = lm > p.last ? lm : p.last;
+    if (sb && __all(p.done != 0)) return true;                     // every pixel of the block is saturated
   }
   return false;
 }
