@@ -43,7 +43,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->keys_b = take(cap * 4);
   L->vals_a = take(cap * 4);
   L->vals_b = take(cap * 4);
-  L->slot_gid = take(cap * 4);
+  L->sorted_slot = take(cap * 4);
   L->inst_r0 = take(cap * 16);
   L->inst_r1 = take(cap * 16);
   L->inst_r2 = take(cap * 8);

@@ -267,12 +267,12 @@ __global__ __launch_bounds__(1024) void gh_scan_blocksums_kernel(uint32_t* __res
 
 // One thread per (view, Gaussian) IN DEPTH ORDER: block-local scan -> first emit slot of the Gaussian, then one
 // instance per tile of its rect that passes the exact ellipse/tile test (the same test that counted them in the
-// projection kernel), row-major: key = global tile id, payload = the emit slot itself; slot_gid[slot] = view*P+gaussian.
+// projection kernel), row-major: key = global tile id, payload = view*P+gaussian.
 // A Gaussian's instances occupy consecutive slots [slot_begin, slot_begin + tiles): the backward sums its records there.
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
-    const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ slot_begin, const float4* __restrict__ geom,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ slot_gid) {
+    const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ slot_begin, float4* __restrict__ geom,
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = blockIdx.x * GH_BLOCK + tid;
@@ -289,19 +289,25 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   uint32_t off = block_offsets[blockIdx.x] + woff + x - cnt;
   slot_begin[n] = off;
   if (cnt == 0) return;
-  const float4* grec = geom + (size_t)n * 4;
+  float4* grec = geom + (size_t)n * 4;
+  grec[3].x = __uint_as_float(off);                   // same 64-byte line the post-sort gather reads
   const float4 g0 = grec[0];
   const float4 g1 = make_float4(grec[1].x, grec[1].y, 0.0f, 0.0f);      // (C, opacity): exactly the projection kernel's operands
-  const uint32_t r = __float_as_uint(grec[2].y);
+  const float4 g2 = grec[2];
+  const uint32_t r = __float_as_uint(g2.y);
   const int minx = r & 255, miny = (r >> 8) & 255, maxx = (r >> 16) & 255, maxy = r >> 24;
   const uint32_t vbase = (n / (uint32_t)P) * (uint32_t)tiles;
+  const bool small = (maxx - minx) * (maxy - miny) <= 64;               // the projection kernel kept the hit mask
+  const unsigned long long hitmask = ((unsigned long long)__float_as_uint(g2.w) << 32) | __float_as_uint(g2.z);
+  int bit = 0;
   for (int ty = miny; ty < maxy; ++ty)
-    for (int tx = minx; tx < maxx; ++tx) {
-      if (!gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1))) continue;
+    for (int tx = minx; tx < maxx; ++tx, ++bit) {
+      const bool h = small ? ((hitmask >> bit) & 1ull) != 0
+                           : gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
+      if (!h) continue;
       if (off < cap) {
         keys[off] = vbase + (uint32_t)(ty * gx + tx);
-        vals[off] = off;
-        slot_gid[off] = n;
+        vals[off] = n;                                   // the emit slot is recomputed from (n, tile) after the sort
       }
       ++off;
     }
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
 // kernels test one bit instead of repeating the ellipse/rectangle test per wave, forward and backward.
 __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                               const GhCounters* __restrict__ ctr, uint32_t cap, int gx, int tiles,
-                                                              const float4* __restrict__ geom, const uint32_t* __restrict__ slot_gid,
+                                                              const float4* __restrict__ geom, uint32_t* __restrict__ sorted_slot,
                                                               uint2* __restrict__ ranges, float4* __restrict__ r0,
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
                                                               uint32_t* __restrict__ inst_flag) {
@@ -327,11 +333,28 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __r
     if (tp != t) { ranges[tp].y = i; ranges[t].x = i; }
   }
   if (i == n - 1) ranges[t].y = n;
-  const uint32_t gid = slot_gid[vals[i]];
-  const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line
-  const float4 a = grec[0], b = grec[1];
-  const float cb = grec[2].x;
+  const uint32_t gid = vals[i];
+  const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line: record, tile rect, tile hit mask, first emit slot
+  const float4 a = grec[0], b = grec[1], c = grec[2];
+  const uint32_t slot0 = __float_as_uint(grec[3].x);
+  const float cb = c.x;
   const uint32_t tl = t % (uint32_t)tiles, ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
+  // emit slot of (gid, tile): the Gaussian's instances were emitted row-major over the HIT tiles of its rect
+  const uint32_t r = __float_as_uint(c.y);
+  const uint32_t minx = r & 255u, miny = (r >> 8) & 255u, maxx = (r >> 16) & 255u, maxy = r >> 24;
+  const uint32_t bit = (ty - miny) * (maxx - minx) + (tx - minx);
+  uint32_t before;
+  if ((maxx - minx) * (maxy - miny) <= 64u) {
+    const unsigned long long hm = ((unsigned long long)__float_as_uint(c.w) << 32) | __float_as_uint(c.z);
+    before = (uint32_t)__popcll(hm & ((1ull << bit) - 1ull));
+  } else {                                              // rect larger than the mask: recount (rare, huge footprints)
+    before = 0;
+    uint32_t k = 0;
+    for (uint32_t yy = miny; yy < maxy && k < bit; ++yy)
+      for (uint32_t xx = minx; xx < maxx && k < bit; ++xx, ++k)
+        before += gh_block_hit(a, b, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
+  }
+  sorted_slot[i] = slot0 + before;
   const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
   r0[i] = a; r1[i] = b; r2[i] = make_float2(cb, __uint_as_float(m));
 }
@@ -418,13 +441,12 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* k_in = start_b ? kb : ka; uint32_t* k_out = start_b ? ka : kb;
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
-                     (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (const float4*)(ws + L.geom), k_in, v_in,
-                     (uint32_t*)(ws + L.slot_gid));
+                     (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (float4*)(ws + L.geom), k_in, v_in);
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
   const int nblk_d = (int)((g.cap + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,
-                     (const float4*)(ws + L.geom), (const uint32_t*)(ws + L.slot_gid),
+                     (const float4*)(ws + L.geom), (uint32_t*)(ws + L.sorted_slot),
                      (uint2*)(ws + L.ranges), (float4*)(ws + L.inst_r0),
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag));
   gh_launch_tile_order(g, ws, L, s);

@@ -218,16 +218,48 @@ __device__ __forceinline__ bool gh_block_hit(const float4& g0, const float4& g1,
 // Exact tile culling (binning) and the per-instance 4x4-block mask (render kernels) are both this test:
 //   tile (tx, ty):            gh_block_hit(g0, g1, 16 tx, 16 ty, 15)
 //   block (bx, by) of a tile: gh_block_hit(g0, g1, 16 tx + 4 bx, 16 ty + 4 by, 3)   -> bit by*4 + bx
+// Same decision as 16 gh_block_hit(.., 3) calls, with the per-line terms shared: on the vertical line dx = u the
+// parabola in dy is C (dy - dy*)^2 + (A - B^2/C) u^2 with dy* = -B u / C, so an edge costs a clamp, a subtract and an
+// fma (and symmetrically for horizontal lines). The margin of the threshold absorbs the different rounding.
 __device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const float4& g1, float tx0, float ty0) {
+  const float o = g1.y;
+  if (!(o >= 1.0f / 255.0f)) return 0u;
+  const float thr = 2.0f * (__logf(255.0f * o) * 1.0001f + 1e-3f);
+  const float A = g0.z, B = g0.w, C = g1.x;
+  const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+  const float sx = -B * rC, sy = -B * rA;            // dy* = sx * u on a vertical line, dx* = sy * v on a horizontal one
+  const float Kx = A - B * B * rC, Ky = C - B * B * rA;
+  const float ox = tx0 - g0.x, oy = ty0 - g0.y;      // tile origin relative to the centre
+  float u[8], v[8], ux2[8], vy2[8], us[8], vs[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    u[k] = ox + (float)((k >> 1) * 4 + (k & 1) * 3);  // x lines 0,3,4,7,8,11,12,15
+    v[k] = oy + (float)((k >> 1) * 4 + (k & 1) * 3);
+    ux2[k] = Kx * u[k] * u[k]; vy2[k] = Ky * v[k] * v[k];
+    us[k] = sx * u[k]; vs[k] = sy * v[k];
+  }
   uint32_t m = 0;
+  bool nonfinite = !(thr == thr) || !(Kx == Kx) || !(Ky == Ky);
 #pragma unroll
-  for (int by = 0; by < 4; ++by)
+  for (int by = 0; by < 4; ++by) {
+    const float ly = v[2 * by], uy = v[2 * by + 1];
 #pragma unroll
-    for (int bx = 0; bx < 4; ++bx)
-      m |= gh_block_hit(g0, g1, tx0 + (float)(4 * bx), ty0 + (float)(4 * by), 3.0f) ? (1u << (by * 4 + bx)) : 0u;
-  return m;
+    for (int bx = 0; bx < 4; ++bx) {
+      const float lx = u[2 * bx], hx = u[2 * bx + 1];
+      const bool inside = (lx <= 0.0f) && (hx >= 0.0f) && (ly <= 0.0f) && (uy >= 0.0f);
+      const float d0 = fminf(fmaxf(us[2 * bx], ly), uy) - us[2 * bx];          // vertical edges
+      const float d1 = fminf(fmaxf(us[2 * bx + 1], ly), uy) - us[2 * bx + 1];
+      const float e0 = fminf(fmaxf(vs[2 * by], lx), hx) - vs[2 * by];          // horizontal edges
+      const float e1 = fminf(fmaxf(vs[2 * by + 1], lx), hx) - vs[2 * by + 1];
+      const float q0 = C * d0 * d0 + ux2[2 * bx], q1 = C * d1 * d1 + ux2[2 * bx + 1];
+      const float q2 = A * e0 * e0 + vy2[2 * by], q3 = A * e1 * e1 + vy2[2 * by + 1];
+      const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
+      const bool miss = !inside && (qmin * 0.9999f > thr);                     // NaN compares false -> hit
+      m |= miss ? 0u : (1u << (by * 4 + bx));
+    }
+  }
+  return nonfinite ? 0xFFFFu : m;
 }
-
 
 // ---- wave64 cross-lane helpers (DPP; no LDS traffic) ------------------------------------------------
 // DPP controls (gfx9 encoding): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_ror:n 0x120+n,

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
       int maxy = (int)((py + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
       int cnt = (maxx - minx) * (maxy - miny);
       float op = 0.0f;
+      unsigned long long hitmask = 0ull;
       if (cnt > 0) {
         radius = rad;                                   // API output: the reference's 3-sigma radius (App. A.1-6)
         op = in.opacities[i];
@@ -49,9 +50,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         // ellipse reaches a pixel centre (gh_block_hit, conservative within its margin). A dropped tile holds no pixel
         // that would blend this Gaussian, so images and gradients are unchanged; gh_emit_kernel repeats this test.
         const float4 g0 = make_float4(px, py, e.c * dinv, -e.b * dinv), g1 = make_float4(e.a * dinv, op, 0.0f, 0.0f);
-        for (int ty = miny; ty < maxy; ++ty)
-          for (int tx = minx; tx < maxx; ++tx)
-            tiles += gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
+        int bit = 0;                                    // row-major position in the rect; rects of <= 64 tiles keep the
+        for (int ty = miny; ty < maxy; ++ty)            // hit mask so that the emit kernel does not repeat the tests
+          for (int tx = minx; tx < maxx; ++tx, ++bit) {
+            const bool h = gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
+            tiles += h ? 1u : 0u;
+            if (h && bit < 64) hitmask |= 1ull << bit;
+          }
       }
       if (tiles > 0) {
         float rgb[3];
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         grec[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
         grec[1] = make_float4(e.a * dinv, op, rgb[0], rgb[1]);
         // .y = packed tile rect, .z = first emit slot (filled by gh_emit_kernel): the post-sort gather reads one line
-        grec[2] = make_float4(rgb[2], __uint_as_float((unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24)), 0.0f, 0.0f);
+        grec[2] = make_float4(rgb[2], __uint_as_float((unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24)),
+                              __uint_as_float((unsigned)hitmask), __uint_as_float((unsigned)(hitmask >> 32)));
         depth[n] = e.tz;
         dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
         rect[n] = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);

@@ -287,8 +287,8 @@ def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
                 depth=v(lay.depth, N * 4, torch.float32, N), rect=v(lay.rect, N * 4, torch.int32, N),
                 tiles_touched=v(lay.tiles_touched, N * 4, torch.int32, N), slot_begin=v(lay.slot_begin, N * 4, torch.int32, N),
                 depth_order=v(lay.depth_vals_a, N * 4, torch.int32, N),
-                sorted_tile=v(lay.keys_a, cap * 4, torch.int32, cap), sorted_slot=v(lay.vals_a, cap * 4, torch.int32, cap),
-                slot_gid=v(lay.slot_gid, cap * 4, torch.int32, cap),
+                sorted_tile=v(lay.keys_a, cap * 4, torch.int32, cap), sorted_slot=v(lay.sorted_slot, cap * 4, torch.int32, cap),
+                sorted_gid=v(lay.vals_a, cap * 4, torch.int32, cap),
                 inst_r2=v(lay.inst_r2, cap * 8, torch.int32, cap, 2),
                 ranges=v(lay.ranges, ctx.NV * gx * gy * 8, torch.int32, ctx.NV * gx * gy, 2),
                 final_T=v(lay.final_T, pix * 4, torch.float32, ctx.NV, ctx.H, ctx.W),

@@ -127,7 +127,8 @@ typedef struct GhLayout {
   size_t total_bytes;
   size_t counters;       /* GhCounters */
   size_t geom;           /* float4[n_views*P][4]: one 64-byte line per Gaussian:
-                            (px, py, conicA, conicB) (conicC, opacity, r, g) (b, rect bits, 0, 0) (unused) */
+                            (px, py, conicA, conicB) (conicC, opacity, r, g) (b, rect bits, tile hit mask lo, hi)
+                            (first emit slot bits, -, -, -) */
   size_t depth;          /* float [n_views*P] */
   size_t rect;           /* uint32[n_views*P]  minx | miny<<8 | maxx<<16 | maxy<<24 (tile units) */
   size_t clamped;        /* uint8 [n_views*P]  SH colour clamp flags (bit ch) */
@@ -137,9 +138,8 @@ typedef struct GhLayout {
   size_t depth_vals_a, depth_vals_b; /* uint32[n_views*P] level-1 payload: view*P + gaussian; depth order in _a */
   size_t block_sums;     /* uint32[...]        scan scratch */
   size_t keys_a, keys_b; /* uint32[max_instances] level-3 sort: global tile id; sorted result in keys_a */
-  size_t vals_a, vals_b; /* uint32[max_instances] payload = emit slot of the instance (where the backward puts its record);
-                            sorted result in vals_a */
-  size_t slot_gid;       /* uint32[max_instances] emit slot -> view*P + gaussian */
+  size_t vals_a, vals_b; /* uint32[max_instances] payload view*P + gaussian; sorted result in vals_a */
+  size_t sorted_slot;    /* uint32[max_instances] sorted position -> emit slot (where the backward puts its record) */
   size_t inst_r0;        /* float4[max_instances] sorted per-instance render record (px, py, conicA, conicB) */
   size_t inst_r1;        /* float4[max_instances]                                   (conicC, opacity, r, g)  */
   size_t inst_r2;        /* float2[max_instances]                                   (b, bits: 4x4-block mask of the tile) */

@@ -69,7 +69,8 @@ class OracleRender:
 
     def __init__(self, cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None,
                  colors_precomp=None, sh_degree: int = 0, scale_modifier: float = 1.0,
-                 xyz_b=None, opacity_b=None, color_w=None, color_b=None, debug: bool = False):
+                 xyz_b=None, opacity_b=None, color_w=None, color_b=None, debug: bool = False,
+                 debug_capacity: int = 0):
         L = lib()
         self.t = dict(cams=_f32(cams).reshape(-1, _abi.GH_CAM_FLOATS), means3D=_f32(means3D),
                       opacities=_f32(opacities).reshape(-1), scales=_f32(scales), rotations=_f32(rotations),
@@ -95,7 +96,7 @@ class OracleRender:
         dbg = None
         if debug:
             tiles = ((W + 15) // 16) * ((H + 15) // 16)
-            cap = max(1, NV * P * 64)
+            cap = max(1, NV * P * 64, int(debug_capacity or 0))
             d = self.debug
             d["xy"] = torch.zeros(NV, P, 2)
             d["depth"] = torch.zeros(NV, P)
