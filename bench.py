@@ -62,6 +62,18 @@ def pmc_traffic(kernel: str, args, V: int):
         return None
 
 
+def pmc_valu(kernel: str, args, V: int):
+    """VALU busy fraction of `kernel` from the committed SQ counter passes (profiles/pmc_sq.json): the render kernels
+    are bound by vector-ALU issue, not by HBM, so this is the utilisation that explains a low hbm `frac`."""
+    path = os.path.join(ROOT, "profiles", "pmc_sq.json")
+    if args.config != "two_hands" or V != 8 or not os.path.exists(path):
+        return None
+    try:
+        return json.load(open(path))["kernels"][kernel]["valu_busy_frac"]
+    except (KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(scene, seconds: float):
     """The C oracle (oracle/gh_oracle.c, OpenMP over tiles) on the host cores: a reported baseline only."""
     from oracle import oracle_c
@@ -173,6 +185,13 @@ def main():
     value = renders / dt
 
     if rank == 0:
+        # instance count of the published algorithm (every tile of the 3-sigma rects) beside the exactly culled one
+        with torch.no_grad():
+            col = dict(colors_precomp=s.shs.reshape(P, 3)) if s.use_rgb else dict(shs=s.shs, sh_degree=s.sh_degree)
+            _, _, rctx = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=H, W=W, sync=True, **col, **blend)
+            rect = R.workspace_views(rctx)["rect"].long()
+            D_rect = int((((rect >> 16 & 255) - (rect & 255)) * ((rect >> 24 & 255) - (rect >> 8 & 255))).sum())
+            del rctx
         D = R.last_num_rendered()
         ab = algorithmic_bytes(P, V, H, W, D, C=12 if s.use_rgb else 192)
         roofline = None
@@ -185,7 +204,8 @@ def main():
             ach = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": "gh_" + dom + "_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("gh_" + dom + "_kernel", args, V),
-                        "alg_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom]}
+                        "alg_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom],
+                        "valu_busy_frac": pmc_valu("gh_" + dom + "_kernel", args, V)}
         out = {
             "metric": "fwd+bwd renders/sec @512x334, ~100k Gaussians", "value": value, "unit": "renders/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -194,7 +214,8 @@ def main():
                                    f"{'RGB colours' if s.use_rgb else 'SH degree %d colours' % s.sh_degree}, attribute blend "
                                    f"{'on' if s.color_w is not None else 'off'}"
                                    + (" (BASELINE configs[2])" if args.config == "two_hands" else ""),
-                       "views_per_step_per_gpu": V, "instances_per_step_per_gpu": D, "parallelism": f"view-parallel x{world}",
+                       "views_per_step_per_gpu": V, "instances_per_step_per_gpu": D,
+                       "instances_in_3sigma_rects": D_rect, "parallelism": f"view-parallel x{world}",
                        "loss": "mean|img-gt|", "final_loss": float(loss),
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3},
             "roofline": roofline, "stages": stages,

@@ -20,6 +20,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
   if (n < T) { ranges[n] = make_uint2(0u, 0u); tile_walk[n] = 0u; }   // per-tile state of the binning / render stages
   if (n < N) {
     uint32_t dkey = 0xFFFFFFFFu;                        // culled Gaussians sort behind everything and emit nothing
+    unsigned rect_bits = 0;
     const int v = n / P, i = n - v * P;
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     int radius = 0;
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
       int maxx = (int)((px + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
       int maxy = (int)((py + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
       int cnt = (maxx - minx) * (maxy - miny);
+      if (cnt > 0) rect_bits = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);
       float op = 0.0f;
       unsigned long long hitmask = 0ull;
       if (cnt > 0) {
@@ -84,11 +86,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
                               __uint_as_float((unsigned)hitmask), __uint_as_float((unsigned)(hitmask >> 32)));
         depth[n] = e.tz;
         dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
-        rect[n] = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);
         clamped[n] = (uint8_t)cl;
       }
     }
     tiles_touched[n] = tiles;
+    rect[n] = rect_bits;                               // 3-sigma tile rect of every projected Gaussian (0 = none)
     depth_key[n] = dkey;
     depth_val[n] = (uint32_t)n;
     if (radii) radii[n] = radius;

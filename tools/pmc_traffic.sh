@@ -2,6 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/traffic
+exec > gpurun_out/traffic/log.txt 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/traffic/pmc_$C
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d gpurun_out/traffic/pmc_$C -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-stage-timing > gpurun_out/traffic/pmc_$C.log 2>&1
