@@ -1,31 +1,27 @@
 // gh_render.hip — per-tile alpha compositing and its backward (App. A.4).
 //
-// Work decomposition (wave64-native): one 256-thread workgroup per 16x16 tile, one wave per 8x8 pixel
-// quadrant, one pixel per lane. Each wave walks the tile's depth-sorted list on its own:
-//   * 64 list entries at a time are staged in REGISTERS (lane l holds entry base+l; the next 64 are
-//     prefetched while the current ones are consumed),
-//   * every lane tests "its" Gaussian against the wave's quadrant with a conservative bounding box of the
-//     alpha >= 1/255 ellipse; a ballot turns that into a 64-bit hit mask (wavefront compaction),
-//   * the wave iterates the set bits only; the selected Gaussian's 9 floats are broadcast with
-//     v_readlane (SGPR operands, no LDS traffic) and the per-pixel blend is branch-free.
-// The forward pass therefore uses no LDS and no barriers, and a quadrant retires as soon as its 64 pixels
-// are saturated. Culling never changes results: the exact per-pixel tests of App. A.3 still decide.
+// Work decomposition (wave64-native): four 256-thread workgroups per 16x16 tile (one per 8x8 quadrant), one wave per
+// 4x4 pixel block, lane = 4*pixel + depth slot. Each wave walks the tile's depth-sorted list on its own:
+//   * 64 list entries at a time are staged in REGISTERS (lane l holds entry base+l; the next 64 are prefetched while
+//     the current ones are consumed),
+//   * every lane tests the bit of the wave's block in "its" entry's 16-bit block mask (precomputed once per instance
+//     by gh_ranges_kernel with the exact ellipse/rectangle test); a ballot compacts the survivors,
+//   * each trip takes the next four survivors: slot s of every pixel evaluates entry s (ds_bpermute fetch), and the
+//     T / colour recurrence runs in exact list order over the quad as DPP-fused prefix products and sums.
+// The forward uses no LDS memory and no barriers, and a block retires as soon as its 16 pixels are saturated.
+// Culling never changes results: the exact per-pixel tests of App. A.3 still decide.
 //
-// Backward: each pixel replays its list back to front (same staging / culling); the 9 per-Gaussian partial
-// gradients are summed over the 64 lanes with DPP and stored by the quadrant's wave as ITS sub-record of the
-// (tile, Gaussian) instance, at the instance's emit slot, plus a flag byte. No LDS, no barriers, no atomics:
-// the per-Gaussian kernel adds each Gaussian's flagged sub-records (contiguous slots) in fixed order, so the
-// gradients are bitwise reproducible.
+// Backward: same mapping back to front; the nine per-Gaussian partial gradients are summed over the 16 pixels of a
+// slot with DPP + the LDS crossbar, the four waves of a quadrant are combined through a double-buffered LDS stage
+// (one barrier per 64 entries) and stored as the quadrant's sub-record of the (tile, Gaussian) instance at the
+// instance's emit slot, plus a flag byte. No atomics: the per-Gaussian kernel adds each Gaussian's flagged
+// sub-records (contiguous slots) in fixed order, so the gradients are bitwise reproducible.
 #include "gh_internal.h"
 
 __device__ __forceinline__ void gh_tile_coords(int blk, int gx, int tiles, int& v, int& tx, int& ty) {
   v = blk / tiles;
   int t = blk - v * tiles;
   ty = t / gx; tx = t - ty * gx;
-}
-
-__device__ __forceinline__ float gh_bcast(float v, int lane) {   // lane is wave-uniform
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -217,22 +213,6 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 // order: lane l of the flushing wave owns entry l and writes the quadrant's sub-record + flag byte.
 struct GhStateBwd { float T, B0, B1, B2, B3; };   // B3: alpha accumulated behind (mask channel, colour 1)
 
-template <int S, bool ALPHA>
-__device__ __forceinline__ void gh_bwd_chain_step(GhStateBwd& st, int slot, bool contrib, float alpha, float inv1ma, float cr,
-                                                  float cg, float cbl, float& mTn, float& mB0, float& mB1, float& mB2,
-                                                  float& mB3) {
-  const float Tn = st.T * inv1ma;
-  const float oma = 1.0f - alpha;
-  const float nB0 = alpha * cr + oma * st.B0, nB1 = alpha * cg + oma * st.B1, nB2 = alpha * cbl + oma * st.B2;
-  const float nB3 = ALPHA ? alpha + oma * st.B3 : 0.0f;
-  if (slot == S) { mTn = Tn; mB0 = st.B0; mB1 = st.B1; mB2 = st.B2; mB3 = st.B3; }   // state seen by this lane's entry
-  st.T = gh_quad_bcast<S>(contrib ? Tn : st.T);
-  st.B0 = gh_quad_bcast<S>(contrib ? nB0 : st.B0);
-  st.B1 = gh_quad_bcast<S>(contrib ? nB1 : st.B1);
-  st.B2 = gh_quad_bcast<S>(contrib ? nB2 : st.B2);
-  if (ALPHA) st.B3 = gh_quad_bcast<S>(contrib ? nB3 : st.B3);
-}
-
 __device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum over the 16 pixels of this lane's slot
   v += gh_dpp<0x114>(v);                                              // row_shr:4
   v += gh_dpp<0x118>(v);                                              // row_shr:8 -> lanes 12..15 of each row: row sums
@@ -355,9 +335,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       if (ALPHA) dL_dalpha += (1.0f - mB3) * dM;
       dL_dalpha *= mTn;
       dL_dalpha += (-T_final * inv1ma) * bg_dot;
+      // pixels that did not blend the entry contribute nothing: every partial below is a product with dL_dalpha or
+      // dchannel_dcolor (all other factors are finite), so zeroing these two replaces nine selects
+      dL_dalpha = contrib ? dL_dalpha : 0.0f;
       const float dL_dG = op * dL_dalpha;                              // straight-through the 0.99 clamp (App. A.4-2)
       const float gdx = G * dx, gdy = G * dy;
-      const float dchannel_dcolor = alpha * mTn;
+      const float dchannel_dcolor = contrib ? alpha * mTn : 0.0f;
       float r[9];
       r[0] = dL_dG * (-gdx * cA - gdy * cB);
       r[1] = dL_dG * (-gdy * cC - gdx * cB);
@@ -367,7 +350,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       r[5] = G * dL_dalpha;
       r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
 #pragma unroll
-      for (int q = 0; q < 9; ++q) r[q] = gh_slot_sum16(contrib ? r[q] : 0.0f, lane);
+      for (int q = 0; q < 9; ++q) r[q] = gh_slot_sum16(r[q], lane);
       // slots in which at least one pixel blended its entry get a partial record (wave-uniform bookkeeping)
       const bool a0 = (cm & 0x1111111111111111ull) != 0, a1 = (cm & 0x2222222222222222ull) != 0;
       const bool a2 = (cm & 0x4444444444444444ull) != 0, a3 = (cm & 0x8888888888888888ull) != 0;
