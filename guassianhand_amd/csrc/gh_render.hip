@@ -71,6 +71,7 @@ __device__ __forceinline__ float gh_lane_fetch(float v, int src_lane_x4) {   // 
 template <bool ALPHA>
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, int blk,
                                                float pxf, float pyf, GhPixelFwd& p) {
+  const uint32_t slot8 = (uint32_t)slot * 8u;
   const bool hit = (base + lane < total) && ((t.blocks >> blk) & 1u);
   uint64_t mask = __ballot(hit);
   while (mask) {
@@ -79,9 +80,10 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const int n1 = mask != 0; const int j1 = n1 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
     const int n2 = mask != 0; const int j2 = n2 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
     const int n3 = mask != 0; const int j3 = n3 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
-    const int myj = slot == 0 ? j0 : (slot == 1 ? j1 : (slot == 2 ? j2 : j3));
-    const bool have = slot == 0 || (slot == 1 && n1) || (slot == 2 && n2) || (slot == 3 && n3);
-    const int src = myj << 2;
+    // the four entry lanes travel as bytes of one scalar: a lane extracts its slot's with a single v_bfe
+    const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
+    const int src = (int)((packed4 >> slot8) & 0xFFu);              // 4 * entry lane = ds_bpermute address
+    const bool have = slot < 1 + n1 + n2 + n3;
     const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
     const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src), op = gh_lane_fetch(t.b.y, src);
     const float r = gh_lane_fetch(t.b.z, src), g = gh_lane_fetch(t.b.w, src), bl = gh_lane_fetch(t.cb, src);
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int slot = lane & 3, pi = lane >> 2;
+  const uint32_t slot8 = (uint32_t)slot * 8u;
   const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (wid & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (wid >> 1) * 4;
   const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
   const bool inside = x < W && y < H;
@@ -286,9 +289,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       const int n1 = mask != 0; const int j1 = n1 ? 63 - __builtin_clzll(mask) : j0; if (n1) mask &= ~(1ull << j1);
       const int n2 = mask != 0; const int j2 = n2 ? 63 - __builtin_clzll(mask) : j0; if (n2) mask &= ~(1ull << j2);
       const int n3 = mask != 0; const int j3 = n3 ? 63 - __builtin_clzll(mask) : j0; if (n3) mask &= ~(1ull << j3);
-      const int myj = slot == 0 ? j0 : (slot == 1 ? j1 : (slot == 2 ? j2 : j3));
-      const bool have = slot == 0 || (slot == 1 && n1) || (slot == 2 && n2) || (slot == 3 && n3);
-      const int src = myj << 2;
+      const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
+      const int src = (int)((packed4 >> slot8) & 0xFFu);            // one v_bfe: 4 * this slot's entry lane
+      const int myj = src >> 2;
+      const bool have = slot < 1 + n1 + n2 + n3;
       const float gpx = gh_lane_fetch(cur.a.x, src), gpy = gh_lane_fetch(cur.a.y, src), cA = gh_lane_fetch(cur.a.z, src);
       const float cB = gh_lane_fetch(cur.a.w, src), cC = gh_lane_fetch(cur.b.x, src), op = gh_lane_fetch(cur.b.y, src);
       const float cr = gh_lane_fetch(cur.b.z, src), cg = gh_lane_fetch(cur.b.w, src), cbl = gh_lane_fetch(cur.cb, src);
