@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views-per-step", type=int, default=8)
+    ap.add_argument("--dist-backend", default=None, choices=[None, "nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (default: nccl = RCCL); gloo only to exercise the path without N GPUs")
     ap.add_argument("--config", default="two_hands")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,7 +116,9 @@ def main():
     from guassianhand_amd.scenes import make_scene, perturbed_target_xyz
     import torch.distributed as tdist
 
-    rank, local, world = ghdist.init_from_env()
+    if args.dist_backend == "gloo":                     # functional check of the N>1 path on a box with fewer GPUs than ranks
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+    rank, local, world = ghdist.init_from_env(args.dist_backend)
     assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (there is no CPU fallback)"
     dev = torch.device("cuda", local)
@@ -151,6 +155,8 @@ def main():
         loss.backward()
         if world > 1:
             grads = {k: params[k].grad for k in names}
+            if s.use_rgb and "color_b" in grads:         # RGB mode reads color_b[:, 0:3] only (renderer_one_shot.py:328): the
+                grads["color_b"] = grads["color_b"][:, :3]   # other 45 gradient columns are exactly zero on every rank
             loss, grads = ghdist.allreduce_grads(grads, loss.detach(), names)
         return loss
 
