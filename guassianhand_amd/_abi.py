@@ -6,6 +6,7 @@ import ctypes as C
 GH_TILE = 16
 GH_CAM_FLOATS = 40
 GH_FLAG_BLEND_W_PER_GAUSSIAN = 1
+GH_FLAG_BLEND_COLOR_B_RGB = 2
 
 GH_OK = 0
 GH_ERR_INVALID_ARG = -1
@@ -88,6 +89,9 @@ def declare(lib: C.CDLL) -> None:
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
     lib.gh_l1_loss.restype = C.c_int
     lib.gh_l1_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gh_fit_loss.restype = C.c_int
+    lib.gh_fit_loss.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4 + \
+        [C.c_int, C.c_void_p]
     lib.gh_knn_workspace_bytes.restype = C.c_size_t
     lib.gh_knn_workspace_bytes.argtypes = [C.c_int]
     lib.gh_knn_indices.restype = C.c_int
@@ -106,4 +110,4 @@ GH_BWD_RENDER, GH_BWD_PREPROCESS, GH_BWD_ALL = 1, 2, 3
 EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_forward", "gh_backward",
                     "gh_forward_stages", "gh_backward_stages", "gh_uv_sample_forward", "gh_uv_sample_backward",
                     "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_adam_reg_step",
-                    "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss")
+                    "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss", "gh_fit_loss")

@@ -81,6 +81,7 @@ static int check_inputs(const GhDims* d, const GhInputs* in) {
   if (in->shs && d->M == 0) return GH_ERR_INVALID_ARG;
   if (in->colors_precomp && d->M != 0) return GH_ERR_INVALID_ARG;
   if (in->blend_color_b && !in->blend_color_w && in->shs) return GH_ERR_INVALID_ARG;      // SH: b needs w (:334)
+  if ((d->flags & GH_FLAG_BLEND_COLOR_B_RGB) && !in->colors_precomp) return GH_ERR_INVALID_ARG;   // (P,3) biases: RGB mode only
   if (in->shs && (in->blend_color_w || in->blend_color_b) && d->M != 16) return GH_ERR_INVALID_ARG;
   return GH_OK;
 }

@@ -52,3 +52,55 @@ extern "C" int gh_l1_loss(const float* image, const float* target, size_t n, flo
   hipLaunchKernelGGL(gh_partials_sum_kernel, dim3(1), dim3(GH_BLOCK), 0, s, partials, n_partials, inv, loss_out);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
+
+// ---- one-shot fit loss ---------------------------------------------------------------------------------------------
+// Image part of the reference loss (utils.py:180-252, :282-294 with infer_one_shot.py:497, :507-510) for a stack of
+// views, straight on the rasteriser's own layouts:
+//   L = scale * sum_v [ lambda_l1 * mean_{c,y,x} |bb * rgb - gt| + lambda_m * mean_{y,x} (clip(alpha, -0.001, 1) - m)^2 ]
+// image (NV,3,H,W) and alpha (NV,H,W) as the rasteriser writes them, gt_rgb (NV,H,W,3) channel-last and gt_mask
+// (NV,H,W) as the reference holds them, bbox (NV,H,W) optional (pixels with bbox == 0 have their colour zeroed).
+// One thread per pixel: reads 4 + 4 floats, writes the 4 gradients; block partials -> gh_partials_sum_kernel.
+__global__ __launch_bounds__(GH_BLOCK) void gh_fit_loss_kernel(const float* __restrict__ image, const float* __restrict__ alpha,
+                                                                const float* __restrict__ gt_rgb, const float* __restrict__ gt_mask,
+                                                                const float* __restrict__ bbox, int NV, int HW, float k_l1, float k_m,
+                                                                float* __restrict__ dimage, float* __restrict__ dalpha,
+                                                                float* __restrict__ partials) {
+  __shared__ float s_w[GH_BLOCK / GH_WAVE];
+  float acc = 0.0f;
+  const size_t npix = (size_t)NV * HW;
+  for (size_t i = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; i < npix; i += (size_t)gridDim.x * GH_BLOCK) {
+    const size_t v = i / HW, p = i - v * HW;
+    const bool in_box = bbox ? bbox[i] != 0.0f : true;
+    const float* im = image + v * 3 * HW + p;
+    float* di = dimage + v * 3 * HW + p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float d = (in_box ? im[(size_t)c * HW] : 0.0f) - gt_rgb[i * 3 + c];
+      acc += k_l1 * fabsf(d);
+      di[(size_t)c * HW] = in_box ? k_l1 * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) : 0.0f;
+    }
+    const float a = alpha[i];
+    const float ac = fminf(fmaxf(a, -0.001f), 1.0f);
+    const float e = ac - gt_mask[i];
+    acc += k_m * e * e;
+    dalpha[i] = (a >= -0.001f && a <= 1.0f) ? 2.0f * k_m * e : 0.0f;      // torch.clamp passes the gradient on [min, max]
+  }
+  acc = gh_wave_sum_to63(acc);
+  if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ((s_w[0] + s_w[1]) + s_w[2]) + s_w[3];
+}
+
+extern "C" int gh_fit_loss(const float* image, const float* alpha, const float* gt_rgb, const float* gt_mask, const float* bbox,
+                           int n_views, int H, int W, float lambda_l1, float lambda_mask, float scale, float* loss_out,
+                           float* dL_dimage, float* dL_dalpha, float* partials, int n_partials, void* hip_stream) {
+  if (n_views < 1 || H < 1 || W < 1 || n_partials < 1) return GH_ERR_INVALID_ARG;
+  if (!image || !alpha || !gt_rgb || !gt_mask || !loss_out || !dL_dimage || !dL_dalpha || !partials) return GH_ERR_INVALID_ARG;
+  (void)hipGetLastError();
+  const int HW = H * W;
+  hipStream_t s = (hipStream_t)hip_stream;
+  hipLaunchKernelGGL(gh_fit_loss_kernel, dim3((unsigned)n_partials), dim3(GH_BLOCK), 0, s, image, alpha, gt_rgb, gt_mask, bbox,
+                     n_views, HW, scale * lambda_l1 / (3.0f * (float)HW), scale * lambda_mask / (float)HW, dL_dimage, dL_dalpha, partials);
+  hipLaunchKernelGGL(gh_partials_sum_kernel, dim3(1), dim3(GH_BLOCK), 0, s, partials, n_partials, 1.0f, loss_out);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}

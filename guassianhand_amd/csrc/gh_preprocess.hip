@@ -71,7 +71,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
               const float* w = in.blend_color_w + ((flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? (size_t)i * 48 : 0);
               col = col * w[ch]; col = col + w[3 + ch]; col = col - 1.0f;
             }
-            if (in.blend_color_b) col = col + in.blend_color_b[(size_t)i * 48 + ch];
+            if (in.blend_color_b) col = col + in.blend_color_b[(size_t)i * ((flags & GH_FLAG_BLEND_COLOR_B_RGB) ? 3 : 48) + ch];
             rgb[ch] = col;
           }
         } else {                                       // SH colours: evaluated by gh_sh_colour_fwd_kernel (gh_sh.hip)
@@ -299,9 +299,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
         for (int ch = 0; ch < 3; ++ch) gr.dL_dcolors[3 * i + ch] = w ? araw[ch] * w[ch] : araw[ch];
       }
       if (in.blend_color_b && gr.dL_dblend_color_b) {
-        float* o = gr.dL_dblend_color_b + (size_t)i * 48;
-        o[0] = araw[0]; o[1] = araw[1]; o[2] = araw[2];
-        for (int k = 3; k < 48; ++k) o[k] = 0.0f;
+        if (flags & GH_FLAG_BLEND_COLOR_B_RGB) {
+          float* o = gr.dL_dblend_color_b + (size_t)i * 3;
+          o[0] = araw[0]; o[1] = araw[1]; o[2] = araw[2];
+        } else {
+          float* o = gr.dL_dblend_color_b + (size_t)i * 48;
+          o[0] = araw[0]; o[1] = araw[1]; o[2] = araw[2];
+          for (int k = 3; k < 48; ++k) o[k] = 0.0f;
+        }
       }
       if (w && wpg && gr.dL_dblend_color_w) {
         float* o = gr.dL_dblend_color_w + (size_t)i * 48;

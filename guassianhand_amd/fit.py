@@ -74,6 +74,8 @@ class OneShotFit(nn.Module):
         self.map_hw = (Hm, Wm)
         self.lr0, self.epoch = lr, 0
         self.active = uv.is_cuda if active_texels is None else bool(active_texels)
+        self._default_render = render_fn is None
+        self._cams, self._cams_key = None, None
         if render_fn is None:
             from .renderer import render_views
             render_fn = render_views
@@ -82,7 +84,10 @@ class OneShotFit(nn.Module):
             # active-texel mode: compact (U,C) storage of the texels the Gaussians can reach, fused regulariser + Adam
             self.texels = ActiveTexels(self.uv, Hm, Wm)
             U = self.texels.U
-            self.color_b_tex = torch.zeros(U, 48, device=dev)
+            # RGB mode reads color_b.view(-1,16,3)[:,0,:] only (renderer_one_shot.py:328): the other 45 channels never get
+            # an image gradient and stay 0 like the inactive texels, so only 3 channels are stored (GH_FLAG_BLEND_COLOR_B_RGB)
+            self.cb_channels = 3 if use_rgb else 48
+            self.color_b_tex = torch.zeros(U, self.cb_channels, device=dev)
             self.opacity_b_tex = torch.zeros(U, 1, device=dev)
             self._adam = {
                 "color_w": AdamReg(self.color_w.data, lr),
@@ -100,7 +105,12 @@ class OneShotFit(nn.Module):
     @property
     def color_b(self) -> torch.Tensor:
         """(48,Hm,Wm), the layout of the reference parameter (infer_one_shot.py:160)."""
-        return to_reference_layout(self.texels.dense(self.color_b_tex) if self.active else self.color_b_map)
+        if not self.active:
+            return to_reference_layout(self.color_b_map)
+        d = self.texels.dense(self.color_b_tex)
+        if d.shape[-1] != 48:
+            d = torch.cat([d, d.new_zeros(*d.shape[:2], 48 - d.shape[-1])], -1)
+        return to_reference_layout(d)
 
     @property
     def opacity_b(self) -> torch.Tensor:
@@ -116,9 +126,10 @@ class OneShotFit(nn.Module):
                 self.color_b_map.copy_(cb); self.opacity_b_map.copy_(ob)
             return
         ct, ot = self.texels.compact(cb), self.texels.compact(ob)
-        if float((self.texels.dense(ct) - cb).abs().max()) != 0.0 or float((self.texels.dense(ot) - ob).abs().max()) != 0.0:
-            raise ValueError("maps are non-zero outside the active texels: construct OneShotFit(active_texels=False)")
-        self.color_b_tex.copy_(ct); self.opacity_b_tex.copy_(ot)
+        if float((self.texels.dense(ct) - cb).abs().max()) != 0.0 or float((self.texels.dense(ot) - ob).abs().max()) != 0.0 \
+                or float(ct[:, self.cb_channels:].abs().max() if self.cb_channels < 48 else 0.0) != 0.0:
+            raise ValueError("maps are non-zero outside the active texels / channels: construct OneShotFit(active_texels=False)")
+        self.color_b_tex.copy_(ct[:, :self.cb_channels]); self.opacity_b_tex.copy_(ot)
 
     # -- pieces ----------------------------------------------------------------------------------------
     def blend_values(self) -> Dict[str, torch.Tensor]:
@@ -137,9 +148,16 @@ class OneShotFit(nn.Module):
         return 100.0 * self.color_b_map.abs().mean() + self.opacity_b_map.pow(2.0).mean()   # infer_one_shot.py:514-518
 
     def render(self, w2cs, Ks, H, W, bg, blend: Dict[str, torch.Tensor], sync: bool = True):
+        kw = {}
+        if self._default_render:                                      # the camera records of a fit never change: pack them once
+            key = (w2cs.data_ptr(), Ks.data_ptr(), bg.data_ptr(), w2cs.shape[0], H, W, w2cs._version, Ks._version, bg._version)
+            if self._cams_key != key:
+                from .camera import pack_cameras_from_w2c
+                self._cams, self._cams_key = pack_cameras_from_w2c(w2cs, Ks, H, W, bg), key
+            kw["cams"] = self._cams
         return self.render_fn(self.gs, w2cs, Ks, H, W, bg, color_w=blend["color_w"], xyz_b=blend["xyz_b"],
                               color_b=blend["color_b"], opacity_b=blend["opacity_b"], use_rgb=self.use_rgb,
-                              sh_degree=self.sh_degree, sync=sync)
+                              sh_degree=self.sh_degree, sync=sync, **kw)
 
     # -- one optimisation step over all cameras (sharded over ranks) ------------------------------------
     def step(self, w2cs, Ks, H: int, W: int, bg, gt_rgb, gt_mask, bbox_mask=None, sync: bool = True) -> torch.Tensor:
@@ -155,15 +173,25 @@ class OneShotFit(nn.Module):
         names = ["color_w", "color_b", "opacity_b"] if self.active else \
             [k for k in ("color_w", "color_b", "opacity_b") if blend[k].requires_grad]
         leaves = {k: (blend[k].detach().requires_grad_(True) if k in names else blend[k]) for k in blend}
-        loss_img = torch.zeros((), device=self.color_w.device)
-        grads = {k: torch.zeros_like(leaves[k]) for k in names}
-        if mine:                                                      # graph B: rasteriser + image loss
-            out = self.render(w2cs[mine], Ks[mine], H, W, bg, leaves, sync=sync)
-            loss_img = fit_loss(out["comp_rgb"], out["comp_mask"], gt_rgb[mine], gt_mask[mine],
-                                None if bbox_mask is None else bbox_mask[mine]) / n_total
+        if not mine:                                                  # more ranks than cameras: this rank only joins the reduction
+            loss_img = torch.zeros((), device=self.color_w.device)
+            grads = {k: torch.zeros_like(leaves[k]) for k in names}
+        else:                                                      # graph B: rasteriser + image loss
+            allv = len(mine) == n_total
+            out = self.render(w2cs if allv else w2cs[mine], Ks if allv else Ks[mine], H, W, bg, leaves, sync=sync)
+            sel = (lambda t: t) if len(mine) == n_total else (lambda t: t[mine])
+            if "image_chw" in out and out["image_chw"].is_cuda:      # fused loss + gradients on the rasteriser's layouts
+                from .loss import fit_image_loss
+                loss_img = fit_image_loss(out["image_chw"], out["alpha"], sel(gt_rgb), sel(gt_mask),
+                                          None if bbox_mask is None else sel(bbox_mask).float(), scale=1.0 / n_total)
+            else:
+                loss_img = fit_loss(out["comp_rgb"], out["comp_mask"], sel(gt_rgb), sel(gt_mask),
+                                    None if bbox_mask is None else sel(bbox_mask)) / n_total
             g = torch.autograd.grad(loss_img, [leaves[k] for k in names], allow_unused=True)
             grads = {k: (gi if gi is not None else torch.zeros_like(leaves[k])) for k, gi in zip(names, g)}
-        if self.use_rgb and "color_b" in grads:                       # RGB mode touches color_b[:, 0:3] only (:328)
+        if world == 1:
+            loss_tot, red = loss_img.detach(), grads
+        elif self.use_rgb and "color_b" in grads and grads["color_b"].shape[1] == 48:   # RGB mode touches color_b[:, 0:3] only (:328)
             small = dict(grads)
             small["color_b"] = grads["color_b"][:, :3].contiguous()
             loss_tot, red = ghdist.allreduce_grads(small, loss_img.detach(), sorted(small))

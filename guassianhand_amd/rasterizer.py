@@ -146,7 +146,7 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 
 class _Ctx:
-    __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "stream", "alpha")
+    __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "stream", "alpha")
 
 
 def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None, colors_precomp=None,
@@ -178,6 +178,13 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             wpg = True
         else:
             raise ValueError("color_w must have 48 or P*48 elements")
+    b_rgb = False
+    if t["color_b"] is not None:
+        if t["color_b"].numel() == P * 3 and colors_precomp is not None:     # the 3 columns RGB mode reads (renderer_one_shot.py:328)
+            flags |= _abi.GH_FLAG_BLEND_COLOR_B_RGB
+            b_rgb = True
+        elif t["color_b"].numel() != P * 48:
+            raise ValueError("color_b must have P*48 elements (or P*3 with colors_precomp)")
     key = (P, NV, H, W)
     while True:
         cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))
@@ -229,6 +236,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         break
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
+    ctx.b_rgb = b_rgb
     ctx.alpha = alpha
     return image, radii, ctx
 
@@ -250,7 +258,7 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
              xyz_b=mk(3) if t["xyz_b"] is not None else None,
              opacity_b=mk(P) if t["opacity_b"] is not None else None,
              color_w=(mk(P, 48) if ctx.wpg else mk(48)) if t["color_w"] is not None else None,
-             color_b=mk(P, 48) if t["color_b"] is not None else None)
+             color_b=mk(P, 3 if ctx.b_rgb else 48) if t["color_b"] is not None else None)
     gr = _abi.GhGrads(dL_dimage=_ptr(g), dL_dalpha=_ptr(ga), dL_dmeans3D=_ptr(o["means3D"]), dL_dmeans2D=_ptr(o["means2D"]),
                       dL_dopacities=_ptr(o["opacities"]), dL_dscales=_ptr(o["scales"]), dL_drotations=_ptr(o["rotations"]),
                       dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]), dL_dblend_xyz_b=_ptr(o["xyz_b"]),

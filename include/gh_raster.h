@@ -53,6 +53,8 @@ typedef enum GhStatus {
 /* Flags for GhDims.flags */
 #define GH_FLAG_NONE 0u
 #define GH_FLAG_BLEND_W_PER_GAUSSIAN 1u /* color_w is (P,48) instead of (48,) — renderer_one_shot_edit.py:489-500 */
+#define GH_FLAG_BLEND_COLOR_B_RGB 2u    /* colors_precomp mode only: blend_color_b and dL_dblend_color_b are (P,3), the
+                                           three columns of the (P,48) view that renderer_one_shot.py:328 reads */
 
 /*
  * One camera, GH_CAM_FLOATS consecutive floats in DEVICE memory (built by the caller without a host sync):
@@ -244,6 +246,17 @@ int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_s
  */
 int gh_l1_loss(const float* image, const float* target, size_t n, float* loss_out, float* dL_dimage, float* partials,
                int n_partials, void* hip_stream);
+
+/*
+ * Image part of the one-shot fit loss for a stack of views (utils.py:180-252, :282-294; infer_one_shot.py:497, :507-510):
+ *   loss = scale * sum_v [ lambda_l1 * mean|bbox*rgb - gt_rgb| + lambda_mask * mean((clip(alpha, -0.001, 1) - gt_mask)^2) ]
+ * with its gradients w.r.t. the rasteriser outputs, in one pass. image (n_views,3,H,W) and alpha (n_views,H,W) are
+ * GhOutputs' layouts; gt_rgb (n_views,H,W,3) and gt_mask (n_views,H,W) the reference's; bbox (n_views,H,W) fp32 or
+ * NULL (colour is zeroed where bbox == 0). dL_dimage / dL_dalpha are what GhGrads takes. partials: n_partials floats.
+ */
+int gh_fit_loss(const float* image, const float* alpha, const float* gt_rgb, const float* gt_mask, const float* bbox,
+                int n_views, int H, int W, float lambda_l1, float lambda_mask, float scale, float* loss_out,
+                float* dL_dimage, float* dL_dalpha, float* partials, int n_partials, void* hip_stream);
 
 /*
  * Interaction mask of the interaction-aware step (infer_one_shot.py:247-250):

@@ -164,3 +164,26 @@ def test_mask_pass_is_accumulated_alpha(dev):
     T = workspace_views(ctx)["final_T"]
     assert (img[0, 0] - (1 - T[0])).abs().max() < 2e-6
     assert torch.equal(img[0, 0], img[0, 1]) and torch.equal(img[0, 1], img[0, 2])
+
+
+def test_rgb_compact_color_b_equals_padded_reference_layout(dev):
+    """GH_FLAG_BLEND_COLOR_B_RGB: with colors_precomp the blend reads color_b.view(-1,16,3)[:,0,:] only
+    (renderer_one_shot.py:328), so a (P,3) tensor of those columns must give the image and gradients of the (P,48) one."""
+    from guassianhand_amd.rasterizer import rasterize_views
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=2, P=2500, blend=True).to(dev)
+    cams = sc.cams()
+    outs = []
+    for compact in (False, True):
+        cb = (sc.color_b[:, :3].contiguous() if compact else sc.color_b.clone()).requires_grad_(True)
+        xyz = sc.xyz.clone().requires_grad_(True)
+        img, _ = rasterize_views(cams, xyz, sc.opacity, sc.scaling, sc.rotation, sc.shs, H=sc.H, W=sc.W, use_rgb=True,
+                                 xyz_b=sc.xyz_b, opacity_b=sc.opacity_b, color_w=sc.color_w, color_b=cb)
+        (img * torch.linspace(0, 1, img.numel(), device=dev).view_as(img)).sum().backward()
+        outs.append((img.detach(), xyz.grad, cb.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[1][2].shape == (sc.P, 3) and torch.equal(outs[0][2][:, :3], outs[1][2])
+    assert float(outs[0][2][:, 3:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        rasterize_views(cams, sc.xyz, sc.opacity, sc.scaling, sc.rotation, sc.shs, H=sc.H, W=sc.W, use_rgb=True,
+                        color_w=sc.color_w, color_b=sc.color_b[:, :5].contiguous())

@@ -196,3 +196,27 @@ def test_fused_l1_loss_matches_torch(dev):
         assert float(la) == pytest.approx(float(lb), rel=1e-5)
         assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
         assert float(a.grad.view(-1)[0]) == 0.0
+
+
+def test_fused_fit_loss_matches_torch_restatement(dev):
+    """gh_fit_loss == fit.fit_loss (the torch restatement of utils.py:180-294 / infer_one_shot.py:497-510) in value and
+    in the gradients w.r.t. the rasteriser outputs: L1 with sign(0) = 0, bbox zeroing, the clip(-0.001, 1) of the mask
+    term (alpha above 1 and below -0.001 carry no gradient), per-view means summed and scaled."""
+    from guassianhand_amd import fit as F
+    from guassianhand_amd.loss import fit_image_loss
+    g = torch.Generator().manual_seed(31)
+    NV, H, W = 3, 37, 29
+    img = torch.rand(NV, 3, H, W, generator=g).to(dev)
+    alpha = (torch.rand(NV, H, W, generator=g) * 1.3 - 0.1).to(dev)               # spans both clip edges
+    gt_rgb = torch.rand(NV, H, W, 3, generator=g).to(dev)
+    gt_mask = (torch.rand(NV, H, W, generator=g) > 0.5).float().to(dev)
+    img.view(-1)[::11] = gt_rgb.permute(0, 3, 1, 2).reshape(-1)[::11]             # exact ties
+    for bbox in (None, (torch.rand(NV, H, W, generator=g) > 0.3).to(dev)):
+        a1, b1 = img.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+        a2, b2 = img.clone().requires_grad_(True), alpha.clone().requires_grad_(True)
+        l1 = fit_image_loss(a1, b1, gt_rgb, gt_mask, None if bbox is None else bbox.float(), scale=1.0 / 8)
+        l2 = F.fit_loss(a2.permute(0, 2, 3, 1), b2.unsqueeze(-1).expand(-1, -1, -1, 3), gt_rgb, gt_mask, bbox) / 8
+        (3.0 * l1).backward(); (3.0 * l2).backward()
+        assert float(l1) == pytest.approx(float(l2), rel=2e-6)
+        assert torch.allclose(a1.grad, a2.grad, rtol=1e-5, atol=1e-9)
+        assert torch.allclose(b1.grad, b2.grad, rtol=1e-5, atol=1e-9)

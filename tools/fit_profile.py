@@ -30,8 +30,8 @@ for active in (True, False):
     print(f"fit step [{mode}]: {ms:.3f} ms (8 views, P={sc.P}, maps 48x1024x2048)")
     print("  blend_values (lookup fwd): %.3f ms" % t(lambda: f.blend_values()))
     if active:
-        go = torch.ones(sc.P, 48, device=dev)
-        print("  gather backward (48 ch): %.3f ms" % t(lambda: uv_gather_backward(go, f.texels, f._adam["color_b"].grad)))
+        go = torch.ones(sc.P, f.cb_channels, device=dev)
+        print(f"  gather backward ({f.cb_channels} ch): %.3f ms" % t(lambda: uv_gather_backward(go, f.texels, f._adam["color_b"].grad)))
         f._adam["color_b"].grad.zero_()
         print("  fused regulariser + Adam (3 tensors): %.3f ms" % t(lambda: [a.step() for a in f._adam.values()]))
     else:
