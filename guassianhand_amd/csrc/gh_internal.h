@@ -17,6 +17,7 @@ struct GhGrid {
   int tile_bits, n_pass;
   int64_t cap;                        // max_instances
   int nblk_sort;                      // ceil(cap / GH_SORT_TILE)
+  int n_items;                        // capacity of the backward work list: NV*tiles + cap/GH_SEGMENT + 2
 };
 
 static inline GhGrid gh_make_grid(const GhDims* d) {
@@ -29,6 +30,7 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
   g.cap = d->max_instances;
   g.nblk_sort = (int)((g.cap + GH_SORT_TILE - 1) / GH_SORT_TILE);
   if (g.nblk_sort < 1) g.nblk_sort = 1;
+  g.n_items = (int)((size_t)g.NV * g.tiles + (size_t)g.cap / GH_SEGMENT + 2);
   return g;
 }
 

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
     const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
     int tiles, float* __restrict__ image, float* __restrict__ alpha_img, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk) {
+    uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
+    float* __restrict__ ckpt_a, float4* __restrict__ final_C) {
   int v, tx, ty;
   const int tile = (int)tile_order[blockIdx.x >> 2];      // heaviest tiles are launched first
   const int quad = blockIdx.x & 3;
@@ -153,6 +154,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   const uint2 range = ranges[tile];
   const int total = (int)(range.y - range.x);
   r0 += range.x; r1 += range.x; r2 += range.x;
+  // state checkpoints for the segmented backward: slot of (tile, position m*GH_SEGMENT) = range.x/GH_SEGMENT + tile + m - 1
+  // (disjoint between tiles because floor(a+b) >= floor(a) + floor(b)); pixel = row-major index inside the tile
+  const size_t ck0 = ((size_t)(range.x / GH_SEGMENT) + (size_t)tile) * 256 + (size_t)((y - ty * GH_TILE) * GH_TILE + (x - tx * GH_TILE));
 
   GhPixelFwd p;
   p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.done = inside ? 0 : 1;
@@ -166,6 +170,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       if (base + GH_WAVE >= total) break;
       gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
       if (gh_fwd_consume<ALPHA>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p)) break;
+      const int next = base + 2 * GH_WAVE;              // wave-uniform: a checkpoint every GH_SEGMENT entries (rare)
+      if ((next % GH_SEGMENT) == 0 && next < total && inside && slot == 0) {
+        const size_t ck = ck0 + (size_t)(next / GH_SEGMENT - 1) * 256;
+        ckpt_rgb[ck] = make_float4(p.T, p.C0, p.C1, p.C2);
+        if (ALPHA) ckpt_a[ck] = p.A;
+      }
     }
   }
   if (total > 0) {                                   // walked length of the tile = max n_contrib (orders the backward)
@@ -179,6 +189,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const size_t pix = ((size_t)v * H + y) * W + x;
     final_T[pix] = p.T;
     n_contrib[pix] = p.last;
+    final_C[pix] = make_float4(p.C0, p.C1, p.C2, p.A);
     float* img = image + (size_t)v * 3 * H * W + (size_t)y * W + x;
     img[0] = fmaf(p.T, bg[0], p.C0);
     img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1);
@@ -195,12 +206,13 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   const float4* r0 = (const float4*)(ws + L.inst_r0); const float4* r1 = (const float4*)(ws + L.inst_r1);
   const float2* r2 = (const float2*)(ws + L.inst_r2);
   float* fT = (float*)(ws + L.final_T); uint32_t* nc = (uint32_t*)(ws + L.n_contrib); uint32_t* tw = (uint32_t*)(ws + L.tile_walk);
+  float4* ck = (float4*)(ws + L.ckpt_rgb); float* cka = (float*)(ws + L.ckpt_a); float4* fC = (float4*)(ws + L.final_C);
   if (alpha)
     hipLaunchKernelGGL(gh_render_fwd_kernel<true>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw);
+                       g.tiles, image, alpha, fT, nc, tw, ck, cka, fC);
   else
     hipLaunchKernelGGL(gh_render_fwd_kernel<false>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw);
+                       g.tiles, image, alpha, fT, nc, tw, ck, cka, fC);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -225,16 +237,21 @@ __device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum ove
 
 template <bool ALPHA>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ sorted_slot,
+    const uint2* __restrict__ ranges, const uint2* __restrict__ items, const GhCounters* __restrict__ ctr,
+    const uint32_t* __restrict__ sorted_slot,
     const float4* __restrict__ r0, const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams,
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float4* __restrict__ ckpt_rgb, const float* __restrict__ ckpt_a, const float4* __restrict__ final_C,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, float* __restrict__ inst_grad,
     uint8_t* __restrict__ inst_flag) {
   __shared__ float s_part[2][GH_BLOCK / GH_WAVE][GH_WAVE][GH_REC];    // [buffer][wave][entry][9 used]  (24 KB)
   __shared__ uint64_t s_mask[2][GH_BLOCK / GH_WAVE];                  // entries a wave wrote
   __shared__ int s_qlast;
   int v, tx, ty;
-  const int tile = (int)tile_order[blockIdx.x >> 2];
+  if ((blockIdx.x >> 2) >= ctr->reserved[1]) return;     // grid is sized for the capacity of the work list
+  const uint2 item = items[blockIdx.x >> 2];             // (tile, depth segment): longest items are launched first
+  const int tile = (int)item.x;
+  const int seg_lo = (int)item.y * GH_SEGMENT, seg_hi = seg_lo + GH_SEGMENT;
   const int quad = blockIdx.x & 3;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -270,17 +287,32 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   if (lane == 0) atomicMax(&s_qlast, wave_last);
   __syncthreads();
   const int qlast = s_qlast;               // ... by no pixel of the quadrant
-  if (qlast == 0) return;                  // block-uniform
+  if (qlast <= seg_lo) return;             // block-uniform: the quadrant blended nothing inside this depth segment
+  const int qend = qlast < seg_hi ? qlast : seg_hi;
 
+  // State behind the segment. A pixel whose last blended entry lies inside (or before) the segment starts from
+  // (T_final, nothing behind), as the unsegmented walk does. A pixel that blends entries behind the cut starts from
+  // the forward's own state at the cut: T = transmittance in front of entry seg_hi, colour behind it =
+  // (final colour - colour accumulated in front of the cut) / T  — exact T instead of T_final divided back up.
   GhStateBwd st;
   st.T = T_final; st.B0 = st.B1 = st.B2 = st.B3 = 0.0f;
-  const int nb = (qlast + GH_WAVE - 1) / GH_WAVE;
+  if (inside && last > seg_hi) {
+    const size_t ck = ((size_t)(range.x / GH_SEGMENT) + (size_t)tile + (size_t)item.y) * 256 +
+                      (size_t)((y - ty * GH_TILE) * GH_TILE + (x - tx * GH_TILE));
+    const float4 c = ckpt_rgb[ck];
+    const float4 fc = final_C[((size_t)v * H + y) * W + x];
+    const float iT = 1.0f / c.x;           // > 1e-4: the pixel was still open at the cut
+    st.T = c.x;
+    st.B0 = (fc.x - c.y) * iT; st.B1 = (fc.y - c.z) * iT; st.B2 = (fc.z - c.w) * iT;
+    if (ALPHA) st.B3 = (fc.w - ckpt_a[ck]) * iT;
+  }
+  const int nb = (qend - seg_lo + GH_WAVE - 1) / GH_WAVE;
   GhBatch cur, nxt;
-  gh_load_batch(cur, r0, r1, r2, (nb - 1) * GH_WAVE + lane, qlast);
+  gh_load_batch(cur, r0, r1, r2, seg_lo + (nb - 1) * GH_WAVE + lane, qend);
   for (int k = nb - 1; k >= 0; --k) {
     const int buf = k & 1;
-    const int sbase = k * GH_WAVE;
-    gh_load_batch(nxt, r0, r1, r2, (k > 0 ? (k - 1) * GH_WAVE : 0) + lane, qlast);   // next batch in flight
+    const int sbase = seg_lo + k * GH_WAVE;
+    gh_load_batch(nxt, r0, r1, r2, seg_lo + (k > 0 ? (k - 1) * GH_WAVE : 0) + lane, qend);   // next batch in flight
     uint64_t processed = 0;
     uint64_t mask = __ballot((sbase + lane < wave_last) && ((cur.blocks >> blk) & 1u));
     while (mask) {
@@ -374,7 +406,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     __syncthreads();
     if (wid == (k & 3)) {                       // flush batch k: lane l owns entry l; fixed wave order => reproducible
       const int pos = sbase + lane;
-      if (pos < qlast) {
+      if (pos < qend) {
         float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool any = false;
 #pragma unroll
@@ -404,12 +436,14 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   if (g.cap == 0) return;
   // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (same n_contrib)
   gh_launch_tile_order_bwd(g, ws, L, s);
-  const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
+  const dim3 grid(4 * (unsigned)g.n_items), block(GH_BLOCK);      // capacity of the work list; surplus blocks exit at once
   auto launch = [&](auto kern) {
-    hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(ws + L.ranges), (const uint32_t*)(ws + L.tile_order_bwd),
+    hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(ws + L.ranges), (const uint2*)(ws + L.bwd_items),
+                       (const GhCounters*)(ws + L.counters),
                        (const uint32_t*)(ws + L.sorted_slot), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
                        (const float2*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
-                       (const uint32_t*)(ws + L.n_contrib), dL_dimage, dL_dalpha, (float*)(ws + L.inst_grad),
+                       (const uint32_t*)(ws + L.n_contrib), (const float4*)(ws + L.ckpt_rgb), (const float*)(ws + L.ckpt_a),
+                       (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, (float*)(ws + L.inst_grad),
                        (uint8_t*)(ws + L.inst_flag));
   };
   if (dL_dalpha) launch(gh_render_bwd_kernel<true>); else launch(gh_render_bwd_kernel<false>);
