@@ -55,7 +55,6 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   const size_t n_items = (size_t)g.NV * g.tiles + cap / GH_SEGMENT + 2;       // backward work items / checkpoint slots
   L->bwd_items = take(n_items * 8);
   L->ckpt_rgb = take(n_items * 256 * 16);
-  L->ckpt_a = take(n_items * 256 * 4);
   L->final_C = take(pix * 16);
   L->final_T = take(pix * 4);
   L->n_contrib = take(pix * 4);

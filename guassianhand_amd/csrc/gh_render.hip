@@ -139,7 +139,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
     int tiles, float* __restrict__ image, float* __restrict__ alpha_img, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
-    float* __restrict__ ckpt_a, float4* __restrict__ final_C) {
+    float4* __restrict__ final_C) {
   int v, tx, ty;
   const int tile = (int)tile_order[blockIdx.x >> 2];      // heaviest tiles are launched first
   const int quad = blockIdx.x & 3;
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       if ((next % GH_SEGMENT) == 0 && next < total && inside && slot == 0) {
         const size_t ck = ck0 + (size_t)(next / GH_SEGMENT - 1) * 256;
         ckpt_rgb[ck] = make_float4(p.T, p.C0, p.C1, p.C2);
-        if (ALPHA) ckpt_a[ck] = p.A;
       }
     }
   }
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const size_t pix = ((size_t)v * H + y) * W + x;
     final_T[pix] = p.T;
     n_contrib[pix] = p.last;
-    final_C[pix] = make_float4(p.C0, p.C1, p.C2, p.A);
+    final_C[pix] = make_float4(p.C0, p.C1, p.C2, 0.0f);
     float* img = image + (size_t)v * 3 * H * W + (size_t)y * W + x;
     img[0] = fmaf(p.T, bg[0], p.C0);
     img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1);
@@ -206,13 +205,13 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   const float4* r0 = (const float4*)(ws + L.inst_r0); const float4* r1 = (const float4*)(ws + L.inst_r1);
   const float2* r2 = (const float2*)(ws + L.inst_r2);
   float* fT = (float*)(ws + L.final_T); uint32_t* nc = (uint32_t*)(ws + L.n_contrib); uint32_t* tw = (uint32_t*)(ws + L.tile_walk);
-  float4* ck = (float4*)(ws + L.ckpt_rgb); float* cka = (float*)(ws + L.ckpt_a); float4* fC = (float4*)(ws + L.final_C);
+  float4* ck = (float4*)(ws + L.ckpt_rgb); float4* fC = (float4*)(ws + L.final_C);
   if (alpha)
     hipLaunchKernelGGL(gh_render_fwd_kernel<true>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw, ck, cka, fC);
+                       g.tiles, image, alpha, fT, nc, tw, ck, fC);
   else
     hipLaunchKernelGGL(gh_render_fwd_kernel<false>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw, ck, cka, fC);
+                       g.tiles, image, alpha, fT, nc, tw, ck, fC);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const uint32_t* __restrict__ sorted_slot,
     const float4* __restrict__ r0, const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams,
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
-    const float4* __restrict__ ckpt_rgb, const float* __restrict__ ckpt_a, const float4* __restrict__ final_C,
+    const float4* __restrict__ ckpt_rgb, const float4* __restrict__ final_C,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, float* __restrict__ inst_grad,
     uint8_t* __restrict__ inst_flag) {
   __shared__ float s_part[2][GH_BLOCK / GH_WAVE][GH_WAVE][GH_REC];    // [buffer][wave][entry][9 used]  (24 KB)
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const float iT = 1.0f / c.x;           // > 1e-4: the pixel was still open at the cut
     st.T = c.x;
     st.B0 = (fc.x - c.y) * iT; st.B1 = (fc.y - c.z) * iT; st.B2 = (fc.z - c.w) * iT;
-    if (ALPHA) st.B3 = (fc.w - ckpt_a[ck]) * iT;
+    if (ALPHA) st.B3 = (c.x - T_final) * iT;   // alpha behind the cut = (T_cut - T_final) / T_cut exactly: no sum to difference
   }
   const int nb = (qend - seg_lo + GH_WAVE - 1) / GH_WAVE;
   GhBatch cur, nxt;
@@ -442,7 +441,7 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                        (const GhCounters*)(ws + L.counters),
                        (const uint32_t*)(ws + L.sorted_slot), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
                        (const float2*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
-                       (const uint32_t*)(ws + L.n_contrib), (const float4*)(ws + L.ckpt_rgb), (const float*)(ws + L.ckpt_a),
+                       (const uint32_t*)(ws + L.n_contrib), (const float4*)(ws + L.ckpt_rgb),
                        (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, (float*)(ws + L.inst_grad),
                        (uint8_t*)(ws + L.inst_flag));
   };

@@ -52,7 +52,7 @@ typedef enum GhStatus {
 
 /* Flags for GhDims.flags */
 #define GH_FLAG_NONE 0u
-#define GH_SEGMENT 1024 /* depth segment (list entries) of the backward: segments of a tile are processed by different workgroups */
+#define GH_SEGMENT 256 /* depth segment (list entries) of the backward: segments of a tile are processed by different workgroups */
 #define GH_FLAG_BLEND_W_PER_GAUSSIAN 1u /* color_w is (P,48) instead of (48,) — renderer_one_shot_edit.py:489-500 */
 #define GH_FLAG_BLEND_COLOR_B_RGB 2u    /* colors_precomp mode only: blend_color_b and dL_dblend_color_b are (P,3), the
                                            three columns of the (P,48) view that renderer_one_shot.py:328 reads */
@@ -153,8 +153,7 @@ typedef struct GhLayout {
   size_t bwd_items;      /* uint2 [n_views*tiles + max_instances/GH_SEGMENT + 2] backward work items (tile, depth segment), longest first */
   size_t ckpt_rgb;       /* float4[slots][256] forward state (T, C0, C1, C2) of every pixel of a tile at list positions that are
                             multiples of GH_SEGMENT; slots = max_instances/GH_SEGMENT + n_views*tiles + 2 */
-  size_t ckpt_a;         /* float [slots][256] accumulated alpha at the same positions (fused mask channel only) */
-  size_t final_C;        /* float4[n_views*H*W] colour (and alpha) accumulated by the forward, without background */
+  size_t final_C;        /* float4[n_views*H*W] colour accumulated by the forward, without background */
   size_t final_T;        /* float [n_views*H*W] */
   size_t n_contrib;      /* uint32[n_views*H*W] */
   size_t inst_grad;      /* float[max_instances][4][12] per-(instance, quadrant) gradient sub-records (backward scratch) */
