@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step (forward + loss + backward) in a HIP graph and replay it in the timed loop; for "
+                         "launch-bound shapes such as 1 view/step (implies --no-stage-timing, N=1 only)")
     args = ap.parse_args()
 
     from guassianhand_amd import dist as ghdist
@@ -170,16 +173,35 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         step(sync=False)
     R.check_overflow()
+    graph = None
+    if args.graph:
+        assert world == 1, "--graph is a single-GPU mode"
+        args.no_stage_timing = True
+        R.set_graph_mode(True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step(sync=False)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = step(sync=False)
+        graph.replay()
     if not args.no_stage_timing:
         R.enable_stage_timing(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if graph is not None:
+            graph.replay()
+            continue
         loss = step(sync=False)
     t_enq = time.perf_counter() - t0                 # host time to enqueue the timed steps (GPU-bound if << dt)
     barrier()
     dt = time.perf_counter() - t0
     R.check_overflow()
+    if graph is not None:
+        R.set_graph_mode(False)
     stage_ms = R.stage_timing_summary() if not args.no_stage_timing else {}
     R.enable_stage_timing(False)
 
@@ -223,7 +245,8 @@ def main():
                        "views_per_step_per_gpu": V, "instances_per_step_per_gpu": D,
                        "instances_in_3sigma_rects": D_rect, "parallelism": f"view-parallel x{world}",
                        "loss": "mean|img-gt|", "final_loss": float(loss),
-                       "host_enqueue_ms_per_step": t_enq / args.steps * 1e3},
+                       "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+                       "hip_graph": bool(args.graph)},
             "roofline": roofline, "stages": stages,
         }
         if world == 1 and not args.no_cpu_baseline:
