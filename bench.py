@@ -6,7 +6,8 @@ against the HBM roofline. One *render* = one image forward + its backward under 
 (SURVEY.md §8d). One *step* = one pass of the hot path over one batch: `--views-per-step` cameras of the
 ring (the 8 novel views of the one-shot fit loop, BASELINE configs[3]) rendered in one view-batched launch
 sequence per rank, gradients w.r.t. all Gaussian attributes and the blend parameters, and (N>1) one RCCL
-all-reduce of the fused gradient block. Workload = BASELINE configs[2]: two interacting hands,
+all-reduce of the scalar loss (views are independent; `--allreduce-grads` adds the fused gradient block, as the
+sharded fit loop needs). Workload = BASELINE configs[2]: two interacting hands,
 P = 98,562 Gaussians, interaction-aware attribute blend on, RGB colours, 512x334.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
@@ -108,6 +109,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--allreduce-grads", action="store_true",
+                    help="N>1: also all-reduce the per-Gaussian gradient block every step (what the sharded fit loop does); "
+                         "default is the north star's protocol: independent views, RCCL for the scalar loss only")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step (forward + loss + backward) in a HIP graph and replay it in the timed loop; for "
                          "launch-bound shapes such as 1 view/step (implies --no-stage-timing, N=1 only)")
@@ -157,10 +161,14 @@ def main():
         loss = l1_mean_loss(img, gt)                 # mean|img - gt| and dL/dimg in one fused pass (gh_l1_loss)
         loss.backward()
         if world > 1:
-            grads = {k: params[k].grad for k in names}
-            if s.use_rgb and "color_b" in grads:         # RGB mode reads color_b[:, 0:3] only (renderer_one_shot.py:328): the
-                grads["color_b"] = grads["color_b"][:, :3]   # other 45 gradient columns are exactly zero on every rank
-            loss, grads = ghdist.allreduce_grads(grads, loss.detach(), names)
+            if args.allreduce_grads:                     # data-parallel fit: sum the gradient block at the rasteriser boundary
+                grads = {k: params[k].grad for k in names}
+                if s.use_rgb and "color_b" in grads:     # RGB mode reads color_b[:, 0:3] only (renderer_one_shot.py:328): the
+                    grads["color_b"] = grads["color_b"][:, :3]   # other 45 gradient columns are exactly zero on every rank
+                loss, grads = ghdist.allreduce_grads(grads, loss.detach(), names)
+            else:                                        # BASELINE north star: views are independent, RCCL only for the loss
+                loss = loss.detach().clone()
+                tdist.all_reduce(loss, op=tdist.ReduceOp.SUM)
         return loss
 
     def barrier():
@@ -244,6 +252,8 @@ def main():
                                    + (" (BASELINE configs[2])" if args.config == "two_hands" else ""),
                        "views_per_step_per_gpu": V, "instances_per_step_per_gpu": D,
                        "instances_in_3sigma_rects": D_rect, "parallelism": f"view-parallel x{world}",
+                       "collective": None if world == 1 else ("all-reduce(loss + gradient block)" if args.allreduce_grads
+                                                              else "all-reduce(loss)"),
                        "loss": "mean|img-gt|", "final_loss": float(loss),
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
                        "hip_graph": bool(args.graph)},
