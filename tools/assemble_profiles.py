@@ -28,7 +28,7 @@ sq = {"note": "VALU busy fraction = SQ_ACTIVE_INST_VALU*4 / (GRBM_GUI_ACTIVE/8 *
 for k in ("gh_render_fwd_kernel", "gh_render_bwd_kernel"):
     a, g = vals[(k, "SQ_ACTIVE_INST_VALU")], vals[(k, "GRBM_GUI_ACTIVE")]
     sq["kernels"][k] = {"valu_busy_frac": a * 4 / (g / 8 * 1024), "valu_insts_per_launch": vals[(k, "SQ_INSTS_VALU")],
-                        "lds_insts_per_launch": vals[(k, "SQ_INSTS_LDS")], "lds_busy_frac": vals[(k, "SQ_ACTIVE_INST_LDS")] * 4 / (g / 8 * 256),
+                        "lds_insts_per_launch": vals[(k, "SQ_INSTS_LDS")],
                         "gpu_cycles": g / 8}
 json.dump(sq, open("profiles/pmc_sq.json", "w"), indent=1)
 print(json.dumps(sq["kernels"], indent=1))
