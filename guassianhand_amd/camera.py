@@ -7,8 +7,7 @@ include/gh_raster.h describes.
 """
 from __future__ import annotations
 
-import math
-from typing import Optional, Sequence
+from typing import Sequence
 
 import torch
 

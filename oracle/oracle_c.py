@@ -10,7 +10,6 @@ import os
 import subprocess
 from typing import Dict, Optional
 
-import numpy as np
 import torch
 
 from guassianhand_amd import _abi

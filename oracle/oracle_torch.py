@@ -16,7 +16,6 @@ clamp is straight-through (App. A.4-2); the 1.3*tanfov clamp freezes the clamped
 """
 from __future__ import annotations
 
-import math
 from typing import Optional
 
 import torch
