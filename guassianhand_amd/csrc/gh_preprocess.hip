@@ -84,6 +84,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         // .y = packed tile rect, .z = first emit slot (filled by gh_emit_kernel): the post-sort gather reads one line
         grec[2] = make_float4(rgb[2], __uint_as_float((unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24)),
                               __uint_as_float((unsigned)hitmask), __uint_as_float((unsigned)(hitmask >> 32)));
+        grec[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // completes the 64-byte line (full-line write; .x = first emit slot later)
         depth[n] = e.tz;
         dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
         clamped[n] = (uint8_t)cl;
