@@ -277,7 +277,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = blockIdx.x * GH_BLOCK + tid;
   const uint32_t n = i < N ? perm[i] : 0u;
+  float4* grec = geom + (size_t)n * 4;
   const uint32_t cnt = i < N ? tiles_touched[n] : 0u;
+  const float4 g2 = grec[2];                            // rect + tile hit mask: issued before the scan, not after it
   uint32_t x = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
@@ -289,16 +291,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   uint32_t off = block_offsets[blockIdx.x] + woff + x - cnt;
   slot_begin[n] = off;
   if (cnt == 0) return;
-  float4* grec = geom + (size_t)n * 4;
   grec[3].x = __uint_as_float(off);                   // same 64-byte line the post-sort gather reads
-  const float4 g0 = grec[0];
-  const float4 g1 = make_float4(grec[1].x, grec[1].y, 0.0f, 0.0f);      // (C, opacity): exactly the projection kernel's operands
-  const float4 g2 = grec[2];
   const uint32_t r = __float_as_uint(g2.y);
   const int minx = r & 255, miny = (r >> 8) & 255, maxx = (r >> 16) & 255, maxy = r >> 24;
   const uint32_t vbase = (n / (uint32_t)P) * (uint32_t)tiles;
   const bool small = (maxx - minx) * (maxy - miny) <= 64;               // the projection kernel kept the hit mask
   const unsigned long long hitmask = ((unsigned long long)__float_as_uint(g2.w) << 32) | __float_as_uint(g2.z);
+  float4 g0 = make_float4(0, 0, 0, 0), g1 = g0;
+  if (!small) { g0 = grec[0]; g1 = make_float4(grec[1].x, grec[1].y, 0.0f, 0.0f); }   // (C, opacity): the projection kernel's operands
   int bit = 0;
   for (int ty = miny; ty < maxy; ++ty)
     for (int tx = minx; tx < maxx; ++tx, ++bit) {
