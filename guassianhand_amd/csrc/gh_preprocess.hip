@@ -189,18 +189,25 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
       const float4 r0 = r[0], r1 = r[1]; const float r2 = r[2].x;
       s9[0] = r0.x; s9[1] = r0.y; s9[2] = r0.z; s9[3] = r0.w; s9[4] = r1.x; s9[5] = r1.y; s9[6] = r1.z; s9[7] = r1.w; s9[8] = r2;
     }
-    const float g_px = s9[0], g_py = s9[1], gA = s9[2], gB = s9[3], gC = s9[4], g_o = s9[5];
-    if (live && gr.dL_dmeans2D) {
-      gr.dL_dmeans2D[3 * n] = vis ? g_px * 0.5f * (float)W : 0.0f;
-      gr.dL_dmeans2D[3 * n + 1] = vis ? g_py * 0.5f * (float)H : 0.0f;
-      gr.dL_dmeans2D[3 * n + 2] = 0.0f;
-    }
+    float g_px = 0.0f, g_py = 0.0f;
     float dm[3] = {0, 0, 0};
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     const float* V = cam; const float* PM = cam + 16;
     if (vis) {
       GhGeo e;
       gh_geo_forward(in, cam, i, mod, H, W, e);
+      // The render backward sums the raw pixel moments of h = G * dL/dalpha per instance:
+      //   s9[0..5] = sum h dx, sum h dy, sum h dx^2, sum h dx dy, sum h dy^2, sum h     (dx = px_gaussian - px_pixel)
+      // the factors that are constant per (view, Gaussian) — opacity and the conic — are applied here, once, instead of
+      // per pixel and list entry:  dL/dG = o * dL/dalpha,  dL/d(px,py) = -o (A Shx + B Shy, C Shy + B Shx),
+      // dL/d(A,B,C) = -o (Shxx / 2, Shxy, Shyy / 2),  dL/do = Sh.
+      float op = in.opacities[i];
+      if (in.blend_opacity_b) op = op + in.blend_opacity_b[i];
+      const float dinv = 1.0f / e.det;
+      const float cA = e.c * dinv, cB = -e.b * dinv, cC = e.a * dinv;
+      g_px = -op * (cA * s9[0] + cB * s9[1]);
+      g_py = -op * (cC * s9[1] + cB * s9[0]);
+      const float gA = -0.5f * op * s9[2], gB = -op * s9[3], gC = -0.5f * op * s9[4], g_o = s9[5];
       // ---- colour ----
       if (rgb_mode) {
         araw[0] += s9[6]; araw[1] += s9[7]; araw[2] += s9[8];
@@ -278,6 +285,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
       for (int a2 = 0; a2 < 3; ++a2) dm[a2] += dhx * PM[4 * a2] + dhy * PM[4 * a2 + 1] + dhw * PM[4 * a2 + 3];
       am[0] += dm[0]; am[1] += dm[1]; am[2] += dm[2];
       ao += g_o;
+    }
+    if (live && gr.dL_dmeans2D) {
+      gr.dL_dmeans2D[3 * n] = vis ? g_px * 0.5f * (float)W : 0.0f;
+      gr.dL_dmeans2D[3 * n + 1] = vis ? g_py * 0.5f * (float)H : 0.0f;
+      gr.dL_dmeans2D[3 * n + 2] = 0.0f;
     }
     if (red_x) { gh_block_acc(s_part, 48, dm[0]); gh_block_acc(s_part, 49, dm[1]); gh_block_acc(s_part, 50, dm[2]); }
   }

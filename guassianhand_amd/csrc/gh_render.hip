@@ -373,16 +373,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       // pixels that did not blend the entry contribute nothing: every partial below is a product with dL_dalpha or
       // dchannel_dcolor (all other factors are finite), so zeroing these two replaces nine selects
       dL_dalpha = contrib ? dL_dalpha : 0.0f;
-      const float dL_dG = op * dL_dalpha;                              // straight-through the 0.99 clamp (App. A.4-2)
-      const float gdx = G * dx, gdy = G * dy;
+      // Raw pixel moments of h = G * dL/dalpha; opacity and conic factors are constant per instance and are applied
+      // after all sums, once per (view, Gaussian), by gh_preprocess_bwd_kernel (the 0.99 clamp is straight-through,
+      // App. A.4-2): 6 multiplies here instead of 20.
+      const float h = G * dL_dalpha;
+      const float hx = h * dx, hy = h * dy;
       const float dchannel_dcolor = contrib ? alpha * mTn : 0.0f;
       float r[9];
-      r[0] = dL_dG * (-gdx * cA - gdy * cB);
-      r[1] = dL_dG * (-gdy * cC - gdx * cB);
-      r[2] = -0.5f * gdx * dx * dL_dG;
-      r[3] = -gdx * dy * dL_dG;
-      r[4] = -0.5f * gdy * dy * dL_dG;
-      r[5] = G * dL_dalpha;
+      r[0] = hx; r[1] = hy;
+      r[2] = hx * dx; r[3] = hx * dy; r[4] = hy * dy;
+      r[5] = h;
       r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
 #pragma unroll
       for (int q = 0; q < 9; ++q) r[q] = gh_slot_sum16(r[q], lane);
