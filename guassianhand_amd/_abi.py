@@ -7,6 +7,7 @@ GH_TILE = 16
 GH_CAM_FLOATS = 40
 GH_FLAG_BLEND_W_PER_GAUSSIAN = 1
 GH_FLAG_BLEND_COLOR_B_RGB = 2
+GH_FLAG_PER_VIEW_GAUSSIANS = 4
 
 GH_OK = 0
 GH_ERR_INVALID_ARG = -1

@@ -63,7 +63,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   const bool sh_mode = d->M != 0;
   L->sh_rgb = take(sh_mode ? N * 16 : 0);
   L->dmean_sh = take(sh_mode ? N * 16 : 0);
-  L->sh_scratch = take(sh_mode ? (((size_t)d->P * 16 + GH_BLOCK - 1) / GH_BLOCK + 1) * 64 * 4 : 0);
+  L->sh_scratch = take(sh_mode ? ((N * 16 + GH_BLOCK - 1) / GH_BLOCK + 1) * 64 * 4 : 0);   // sized for the pose-batch row count
   L->grad_sums = take(N * 48);
   L->bwd_scratch = take((nblk_pre + 1) * 64 * 4);
   L->total_bytes = off;

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
   if (n < N) {
     uint32_t dkey = 0xFFFFFFFFu;                        // culled Gaussians sort behind everything and emit nothing
     unsigned rect_bits = 0;
-    const int v = n / P, i = n - v * P;
+    const int v = n / P;
+    const int i = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? n : n - v * P;     // row of the attribute arrays (pose batch: own rows per view)
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     int radius = 0;
     GhGeo e;
@@ -167,8 +168,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ dmean_sh, const float4* __restrict__ gsum,
     float* __restrict__ scratch) {
   __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
+  // i = row of the attribute arrays. Shared Gaussians: P rows, each seen by all NV views. Pose batch
+  // (GH_FLAG_PER_VIEW_GAUSSIANS): NV*P rows, row i is seen by view i / P only.
+  const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   const int i = blockIdx.x * GH_BLOCK + threadIdx.x;
-  const bool live = i < P;
+  const bool live = i < (per_view ? NV * P : P);
+  const int v_lo = per_view ? (live ? i / P : 0) : 0, v_hi = per_view ? v_lo + 1 : NV;
   constexpr bool rgb_mode = RGB_MODE;
   const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   const bool red_w = rgb_mode && in.blend_color_w && !wpg && gr.dL_dblend_color_w;   // global (48,) weights: block reduce
@@ -180,8 +185,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
   __syncthreads();
 
   float am[3] = {0, 0, 0}, as[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, araw[3] = {0, 0, 0}, ao = 0.0f;
-  for (int v = 0; v < NV; ++v) {
-    const size_t n = (size_t)v * P + (live ? i : 0);
+  for (int v = v_lo; v < v_hi; ++v) {
+    const size_t n = per_view ? (size_t)(live ? i : 0) : (size_t)v * P + (live ? i : 0);
     const bool vis = live && tiles_touched[n] != 0;
     float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (vis) {
@@ -363,7 +368,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_blend_reduce_kernel(const float* 
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
                               const GhLayout& L, hipStream_t s) {
   if (g.P == 0) return;
-  int nblk = (g.P + GH_BLOCK - 1) / GH_BLOCK;
+  const int rows = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.N : g.P;
+  int nblk = (rows + GH_BLOCK - 1) / GH_BLOCK;
   auto kern = in->colors_precomp ? gh_preprocess_bwd_kernel<true> : gh_preprocess_bwd_kernel<false>;
   const int nblk_n = (g.N + GH_BLOCK - 1) / GH_BLOCK;
   hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,

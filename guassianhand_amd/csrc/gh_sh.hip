@@ -45,7 +45,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in,
   const int n = t >> 4, k = t & 15;
   const bool live = n < N;
   const int nn = live ? n : 0;
-  const int v = nn / P, i = nn - v * P;
+  const int v = nn / P;
+  const int i = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? nn : nn - v * P;
   const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
   float mx = in.means3D[3 * i], my = in.means3D[3 * i + 1], mz = in.means3D[3 * i + 2];
   if (in.blend_xyz_b) { mx = mx + in.blend_xyz_b[0]; my = my + in.blend_xyz_b[1]; mz = mz + in.blend_xyz_b[2]; }
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd_kernel(
   __shared__ float s_cw[GH_BLOCK / 16][48];
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   const int i0 = t >> 4, k = t & 15;
-  const bool live = i0 < P;
+  const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;      // pose batch: NV*P rows, row i belongs to view i / P
+  const bool live = i0 < (per_view ? NV * P : P);
   const int i = live ? i0 : 0;
   const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   const bool has_w = in.blend_color_w != nullptr, has_b = in.blend_color_b != nullptr;
@@ -126,8 +128,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd_kernel(
   float mx = in.means3D[3 * i], my = in.means3D[3 * i + 1], mz = in.means3D[3 * i + 2];
   if (in.blend_xyz_b) { mx = mx + in.blend_xyz_b[0]; my = my + in.blend_xyz_b[1]; mz = mz + in.blend_xyz_b[2]; }
   float dsh[3] = {0, 0, 0}, dcb[3] = {0, 0, 0}, dcw[3] = {0, 0, 0};
-  for (int v = 0; v < NV; ++v) {
-    const size_t n = (size_t)v * P + i;
+  const int v_lo = per_view ? i / P : 0, v_hi = per_view ? v_lo + 1 : NV;
+  for (int v = v_lo; v < v_hi; ++v) {
+    const size_t n = per_view ? (size_t)i : (size_t)v * P + i;
     const bool vis = live && tiles_touched[n] != 0;                  // row-uniform
     float g[3] = {0, 0, 0};
     if (vis) {
@@ -197,7 +200,7 @@ void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* i
 int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws, const GhLayout& L,
                             hipStream_t s) {
   if (g.P == 0 || !in->shs) return 0;
-  const size_t threads = (size_t)g.P * 16;
+  const size_t threads = (size_t)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.N : g.P) * 16;
   const int nblk = (int)((threads + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_sh_colour_bwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, d->sh_degree, d->M, d->flags,
                      (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.sh_rgb), (const float4*)(ws + L.grad_sums),

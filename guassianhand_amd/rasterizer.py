@@ -146,14 +146,17 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 
 class _Ctx:
-    __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "stream", "alpha")
+    __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "rows", "stream", "alpha")
 
 
 def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None, colors_precomp=None,
                    sh_degree: int = 0, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
-                   color_b=None, max_instances: Optional[int] = None, sync: bool = True, return_alpha: bool = False):
+                   color_b=None, max_instances: Optional[int] = None, sync: bool = True, return_alpha: bool = False,
+                   per_view_gaussians: bool = False):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
-    with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha."""
+    with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha.
+    per_view_gaussians (pose batch, the batch loop of GS3DRenderer.forward): every per-Gaussian tensor holds NV*P rows and
+    view v renders rows [v*P, (v+1)*P) — NV different Gaussian sets in one launch sequence."""
     global _last_D
     L = _lib.lib()
     dev = means3D.device
@@ -166,24 +169,29 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
              shs=_prep(shs, dev), colors_precomp=_prep(colors_precomp, dev), xyz_b=_prep(xyz_b, dev),
              opacity_b=None if opacity_b is None else _prep(opacity_b, dev).reshape(-1),
              color_w=_prep(color_w, dev), color_b=_prep(color_b, dev))
-    P, NV = t["means3D"].shape[0], t["cams"].shape[0]
+    rows, NV = t["means3D"].shape[0], t["cams"].shape[0]
     M = 0 if shs is None else t["shs"].shape[1]
     flags = 0
+    if per_view_gaussians:
+        if NV == 0 or rows % NV:
+            raise ValueError("per_view_gaussians: the Gaussian tensors must hold n_views * P rows")
+        flags |= _abi.GH_FLAG_PER_VIEW_GAUSSIANS
+    P = rows // NV if per_view_gaussians else rows
     wpg = False
     if t["color_w"] is not None:
         if t["color_w"].numel() == 48:
             pass
-        elif t["color_w"].numel() == P * 48:
+        elif t["color_w"].numel() == rows * 48:
             flags |= _abi.GH_FLAG_BLEND_W_PER_GAUSSIAN
             wpg = True
         else:
             raise ValueError("color_w must have 48 or P*48 elements")
     b_rgb = False
     if t["color_b"] is not None:
-        if t["color_b"].numel() == P * 3 and colors_precomp is not None:     # the 3 columns RGB mode reads (renderer_one_shot.py:328)
+        if t["color_b"].numel() == rows * 3 and colors_precomp is not None:  # the 3 columns RGB mode reads (renderer_one_shot.py:328)
             flags |= _abi.GH_FLAG_BLEND_COLOR_B_RGB
             b_rgb = True
-        elif t["color_b"].numel() != P * 48:
+        elif t["color_b"].numel() != rows * 48:
             raise ValueError("color_b must have P*48 elements (or P*3 with colors_precomp)")
     key = (P, NV, H, W)
     while True:
@@ -236,7 +244,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         break
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
-    ctx.b_rgb = b_rgb
+    ctx.b_rgb, ctx.rows = b_rgb, rows
     ctx.alpha = alpha
     return image, radii, ctx
 
@@ -252,13 +260,14 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
     g = dL_dimage.detach().to(torch.float32).reshape(NV, 3, ctx.H, ctx.W).contiguous()
     ga = None if dL_dalpha is None else dL_dalpha.detach().to(torch.float32).reshape(NV, ctx.H, ctx.W).contiguous()
     mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
-    o = dict(means3D=mk(P, 3), means2D=mk(NV, P, 3) if want_means2D else None, opacities=mk(P), scales=mk(P, 3),
-             rotations=mk(P, 4), shs=mk(P, M, 3) if M else None,
-             colors_precomp=mk(P, 3) if t["colors_precomp"] is not None else None,
+    R_ = ctx.rows                                  # rows of the per-Gaussian tensors (P, or NV*P for a pose batch)
+    o = dict(means3D=mk(R_, 3), means2D=mk(NV, P, 3) if want_means2D else None, opacities=mk(R_), scales=mk(R_, 3),
+             rotations=mk(R_, 4), shs=mk(R_, M, 3) if M else None,
+             colors_precomp=mk(R_, 3) if t["colors_precomp"] is not None else None,
              xyz_b=mk(3) if t["xyz_b"] is not None else None,
-             opacity_b=mk(P) if t["opacity_b"] is not None else None,
-             color_w=(mk(P, 48) if ctx.wpg else mk(48)) if t["color_w"] is not None else None,
-             color_b=mk(P, 3 if ctx.b_rgb else 48) if t["color_b"] is not None else None)
+             opacity_b=mk(R_) if t["opacity_b"] is not None else None,
+             color_w=(mk(R_, 48) if ctx.wpg else mk(48)) if t["color_w"] is not None else None,
+             color_b=mk(R_, 3 if ctx.b_rgb else 48) if t["color_b"] is not None else None)
     gr = _abi.GhGrads(dL_dimage=_ptr(g), dL_dalpha=_ptr(ga), dL_dmeans3D=_ptr(o["means3D"]), dL_dmeans2D=_ptr(o["means2D"]),
                       dL_dopacities=_ptr(o["opacities"]), dL_dscales=_ptr(o["scales"]), dL_drotations=_ptr(o["rotations"]),
                       dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]), dL_dblend_xyz_b=_ptr(o["xyz_b"]),
@@ -358,13 +367,13 @@ class GaussianRasterizer(nn.Module):
 # ---------------------------------------------------------------------------------------------------
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, want_alpha, xyz, opacity,
+    def forward(ctx, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, want_alpha, per_view, xyz, opacity,
                 scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b):
         kw = dict(colors_precomp=shs.reshape(shs.shape[0], 3)) if use_rgb else dict(shs=shs)
         image, radii, rctx = raster_forward(cams, xyz, opacity, scaling, rotation, H=H, W=W, sh_degree=sh_degree,
                                             scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b,
                                             color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances,
-                                            return_alpha=want_alpha, **kw)
+                                            return_alpha=want_alpha, per_view_gaussians=per_view, **kw)
         ctx.rctx = rctx
         ctx.use_rgb = use_rgb
         ctx.shapes = [None if t is None else t.shape for t in (xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b)]
@@ -383,15 +392,18 @@ class _RasterizeViews(torch.autograd.Function):
         s = ctx.shapes
         col = g["colors_precomp"] if ctx.use_rgb else g["shs"]
         opt = lambda k, i: g[k].reshape(s[i]) if (s[i] is not None and k in g) else None
-        return (None,) * 9 + (g["means3D"].reshape(s[0]), g["opacities"].reshape(s[1]), g["scales"].reshape(s[2]),
+        return (None,) * 10 + (g["means3D"].reshape(s[0]), g["opacities"].reshape(s[1]), g["scales"].reshape(s[2]),
                               g["rotations"].reshape(s[3]), col.reshape(s[4]), opt("xyz_b", 5), opt("opacity_b", 6),
                               opt("color_w", 7), opt("color_b", 8))
 
 
 def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *, H: int, W: int, use_rgb: bool,
                     sh_degree: int = 3, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
-                    color_b=None, sync: bool = True, max_instances: Optional[int] = None, return_alpha: bool = False):
+                    color_b=None, sync: bool = True, max_instances: Optional[int] = None, return_alpha: bool = False,
+                    per_view_gaussians: bool = False):
     """View-batched render with the attribute blend of renderer_one_shot.py:298-334 fused into the kernels.
+    per_view_gaussians=True renders a POSE BATCH: the Gaussian tensors hold Nv*P rows and camera v sees rows
+    [v*P, (v+1)*P) only — the batch loop of GS3DRenderer.forward (renderer_one_shot.py:615-633) in one launch sequence.
 
     cams: (Nv, GH_CAM_FLOATS) from camera.pack_cameras_from_w2c; returns (images (Nv,3,H,W), radii (Nv,P)) or, with
     return_alpha, (images, alpha (Nv,H,W), radii): alpha is the reference's mask render (colour 1, bg 0,
@@ -399,6 +411,7 @@ def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *,
     Differentiable w.r.t. xyz, opacity, scaling, rotation, shs and the blend parameters (through image and alpha).
     """
     image, alpha, radii = _RasterizeViews.apply(cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier),
-                                 bool(use_rgb), bool(sync), max_instances, bool(return_alpha), xyz, opacity, scaling,
+                                 bool(use_rgb), bool(sync), max_instances, bool(return_alpha), bool(per_view_gaussians), xyz, opacity,
+                                 scaling,
                                  rotation, shs, xyz_b, opacity_b, color_w, color_b)
     return (image, alpha, radii) if return_alpha else (image, radii)

@@ -54,6 +54,9 @@ typedef enum GhStatus {
 #define GH_FLAG_NONE 0u
 #define GH_SEGMENT 256 /* depth segment (list entries) of the backward: segments of a tile are processed by different workgroups */
 #define GH_FLAG_BLEND_W_PER_GAUSSIAN 1u /* color_w is (P,48) instead of (48,) — renderer_one_shot_edit.py:489-500 */
+#define GH_FLAG_PER_VIEW_GAUSSIANS 4u /* pose batch (the batch loop of GS3DRenderer.forward, renderer_one_shot.py:615-633): every
+                                         per-Gaussian input / gradient array holds n_views*P rows and view v renders rows
+                                         [v*P, (v+1)*P) only (its own pose); color_w (48,), xyz_b stay shared */
 #define GH_FLAG_BLEND_COLOR_B_RGB 2u    /* colors_precomp mode only: blend_color_b and dL_dblend_color_b are (P,3), the
                                            three columns of the (P,48) view that renderer_one_shot.py:328 reads */
 

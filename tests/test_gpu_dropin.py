@@ -187,3 +187,45 @@ def test_rgb_compact_color_b_equals_padded_reference_layout(dev):
     with pytest.raises(ValueError):
         rasterize_views(cams, sc.xyz, sc.opacity, sc.scaling, sc.rotation, sc.shs, H=sc.H, W=sc.W, use_rgb=True,
                         color_w=sc.color_w, color_b=sc.color_b[:, :5].contiguous())
+
+
+@pytest.mark.parametrize("use_rgb", [True, False])
+def test_pose_batch_equals_per_item_renders(dev, use_rgb):
+    """GH_FLAG_PER_VIEW_GAUSSIANS: a batch of DIFFERENT Gaussian sets (the batch loop of GS3DRenderer.forward,
+    renderer_one_shot.py:615-633), one camera each, in one launch sequence == rendering every item on its own:
+    images bit-identical, per-Gaussian gradients identical, shared blend parameters (color_w, xyz_b) summed."""
+    from guassianhand_amd.rasterizer import rasterize_views
+    from guassianhand_amd.scenes import make_scene
+    B, P = 3, 1500
+    items = [make_scene("random1k", n_views=1, P=P, use_rgb=use_rgb, blend=True, seed=100 + b).to(dev) for b in range(B)]
+    ref = items[0]
+    H, W = ref.H, ref.W
+    cams = torch.cat([it.cams() for it in items])
+    color_w, xyz_b = ref.color_w, torch.tensor([0.004, -0.003, 0.002], device=dev)
+    dimg = torch.randn(B, 3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
+    names = ("xyz", "opacity", "scaling", "rotation", "shs", "opacity_b", "color_b")
+
+    def leaves(ts):
+        return [t.clone().requires_grad_(True) for t in ts]
+
+    # per item
+    per_imgs, per_grads, gw, gx = [], [], 0, 0
+    for b, it in enumerate(items):
+        xs = leaves([getattr(it, k) for k in names])
+        cw, xb = leaves([color_w, xyz_b])
+        img, _ = rasterize_views(cams[b:b + 1], xs[0], xs[1], xs[2], xs[3], xs[4], H=H, W=W, use_rgb=use_rgb, sh_degree=it.sh_degree,
+                                 xyz_b=xb, opacity_b=xs[5], color_w=cw, color_b=xs[6])
+        (img * dimg[b:b + 1]).sum().backward()
+        per_imgs.append(img.detach()); per_grads.append([x.grad for x in xs]); gw = gw + cw.grad; gx = gx + xb.grad
+    # as one pose batch
+    xs = leaves([torch.cat([getattr(it, k) for it in items]) for k in names])
+    cw, xb = leaves([color_w, xyz_b])
+    img, radii = rasterize_views(cams, xs[0], xs[1], xs[2], xs[3], xs[4], H=H, W=W, use_rgb=use_rgb, sh_degree=ref.sh_degree,
+                                 xyz_b=xb, opacity_b=xs[5], color_w=cw, color_b=xs[6], per_view_gaussians=True)
+    (img * dimg).sum().backward()
+    assert radii.shape == (B, P)
+    assert torch.equal(img.detach(), torch.cat(per_imgs))
+    for j, k in enumerate(names):
+        want = torch.cat([g[j] for g in per_grads])
+        assert torch.equal(xs[j].grad, want), k
+    assert torch.allclose(cw.grad, gw, rtol=1e-4, atol=1e-6) and torch.allclose(xb.grad, gx, rtol=1e-4, atol=1e-6)
