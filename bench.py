@@ -55,7 +55,7 @@ def pmc_traffic(kernel: str, args, V: int):
     (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md). Only valid for the workload
     the counters were collected on; otherwise null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if args.config != "two_hands" or V != 8 or not os.path.exists(path):
+    if args.config != "two_hands" or V != 8 or args.pose_batch or not os.path.exists(path):
         return None
     try:
         return json.load(open(path))["kernels"][kernel]["traffic_bytes"]
@@ -67,7 +67,7 @@ def pmc_valu(kernel: str, args, V: int):
     """VALU busy fraction of `kernel` from the committed SQ counter passes (profiles/pmc_sq.json): the render kernels
     are bound by vector-ALU issue, not by HBM, so this is the utilisation that explains a low hbm `frac`."""
     path = os.path.join(ROOT, "profiles", "pmc_sq.json")
-    if args.config != "two_hands" or V != 8 or not os.path.exists(path):
+    if args.config != "two_hands" or V != 8 or args.pose_batch or not os.path.exists(path):
         return None
     try:
         return json.load(open(path))["kernels"][kernel]["valu_busy_frac"]
@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="N>1: also all-reduce the per-Gaussian gradient block every step (what the sharded fit loop does); "
                          "default is the north star's protocol: independent views, RCCL for the scalar loss only")
+    ap.add_argument("--pose-batch", action="store_true",
+                    help="every view of a step is a DIFFERENT pose (its own Gaussian set, BASELINE configs[4] 'mixed poses'): "
+                         "one launch sequence with GH_FLAG_PER_VIEW_GAUSSIANS instead of shared Gaussians seen by all views")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step (forward + loss + backward) in a HIP graph and replay it in the timed loop; for "
                          "launch-bound shapes such as 1 view/step (implies --no-stage-timing, N=1 only)")
@@ -133,17 +136,26 @@ def main():
 
     V = args.views_per_step
     scene_cpu = make_scene(args.config, n_views=V * world)
+    scene_one = scene_cpu                            # one pose: what the CPU baseline renders
     mine = [rank * V + i for i in range(V)]          # weak scaling: V views per rank
+    if args.pose_batch:                              # V poses per rank: concatenate V different scenes, camera v of pose v
+        import dataclasses
+        from guassianhand_amd.scenes import SEED
+        poses = [make_scene(args.config, n_views=V * world, seed=SEED + 1000 * (rank * V + b)) for b in range(V)]
+        cat = lambda k: None if getattr(poses[0], k) is None else torch.cat([getattr(p_, k) for p_ in poses])
+        scene_cpu = dataclasses.replace(poses[0], **{k: cat(k) for k in ("xyz", "opacity", "rotation", "scaling", "shs", "color_b", "opacity_b")})
     s = scene_cpu.to(dev)
     cams = s.cams()[mine].contiguous()
-    H, W, P = s.H, s.W, s.P
+    H, W = s.H, s.W
+    P = s.P // V if args.pose_batch else s.P
+    pv = dict(per_view_gaussians=True) if args.pose_batch else {}
 
     # ground truth = render of a perturbed copy (positions + N(0, 1 mm)), forward only
     gt_xyz = perturbed_target_xyz(scene_cpu).to(dev)
     blend = dict(xyz_b=s.xyz_b, opacity_b=s.opacity_b, color_w=s.color_w, color_b=s.color_b)
     with torch.no_grad():
         gt, _ = R.rasterize_views(cams, gt_xyz, s.opacity, s.scaling, s.rotation, s.shs, H=H, W=W, use_rgb=s.use_rgb,
-                                  sh_degree=s.sh_degree, sync=True, **blend)
+                                  sh_degree=s.sh_degree, sync=True, **blend, **pv)
     gt = gt.detach()
 
     names = ["xyz", "opacity", "scaling", "rotation", "shs"] + [k for k, v in blend.items() if v is not None]
@@ -157,7 +169,7 @@ def main():
         img, _ = R.rasterize_views(cams, params["xyz"], params["opacity"], params["scaling"], params["rotation"],
                                    params["shs"], H=H, W=W, use_rgb=s.use_rgb, sh_degree=s.sh_degree, sync=sync,
                                    xyz_b=params.get("xyz_b"), opacity_b=params.get("opacity_b"),
-                                   color_w=params.get("color_w"), color_b=params.get("color_b"))
+                                   color_w=params.get("color_w"), color_b=params.get("color_b"), **pv)
         loss = l1_mean_loss(img, gt)                 # mean|img - gt| and dL/dimg in one fused pass (gh_l1_loss)
         loss.backward()
         if world > 1:
@@ -223,8 +235,8 @@ def main():
     if rank == 0:
         # instance count of the published algorithm (every tile of the 3-sigma rects) beside the exactly culled one
         with torch.no_grad():
-            col = dict(colors_precomp=s.shs.reshape(P, 3)) if s.use_rgb else dict(shs=s.shs, sh_degree=s.sh_degree)
-            _, _, rctx = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=H, W=W, sync=True, **col, **blend)
+            col = dict(colors_precomp=s.shs.reshape(-1, 3)) if s.use_rgb else dict(shs=s.shs, sh_degree=s.sh_degree)
+            _, _, rctx = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=H, W=W, sync=True, **col, **blend, **pv)
             rect = R.workspace_views(rctx)["rect"].long()
             D_rect = int((((rect >> 16 & 255) - (rect & 255)) * ((rect >> 24 & 255) - (rect >> 8 & 255))).sum())
             del rctx
@@ -249,7 +261,8 @@ def main():
             "config": {"workload": f"{args.config}: P={P} Gaussians, {H}x{W}, "
                                    f"{'RGB colours' if s.use_rgb else 'SH degree %d colours' % s.sh_degree}, attribute blend "
                                    f"{'on' if s.color_w is not None else 'off'}"
-                                   + (" (BASELINE configs[2])" if args.config == "two_hands" else ""),
+                                   + (" (BASELINE configs[2])" if args.config == "two_hands" and not args.pose_batch else "")
+                                   + (", pose batch: every view its own Gaussian set" if args.pose_batch else ""),
                        "views_per_step_per_gpu": V, "instances_per_step_per_gpu": D,
                        "instances_in_3sigma_rects": D_rect, "parallelism": f"view-parallel x{world}",
                        "collective": None if world == 1 else ("all-reduce(loss + gradient block)" if args.allreduce_grads
@@ -260,7 +273,7 @@ def main():
             "roofline": roofline, "stages": stages,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene_cpu, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(scene_one, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
