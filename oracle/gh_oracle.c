@@ -252,6 +252,9 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
   const int P = d->P, NV = d->n_views, H = d->H, W = d->W;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, tiles = gx * gy;
   if (gx > 255 || gy > 255 || d->sh_degree > 3) return GH_ERR_UNSUPPORTED;
+  /* layout variants of the product (compact colour biases, pose batch) are checked against this oracle through their
+   * reference-layout equivalents (tests/test_gpu_dropin.py); the oracle itself only speaks the reference layouts */
+  if (d->flags & ~GH_FLAG_BLEND_W_PER_GAUSSIAN) return GH_ERR_UNSUPPORTED;
   GhoCtx* c = (GhoCtx*)calloc(1, sizeof(GhoCtx));
   c->dims = *d;
   c->g = (GView*)calloc((size_t)NV * P + 1, sizeof(GView));
