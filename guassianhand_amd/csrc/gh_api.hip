@@ -58,7 +58,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->final_C = take(pix * 16);
   L->final_T = take(pix * 4);
   L->n_contrib = take(pix * 4);
-  L->inst_grad = take(cap * 4 * GH_REC * 4);
+  L->inst_grad = take(cap * 4 * GH_REC_G * 4);
   L->inst_flag = take(cap * 4);
   const bool sh_mode = d->M != 0;
   L->sh_rgb = take(sh_mode ? N * 16 : 0);

@@ -10,7 +10,10 @@
 #define GH_BLOCK 256                 // 4 waves: one 8x8 pixel quadrant of a 16x16 tile per wave
 #define GH_SORT_ITEMS 16             // keys per thread per radix pass
 #define GH_SORT_TILE (GH_BLOCK * GH_SORT_ITEMS)
-#define GH_REC 12                    // floats per per-instance gradient record (9 used)
+#define GH_REC 12                    // LDS stride (floats) of a partial gradient record (9 used; float4-aligned)
+#define GH_REC_G 9                   // floats per (instance, quadrant) sub-record in HBM: packed, three 12-byte accesses
+
+struct GhF3 { float x, y, z; };      // 12-byte access (global_load/store_dwordx3)
 
 struct GhGrid {
   int P, NV, H, W, gx, gy, tiles, N;  // N = NV*P

@@ -148,10 +148,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if ((f >> (8 * q)) & 1u) {
-        const float4* r = (const float4*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC);
-        const float4 r0 = r[0], r1 = r[1]; const float r2 = r[2].x;
-        s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r0.w;
-        s9[4] += r1.x; s9[5] += r1.y; s9[6] += r1.z; s9[7] += r1.w; s9[8] += r2;
+        const GhF3* r = (const GhF3*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC_G);
+        const GhF3 r0 = r[0], r1 = r[1], r2 = r[2];
+        s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r1.x; s9[4] += r1.y;
+        s9[5] += r1.z; s9[6] += r2.x; s9[7] += r2.y; s9[8] += r2.z;
       }
     }
   }

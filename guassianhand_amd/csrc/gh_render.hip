@@ -418,10 +418,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
         }
         if (any) {
           const uint32_t sl = slots[pos];
-          float4* rec = (float4*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC);
-          rec[0] = make_float4(s9[0], s9[1], s9[2], s9[3]);
-          rec[1] = make_float4(s9[4], s9[5], s9[6], s9[7]);
-          rec[2] = make_float4(s9[8], 0.0f, 0.0f, 0.0f);
+          GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC_G);
+          rec[0] = GhF3{s9[0], s9[1], s9[2]};
+          rec[1] = GhF3{s9[3], s9[4], s9[5]};
+          rec[2] = GhF3{s9[6], s9[7], s9[8]};
           inst_flag[(size_t)sl * 4 + quad] = 1;
         }
       }

@@ -159,7 +159,7 @@ typedef struct GhLayout {
   size_t final_C;        /* float4[n_views*H*W] colour accumulated by the forward, without background */
   size_t final_T;        /* float [n_views*H*W] */
   size_t n_contrib;      /* uint32[n_views*H*W] */
-  size_t inst_grad;      /* float[max_instances][4][12] per-(instance, quadrant) gradient sub-records (backward scratch) */
+  size_t inst_grad;      /* float[max_instances][4][9] per-(instance, quadrant) gradient sub-records (backward scratch) */
   size_t inst_flag;      /* uint8[max_instances][4]     1 where the quadrant wrote its sub-record (zeroed per backward) */
   size_t sh_rgb;         /* float4[n_views*P] SH colour stage output (r, g, b, clamp-flag bits); unused with colors_precomp */
   size_t dmean_sh;       /* float4[n_views*P] d(loss)/d(mean) through the SH view direction (backward scratch) */
