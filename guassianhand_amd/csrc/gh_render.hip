@@ -99,7 +99,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float P3 = P2 * gh_quad_bcast<2>(f);
     const float P4 = P3 * gh_quad_bcast<3>(f);
     const float Pm = slot == 0 ? p.T : (slot == 1 ? P1 : (slot == 2 ? P2 : P3));   // T seen by this lane's entry
-    const float Pn = slot == 0 ? P1 : (slot == 1 ? P2 : (slot == 2 ? P3 : P4));   // ... and right after it
+    const float Pn = Pm * f;                 // ... and right after it: the same product as P_{slot+1} (own f == its broadcast)
     // Early stop (App. A.3): the FIRST entry of a pixel with T(1-alpha) < 1e-4 is not blended and ends the pixel.
     // Up to and including that entry the prefix products above are exactly the sequential ones, so the stop slot, the
     // entries blended before it and the T they leave behind are all read off the same values; flags of later slots
@@ -120,11 +120,11 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     p.C2 = ((((p.C2 + gh_quad_bcast<0>(m2)) + gh_quad_bcast<1>(m2)) + gh_quad_bcast<2>(m2)) + gh_quad_bcast<3>(m2));
     if (ALPHA) p.A = ((((p.A + gh_quad_bcast<0>(w)) + gh_quad_bcast<1>(w)) + gh_quad_bcast<2>(w)) + gh_quad_bcast<3>(w));
     p.T = Tn;
-    // n_contrib: position of the last blended entry = highest blended slot of the pixel (entries ascend with slot; the
-    // four positions are wave-uniform scalars)
+    // n_contrib: position of the last blended entry = highest blended slot of the pixel (entries ascend with slot).
+    // Branch-free: highest set bit of the pixel's blend flags selects the entry lane from the packed scalar.
     const uint32_t qbl = (uint32_t)(__ballot(blend) >> (lane & 60)) & 0xFu;
-    const uint32_t lm = (qbl & 8u) ? (uint32_t)(base + j3 + 1) : ((qbl & 4u) ? (uint32_t)(base + j2 + 1)
-                      : ((qbl & 2u) ? (uint32_t)(base + j1 + 1) : ((qbl & 1u) ? (uint32_t)(base + j0 + 1) : 0u)));
+    const uint32_t hb = 31u - (uint32_t)__builtin_clz(qbl | 1u);
+    const uint32_t lm = qbl ? (uint32_t)base + 1u + ((packed4 >> (hb * 8u)) & 0xFFu) / 4u : 0u;
     p.last = lm > p.last ? lm : p.last;
     if (sb && __all(p.done != 0)) return true;                     // every pixel of the block is saturated
   }
