@@ -63,6 +63,18 @@ __device__ __forceinline__ int gh_quad_bcast_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xF, 0xF, false);
 }
 
+// acc = (((acc + m[slot 0]) + m[slot 1]) + m[slot 2]) + m[slot 3] over the lane's quad: four DPP-fused adds. Written as
+// assembly because the compiler lowers the equivalent intrinsics to v_mov 0 + v_mov_dpp + v_add per term (3x the
+// instructions). The s_nop covers the VALU-write -> DPP-read hazard on m (2 wait states); acc is the non-DPP operand.
+__device__ __forceinline__ void gh_quad_accumulate(float& acc, float m) {
+  asm volatile("s_nop 1\n\t"
+               "v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+               "v_add_f32_dpp %0, %1, %0 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+               : "+v"(acc) : "v"(m));
+}
+
 __device__ __forceinline__ float gh_lane_fetch(float v, int src_lane_x4) {   // per-lane source (LDS crossbar, no LDS memory)
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane_x4, __builtin_bit_cast(int, v)));
 }
@@ -115,10 +127,10 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     }
     const float w = blend ? alpha * Pm : 0.0f;                     // C + c*0 == C exactly
     const float m0 = r * w, m1 = g * w, m2 = bl * w;
-    p.C0 = ((((p.C0 + gh_quad_bcast<0>(m0)) + gh_quad_bcast<1>(m0)) + gh_quad_bcast<2>(m0)) + gh_quad_bcast<3>(m0));
-    p.C1 = ((((p.C1 + gh_quad_bcast<0>(m1)) + gh_quad_bcast<1>(m1)) + gh_quad_bcast<2>(m1)) + gh_quad_bcast<3>(m1));
-    p.C2 = ((((p.C2 + gh_quad_bcast<0>(m2)) + gh_quad_bcast<1>(m2)) + gh_quad_bcast<2>(m2)) + gh_quad_bcast<3>(m2));
-    if (ALPHA) p.A = ((((p.A + gh_quad_bcast<0>(w)) + gh_quad_bcast<1>(w)) + gh_quad_bcast<2>(w)) + gh_quad_bcast<3>(w));
+    gh_quad_accumulate(p.C0, m0);              // C = (((C + m[slot 0]) + m[slot 1]) + m[slot 2]) + m[slot 3], in list order
+    gh_quad_accumulate(p.C1, m1);
+    gh_quad_accumulate(p.C2, m2);
+    if (ALPHA) gh_quad_accumulate(p.A, w);
     p.T = Tn;
     // n_contrib: position of the last blended entry = highest blended slot of the pixel (entries ascend with slot).
     // Branch-free: highest set bit of the pixel's blend flags selects the entry lane from the packed scalar.
