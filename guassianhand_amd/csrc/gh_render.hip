@@ -75,6 +75,16 @@ __device__ __forceinline__ void gh_quad_accumulate(float& acc, float m) {
                : "+v"(acc) : "v"(m));
 }
 
+// P1 = T * f[slot 0], P2 = P1 * f[slot 1], P3 = P2 * f[slot 2] (f[slot k] = the quad's lane k): the sequential prefix
+// products of the recurrence as three DPP-fused multiplies (assembly for the same reason as above).
+__device__ __forceinline__ void gh_quad_prefix3(float T, float f, float& P1, float& P2, float& P3) {
+  asm volatile("s_nop 1\n\t"
+               "v_mul_f32_dpp %0, %3, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+               "v_mul_f32_dpp %1, %3, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+               "v_mul_f32_dpp %2, %3, %1 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+               : "=&v"(P1), "=&v"(P2), "=&v"(P3) : "v"(f), "v"(T));
+}
+
 __device__ __forceinline__ float gh_lane_fetch(float v, int src_lane_x4) {   // per-lane source (LDS crossbar, no LDS memory)
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane_x4, __builtin_bit_cast(int, v)));
 }
@@ -106,12 +116,11 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     // The recurrence collapses to DPP-fused prefix products / sums over the quad, in exact list order.
     const bool valid = (p.done == 0) && ok;
     const float f = valid ? 1.0f - alpha : 1.0f;                   // x*1 == x: skipped entries leave T bit-identical
-    const float P1 = p.T * gh_quad_bcast<0>(f);                    // T before slot 1, 2, 3 and after the trip
-    const float P2 = P1 * gh_quad_bcast<1>(f);
-    const float P3 = P2 * gh_quad_bcast<2>(f);
-    const float P4 = P3 * gh_quad_bcast<3>(f);
+    float P1, P2, P3;                                              // T before slot 1, 2, 3: three DPP-fused multiplies
+    gh_quad_prefix3(p.T, f, P1, P2, P3);
     const float Pm = slot == 0 ? p.T : (slot == 1 ? P1 : (slot == 2 ? P2 : P3));   // T seen by this lane's entry
     const float Pn = Pm * f;                 // ... and right after it: the same product as P_{slot+1} (own f == its broadcast)
+    const float P4 = gh_quad_bcast<3>(Pn);   // T after the trip
     // Early stop (App. A.3): the FIRST entry of a pixel with T(1-alpha) < 1e-4 is not blended and ends the pixel.
     // Up to and including that entry the prefix products above are exactly the sequential ones, so the stop slot, the
     // entries blended before it and the T they leave behind are all read off the same values; flags of later slots
