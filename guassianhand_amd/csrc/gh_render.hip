@@ -67,7 +67,7 @@ __device__ __forceinline__ int gh_quad_bcast_i(int v) {
 // assembly because the compiler lowers the equivalent intrinsics to v_mov 0 + v_mov_dpp + v_add per term (3x the
 // instructions). The s_nop covers the VALU-write -> DPP-read hazard on m (2 wait states); acc is the non-DPP operand.
 __device__ __forceinline__ void gh_quad_accumulate(float& acc, float m) {
-  asm volatile("s_nop 1\n\t"
+  asm("s_nop 1\n\t"
                "v_add_f32_dpp %0, %1, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
                "v_add_f32_dpp %0, %1, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
                "v_add_f32_dpp %0, %1, %0 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -75,10 +75,23 @@ __device__ __forceinline__ void gh_quad_accumulate(float& acc, float m) {
                : "+v"(acc) : "v"(m));
 }
 
+// Value for this lane's slot: a0 in slot-0 lanes, a1 in slot-1 lanes, ... (lane = 4*pixel + slot, so the lane sets are
+// the constant masks 0x1111.., 0x2222.., ...). Three v_cndmask with literal lane masks; the compiler otherwise turns
+// the nested ?: into exec-mask branches.
+__device__ __forceinline__ float gh_slot_select(float a0, float a1, float a2, float a3) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %5\n\t"
+               "v_cndmask_b32_e64 %0, %0, %3, %6\n\t"
+               "v_cndmask_b32_e64 %0, %0, %4, %7"
+               : "=&v"(r) : "v"(a0), "v"(a1), "v"(a2), "v"(a3),
+                 "s"(0x2222222222222222ull), "s"(0x4444444444444444ull), "s"(0x8888888888888888ull));
+  return r;
+}
+
 // P1 = T * f[slot 0], P2 = P1 * f[slot 1], P3 = P2 * f[slot 2] (f[slot k] = the quad's lane k): the sequential prefix
 // products of the recurrence as three DPP-fused multiplies (assembly for the same reason as above).
 __device__ __forceinline__ void gh_quad_prefix3(float T, float f, float& P1, float& P2, float& P3) {
-  asm volatile("s_nop 1\n\t"
+  asm("s_nop 1\n\t"
                "v_mul_f32_dpp %0, %3, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
                "v_mul_f32_dpp %1, %3, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
                "v_mul_f32_dpp %2, %3, %1 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
@@ -118,7 +131,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float f = valid ? 1.0f - alpha : 1.0f;                   // x*1 == x: skipped entries leave T bit-identical
     float P1, P2, P3;                                              // T before slot 1, 2, 3: three DPP-fused multiplies
     gh_quad_prefix3(p.T, f, P1, P2, P3);
-    const float Pm = slot == 0 ? p.T : (slot == 1 ? P1 : (slot == 2 ? P2 : P3));   // T seen by this lane's entry
+    const float Pm = gh_slot_select(p.T, P1, P2, P3);             // T seen by this lane's entry
     const float Pn = Pm * f;                 // ... and right after it: the same product as P_{slot+1} (own f == its broadcast)
     const float P4 = gh_quad_bcast<3>(Pn);   // T after the trip
     // Early stop (App. A.3): the FIRST entry of a pixel with T(1-alpha) < 1e-4 is not blended and ends the pixel.
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       const float ac0 = contrib ? alpha * cr : 0.0f, ac1 = contrib ? alpha * cg : 0.0f, ac2 = contrib ? alpha * cbl : 0.0f;
       const float T1 = st.T * gh_quad_bcast<0>(f), T2 = T1 * gh_quad_bcast<1>(f), T3 = T2 * gh_quad_bcast<2>(f),
                   T4 = T3 * gh_quad_bcast<3>(f);
-      const float mTn = slot == 0 ? T1 : (slot == 1 ? T2 : (slot == 2 ? T3 : T4));      // T right after this lane's entry
+      const float mTn = gh_slot_select(T1, T2, T3, T4);                                  // T right after this lane's entry
 #define GH_B_CHAIN(B, A, MINE)                                                              \
       float MINE;                                                                           \
       {                                                                                     \
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
         const float b2 = b1 * gh_quad_bcast<1>(m) + gh_quad_bcast<1>(A);                    \
         const float b3 = b2 * gh_quad_bcast<2>(m) + gh_quad_bcast<2>(A);                    \
         const float b4 = b3 * gh_quad_bcast<3>(m) + gh_quad_bcast<3>(A);                    \
-        MINE = slot == 0 ? B : (slot == 1 ? b1 : (slot == 2 ? b2 : b3));   /* colour behind this lane's entry */ \
+        MINE = gh_slot_select(B, b1, b2, b3);   /* colour behind this lane's entry */ \
         B = b4;                                                                             \
       }
       GH_B_CHAIN(st.B0, ac0, mB0)
