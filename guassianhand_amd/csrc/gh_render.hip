@@ -75,6 +75,22 @@ __device__ __forceinline__ void gh_quad_accumulate(float& acc, float m) {
                : "+v"(acc) : "v"(m));
 }
 
+// b1 = B*m[0] + a[0], b2 = b1*m[1] + a[1], b3 = b2*m[2] + a[2], b4 = b3*m[3] + a[3]  (x[k] = the quad's lane k): the backward's
+// affine recurrence over the four slots as eight DPP-fused instructions.
+__device__ __forceinline__ void gh_quad_affine4(float B, float m, float a, float& b1, float& b2, float& b3, float& b4) {
+  float t;
+  asm("s_nop 1\n\t"
+      "v_mul_f32_dpp %4, %5, %7 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %6, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %4, %5, %0 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %6, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %4, %5, %1 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %6, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_mul_f32_dpp %4, %5, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %6, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+      : "=&v"(b1), "=&v"(b2), "=&v"(b3), "=&v"(b4), "=&v"(t) : "v"(m), "v"(a), "v"(B));
+}
+
 // Value for this lane's slot: a0 in slot-0 lanes, a1 in slot-1 lanes, ... (lane = 4*pixel + slot, so the lane sets are
 // the constant masks 0x1111.., 0x2222.., ...). Three v_cndmask with literal lane masks; the compiler otherwise turns
 // the nested ?: into exec-mask branches.
@@ -382,11 +398,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
 #define GH_B_CHAIN(B, A, MINE)                                                              \
       float MINE;                                                                           \
       {                                                                                     \
-        const float b1 = B * gh_quad_bcast<0>(m) + gh_quad_bcast<0>(A);                     \
-        const float b2 = b1 * gh_quad_bcast<1>(m) + gh_quad_bcast<1>(A);                    \
-        const float b3 = b2 * gh_quad_bcast<2>(m) + gh_quad_bcast<2>(A);                    \
-        const float b4 = b3 * gh_quad_bcast<3>(m) + gh_quad_bcast<3>(A);                    \
-        MINE = gh_slot_select(B, b1, b2, b3);   /* colour behind this lane's entry */ \
+        float b1, b2, b3, b4;                                                               \
+        gh_quad_affine4(B, m, A, b1, b2, b3, b4);                                           \
+        MINE = gh_slot_select(B, b1, b2, b3);   /* colour behind this lane's entry */       \
         B = b4;                                                                             \
       }
       GH_B_CHAIN(st.B0, ac0, mB0)
