@@ -432,8 +432,26 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       r[2] = hx * dx; r[3] = hx * dy; r[4] = hy * dy;
       r[5] = h;
       r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
+      // Sum every value over the 16 pixels of each slot. In-row half with DPP: lanes 12..15 of each row then hold the row's
+      // sums for slots 0..3. Before the cross-row half (the LDS crossbar, by far the most expensive step) four values are
+      // PACKED into one register — value 4g+1 / +2 / +3 moves to lanes 8..11 / 4..7 / 0..3 of its row with bank-masked
+      // row shifts — so the xor-16 / xor-32 butterfly runs 3 times per trip instead of 9.
 #pragma unroll
-      for (int q = 0; q < 9; ++q) r[q] = gh_slot_sum16(r[q], lane);
+      for (int q = 0; q < 9; ++q) { r[q] += gh_dpp<0x114>(r[q]); r[q] += gh_dpp<0x118>(r[q]); }
+      float R[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        int pk = __builtin_bit_cast(int, r[4 * g]);
+        if (g < 2) {
+          pk = __builtin_amdgcn_update_dpp(pk, __builtin_bit_cast(int, r[4 * g + 1]), 0x104, 0xF, 0x4, false);   // row_shl:4  -> bank 2
+          pk = __builtin_amdgcn_update_dpp(pk, __builtin_bit_cast(int, r[4 * g + 2]), 0x108, 0xF, 0x2, false);   // row_shl:8  -> bank 1
+          pk = __builtin_amdgcn_update_dpp(pk, __builtin_bit_cast(int, r[4 * g + 3]), 0x10C, 0xF, 0x1, false);   // row_shl:12 -> bank 0
+        }
+        float v = __builtin_bit_cast(float, pk);
+        v += gh_lane_fetch(v, (lane ^ 16) << 2);
+        v += gh_lane_fetch(v, (lane ^ 32) << 2);             // every row: bank b holds the total of value 4g + 3 - b, slot = lane & 3
+        R[g] = v;
+      }
       // slots in which at least one pixel blended its entry get a partial record (wave-uniform bookkeeping)
       const bool a0 = (cm & 0x1111111111111111ull) != 0, a1 = (cm & 0x2222222222222222ull) != 0;
       const bool a2 = (cm & 0x4444444444444444ull) != 0, a3 = (cm & 0x8888888888888888ull) != 0;
@@ -442,11 +460,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       if (a2) processed |= 1ull << j2;
       if (a3) processed |= 1ull << j3;
       const bool mine = slot == 0 ? a0 : (slot == 1 ? a1 : (slot == 2 ? a2 : a3));
-      if (lane >= 60 && mine) {                                        // lanes 60..63 hold slot 0..3's totals
-        float4* pr = (float4*)&s_part[buf][wid][myj][0];
-        pr[0] = make_float4(r[0], r[1], r[2], r[3]);
-        pr[1] = make_float4(r[4], r[5], r[6], r[7]);
-        s_part[buf][wid][myj][8] = r[8];
+      if (lane >= 48 && mine) {                                        // row 3: lane 48 + 4b + slot holds values 3-b, 7-b (and 8 for b = 3)
+        float* pr = &s_part[buf][wid][myj][0];
+        const int q0 = 3 - ((lane >> 2) & 3);
+        pr[q0] = R[0];
+        pr[4 + q0] = R[1];
+        if (lane >= 60) pr[8] = R[2];
       }
     }
     if (lane == 0) s_mask[buf][wid] = processed;
