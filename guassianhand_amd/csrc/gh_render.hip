@@ -58,6 +58,10 @@ template <int S>
 __device__ __forceinline__ float gh_quad_bcast(float v) {     // value of the quad's lane S, in all 4 lanes
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), S * 0x55, 0xF, 0xF, false));
 }
+template <int CTRL>
+__device__ __forceinline__ int gh_quad_perm_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
 template <int S>
 __device__ __forceinline__ int gh_quad_bcast_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xF, 0xF, false);
@@ -170,12 +174,9 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     gh_quad_accumulate(p.C2, m2);
     if (ALPHA) gh_quad_accumulate(p.A, w);
     p.T = Tn;
-    // n_contrib: position of the last blended entry = highest blended slot of the pixel (entries ascend with slot).
-    // Branch-free: highest set bit of the pixel's blend flags selects the entry lane from the packed scalar.
-    const uint32_t qbl = (uint32_t)(__ballot(blend) >> (lane & 60)) & 0xFu;
-    const uint32_t hb = 31u - (uint32_t)__builtin_clz(qbl | 1u);
-    const uint32_t lm = qbl ? (uint32_t)base + 1u + ((packed4 >> (hb * 8u)) & 0xFFu) / 4u : 0u;
-    p.last = lm > p.last ? lm : p.last;
+    // n_contrib: every lane remembers the last entry of ITS slot that was blended; the pixel's value is the maximum
+    // over its four lanes, taken once after the walk.
+    p.last = blend ? (uint32_t)(base + 1) + (uint32_t)(src >> 2) : p.last;   // per LANE (positions ascend); quad max at the end
     if (sb && __all(p.done != 0)) return true;                     // every pixel of the block is saturated
   }
   return false;
@@ -226,6 +227,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
         ckpt_rgb[ck] = make_float4(p.T, p.C0, p.C1, p.C2);
       }
     }
+  }
+  {                                                  // n_contrib of the pixel = max over the four slot lanes of its quad
+    const uint32_t a = (uint32_t)gh_quad_perm_i<0xB1>((int)p.last);      // quad_perm [1,0,3,2]
+    p.last = a > p.last ? a : p.last;
+    const uint32_t b = (uint32_t)gh_quad_perm_i<0x4E>((int)p.last);      // quad_perm [2,3,0,1]
+    p.last = b > p.last ? b : p.last;
   }
   if (total > 0) {                                   // walked length of the tile = max n_contrib (orders the backward)
     uint32_t m = p.last;
