@@ -460,14 +460,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
         R[g] = v;
       }
       // slots in which at least one pixel blended its entry get a partial record (wave-uniform bookkeeping)
-      const bool a0 = (cm & 0x1111111111111111ull) != 0, a1 = (cm & 0x2222222222222222ull) != 0;
-      const bool a2 = (cm & 0x4444444444444444ull) != 0, a3 = (cm & 0x8888888888888888ull) != 0;
-      if (a0) processed |= 1ull << j0;
-      if (a1) processed |= 1ull << j1;
-      if (a2) processed |= 1ull << j2;
-      if (a3) processed |= 1ull << j3;
-      const bool mine = slot == 0 ? a0 : (slot == 1 ? a1 : (slot == 2 ? a2 : a3));
-      if (lane >= 48 && mine) {                                        // row 3: lane 48 + 4b + slot holds values 3-b, 7-b (and 8 for b = 3)
+      uint64_t wm = 0;                                   // lanes of the slots that get a record (scalar arithmetic)
+      if (cm & 0x1111111111111111ull) { processed |= 1ull << j0; wm |= 0x1111000000000000ull; }
+      if (cm & 0x2222222222222222ull) { processed |= 1ull << j1; wm |= 0x2222000000000000ull; }
+      if (cm & 0x4444444444444444ull) { processed |= 1ull << j2; wm |= 0x4444000000000000ull; }
+      if (cm & 0x8888888888888888ull) { processed |= 1ull << j3; wm |= 0x8888000000000000ull; }
+      if ((wm >> lane) & 1ull) {                                        // row 3: lane 48 + 4b + slot holds values 3-b, 7-b (and 8 for b = 3)
         float* pr = &s_part[buf][wid][myj][0];
         const int q0 = 3 - ((lane >> 2) & 3);
         pr[q0] = R[0];
