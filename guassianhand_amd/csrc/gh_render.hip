@@ -392,13 +392,15 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       const uint64_t cm = __ballot(contrib);
       if (cm == 0) continue;                                           // wave-uniform: nothing blended by this block
       // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
-      const float inv1ma = __builtin_amdgcn_rcpf(1.0f - alpha);
       // Reverse recurrence over the quad as DPP-fused prefix products / affine updates, in exact processing order:
       //   T <- T * f,  B <- B * m + a   with (f, m, a) = (1/(1-alpha), 1-alpha, alpha*c) where the pixel blended the
-      //   entry and (1, 1, 0) otherwise (x*1 and x+0 leave the state bit-identical).
-      const float f = contrib ? inv1ma : 1.0f;
-      const float m = contrib ? 1.0f - alpha : 1.0f;
-      const float ac0 = contrib ? alpha * cr : 0.0f, ac1 = contrib ? alpha * cg : 0.0f, ac2 = contrib ? alpha * cbl : 0.0f;
+      //   entry and (1, 1, 0) otherwise (x*1 and x+0 leave the state bit-identical). One select does it all: with the
+      //   EFFECTIVE alpha = 0 for pixels that did not blend the entry, m = 1, f = rcp(1) = 1 and a = 0 fall out exactly.
+      const float ae = contrib ? alpha : 0.0f;
+      const float m = 1.0f - ae;
+      const float inv1ma = __builtin_amdgcn_rcpf(m);      // v_rcp_f32 (<= 1 ulp; exact for 1). Gradients carry a 1e-3 rtol.
+      const float f = inv1ma;
+      const float ac0 = ae * cr, ac1 = ae * cg, ac2 = ae * cbl;
       const float T1 = st.T * gh_quad_bcast<0>(f), T2 = T1 * gh_quad_bcast<1>(f), T3 = T2 * gh_quad_bcast<2>(f),
                   T4 = T3 * gh_quad_bcast<3>(f);
       const float mTn = gh_slot_select(T1, T2, T3, T4);                                  // T right after this lane's entry
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       GH_B_CHAIN(st.B2, ac2, mB2)
       float mB3 = 0.0f;
       if (ALPHA) {
-        const float ac3 = contrib ? alpha : 0.0f;
+        const float ac3 = ae;
         GH_B_CHAIN(st.B3, ac3, mB3x)
         mB3 = mB3x;
       }
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       // App. A.4-2): 6 multiplies here instead of 20.
       const float h = G * dL_dalpha;
       const float hx = h * dx, hy = h * dy;
-      const float dchannel_dcolor = contrib ? alpha * mTn : 0.0f;
+      const float dchannel_dcolor = ae * mTn;
       float r[9];
       r[0] = hx; r[1] = hy;
       r[2] = hx * dx; r[3] = hx * dy; r[4] = hy * dy;
