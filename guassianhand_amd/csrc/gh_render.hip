@@ -58,6 +58,9 @@ template <int S>
 __device__ __forceinline__ float gh_quad_bcast(float v) {     // value of the quad's lane S, in all 4 lanes
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), S * 0x55, 0xF, 0xF, false));
 }
+// wave64 ballot of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0/1 integer first)
+__device__ __forceinline__ uint64_t gh_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 template <int CTRL>
 __device__ __forceinline__ int gh_quad_perm_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
@@ -128,9 +131,10 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
                                                float pxf, float pyf, GhPixelFwd& p) {
   const uint32_t slot8 = (uint32_t)slot * 8u;
   const bool hit = (base + lane < total) && ((t.blocks >> blk) & 1u);
-  uint64_t mask = __ballot(hit);
+  uint64_t mask = gh_ballot(hit);
   while (mask) {
     // next four set bits, ascending (wave-uniform scalar work)
+    const int nh = __builtin_popcountll(mask);                      // entries left in this batch (>= 1)
     const int j0 = __builtin_ctzll(mask); mask &= mask - 1;
     const int n1 = mask != 0; const int j1 = n1 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
     const int n2 = mask != 0; const int j2 = n2 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
@@ -138,7 +142,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     // the four entry lanes travel as bytes of one scalar: a lane extracts its slot's with a single v_bfe
     const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
     const int src = (int)((packed4 >> slot8) & 0xFFu);              // 4 * entry lane = ds_bpermute address
-    const bool have = slot < 1 + n1 + n2 + n3;
+    const bool have = slot < nh;
     const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
     const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src), op = gh_lane_fetch(t.b.y, src);
     const float r = gh_lane_fetch(t.b.z, src), g = gh_lane_fetch(t.b.w, src), bl = gh_lane_fetch(t.cb, src);
@@ -160,7 +164,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     // (computed from products that never happen) are masked by the first one.
     bool blend = valid;
     float Tn = P4;
-    const uint64_t sb = __ballot(valid && Pn < 0.0001f);
+    const uint64_t sb = gh_ballot(valid && Pn < 0.0001f);
     if (sb) {                                                      // wave-uniform, rare
       const uint32_t qb = (uint32_t)(sb >> (lane & 60)) & 0xFu;   // stop flags of this pixel's four slots
       blend = valid && ((qb & ((2u << slot) - 1u)) == 0u);         // no stop at or before this slot
@@ -370,9 +374,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const int sbase = seg_lo + k * GH_WAVE;
     gh_load_batch(nxt, r0, r1, r2, seg_lo + (k > 0 ? (k - 1) * GH_WAVE : 0) + lane, qend);   // next batch in flight
     uint64_t processed = 0;
-    uint64_t mask = __ballot((sbase + lane < wave_last) && ((cur.blocks >> blk) & 1u));
+    uint64_t mask = gh_ballot((sbase + lane < wave_last) && ((cur.blocks >> blk) & 1u));
     while (mask) {
       // next four set bits, descending (back to front); wave-uniform scalar work
+      const int nh = __builtin_popcountll(mask);                     // entries left in this batch (>= 1)
       const int j0 = 63 - __builtin_clzll(mask); mask &= ~(1ull << j0);
       const int n1 = mask != 0; const int j1 = n1 ? 63 - __builtin_clzll(mask) : j0; if (n1) mask &= ~(1ull << j1);
       const int n2 = mask != 0; const int j2 = n2 ? 63 - __builtin_clzll(mask) : j0; if (n2) mask &= ~(1ull << j2);
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
       const int src = (int)((packed4 >> slot8) & 0xFFu);            // one v_bfe: 4 * this slot's entry lane
       const int myj = src >> 2;
-      const bool have = slot < 1 + n1 + n2 + n3;
+      const bool have = slot < nh;
       const float gpx = gh_lane_fetch(cur.a.x, src), gpy = gh_lane_fetch(cur.a.y, src), cA = gh_lane_fetch(cur.a.z, src);
       const float cB = gh_lane_fetch(cur.a.w, src), cC = gh_lane_fetch(cur.b.x, src), op = gh_lane_fetch(cur.b.y, src);
       const float cr = gh_lane_fetch(cur.b.z, src), cg = gh_lane_fetch(cur.b.w, src), cbl = gh_lane_fetch(cur.cb, src);
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       const float G = gh_exp(fminf(power, 0.0f));
       const float alpha = fminf(0.99f, op * G);
       const bool contrib = have && (sbase + myj < last) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-      const uint64_t cm = __ballot(contrib);
+      const uint64_t cm = gh_ballot(contrib);
       if (cm == 0) continue;                                           // wave-uniform: nothing blended by this block
       // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
       // Reverse recurrence over the quad as DPP-fused prefix products / affine updates, in exact processing order:
