@@ -119,12 +119,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     const bool valid = idx < n;
     key[r] = valid ? keys_in[idx] : ~0u;
     const uint32_t dg = (key[r] >> shift) & dmask;
-    uint64_t peers = __ballot(valid);
+    uint64_t peers = gh_ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
       if ((dmask >> b) & 1u) {                  // wave-uniform: only the bits of this pass
         const bool bit = (dg >> b) & 1u;
-        const uint64_t m = __ballot(bit);
+        const uint64_t m = gh_ballot(bit);
         peers &= bit ? m : ~m;
       }
     }

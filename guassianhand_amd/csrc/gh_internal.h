@@ -266,6 +266,9 @@ __device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const floa
   return nonfinite ? 0xFFFFu : m;
 }
 
+// wave64 ballot of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0/1 integer first)
+__device__ __forceinline__ uint64_t gh_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // ---- wave64 cross-lane helpers (DPP; no LDS traffic) ------------------------------------------------
 // DPP controls (gfx9 encoding): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_ror:n 0x120+n,
 // row_mirror 0x140, row_half_mirror 0x141, row_bcast15 0x142, row_bcast31 0x143.

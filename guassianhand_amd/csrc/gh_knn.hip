@@ -150,7 +150,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_knn_query_kernel(const float4* __
           a = cell_start[base + xlo]; b = cell_start[base + xhi + 1];
         }
       }
-      unsigned long long m = __ballot(b > a);
+      unsigned long long m = gh_ballot(b > a);
       while (m) {
         const int l = __builtin_ctzll(m);
         m &= m - 1;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_knn_query_kernel(const float4* __
           const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(p.w);
           const unsigned long long tau = list[K - 1];
           const bool surv = valid && key < tau;
-          unsigned long long sm = __ballot(surv);
+          unsigned long long sm = gh_ballot(surv);
           if (!sm) continue;
           // merge the survivors into the sorted list by rank counting
           const unsigned long long a0 = list[lane], a1 = list[lane + 64];
