@@ -291,7 +291,6 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   uint32_t off = block_offsets[blockIdx.x] + woff + x - cnt;
   slot_begin[n] = off;
   if (cnt == 0) return;
-  grec[3].x = __uint_as_float(off);                   // same 64-byte line the post-sort gather reads
   const uint32_t r = __float_as_uint(g2.y);
   const int minx = r & 255, miny = (r >> 8) & 255, maxx = (r >> 16) & 255, maxy = r >> 24;
   const uint32_t vbase = (n / (uint32_t)P) * (uint32_t)tiles;
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __r
                                                               const float4* __restrict__ geom, uint32_t* __restrict__ sorted_slot,
                                                               uint2* __restrict__ ranges, float4* __restrict__ r0,
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
-                                                              uint32_t* __restrict__ inst_flag) {
+                                                              uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -334,9 +333,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __r
   }
   if (i == n - 1) ranges[t].y = n;
   const uint32_t gid = vals[i];
-  const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line: record, tile rect, tile hit mask, first emit slot
+  const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line: record, tile rect, tile hit mask
   const float4 a = grec[0], b = grec[1], c = grec[2];
-  const uint32_t slot0 = __float_as_uint(grec[3].x);
+  const uint32_t slot0 = slot_begin[gid];            // first emit slot (4-byte gather from an L2-sized array; keeping it
+                                                     // in the geometry line cost the emit kernel a scattered line write)
   const float cb = c.x;
   const uint32_t tl = t % (uint32_t)tiles, ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
   // emit slot of (gid, tile): the Gaussian's instances were emitted row-major over the HIT tiles of its rect
@@ -500,6 +500,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,
                      (const float4*)(ws + L.geom), (uint32_t*)(ws + L.sorted_slot),
                      (uint2*)(ws + L.ranges), (float4*)(ws + L.inst_r0),
-                     (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag));
+                     (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
+                     (const uint32_t*)(ws + L.slot_begin));
   gh_launch_tile_order(g, ws, L, s);
 }

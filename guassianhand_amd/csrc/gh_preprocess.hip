@@ -82,10 +82,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         float4* grec = geom + (size_t)n * 4;           // one 64-byte line per Gaussian
         grec[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
         grec[1] = make_float4(e.a * dinv, op, rgb[0], rgb[1]);
-        // .y = packed tile rect, .z = first emit slot (filled by gh_emit_kernel): the post-sort gather reads one line
+        // .y = packed tile rect, .zw = tile hit mask: the post-sort gather reads one line
         grec[2] = make_float4(rgb[2], __uint_as_float((unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24)),
                               __uint_as_float((unsigned)hitmask), __uint_as_float((unsigned)(hitmask >> 32)));
-        grec[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // completes the 64-byte line (full-line write; .x = first emit slot later)
+        grec[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // completes the 64-byte line (full-line write)
         depth[n] = e.tz;
         dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
         clamped[n] = (uint8_t)cl;
@@ -126,39 +126,51 @@ __device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, floa
 
 // One thread per Gaussian; loops the views so gradients w.r.t. view-independent attributes are summed
 // in registers/own memory in a fixed order (no atomics, bitwise reproducible).
-// Fixed-order sum of every Gaussian's per-(instance, quadrant) gradient sub-records: one thread per (view,
-// Gaussian), its instances are the consecutive emit slots [slot_begin, slot_begin + tiles). Few registers, so
-// the scattered 48-byte reads run at full occupancy; the chain-rule kernel then reads the 9 sums coalesced.
-// Threads are assigned in DEPTH order (perm = the level-1 sort result): emit slots were handed out in that order, so
-// the threads of a wave read one contiguous stretch of sub-records.
-__global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t cap, const uint32_t* __restrict__ perm,
+// Fixed-order sum of every Gaussian's per-(instance, quadrant) gradient sub-records; its instances are the
+// consecutive emit slots [slot_begin, slot_begin + tiles). Few registers, so the reads run at full occupancy; the
+// chain-rule kernel then reads the 9 sums coalesced. Gaussians are taken in INDEX order: slot_begin / tiles_touched /
+// the 48-byte sums are then coalesced and only the stretch of sub-records is a random (but contiguous) read; walking
+// them in depth order (contiguous sub-records, three scattered per-Gaussian accesses) measured 10 us slower.
+__global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t cap,
                                                                   const uint32_t* __restrict__ slot_begin,
                                                                   const uint32_t* __restrict__ tiles_touched,
                                                                   const float* __restrict__ inst_grad,
                                                                   const uint32_t* __restrict__ inst_flag, float4* __restrict__ gsum) {
-  const int j = blockIdx.x * GH_BLOCK + threadIdx.x;
-  if (j >= N) return;
-  const uint32_t n = perm[j];
-  uint32_t o0 = slot_begin[n], o1 = o0 + tiles_touched[n];
-  if (o1 > cap) o1 = cap;
-  if (o0 > o1) o0 = o1;
+  // FOUR lanes per (view, Gaussian), one per quadrant: the quad reads the 144 contiguous bytes of an instance's four
+  // sub-records.
+  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int j = t >> 2, q = t & 3;
+  const bool live = j < N;                              // whole quads are live or not; no early return (DPP below)
+  const uint32_t n = live ? (uint32_t)j : 0u;
+  uint32_t o0 = 0, o1 = 0;
+  if (live) {
+    o0 = slot_begin[n]; o1 = o0 + tiles_touched[n];
+    if (o1 > cap) o1 = cap;
+    if (o0 > o1) o0 = o1;
+  }
   float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (uint32_t sidx = o0; sidx < o1; ++sidx) {
     const uint32_t f = inst_flag[sidx];                      // 4 quadrant flag bytes of this tile instance
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if ((f >> (8 * q)) & 1u) {
-        const GhF3* r = (const GhF3*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC_G);
-        const GhF3 r0 = r[0], r1 = r[1], r2 = r[2];
-        s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r1.x; s9[4] += r1.y;
-        s9[5] += r1.z; s9[6] += r2.x; s9[7] += r2.y; s9[8] += r2.z;
-      }
+    if ((f >> (8 * q)) & 1u) {
+      const GhF3* r = (const GhF3*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC_G);
+      const GhF3 r0 = r[0], r1 = r[1], r2 = r[2];
+      s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r1.x; s9[4] += r1.y;
+      s9[5] += r1.z; s9[6] += r2.x; s9[7] += r2.y; s9[8] += r2.z;
     }
   }
-  float4* o = gsum + (size_t)n * 3;
-  o[0] = make_float4(s9[0], s9[1], s9[2], s9[3]);
-  o[1] = make_float4(s9[4], s9[5], s9[6], s9[7]);
-  o[2] = make_float4(s9[8], 0.0f, 0.0f, 0.0f);
+  // quadrants combined in fixed order, (q0 + q1) + (q2 + q3), in every lane of the quad
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    s9[k] += gh_dpp<0xB1>(s9[k]);                            // quad_perm [1,0,3,2]
+    s9[k] += gh_dpp<0x4E>(s9[k]);                            // quad_perm [2,3,0,1]
+  }
+  if (live && q < 3) {                                       // three lanes write the 48-byte sum record
+    float4 o;
+    if (q == 0) o = make_float4(s9[0], s9[1], s9[2], s9[3]);
+    else if (q == 1) o = make_float4(s9[4], s9[5], s9[6], s9[7]);
+    else o = make_float4(s9[8], 0.0f, 0.0f, 0.0f);
+    gsum[(size_t)n * 3 + q] = o;
+  }
 }
 
 // RGB_MODE is a template parameter so the colours-precomputed path does not pay the registers of the SH path.
@@ -371,9 +383,9 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   const int rows = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.N : g.P;
   int nblk = (rows + GH_BLOCK - 1) / GH_BLOCK;
   auto kern = in->colors_precomp ? gh_preprocess_bwd_kernel<true> : gh_preprocess_bwd_kernel<false>;
-  const int nblk_n = (g.N + GH_BLOCK - 1) / GH_BLOCK;
+  const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
-                     (const uint32_t*)(ws + L.depth_vals_a), (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched),
+                     (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched),
                      (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
   const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, ws, L, s);     // SH mode only; no-op with colors_precomp
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,

@@ -282,7 +282,7 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 // of the slot (row_shr:4, row_shr:8, then xor-16 / xor-32 through the LDS crossbar) and the four waves of the
 // quadrant are combined through a double-buffered LDS stage, one barrier per 64 list entries, in fixed wave
 // order: lane l of the flushing wave owns entry l and writes the quadrant's sub-record + flag byte.
-struct GhStateBwd { float T, B0, B1, B2, B3; };   // B3: alpha accumulated behind (mask channel, colour 1)
+struct GhStateBwd { float T, Bs; };   // Bs = dL/dpixel . (colour behind), the only form the colour behind is needed in
 
 __device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum over the 16 pixels of this lane's slot
   v += gh_dpp<0x114>(v);                                              // row_shr:4
@@ -290,6 +290,18 @@ __device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum ove
   v += gh_lane_fetch(v, (lane ^ 16) << 2);
   v += gh_lane_fetch(v, (lane ^ 32) << 2);                            // lanes 12..15 (+16k): totals per slot
   return v;
+}
+
+// r[q] += row_shr:4, then += row_shr:8, for nine values: lanes 12..15 of every row end up with the row's sums per slot.
+// Assembly because the compiler splits four of the eighteen fused DPP adds into v_mov_dpp + v_add. The two steps of a
+// value are nine instructions apart (VALU write -> DPP read needs two wait states); s_nop covers the producer of r[8].
+__device__ __forceinline__ void gh_row_sum9(float (&r)[9]) {
+#define GH_RS(N, SH) "v_add_f32_dpp %" #N ", %" #N ", %" #N " row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm("s_nop 1\n\t"
+      GH_RS(0, 4) GH_RS(1, 4) GH_RS(2, 4) GH_RS(3, 4) GH_RS(4, 4) GH_RS(5, 4) GH_RS(6, 4) GH_RS(7, 4) GH_RS(8, 4)
+      GH_RS(0, 8) GH_RS(1, 8) GH_RS(2, 8) GH_RS(3, 8) GH_RS(4, 8) GH_RS(5, 8) GH_RS(6, 8) GH_RS(7, 8) GH_RS(8, 8)
+      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]));
+#undef GH_RS
 }
 
 template <bool ALPHA>
@@ -335,7 +347,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     d0 = dimg[0]; d1 = dimg[(size_t)H * W]; d2 = dimg[(size_t)2 * H * W];
     if (ALPHA) dM = dL_dalpha_img[pix];             // fused mask channel: colour 1, background 0
   }
-  const float bg_dot = bg[0] * d0 + bg[1] * d1 + bg[2] * d2;
+  // background term and (ALPHA) the mask channel: both are multiples of T_final / (1 - alpha_k)
+  const float bg_dot = (bg[0] * d0 + bg[1] * d1 + bg[2] * d2) - dM;
   int wave_last = last;                    // list positions >= wave_last were blended by no pixel of this 4x4 block
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(wave_last, o); wave_last = t > wave_last ? t : wave_last; }
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   // the forward's own state at the cut: T = transmittance in front of entry seg_hi, colour behind it =
   // (final colour - colour accumulated in front of the cut) / T  — exact T instead of T_final divided back up.
   GhStateBwd st;
-  st.T = T_final; st.B0 = st.B1 = st.B2 = st.B3 = 0.0f;
+  st.T = T_final; st.Bs = 0.0f;
   if (inside && last > seg_hi) {
     const size_t ck = ((size_t)(range.x / GH_SEGMENT) + (size_t)tile + (size_t)item.y) * 256 +
                       (size_t)((y - ty * GH_TILE) * GH_TILE + (x - tx * GH_TILE));
@@ -360,8 +373,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const float4 fc = final_C[((size_t)v * H + y) * W + x];
     const float iT = 1.0f / c.x;           // > 1e-4: the pixel was still open at the cut
     st.T = c.x;
-    st.B0 = (fc.x - c.y) * iT; st.B1 = (fc.y - c.z) * iT; st.B2 = (fc.z - c.w) * iT;
-    if (ALPHA) st.B3 = (c.x - T_final) * iT;   // alpha behind the cut = (T_cut - T_final) / T_cut exactly: no sum to difference
+    st.Bs = fmaf(d2, (fc.z - c.w) * iT, fmaf(d1, (fc.y - c.z) * iT, d0 * ((fc.x - c.y) * iT)));
   }
   const int nb = (qend - seg_lo + GH_WAVE - 1) / GH_WAVE;
   GhBatch cur, nxt;
@@ -402,32 +414,23 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       const float m = 1.0f - ae;
       const float inv1ma = __builtin_amdgcn_rcpf(m);      // v_rcp_f32 (<= 1 ulp; exact for 1). Gradients carry a 1e-3 rtol.
       const float f = inv1ma;
-      const float ac0 = ae * cr, ac1 = ae * cg, ac2 = ae * cbl;
+      // The three colour channels only ever enter dL/dalpha through their dot product with dL/dpixel, and the recurrence
+      // of the colour behind is linear, so ONE scalar chain carries Bs = d . B:  Bs <- Bs * m + ae * (d . c).
+      const float e = fmaf(d2, cbl, fmaf(d1, cg, d0 * cr));                             // d . c of this lane's entry
+      const float ace = ae * e;
       const float T1 = st.T * gh_quad_bcast<0>(f), T2 = T1 * gh_quad_bcast<1>(f), T3 = T2 * gh_quad_bcast<2>(f),
                   T4 = T3 * gh_quad_bcast<3>(f);
       const float mTn = gh_slot_select(T1, T2, T3, T4);                                  // T right after this lane's entry
-#define GH_B_CHAIN(B, A, MINE)                                                              \
-      float MINE;                                                                           \
-      {                                                                                     \
-        float b1, b2, b3, b4;                                                               \
-        gh_quad_affine4(B, m, A, b1, b2, b3, b4);                                           \
-        MINE = gh_slot_select(B, b1, b2, b3);   /* colour behind this lane's entry */       \
-        B = b4;                                                                             \
+      float mBs;
+      {
+        float b1, b2, b3, b4;
+        gh_quad_affine4(st.Bs, m, ace, b1, b2, b3, b4);
+        mBs = gh_slot_select(st.Bs, b1, b2, b3);                                         // d . (colour behind this lane's entry)
+        st.Bs = b4;
       }
-      GH_B_CHAIN(st.B0, ac0, mB0)
-      GH_B_CHAIN(st.B1, ac1, mB1)
-      GH_B_CHAIN(st.B2, ac2, mB2)
-      float mB3 = 0.0f;
-      if (ALPHA) {
-        const float ac3 = ae;
-        GH_B_CHAIN(st.B3, ac3, mB3x)
-        mB3 = mB3x;
-      }
-#undef GH_B_CHAIN
       st.T = T4;
-      float dL_dalpha = (cr - mB0) * d0 + (cg - mB1) * d1 + (cbl - mB2) * d2;
-      if (ALPHA) dL_dalpha += (1.0f - mB3) * dM;
-      dL_dalpha *= mTn;
+      // the mask channel A = 1 - T_final has dA/dalpha_k = T_final / (1 - alpha_k): it rides on the background term
+      float dL_dalpha = (e - mBs) * mTn;
       dL_dalpha += (-T_final * inv1ma) * bg_dot;
       // pixels that did not blend the entry contribute nothing: every partial below is a product with dL_dalpha or
       // dchannel_dcolor (all other factors are finite), so zeroing these two replaces nine selects
@@ -447,8 +450,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       // sums for slots 0..3. Before the cross-row half (the LDS crossbar, by far the most expensive step) four values are
       // PACKED into one register — value 4g+1 / +2 / +3 moves to lanes 8..11 / 4..7 / 0..3 of its row with bank-masked
       // row shifts — so the xor-16 / xor-32 butterfly runs 3 times per trip instead of 9.
-#pragma unroll
-      for (int q = 0; q < 9; ++q) { r[q] += gh_dpp<0x114>(r[q]); r[q] += gh_dpp<0x118>(r[q]); }
+      gh_row_sum9(r);
       float R[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
