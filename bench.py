@@ -171,16 +171,21 @@ def main():
                                    xyz_b=params.get("xyz_b"), opacity_b=params.get("opacity_b"),
                                    color_w=params.get("color_w"), color_b=params.get("color_b"), **pv)
         loss = l1_mean_loss(img, gt)                 # mean|img - gt| and dL/dimg in one fused pass (gh_l1_loss)
+        work = None
+        if world > 1 and not args.allreduce_grads:
+            # BASELINE north star: views are independent, RCCL only for the loss. The scalar all-reduce is issued as soon
+            # as the loss exists and runs on RCCL's own stream underneath the backward pass.
+            loss_sum = loss.detach().clone()
+            work = tdist.all_reduce(loss_sum, op=tdist.ReduceOp.SUM, async_op=True)
         loss.backward()
-        if world > 1:
-            if args.allreduce_grads:                     # data-parallel fit: sum the gradient block at the rasteriser boundary
-                grads = {k: params[k].grad for k in names}
-                if s.use_rgb and "color_b" in grads:     # RGB mode reads color_b[:, 0:3] only (renderer_one_shot.py:328): the
-                    grads["color_b"] = grads["color_b"][:, :3]   # other 45 gradient columns are exactly zero on every rank
-                loss, grads = ghdist.allreduce_grads(grads, loss.detach(), names)
-            else:                                        # BASELINE north star: views are independent, RCCL only for the loss
-                loss = loss.detach().clone()
-                tdist.all_reduce(loss, op=tdist.ReduceOp.SUM)
+        if work is not None:
+            work.wait()                              # stream-level dependency for RCCL (no host block); gloo blocks
+            loss = loss_sum
+        elif world > 1:                              # data-parallel fit: sum the gradient block at the rasteriser boundary
+            grads = {k: params[k].grad for k in names}
+            if s.use_rgb and "color_b" in grads:     # RGB mode reads color_b[:, 0:3] only (renderer_one_shot.py:328): the
+                grads["color_b"] = grads["color_b"][:, :3]   # other 45 gradient columns are exactly zero on every rank
+            loss, grads = ghdist.allreduce_grads(grads, loss.detach(), names)
         return loss
 
     def barrier():

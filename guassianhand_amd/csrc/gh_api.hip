@@ -65,7 +65,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->dmean_sh = take(sh_mode ? N * 16 : 0);
   L->sh_scratch = take(sh_mode ? ((N * 16 + GH_BLOCK - 1) / GH_BLOCK + 1) * 64 * 4 : 0);   // sized for the pose-batch row count
   L->grad_sums = take(N * 48);
-  L->bwd_scratch = take((nblk_pre + 1) * 64 * 4);
+  L->bwd_scratch = take((2 * nblk_pre + 2) * 64 * 4);     // per-block partials of the chain-rule kernel (<= 2N lanes)
   L->total_bytes = off;
   return GH_OK;
 }
@@ -132,6 +132,8 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
   rc = check_inputs(d, in);
   if (rc != GH_OK) return rc;
   if (!gr || !gr->dL_dimage || !workspace) return GH_ERR_INVALID_ARG;
+  // 48-wide gradient rows are written as float4s
+  if ((((uintptr_t)gr->dL_dblend_color_b | (uintptr_t)gr->dL_dblend_color_w) & 15) != 0) return GH_ERR_INVALID_ARG;
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;

@@ -173,19 +173,37 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t
   }
 }
 
+// Sum over the aligned group of G = 2^lg lanes this lane belongs to, in every lane of the group; fixed order, so the
+// result is bitwise reproducible. Steps 4 and 8 use the row mirrors: the quads / 8-lane groups are uniform by then, so
+// the mirrored lane holds exactly the other half's sum. All lanes of the wave must be active.
+__device__ __forceinline__ float gh_group_sum(float v, int lg) {
+  if (lg > 0) v += gh_dpp<0xB1>(v);          // quad_perm [1,0,3,2]
+  if (lg > 1) v += gh_dpp<0x4E>(v);          // quad_perm [2,3,0,1]
+  if (lg > 2) v += gh_dpp<0x141>(v);         // row_half_mirror
+  if (lg > 3) v += gh_dpp<0x140>(v);         // row_mirror
+  if (lg > 4) v += __shfl_xor(v, 16);
+  if (lg > 5) v += __shfl_xor(v, 32);
+  return v;
+}
+
 // RGB_MODE is a template parameter so the colours-precomputed path does not pay the registers of the SH path.
+// Chain rule per (view, Gaussian): a group of G = 2^lg adjacent lanes shares one row of the attribute arrays and
+// splits its views (lane vv takes views vv, vv + G, ...), so 8 views run 8-wide instead of as a loop of 8 in one thread
+// (P threads cannot fill 256 CUs); the per-view results are combined over the group in fixed order (gh_group_sum), no
+// atomics, bitwise reproducible. Pose batch (GH_FLAG_PER_VIEW_GAUSSIANS): NV*P rows, row i is seen by view i / P only
+// and G = 1.
 template <bool RGB_MODE>
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
-    GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags,
+    GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags, int lg,
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ dmean_sh, const float4* __restrict__ gsum,
     float* __restrict__ scratch) {
   __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
-  // i = row of the attribute arrays. Shared Gaussians: P rows, each seen by all NV views. Pose batch
-  // (GH_FLAG_PER_VIEW_GAUSSIANS): NV*P rows, row i is seen by view i / P only.
   const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
-  const int i = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int G = 1 << lg;
+  const int slot = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int i = slot >> lg, vv = slot & (G - 1);        // row of the attribute arrays, lane inside its view group
   const bool live = i < (per_view ? NV * P : P);
-  const int v_lo = per_view ? (live ? i / P : 0) : 0, v_hi = per_view ? v_lo + 1 : NV;
+  const int n_rounds = per_view ? 1 : (NV + G - 1) / G;  // uniform over the wave: the block sums below need every lane
   constexpr bool rgb_mode = RGB_MODE;
   const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   const bool red_w = rgb_mode && in.blend_color_w && !wpg && gr.dL_dblend_color_w;   // global (48,) weights: block reduce
@@ -197,9 +215,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
   __syncthreads();
 
   float am[3] = {0, 0, 0}, as[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, araw[3] = {0, 0, 0}, ao = 0.0f;
-  for (int v = v_lo; v < v_hi; ++v) {
+  for (int k = 0; k < n_rounds; ++k) {
+    const int v_raw = per_view ? (live ? i / P : 0) : vv + k * G;
+    const bool vok = per_view || v_raw < NV;
+    const int v = vok ? v_raw : 0;
     const size_t n = per_view ? (size_t)(live ? i : 0) : (size_t)v * P + (live ? i : 0);
-    const bool vis = live && tiles_touched[n] != 0;
+    const bool vis = live && vok && tiles_touched[n] != 0;
     float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (vis) {
       const float4* r = gsum + n * 3;
@@ -303,7 +324,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
       am[0] += dm[0]; am[1] += dm[1]; am[2] += dm[2];
       ao += g_o;
     }
-    if (live && gr.dL_dmeans2D) {
+    if (live && vok && gr.dL_dmeans2D) {
       gr.dL_dmeans2D[3 * n] = vis ? g_px * 0.5f * (float)W : 0.0f;
       gr.dL_dmeans2D[3 * n + 1] = vis ? g_py * 0.5f * (float)H : 0.0f;
       gr.dL_dmeans2D[3 * n + 2] = 0.0f;
@@ -311,7 +332,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     if (red_x) { gh_block_acc(s_part, 48, dm[0]); gh_block_acc(s_part, 49, dm[1]); gh_block_acc(s_part, 50, dm[2]); }
   }
 
-  if (live) {
+  // per-view results -> per-Gaussian sums, in every lane of the group
+#pragma unroll
+  for (int c3 = 0; c3 < 3; ++c3) { am[c3] = gh_group_sum(am[c3], lg); as[c3] = gh_group_sum(as[c3], lg); }
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) aq[c4] = gh_group_sum(aq[c4], lg);
+  ao = gh_group_sum(ao, lg);
+  if (rgb_mode) {
+#pragma unroll
+    for (int c3 = 0; c3 < 3; ++c3) araw[c3] = gh_group_sum(araw[c3], lg);
+  }
+  const bool writer = live && vv == 0;                  // one lane per row writes / contributes the per-Gaussian terms
+  if (writer) {
     if (gr.dL_dmeans3D) { gr.dL_dmeans3D[3 * i] = am[0]; gr.dL_dmeans3D[3 * i + 1] = am[1]; gr.dL_dmeans3D[3 * i + 2] = am[2]; }
     if (gr.dL_dopacities) gr.dL_dopacities[i] = ao;
     if (gr.dL_dblend_opacity_b && in.blend_opacity_b) gr.dL_dblend_opacity_b[i] = ao;
@@ -323,33 +355,35 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     const float* w = in.blend_color_w ? in.blend_color_w + (wpg ? (size_t)(live ? i : 0) * 48 : 0) : nullptr;
     float c[3] = {0, 0, 0};
     if (live) { c[0] = in.colors_precomp[3 * i]; c[1] = in.colors_precomp[3 * i + 1]; c[2] = in.colors_precomp[3 * i + 2]; }
-    if (live) {
+    if (writer) {
       if (gr.dL_dcolors) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) gr.dL_dcolors[3 * i + ch] = w ? araw[ch] * w[ch] : araw[ch];
       }
-      if (in.blend_color_b && gr.dL_dblend_color_b) {
-        if (flags & GH_FLAG_BLEND_COLOR_B_RGB) {
-          float* o = gr.dL_dblend_color_b + (size_t)i * 3;
-          o[0] = araw[0]; o[1] = araw[1]; o[2] = araw[2];
-        } else {
-          float* o = gr.dL_dblend_color_b + (size_t)i * 48;
-          o[0] = araw[0]; o[1] = araw[1]; o[2] = araw[2];
-          for (int k = 3; k < 48; ++k) o[k] = 0.0f;
-        }
+      if (in.blend_color_b && gr.dL_dblend_color_b && (flags & GH_FLAG_BLEND_COLOR_B_RGB)) {
+        float* o = gr.dL_dblend_color_b + (size_t)i * 3;
+        o[0] = araw[0]; o[1] = araw[1]; o[2] = araw[2];
+      }
+    }
+    // 48-wide rows (the reference's (P,48) bias / weight samples, of which RGB mode reads 3 / 6 entries): the lanes of
+    // the view group write the row together as float4s, one coalesced 192-byte row instead of 48 scalar stores per thread
+    if (live) {
+      if (in.blend_color_b && gr.dL_dblend_color_b && !(flags & GH_FLAG_BLEND_COLOR_B_RGB)) {
+        float4* o = (float4*)(gr.dL_dblend_color_b + (size_t)i * 48);
+        for (int k = vv; k < 12; k += G) o[k] = k == 0 ? make_float4(araw[0], araw[1], araw[2], 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
       if (w && wpg && gr.dL_dblend_color_w) {
-        float* o = gr.dL_dblend_color_w + (size_t)i * 48;
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) { o[ch] = araw[ch] * c[ch]; o[3 + ch] = araw[ch]; }
-        for (int k = 6; k < 48; ++k) o[k] = 0.0f;
+        float4* o = (float4*)(gr.dL_dblend_color_w + (size_t)i * 48);
+        for (int k = vv; k < 12; k += G)
+          o[k] = k == 0 ? make_float4(araw[0] * c[0], araw[1] * c[1], araw[2] * c[2], araw[0])
+                        : (k == 1 ? make_float4(araw[1], araw[2], 0.0f, 0.0f) : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
       }
     }
     if (red_w) {
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
-        gh_block_acc(s_part, ch, live ? araw[ch] * c[ch] : 0.0f);
-        gh_block_acc(s_part, 3 + ch, live ? araw[ch] : 0.0f);
+        gh_block_acc(s_part, ch, writer ? araw[ch] * c[ch] : 0.0f);
+        gh_block_acc(s_part, 3 + ch, writer ? araw[ch] : 0.0f);
       }
     }
   }
@@ -380,8 +414,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_blend_reduce_kernel(const float* 
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
                               const GhLayout& L, hipStream_t s) {
   if (g.P == 0) return;
-  const int rows = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.N : g.P;
-  int nblk = (rows + GH_BLOCK - 1) / GH_BLOCK;
+  const bool per_view = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
+  const int rows = per_view ? g.N : g.P;
+  int lg = 0;                                            // lanes per row: the smallest power of two >= n_views, at most 64
+  if (!per_view) while ((1 << lg) < g.NV && lg < 6) ++lg;
+  int nblk = (int)((((size_t)rows << lg) + GH_BLOCK - 1) / GH_BLOCK);   // <= 2 N / 256 + 1: bwd_scratch holds 64 floats per block
   auto kern = in->colors_precomp ? gh_preprocess_bwd_kernel<true> : gh_preprocess_bwd_kernel<false>;
   const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
@@ -389,7 +426,7 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                      (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
   const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, ws, L, s);     // SH mode only; no-op with colors_precomp
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
-                     d->sh_degree, d->M, d->scale_modifier, d->flags,
+                     d->sh_degree, d->M, d->scale_modifier, d->flags, lg,
                      (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.dmean_sh),
                      (const float4*)(ws + L.grad_sums), (float*)(ws + L.bwd_scratch));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;

@@ -125,7 +125,7 @@ typedef struct GhGrads {
   float* dL_dblend_xyz_b;     /* (3,) */
   float* dL_dblend_opacity_b; /* (P,) */
   float* dL_dblend_color_w;   /* (48,) or (P,48) */
-  float* dL_dblend_color_b;   /* (P,48) */
+  float* dL_dblend_color_b;   /* (P,48), 16-byte aligned (rows are written as float4s) */
 } GhGrads;
 
 /* Byte offsets of the internal arrays inside the workspace (public so tests can inspect every stage). */

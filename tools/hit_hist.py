@@ -33,3 +33,5 @@ print("batch-waves with hits:", h.numel(), "mean hits", float(h.float().mean()))
 print("4-wide trips now:", int(trips4))
 print("8-wide design: full-8 trips", int(packed), "partial-8 trips (5..7 hits)", int(partial8), "single 4-wide trips", int(single))
 print("hits histogram (1..16+):", torch.bincount(h.clamp(max=17))[1:].tolist())
+hits = int(h.sum())
+print("slot utilisation of the 4-wide trips:", hits / (4.0 * int(trips4)), " hits", hits, " ideal trips (cross-batch packing)", (hits + 3) // 4)
