@@ -50,7 +50,8 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   const size_t tab_n = gh_radix_table_words(N), tab_d = gh_radix_table_words((size_t)g.cap);
   L->sort_tables = take((tab_n > tab_d ? tab_n : tab_d) * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
-  L->tile_walk = take((size_t)g.NV * g.tiles * 4);       // directly after ranges: both are cleared by one memset
+  L->tile_walk = take((size_t)g.NV * g.tiles * 8);       // walked entries [T] + completion counters [T]; directly after
+                                                         // ranges: all cleared by one memset when there is nothing to project
   L->tile_order = take((size_t)g.NV * g.tiles * 4);
   const size_t n_items = (size_t)g.NV * g.tiles + cap / GH_SEGMENT + 2;       // backward work items / checkpoint slots
   L->bwd_items = take(n_items * 8);

@@ -363,18 +363,17 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __r
 // length (256 buckets of 16 entries, longest first). Workgroups are dispatched in blockIdx order, so the heavy
 // tiles start at t=0 and the light / empty ones fill in behind them instead of forming the tail.
 // One block; the order inside a bucket is arbitrary (it only affects scheduling, never results).
-// The key is the tile's list length (forward) or, when `walk` is given, the number of list entries the forward
-// actually walked before every pixel saturated (backward: exact work proxy).
-__global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ walk,
-                                                              int ntiles, uint32_t* __restrict__ order) {
+// The key is the tile's list length. (The backward's order comes from the forward itself: gh_render_fwd_kernel.)
+__global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int ntiles,
+                                                              uint32_t* __restrict__ order) {
   __shared__ uint32_t s_cnt[256];
   __shared__ uint32_t s_w[4];
   const int tid = threadIdx.x;
   if (tid < 256) s_cnt[tid] = 0;
   __syncthreads();
   for (int t = tid; t < ntiles; t += 1024) {
-    uint32_t len;
-    if (walk) len = walk[t]; else { const uint2 r = ranges[t]; len = r.y - r.x; }
+    const uint2 r = ranges[t];
+    const uint32_t len = r.y - r.x;
     uint32_t b = (len + 15u) >> 4; b = b > 255u ? 255u : b;
     atomicAdd(&s_cnt[255u - b], 1u);                 // bucket 0 = longest lists
   }
@@ -397,73 +396,16 @@ __global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __rest
   }
   __syncthreads();
   for (int t = tid; t < ntiles; t += 1024) {
-    uint32_t len;
-    if (walk) len = walk[t]; else { const uint2 r = ranges[t]; len = r.y - r.x; }
+    const uint2 r = ranges[t];
+    const uint32_t len = r.y - r.x;
     uint32_t b = (len + 15u) >> 4; b = b > 255u ? 255u : b;
     order[atomicAdd(&s_cnt[255u - b], 1u)] = (uint32_t)t;
   }
 }
 
 static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
-  hipLaunchKernelGGL(gh_tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint2*)(ws + L.ranges), (const uint32_t*)nullptr,
-                     g.NV * g.tiles, (uint32_t*)(ws + L.tile_order));
-}
-
-// Work list of the backward: the walked prefix of every tile list is cut into depth segments of GH_SEGMENT entries
-// (the forward left the per-pixel state at every cut), one item = (tile, segment) = one set of four quadrant
-// workgroups. Full segments come first, then the remainders longest first (same 256-bucket counting sort as above),
-// so that the long items start at t = 0. One block; the order inside a class only affects scheduling.
-__device__ __forceinline__ uint32_t gh_rem_bucket(uint32_t rem) {       // 1 .. GH_SEGMENT-1 entries -> bucket 1 .. 255
-  const uint32_t b = (rem * 256u + GH_SEGMENT - 1u) / GH_SEGMENT;
-  return b > 255u ? 255u : b;
-}
-
-__global__ __launch_bounds__(1024) void gh_bwd_items_kernel(const uint32_t* __restrict__ walk, int ntiles, uint2* __restrict__ items,
-                                                             GhCounters* __restrict__ ctr) {
-  __shared__ uint32_t s_cnt[256];
-  __shared__ uint32_t s_w[4];
-  __shared__ uint32_t s_full;
-  const int tid = threadIdx.x;
-  if (tid < 256) s_cnt[tid] = 0;
-  if (tid == 0) s_full = 0;
-  __syncthreads();
-  for (int t = tid; t < ntiles; t += 1024) {
-    const uint32_t w = walk[t], nfull = w / GH_SEGMENT, rem = w - nfull * GH_SEGMENT;
-    if (nfull) {
-      const uint32_t pos = atomicAdd(&s_full, nfull);
-      for (uint32_t k = 0; k < nfull; ++k) items[pos + k] = make_uint2((uint32_t)t, k);
-    }
-    if (rem) atomicAdd(&s_cnt[255u - gh_rem_bucket(rem)], 1u);      // bucket 0 = longest remainders
-  }
-  __syncthreads();
-  const int lane = tid & 63, wid = tid >> 6;
-  uint32_t v = 0, x = 0;
-  if (tid < 256) {
-    v = s_cnt[tid];
-    x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wid] = x;
-  }
-  __syncthreads();
-  const uint32_t nfull_total = s_full;
-  if (tid < 256) {
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += s_w[w];
-    s_cnt[tid] = nfull_total + woff + x - v;
-    if (tid == 255) ctr->reserved[1] = nfull_total + woff + x;       // number of work items
-  }
-  __syncthreads();
-  for (int t = tid; t < ntiles; t += 1024) {
-    const uint32_t w = walk[t], nfull = w / GH_SEGMENT, rem = w - nfull * GH_SEGMENT;
-    if (rem) items[atomicAdd(&s_cnt[255u - gh_rem_bucket(rem)], 1u)] = make_uint2((uint32_t)t, nfull);
-  }
-}
-
-void gh_launch_tile_order_bwd(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
-  static_assert(GH_SEGMENT <= 1024 && GH_SEGMENT % (2 * GH_WAVE) == 0, "remainder buckets / checkpoint cadence");
-  hipLaunchKernelGGL(gh_bwd_items_kernel, dim3(1), dim3(1024), 0, s, (const uint32_t*)(ws + L.tile_walk), g.NV * g.tiles,
-                     (uint2*)(ws + L.bwd_items), (GhCounters*)(ws + L.counters));
+  hipLaunchKernelGGL(gh_tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint2*)(ws + L.ranges), g.NV * g.tiles,
+                     (uint32_t*)(ws + L.tile_order));
 }
 
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {

@@ -41,7 +41,6 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
 void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii,
                               char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
-void gh_launch_tile_order_bwd(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha,
                           char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,

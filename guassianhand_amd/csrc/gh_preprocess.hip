@@ -17,7 +17,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
   if (n == 0) {                                        // counters: reserved[0] = element count of the level-1 (depth) sort
     ctr->num_rendered = 0; ctr->overflow = 0; ctr->reserved[0] = (uint32_t)N; ctr->reserved[1] = 0;
   }
-  if (n < T) { ranges[n] = make_uint2(0u, 0u); tile_walk[n] = 0u; }   // per-tile state of the binning / render stages
+  if (n < T) { ranges[n] = make_uint2(0u, 0u); tile_walk[n] = 0u; tile_walk[T + n] = 0u; }   // per-tile state of the later stages
   if (n < N) {
     uint32_t dkey = 0xFFFFFFFFu;                        // culled Gaussians sort behind everything and emit nothing
     unsigned rect_bits = 0;

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
     int tiles, float* __restrict__ image, float* __restrict__ alpha_img, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
-    float4* __restrict__ final_C) {
+    float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr) {
   int v, tx, ty;
   const int tile = (int)tile_order[blockIdx.x >> 2];      // heaviest tiles are launched first
   const int quad = blockIdx.x & 3;
@@ -235,11 +235,29 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint32_t b = (uint32_t)gh_quad_perm_i<0x4E>((int)p.last);      // quad_perm [2,3,0,1]
     p.last = b > p.last ? b : p.last;
   }
-  if (total > 0) {                                   // walked length of the tile = max n_contrib (orders the backward)
+  if (total > 0) {                                   // walked length of the tile = max n_contrib over its 16 waves
     uint32_t m = p.last;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m; }
-    if (lane == 0 && m > 0) atomicMax(&tile_walk[tile], m);
+    if (lane == 0) {
+      // The LAST of the tile's 16 waves (4 quadrant blocks x 4) appends the tile's backward work items, one per depth
+      // segment of the walked prefix: the list is in the order the forward finished the tiles. The backward takes it from
+      // the end, so the tiles that ran longest start first; the order only affects scheduling, never results.
+      // Ordering without fences (an agent-scope release would write back the whole L2): only relaxed agent-scope RMW
+      // atomics carry the data; each returns its old value, so waiting for the return means it has been performed.
+      const uint32_t prev_max = __hip_atomic_fetch_max(&tile_walk[tile], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" :: "v"(prev_max) : "memory");
+      uint32_t* done = tile_walk + (size_t)gridDim.x / 4;          // completion counters follow the T walk entries
+      const uint32_t prev_done = __hip_atomic_fetch_add(&done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev_done == 4u * (GH_BLOCK / GH_WAVE) - 1u) {
+        const uint32_t w = __hip_atomic_fetch_max(&tile_walk[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // final value
+        const uint32_t nseg = (w + GH_SEGMENT - 1u) / GH_SEGMENT;
+        if (nseg) {
+          const uint32_t pos = __hip_atomic_fetch_add(&ctr->reserved[1], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (uint32_t k = 0; k < nseg; ++k) items[pos + k] = make_uint2((uint32_t)tile, k);
+        }
+      }
+    }
   }
   if (inside && slot == 0) {
     const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
@@ -264,12 +282,13 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   const float2* r2 = (const float2*)(ws + L.inst_r2);
   float* fT = (float*)(ws + L.final_T); uint32_t* nc = (uint32_t*)(ws + L.n_contrib); uint32_t* tw = (uint32_t*)(ws + L.tile_walk);
   float4* ck = (float4*)(ws + L.ckpt_rgb); float4* fC = (float4*)(ws + L.final_C);
+  uint2* items = (uint2*)(ws + L.bwd_items); GhCounters* ctr = (GhCounters*)(ws + L.counters);
   if (alpha)
     hipLaunchKernelGGL(gh_render_fwd_kernel<true>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw, ck, fC);
+                       g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr);
   else
     hipLaunchKernelGGL(gh_render_fwd_kernel<false>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw, ck, fC);
+                       g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -317,8 +336,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   __shared__ uint64_t s_mask[2][GH_BLOCK / GH_WAVE];                  // entries a wave wrote
   __shared__ int s_qlast;
   int v, tx, ty;
-  if ((blockIdx.x >> 2) >= ctr->reserved[1]) return;     // grid is sized for the capacity of the work list
-  const uint2 item = items[blockIdx.x >> 2];             // (tile, depth segment): longest items are launched first
+  const uint32_t n_items = ctr->reserved[1];             // written by the forward; the grid is sized for the list's capacity
+  if ((blockIdx.x >> 2) >= n_items) return;
+  const uint2 item = items[n_items - 1u - (blockIdx.x >> 2)];   // (tile, depth segment): the tiles the forward finished last go first
   const int tile = (int)item.x;
   const int seg_lo = (int)item.y * GH_SEGMENT, seg_hi = seg_lo + GH_SEGMENT;
   const int quad = blockIdx.x & 3;
@@ -511,8 +531,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, char* ws, const GhLayout& L, hipStream_t s) {
   if (g.cap == 0) return;
-  // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (same n_contrib)
-  gh_launch_tile_order_bwd(g, ws, L, s);
+  // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (same n_contrib).
+  // The work list (tile, depth segment) was written by the forward's last wave of every tile.
   const dim3 grid(4 * (unsigned)g.n_items), block(GH_BLOCK);      // capacity of the work list; surplus blocks exit at once
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(ws + L.ranges), (const uint2*)(ws + L.bwd_items),

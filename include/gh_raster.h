@@ -151,9 +151,11 @@ typedef struct GhLayout {
   size_t inst_r2;        /* float2[max_instances]                                   (b, bits: 4x4-block mask of the tile) */
   size_t sort_tables;    /* uint32[...]        per-pass digit tables */
   size_t ranges;         /* uint2 [n_views*tiles] [start,end) into the sorted list */
-  size_t tile_walk;      /* uint32[n_views*tiles] list entries actually walked by the forward (max n_contrib of the tile) */
+  size_t tile_walk;      /* uint32[2][n_views*tiles] list entries actually walked by the forward (max n_contrib of the tile);
+                            forward waves that have finished the tile (the last one appends the tile's backward items) */
   size_t tile_order;     /* uint32[n_views*tiles] forward launch order of the render blocks: longest tile lists first */
-  size_t bwd_items;      /* uint2 [n_views*tiles + max_instances/GH_SEGMENT + 2] backward work items (tile, depth segment), longest first */
+  size_t bwd_items;      /* uint2 [n_views*tiles + max_instances/GH_SEGMENT + 2] backward work items (tile, depth segment) in the order the
+                            forward finished the tiles; the backward takes them from the end (long tiles finish last) */
   size_t ckpt_rgb;       /* float4[slots][256] forward state (T, C0, C1, C2) of every pixel of a tile at list positions that are
                             multiples of GH_SEGMENT; slots = max_instances/GH_SEGMENT + n_views*tiles + 2 */
   size_t final_C;        /* float4[n_views*H*W] colour accumulated by the forward, without background */
