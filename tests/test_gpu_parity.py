@@ -249,6 +249,15 @@ def test_frustum_clamp_edge_gradients(dev):
     compare(sc, dev)
 
 
+def test_many_views_chain_rule_groups(dev):
+    """More views than one lane group holds (the chain-rule kernel splits a Gaussian's views over <= 64 lanes and loops
+    for the rest) and a view count that is not a power of two (padded lanes must contribute nothing)."""
+    from guassianhand_amd.scenes import make_scene
+    for nv in (70, 6):
+        compare(make_scene("random1k", n_views=nv, P=300, use_rgb=True, blend=True), dev, check_stages=False)
+    compare(make_scene("random1k", n_views=67, P=120, use_rgb=False, blend=True), dev, check_stages=False)
+
+
 def test_config1_one_hand(dev):
     """BASELINE configs[1]: single right hand, 49,281 Gaussians, 512x334, forward + backward."""
     from guassianhand_amd.scenes import make_scene
