@@ -14,7 +14,9 @@ P = 98,562 Gaussians, interaction-aware attribute blend on, RGB colours, 512x334
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line. Inputs are resident in HBM before the timed region starts.
+Rank 0 prints ONE JSON line. Inputs are resident in HBM before the timed region starts. The timed steps replay one
+captured step (forward + loss + backward) from a HIP graph (`--no-graph`: kernel-by-kernel enqueue); collectives stay
+outside the graph; stage times for the roofline object come from eager steps with HIP events right after the timed region.
 """
 from __future__ import annotations
 
@@ -115,9 +117,10 @@ def main():
     ap.add_argument("--pose-batch", action="store_true",
                     help="every view of a step is a DIFFERENT pose (its own Gaussian set, BASELINE configs[4] 'mixed poses'): "
                          "one launch sequence with GH_FLAG_PER_VIEW_GAUSSIANS instead of shared Gaussians seen by all views")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture one step (forward + loss + backward) in a HIP graph and replay it in the timed loop; for "
-                         "launch-bound shapes such as 1 view/step (implies --no-stage-timing, N=1 only)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="enqueue the timed steps kernel by kernel instead of replaying one step (forward + loss + backward) "
+                         "captured in a HIP graph; the eager loop is bound by the host for small batches or on a slow host")
+    ap.add_argument("--graph", action="store_true", help="(default; kept for older command lines)")
     args = ap.parse_args()
 
     from guassianhand_amd import dist as ghdist
@@ -163,7 +166,8 @@ def main():
     params.update({k: v for k, v in blend.items() if v is not None})
     params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
 
-    def step(sync: bool):
+    def local_step(sync: bool):
+        """One pass of the hot path over this rank's views: forward, loss, backward. No collective."""
         for p in params.values():
             p.grad = None
         img, _ = R.rasterize_views(cams, params["xyz"], params["opacity"], params["scaling"], params["rotation"],
@@ -171,21 +175,29 @@ def main():
                                    xyz_b=params.get("xyz_b"), opacity_b=params.get("opacity_b"),
                                    color_w=params.get("color_w"), color_b=params.get("color_b"), **pv)
         loss = l1_mean_loss(img, gt)                 # mean|img - gt| and dL/dimg in one fused pass (gh_l1_loss)
+        return loss
+
+    def reduce_grads(loss):
+        """Data-parallel fit (--allreduce-grads): sum the gradient block at the rasteriser boundary, one collective."""
+        grads = {k: params[k].grad for k in names}
+        if s.use_rgb and "color_b" in grads:         # RGB mode reads color_b[:, 0:3] only (renderer_one_shot.py:328): the
+            grads["color_b"] = grads["color_b"][:, :3]       # other 45 gradient columns are exactly zero on every rank
+        return ghdist.allreduce_grads(grads, loss.detach(), names)[0]
+
+    def step(sync: bool):
+        """Eager step: kernel-by-kernel enqueue. N>1, north star protocol (views are independent, RCCL only for the loss):
+        the scalar all-reduce is issued as soon as the loss exists and runs on RCCL's own stream underneath the backward."""
+        loss = local_step(sync)
         work = None
         if world > 1 and not args.allreduce_grads:
-            # BASELINE north star: views are independent, RCCL only for the loss. The scalar all-reduce is issued as soon
-            # as the loss exists and runs on RCCL's own stream underneath the backward pass.
             loss_sum = loss.detach().clone()
             work = tdist.all_reduce(loss_sum, op=tdist.ReduceOp.SUM, async_op=True)
         loss.backward()
         if work is not None:
             work.wait()                              # stream-level dependency for RCCL (no host block); gloo blocks
             loss = loss_sum
-        elif world > 1:                              # data-parallel fit: sum the gradient block at the rasteriser boundary
-            grads = {k: params[k].grad for k in names}
-            if s.use_rgb and "color_b" in grads:     # RGB mode reads color_b[:, 0:3] only (renderer_one_shot.py:328): the
-                grads["color_b"] = grads["color_b"][:, :3]   # other 45 gradient columns are exactly zero on every rank
-            loss, grads = ghdist.allreduce_grads(grads, loss.detach(), names)
+        elif world > 1:
+            loss = reduce_grads(loss)
         return loss
 
     def barrier():
@@ -198,37 +210,74 @@ def main():
     for _ in range(max(0, args.warmup - 1)):
         step(sync=False)
     R.check_overflow()
-    graph = None
-    if args.graph:
-        assert world == 1, "--graph is a single-GPU mode"
-        args.no_stage_timing = True
-        R.set_graph_mode(True)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step(sync=False)
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            loss = step(sync=False)
+
+    # The timed steps replay ONE captured step (forward + loss + backward of this rank's views) from a HIP graph: the
+    # launch sequence is ~45 small kernels, and enqueueing them one by one leaves the result at the mercy of the host
+    # (0.5 ms per step on a quiet box, several ms on a busy one). Collectives stay outside the graph.
+    graph, g_loss, graph_note = None, None, None
+    if not args.no_graph:
+        try:                                             # the leaves' AccumulateGrad nodes were created on the default stream
+            torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        except AttributeError:
+            pass
+        try:
+            R.set_graph_mode(True)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                local_step(sync=False).backward()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g_loss = local_step(sync=False)
+                g_loss.backward()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:                           # capture is an optimisation of the enqueue path, never a requirement
+            graph, g_loss, graph_note = None, None, f"graph capture failed ({type(e).__name__}: {e}); eager steps"
+            R.set_graph_mode(False)
+            torch.cuda.synchronize()
+
+    def replay_step(pending):
+        """Graph step. N>1: the loss all-reduce of step k is issued after replay k and overlaps replay k+1."""
         graph.replay()
-    if not args.no_stage_timing:
-        R.enable_stage_timing(True)
+        if world == 1:
+            return g_loss, None
+        if args.allreduce_grads:
+            return reduce_grads(g_loss), None
+        if pending is not None:
+            pending.wait()
+        loss_sum = g_loss.detach().clone()
+        return loss_sum, tdist.all_reduce(loss_sum, op=tdist.ReduceOp.SUM, async_op=True)
+
     barrier()
     t0 = time.perf_counter()
+    pending = None
     for _ in range(args.steps):
         if graph is not None:
-            graph.replay()
-            continue
-        loss = step(sync=False)
+            loss, pending = replay_step(pending)
+        else:
+            loss = step(sync=False)
+    if pending is not None:
+        pending.wait()
     t_enq = time.perf_counter() - t0                 # host time to enqueue the timed steps (GPU-bound if << dt)
     barrier()
     dt = time.perf_counter() - t0
     R.check_overflow()
     if graph is not None:
         R.set_graph_mode(False)
-    stage_ms = R.stage_timing_summary() if not args.no_stage_timing else {}
-    R.enable_stage_timing(False)
+
+    # Stage times for the roofline leg: HIP events around the stage entry points (same stream) on eager steps of the same
+    # workload, run right after the timed region (events cannot sit inside the captured graph, and the timed steps stay
+    # free of the extra event records).
+    stage_ms = {}
+    if not args.no_stage_timing:
+        R.enable_stage_timing(True)
+        for _ in range(args.steps):
+            local_step(sync=False).backward()
+        stage_ms = R.stage_timing_summary()
+        R.enable_stage_timing(False)
+        R.check_overflow()
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -258,6 +307,7 @@ def main():
             roofline = {"bound": "hbm", "kernel": "gh_" + dom + "_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("gh_" + dom + "_kernel", args, V),
                         "alg_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom],
+                        "timing": f"HIP events around the stage entry points, {args.steps} eager steps run right after the timed steps",
                         "valu_busy_frac": pmc_valu("gh_" + dom + "_kernel", args, V)}
         out = {
             "metric": "fwd+bwd renders/sec @512x334, ~100k Gaussians", "value": value, "unit": "renders/s",
@@ -272,9 +322,10 @@ def main():
                        "instances_in_3sigma_rects": D_rect, "parallelism": f"view-parallel x{world}",
                        "collective": None if world == 1 else ("all-reduce(loss + gradient block)" if args.allreduce_grads
                                                               else "all-reduce(loss)"),
-                       "loss": "mean|img-gt|", "final_loss": float(loss),
+                       "loss": "mean|img-gt|", "final_loss": float(loss.detach()),
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
-                       "hip_graph": bool(args.graph)},
+                       "hip_graph": graph is not None, "timed_steps": "HIP graph replay of one captured step" if graph is not None
+                       else "eager kernel-by-kernel enqueue" + (f" [{graph_note}]" if graph_note else "")},
             "roofline": roofline, "stages": stages,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -1,11 +1,12 @@
-"""Copy the summaries of tools/prof_stats.sh, tools/pmc_sq.sh, tools/pmc_traffic.sh and the default bench line from
-gpurun_out/ into profiles/ (tracked). usage: assemble_profiles.py <tag>   e.g. r1f"""
+"""Copy the summaries written by tools/refresh_profiles.sh <tag> (gpurun_out/<tag>/) into profiles/ (tracked).
+usage: assemble_profiles.py <tag>   e.g. r1h"""
 import csv, glob, json, re, shutil, sys
 tag = sys.argv[1]
-shutil.copy("gpurun_out/traffic/pmc_traffic.json", "profiles/pmc_traffic.json")
-shutil.copy("gpurun_out/traffic/pmc_fetch_write_8views.csv", f"profiles/{tag}_pmc_fetch_write_8views.csv")
-shutil.copy("gpurun_out/r1e/bench_default.json", f"profiles/{tag}_bench_default.json")
-rows = list(csv.DictReader(open("gpurun_out/r1e/kernel_stats.csv")))
+O = f"gpurun_out/{tag}"
+shutil.copy(f"{O}/pmc_traffic.json", "profiles/pmc_traffic.json")
+shutil.copy(f"{O}/pmc_fetch_write_8views.csv", f"profiles/{tag}_pmc_fetch_write_8views.csv")
+shutil.copy(f"{O}/bench_default.json", f"profiles/{tag}_bench_default.json")
+rows = list(csv.DictReader(open(f"{O}/kernel_stats.csv")))
 out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline  (MI355X, tools/prof_stats.sh)",
        "name,calls,total_ns,avg_ns,pct,min_ns,max_ns"]
 for r in rows[:34]:
@@ -13,7 +14,7 @@ for r in rows[:34]:
     out.append(f'{n},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.0f},{r["Percentage"]},{r["MinNs"]},{r["MaxNs"]}')
 open(f"profiles/{tag}_kernel_stats_bench_8views.csv", "w").write("\n".join(out) + "\n")
 vals, lines = {}, []
-for f in sorted(glob.glob("gpurun_out/r1e/sum_*.csv")):
+for f in sorted(glob.glob(f"{O}/sum_*.csv")):
     for l in open(f):
         if "render" in l:
             lines.append(l.strip())
