@@ -18,6 +18,16 @@
 // sub-records (contiguous slots) in fixed order, so the gradients are bitwise reproducible.
 #include "gh_internal.h"
 
+// blockIdx -> (work item, quadrant) with the four quadrant workgroups of an item on ONE XCD: workgroups are dealt
+// round-robin over the 8 XCDs (b and b + 8 share one), so inside every run of 32 workgroups item = r & 7, quadrant = r >> 3.
+// The four read the same list records: one L2 fetches them instead of four. A speed choice only (placement is not a
+// contract); the items left over when the count is not a multiple of 8 use the plain mapping.
+__device__ __forceinline__ void gh_item_quad(uint32_t b, uint32_t n_items_grid, uint32_t& item, uint32_t& quad) {
+  const uint32_t full = (n_items_grid >> 3) << 5;        // workgroups covered by whole groups of 8 items
+  if (b < full) { const uint32_t r = b & 31u; item = ((b >> 5) << 3) + (r & 7u); quad = r >> 3; }
+  else { item = b >> 2; quad = b & 3u; }
+}
+
 __device__ __forceinline__ void gh_tile_coords(int blk, int gx, int tiles, int& v, int& tx, int& ty) {
   v = blk / tiles;
   int t = blk - v * tiles;
@@ -193,8 +203,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
     float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr) {
   int v, tx, ty;
-  const int tile = (int)tile_order[blockIdx.x >> 2];      // heaviest tiles are launched first
-  const int quad = blockIdx.x & 3;
+  uint32_t item_idx, quad_u;
+  gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);
+  const int tile = (int)tile_order[item_idx];             // heaviest tiles are launched first
+  const int quad = (int)quad_u;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int slot = lane & 3, pi = lane >> 2;
@@ -337,11 +349,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
   __shared__ int s_qlast;
   int v, tx, ty;
   const uint32_t n_items = ctr->reserved[1];             // written by the forward; the grid is sized for the list's capacity
-  if ((blockIdx.x >> 2) >= n_items) return;
-  const uint2 item = items[n_items - 1u - (blockIdx.x >> 2)];   // (tile, depth segment): the tiles the forward finished last go first
+  uint32_t item_idx, quad_u;
+  gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);
+  if (item_idx >= n_items) return;
+  const uint2 item = items[n_items - 1u - item_idx];     // (tile, depth segment): the tiles the forward finished last go first
   const int tile = (int)item.x;
   const int seg_lo = (int)item.y * GH_SEGMENT, seg_hi = seg_lo + GH_SEGMENT;
-  const int quad = blockIdx.x & 3;
+  const int quad = (int)quad_u;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int slot = lane & 3, pi = lane >> 2;
