@@ -47,7 +47,8 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->inst_r0 = take(cap * 16);
   L->inst_r1 = take(cap * 16);
   L->inst_r2 = take(cap * 8);
-  const size_t tab_n = gh_radix_table_words(N), tab_d = gh_radix_table_words((size_t)g.cap);
+  const size_t tab_n = gh_radix_table_words((size_t)g.P, g.NV);          // per-view depth sort: NV segments of P keys
+  const size_t tab_d = gh_radix_table_words((size_t)g.cap);
   L->sort_tables = take((tab_n > tab_d ? tab_n : tab_d) * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
   L->tile_walk = take((size_t)g.NV * g.tiles * 8);       // walked entries [T] + completion counters [T]; directly after

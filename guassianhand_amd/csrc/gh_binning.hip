@@ -2,35 +2,64 @@
 //
 // The published algorithm sorts D tile instances by the 64-bit key (tile << 32 | depth bits). The same ordering
 // is produced here in two levels, which moves 3x fewer bytes:
-//   1. the N = views*P Gaussians are stably sorted by depth ONCE (32-bit keys, N elements; ties keep index
-//      order, culled ones go last),
-//   2. instances are emitted in that order (one per touched tile, row-major in the rect), so the instance list
-//      is already depth-ordered,
-//   3. a STABLE radix partition by tile id (32-bit keys, D elements, ceil(tile_bits/8) passes) gathers each
+//   1. every view's P Gaussians are stably sorted by depth among themselves (32-bit keys, views = independent
+//      segments of one batched sort; ties keep index order, culled ones go last in their view),
+//   2. instances are emitted in that order (view-major, depth-minor; one per touched tile, row-major in the rect),
+//   3. a STABLE radix partition by global tile id (32-bit keys, D elements, ceil(tile_bits/8) passes) gathers each
 //      tile's entries without disturbing their depth order  ==  stable sort by (tile, depth, index).
+// (A partition by the tile index inside the view alone — one 1024-digit pass instead of two 8-bit ones — was built and
+// measured: the wide pass cost what the two narrow ones cost, and the tile-major / view-minor list layout it produces
+// made the record gather 16 us slower: neighbouring lists no longer share Gaussians.)
 // Then per-tile [start,end) ranges, the per-instance render records in sorted order and the launch order.
 // The instance count D never leaves the device: kernels read their element count from device memory and grids
 // are sized from the caller's capacity (max_instances), so the whole stage is sync-free / graph-capturable.
 #include "gh_internal.h"
 
 // ------------------------------------------------------------------------------------------------
-// LSD radix sort engine: 32-bit keys + 32-bit payload, <= 8-bit digits, element count read from device memory.
-// Each block owns GH_BLOCK * ITEMS consecutive keys.
+// LSD radix sort engine: 32-bit keys + 32-bit payload, digits of up to 8 bits (MAXD = 256 digit slots).
+// Each block owns GH_BLOCK * ITEMS consecutive keys of ONE segment. Two shapes:
+//   * one segment whose element count is read from device memory (*n_ptr, clamped to cap): seg_len = 0, gridDim.y = 1;
+//   * gridDim.y independent segments of exactly seg_len elements each, segment g = elements [g*seg_len, (g+1)*seg_len):
+//     the per-view depth sort (every view's P Gaussians are sorted among themselves, in place in their segment).
+// Tables: table[(seg * ndig + digit) * nblk + block], tot[seg * ndig + digit]; nblk = gridDim.x = blocks per segment.
 __device__ __forceinline__ uint32_t gh_clamp_n(const uint32_t* n_ptr, uint32_t cap) {
   const uint32_t n = *n_ptr;
   return n < cap ? n : cap;
 }
 
+__device__ __forceinline__ uint32_t gh_seg_count(const uint32_t* n_ptr, uint32_t cap, uint32_t seg_len) {
+  return seg_len ? seg_len : gh_clamp_n(n_ptr, cap);
+}
+
+// Exclusive scan of one value per thread over the block (thread order); returns the prefix, *total = block sum.
+// s_w: GH_BLOCK / GH_WAVE words of LDS. Contains two barriers.
+__device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+  __syncthreads();                                     // s_w may still be read by a previous scan
+  if (lane == 63) s_w[wid] = x;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { const uint32_t t = s_w[w]; if (w < wid) woff += t; tot += t; }
+  *total = tot;
+  return woff + x - v;
+}
+
 // Pass part 1: per-block digit histogram -> table[digit][block].
-template <int ITEMS>
+template <int ITEMS, int MAXD>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
-                                                                  uint32_t cap, int shift, uint32_t dmask,
-                                                                  uint32_t* __restrict__ table, int nblk_cap) {
-  __shared__ uint32_t s_hist[256];
-  const uint32_t n = gh_clamp_n(n_ptr, cap);
+                                                                  uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
+                                                                  uint32_t* __restrict__ table) {
+  __shared__ uint32_t s_hist[MAXD];
+  const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
+  const uint32_t seg = blockIdx.y, nblk = gridDim.x, ndig = dmask + 1u;
   const uint32_t base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
   if (base >= n) return;
-  s_hist[threadIdx.x] = 0;
+  keys += (size_t)seg * seg_len;
+  for (uint32_t d = threadIdx.x; d < ndig; d += GH_BLOCK) s_hist[d] = 0;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
@@ -38,19 +67,21 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t*
     if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & dmask], 1u);
   }
   __syncthreads();
-  table[(size_t)threadIdx.x * nblk_cap + blockIdx.x] = s_hist[threadIdx.x];
+  for (uint32_t d = threadIdx.x; d < ndig; d += GH_BLOCK) table[((size_t)seg * ndig + d) * nblk + blockIdx.x] = s_hist[d];
 }
 
-// Pass part 2: one block per digit: exclusive scan of its row over the active blocks, row total -> tot[digit].
+// Pass part 2: one block per (digit, segment): exclusive scan of its row over the active blocks, row total -> tot.
 template <int ITEMS>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ tot,
-                                                                  const uint32_t* __restrict__ n_ptr, uint32_t cap, int nblk_cap) {
+                                                                  const uint32_t* __restrict__ n_ptr, uint32_t cap, uint32_t seg_len,
+                                                                  int nblk_cap) {
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   __shared__ uint32_t s_carry;
-  const uint32_t n = gh_clamp_n(n_ptr, cap);
+  const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
   const int nblk = (int)((n + (GH_BLOCK * ITEMS) - 1) / (GH_BLOCK * ITEMS));
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  uint32_t* row = table + (size_t)blockIdx.x * nblk_cap;
+  const size_t rowi = (size_t)blockIdx.y * gridDim.x + blockIdx.x;       // seg * ndig + digit
+  uint32_t* row = table + rowi * nblk_cap;
   if (tid == 0) s_carry = 0;
   __syncthreads();
   for (int base = 0; base < nblk; base += GH_BLOCK) {
@@ -69,45 +100,57 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __res
     if (tid == GH_BLOCK - 1) s_carry = carry + woff + x;
     __syncthreads();
   }
-  if (tid == 0) tot[blockIdx.x] = s_carry;
+  if (tid == 0) tot[rowi] = s_carry;
 }
 
 // Pass part 3: stable scatter. Ranking is per wave with ballot matching (one ballot per digit bit), waves are
 // ordered through an LDS prefix over their digit counts, so equal digits keep their input order. The tile is first
 // sorted into LDS and then written out, so that each digit run leaves as contiguous global segments.
-template <int ITEMS>
+// Thread t owns the DPT = MAXD / GH_BLOCK consecutive digits [t*DPT, (t+1)*DPT) in the digit-indexed phases.
+template <int ITEMS, int MAXD>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
-    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, int shift, uint32_t dmask,
-    const uint32_t* __restrict__ table, const uint32_t* __restrict__ tot, int nblk_cap) {
-  __shared__ uint32_t s_base[256];                         // global base of (digit, this block)
-  __shared__ uint32_t s_cnt[GH_BLOCK / GH_WAVE][256];      // per-wave digit counters -> per-wave bases
-  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
-  __shared__ uint32_t s_lbase[256];                        // first position of each digit in the locally sorted tile
+    uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
+    int nbit, const uint32_t* __restrict__ table, const uint32_t* __restrict__ tot) {
+  constexpr int DPT = MAXD / GH_BLOCK;
+  constexpr int NW = GH_BLOCK / GH_WAVE;
+  __shared__ uint32_t s_base[MAXD];                        // global base of (digit, this block)
+  __shared__ uint32_t s_cnt[NW][MAXD];                     // per-wave digit counters -> per-wave bases
+  __shared__ uint32_t s_w[NW];
+  __shared__ uint32_t s_lbase[MAXD];                       // first position of each digit in the locally sorted tile
   __shared__ uint32_t s_key[(GH_BLOCK * ITEMS)], s_val[(GH_BLOCK * ITEMS)];
-  const uint32_t n = gh_clamp_n(n_ptr, cap);
+  const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
+  const uint32_t seg = blockIdx.y, nblk = gridDim.x, ndig = dmask + 1u;
   const uint32_t blk_base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
   if (blk_base >= n) return;
+  const size_t seg_off = (size_t)seg * seg_len;
+  keys_in += seg_off; vals_in += seg_off; keys_out += seg_off; vals_out += seg_off;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
   // digit base = exclusive scan over digits of tot[] + this block's row prefix
   {
-    const uint32_t v = (uint32_t)tid <= dmask ? tot[tid] : 0u;
-    uint32_t x = v;
+    uint32_t v[DPT], sum = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wid] = x;
+    for (int k = 0; k < DPT; ++k) {
+      const uint32_t d = (uint32_t)(tid * DPT + k);
+      v[k] = d < ndig ? tot[(size_t)seg * ndig + d] : 0u;
+      sum += v[k];
 #pragma unroll
-    for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) s_cnt[w][tid] = 0;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += s_w[w];
-    s_base[tid] = woff + x - v + ((uint32_t)tid <= dmask ? table[(size_t)tid * nblk_cap + blockIdx.x] : 0u);
+      for (int w = 0; w < NW; ++w) s_cnt[w][d] = 0;
+    }
+    uint32_t total;
+    uint32_t run = gh_block_excl_scan(sum, s_w, &total);
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const uint32_t d = (uint32_t)(tid * DPT + k);
+      s_base[d] = run + (d < ndig ? table[((size_t)seg * ndig + d) * nblk + blockIdx.x] : 0u);
+      run += v[k];
+    }
   }
   __syncthreads();
 
-  // Phase A: rank keys inside the wave. Wave w owns keys [w*1024, (w+1)*1024) of the block's tile,
-  // visited as 16 rounds of 64 consecutive keys, so (round, lane) order == memory order.
+  // Phase A: rank keys inside the wave. Wave w owns keys [w*ITEMS*64, (w+1)*ITEMS*64) of the block's tile,
+  // visited as ITEMS rounds of 64 consecutive keys, so (round, lane) order == memory order.
   uint32_t key[ITEMS];
   uint32_t rank[ITEMS];
   const uint32_t wave_base = blk_base + wid * (ITEMS * GH_WAVE);
@@ -120,13 +163,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     key[r] = valid ? keys_in[idx] : ~0u;
     const uint32_t dg = (key[r] >> shift) & dmask;
     uint64_t peers = gh_ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      if ((dmask >> b) & 1u) {                  // wave-uniform: only the bits of this pass
-        const bool bit = (dg >> b) & 1u;
-        const uint64_t m = gh_ballot(bit);
-        peers &= bit ? m : ~m;
-      }
+    for (int b = 0; b < nbit; ++b) {              // wave-uniform: one ballot per bit of this pass's digit
+      const bool bit = (dg >> b) & 1u;
+      const uint64_t m = gh_ballot(bit);
+      peers &= bit ? m : ~m;
     }
     const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
     uint32_t prev = 0;
@@ -137,23 +177,27 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     rank[r] = prev + before;
   }
   __syncthreads();
-  // Phase B: per-wave bases inside the block's LOCALLY sorted tile (digit = tid): block count per digit, exclusive
-  // scan over the digits, waves in order.
+  // Phase B: per-wave bases inside the block's LOCALLY sorted tile: block count per digit, exclusive scan over the
+  // digits, waves in order.
   {
-    uint32_t c[GH_BLOCK / GH_WAVE];
-    uint32_t tot_d = 0;
+    uint32_t c[DPT][NW], tot_d[DPT], sum = 0;
 #pragma unroll
-    for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { c[w] = s_cnt[w][tid]; tot_d += c[w]; }
-    uint32_t x = tot_d;
+    for (int k = 0; k < DPT; ++k) {
+      const uint32_t d = (uint32_t)(tid * DPT + k);
+      tot_d[k] = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wid] = x;
-    __syncthreads();
-    uint32_t run = x - tot_d;
-    for (int w = 0; w < wid; ++w) run += s_w[w];
-    s_lbase[tid] = run;
+      for (int w = 0; w < NW; ++w) { c[k][w] = s_cnt[w][d]; tot_d[k] += c[k][w]; }
+      sum += tot_d[k];
+    }
+    uint32_t total;
+    uint32_t run = gh_block_excl_scan(sum, s_w, &total);
 #pragma unroll
-    for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { s_cnt[w][tid] = run; run += c[w]; }
+    for (int k = 0; k < DPT; ++k) {
+      const uint32_t d = (uint32_t)(tid * DPT + k);
+      s_lbase[d] = run;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { s_cnt[w][d] = run; run += c[k][w]; }
+    }
   }
   __syncthreads();
   // Phase C: stage the tile in LDS in sorted order ...
@@ -183,40 +227,54 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   }
 }
 
-// Sorts (keys, vals) on bits [0, nbits) with ceil(nbits/8) digits; in/out ping-pong (pointers are swapped so that
-// on return k_in / v_in hold the result). ITEMS keys per thread: 16 for large inputs (bandwidth), 4 for small ones
-// (more, shorter blocks: the pass is latency-bound when it cannot fill the 256 CUs).
+// Sorts (keys, vals) on bits [0, nbits); in/out ping-pong (pointers are swapped so that on return k_in / v_in hold the
+// result). ITEMS keys per thread: 16 for large inputs (bandwidth), 4 for small ones (more, shorter blocks: the pass is
+// latency-bound when it cannot fill the 256 CUs). seg_len / segs: see the top of this section (0 / 1 = one segment with a
+// device-side count).
+
 template <int ITEMS>
 static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr,
-                            uint32_t cap, int nbits, uint32_t* table, hipStream_t s) {
+                            uint32_t cap, int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s) {
+  const size_t per_seg = seg_len ? seg_len : cap;
+  const int nblk = (int)((per_seg + GH_BLOCK * ITEMS - 1) / (GH_BLOCK * ITEMS));
+  if (nblk == 0 || segs == 0) return;
   const int passes = (nbits + 7) / 8;
-  const int nblk = (int)(((size_t)cap + GH_BLOCK * ITEMS - 1) / (GH_BLOCK * ITEMS));
-  if (nblk == 0) return;
-  uint32_t* tot = table + (size_t)256 * nblk;
   for (int p = 0; p < passes; ++p) {
     // spread the bits evenly over the passes (e.g. 13 bits -> 6 + 7)
     const int lo = (nbits * p) / passes, hi = (nbits * (p + 1)) / passes;
     const uint32_t dmask = (1u << (hi - lo)) - 1u;
-    hipLaunchKernelGGL(gh_radix_hist_kernel<ITEMS>, dim3(nblk), dim3(GH_BLOCK), 0, s, k_in, n_ptr, cap, lo, dmask, table, nblk);
-    hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, dim3(dmask + 1), dim3(GH_BLOCK), 0, s, table, tot, n_ptr, cap, nblk);
-    hipLaunchKernelGGL(gh_radix_scatter_kernel<ITEMS>, dim3(nblk), dim3(GH_BLOCK), 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, lo,
-                       dmask, table, tot, nblk);
+    const uint32_t ndig = dmask + 1u;
+    uint32_t* tot = table + (size_t)segs * ndig * nblk;
+    const dim3 gb(nblk, segs), gs(ndig, segs), blk(GH_BLOCK);
+    hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table);
+    hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
+    hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len, lo,
+                       dmask, hi - lo, table, tot);
     uint32_t* t = k_in; k_in = k_out; k_out = t;
     t = v_in; v_in = v_out; v_out = t;
   }
 }
 
-int gh_radix_items(size_t cap) { return cap <= ((size_t)1 << 21) ? 4 : 16; }
+int gh_radix_items(size_t per_segment) { return per_segment <= ((size_t)1 << 21) ? 4 : 16; }
 
-size_t gh_radix_table_words(size_t cap) {
-  const size_t tile = (size_t)GH_BLOCK * gh_radix_items(cap);
-  return 256 * ((cap + tile - 1) / tile) + 256;
+// Table words for sorting `segs` segments of `per_segment` elements (capacity).
+size_t gh_radix_table_words(size_t per_segment, int segs) {
+  const size_t tile = (size_t)GH_BLOCK * gh_radix_items(per_segment);
+  return (size_t)segs * 256 * ((per_segment + tile - 1) / tile) + (size_t)segs * 256;
+}
+
+size_t gh_radix_table_words(size_t cap) { return gh_radix_table_words(cap, 1); }
+
+void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
+                      int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s) {
+  const size_t per_seg = seg_len ? seg_len : cap;
+  if (gh_radix_items(per_seg) == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
+  else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
 }
 
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                    int nbits, uint32_t* table, hipStream_t s) {
-  if (gh_radix_items(cap) == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, table, s);
-  else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, table, s);
+  gh_radix_sort_ex(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, 0u, 1, table, s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -415,10 +473,10 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   const uint32_t cap = (uint32_t)g.cap;
   uint32_t* table = (uint32_t*)(ws + L.sort_tables);
 
-  // level 1: depth order of the Gaussians (keys / payload written by the preprocess kernel; reserved[0] = N)
+  // level 1: depth order of every view's Gaussians (keys / payload written by the preprocess kernel): NV segments of P
   uint32_t* dk_in = (uint32_t*)(ws + L.depth_keys_a); uint32_t* dk_out = (uint32_t*)(ws + L.depth_keys_b);
   uint32_t* dv_in = (uint32_t*)(ws + L.depth_vals_a); uint32_t* dv_out = (uint32_t*)(ws + L.depth_vals_b);
-  gh_radix_sort(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, 32, table, s);
+  gh_radix_sort_ex(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, 32, (uint32_t)g.P, g.NV, table, s);
   const uint32_t* perm = dv_in;                       // 4 passes: the result is back in the *_a buffers
 
   // level 2: emit in depth order

@@ -64,12 +64,15 @@ def compare(sc, dev, check_stages=True, grad_l2=1e-5, grad_rtol=GRAD_RTOL):
         assert torch.equal(torch.stack([g0[inst, 2], g0[inst, 3], g1[inst, 0], g1[inst, 1]], 1), orc.debug["conic_opacity"].reshape(N, 4)[inst])
         assert torch.equal(torch.stack([g1[inst, 2], g1[inst, 3], gb[inst]], 1), orc.debug["rgb"].reshape(N, 3)[inst])
         assert torch.equal(wv["rect"].cpu()[inst], orc.debug["rect"].reshape(N)[inst])
-        # two-level sort (depth order of Gaussians, then stable tile partition): the (tile, gaussian) sequence is a
-        # subsequence, in order, of the oracle's stable sort by tile<<32|depth
-        g_tile = wv["sorted_tile"][:D].cpu().long()
+        # two-level sort (per-view depth order of the Gaussians, then a stable partition by tile): lists are laid out
+        # tile-major / view-minor, so compare per tile: read in ascending global tile id (stable), the (tile, gaussian)
+        # sequence is a subsequence, in order, of the oracle's stable sort by tile<<32|depth
+        g_tile_raw = wv["sorted_tile"][:D].cpu().long()
         g_slot = wv["sorted_slot"][:D].cpu().long()
-        g_gid = wv["sorted_gid"][:D].cpu().long()
+        g_gid_raw = wv["sorted_gid"][:D].cpu().long()
         assert torch.equal(g_slot.sort().values, torch.arange(D))               # emit slots are a permutation of 0..D-1
+        by_tile = torch.argsort(g_tile_raw, stable=True)
+        g_tile, g_gid = g_tile_raw[by_tile], g_gid_raw[by_tile]
         o_tile, o_gid = (orc.debug["sorted_keys"] >> 32).long(), orc.debug["sorted_gid"].long()
         o_pair, g_pair = o_tile * N + o_gid, g_tile * N + g_gid
         order = torch.argsort(o_pair)                                            # pairs are unique
@@ -78,12 +81,14 @@ def compare(sc, dev, check_stages=True, grad_l2=1e-5, grad_rtol=GRAD_RTOL):
         assert torch.equal(so[idx], g_pair)                                      # every GPU instance is an oracle instance ...
         where = order[idx]
         assert bool((where[1:] > where[:-1]).all())                              # ... and they come in the oracle's order
-        # ranges index the culled list consistently
+        # ranges index the culled list consistently: every tile's range is one contiguous run of its own instances
         rng = wv["ranges"].cpu().long()
-        cnt = torch.bincount(g_tile, minlength=rng.shape[0])
-        assert torch.equal(rng[:, 1] - rng[:, 0], cnt) and bool((g_tile[1:] >= g_tile[:-1]).all())
+        cnt = torch.bincount(g_tile_raw, minlength=rng.shape[0])
+        assert torch.equal(rng[:, 1] - rng[:, 0], cnt)
         nz = cnt > 0
-        assert torch.equal(rng[nz, 0], (torch.cumsum(cnt, 0) - cnt)[nz])
+        first = torch.full((rng.shape[0],), D, dtype=torch.long).scatter_reduce(0, g_tile_raw, torch.arange(D), reduce="amin")
+        last = torch.full((rng.shape[0],), -1, dtype=torch.long).scatter_reduce(0, g_tile_raw, torch.arange(D), reduce="amax")
+        assert torch.equal(rng[nz, 0], first[nz]) and torch.equal(rng[nz, 1], last[nz] + 1)
         # per pixel: same transmittance, and the last blended entry is the same Gaussian as in the oracle's list
         assert torch.equal(wv["final_T"].cpu(), orc.debug["final_T"])
         NV, H, W = sc.w2c.shape[0], sc.H, sc.W
@@ -94,7 +99,7 @@ def compare(sc, dev, check_stages=True, grad_l2=1e-5, grad_rtol=GRAD_RTOL):
         assert torch.equal(nc_g > 0, nc_o > 0)
         o_rng = orc.debug["ranges"].long()
         sel = nc_g > 0
-        last_g = g_gid[(rng[tile_of, 0] + nc_g - 1)[sel]]
+        last_g = g_gid_raw[(rng[tile_of, 0] + nc_g - 1)[sel]]
         last_o = o_gid[(o_rng[tile_of, 0] + nc_o - 1)[sel]]
         assert torch.equal(last_g, last_o)
     assert (img.cpu() - orc.image).abs().max().item() <= IMG_LINF
