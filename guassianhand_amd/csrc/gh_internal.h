@@ -8,8 +8,6 @@
 
 #define GH_WAVE 64
 #define GH_BLOCK 256                 // 4 waves: one 8x8 pixel quadrant of a 16x16 tile per wave
-#define GH_SORT_ITEMS 16             // keys per thread per radix pass
-#define GH_SORT_TILE (GH_BLOCK * GH_SORT_ITEMS)
 #define GH_REC 12                    // LDS stride (floats) of a partial gradient record (9 used; float4-aligned)
 #define GH_REC_G 9                   // floats per (instance, quadrant) sub-record in HBM: packed, three 12-byte accesses
 
@@ -19,7 +17,6 @@ struct GhGrid {
   int P, NV, H, W, gx, gy, tiles, N;  // N = NV*P
   int tile_bits, n_pass;
   int64_t cap;                        // max_instances
-  int nblk_sort;                      // ceil(cap / GH_SORT_TILE)
   int n_items;                        // capacity of the backward work list: NV*tiles + cap/GH_SEGMENT + 2
 };
 
@@ -31,8 +28,6 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
   int tb = 1; while ((1ll << tb) < (long long)g.tiles * d->n_views) ++tb;
   g.tile_bits = tb; g.n_pass = 4 + (tb + 7) / 8;   // level-1 depth passes + level-3 tile passes
   g.cap = d->max_instances;
-  g.nblk_sort = (int)((g.cap + GH_SORT_TILE - 1) / GH_SORT_TILE);
-  if (g.nblk_sort < 1) g.nblk_sort = 1;
   g.n_items = (int)((size_t)g.NV * g.tiles + (size_t)g.cap / GH_SEGMENT + 2);
   return g;
 }
