@@ -8,7 +8,7 @@
 
 #define GH_WAVE 64
 #define GH_BLOCK 256                 // 4 waves: one 8x8 pixel quadrant of a 16x16 tile per wave
-#define GH_REC 12                    // LDS stride (floats) of a partial gradient record (9 used; float4-aligned)
+#define GH_REC 9                     // LDS stride (floats) of a partial gradient record: 18 KB per block keeps 8 blocks per CU
 #define GH_REC_G 9                   // floats per (instance, quadrant) sub-record in HBM: packed, three 12-byte accesses
 
 struct GhF3 { float x, y, z; };      // 12-byte access (global_load/store_dwordx3)

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const float4* __restrict__ ckpt_rgb, const float4* __restrict__ final_C,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, float* __restrict__ inst_grad,
     uint8_t* __restrict__ inst_flag) {
-  __shared__ float s_part[2][GH_BLOCK / GH_WAVE][GH_WAVE][GH_REC];    // [buffer][wave][entry][9 used]  (24 KB)
+  __shared__ float s_part[2][GH_BLOCK / GH_WAVE][GH_WAVE][GH_REC];    // [buffer][wave][entry][9]  (18 KB: 8 blocks per CU)
   __shared__ uint64_t s_mask[2][GH_BLOCK / GH_WAVE];                  // entries a wave wrote
   __shared__ int s_qlast;
   int v, tx, ty;
