@@ -228,7 +228,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
 }
 
 // Sorts (keys, vals) on bits [0, nbits); in/out ping-pong (pointers are swapped so that on return k_in / v_in hold the
-// result). ITEMS keys per thread: 16 for large inputs (bandwidth), 4 for small ones (more, shorter blocks: the pass is
+// result). ITEMS keys per thread: 16 for large inputs (bandwidth), 8 / 4 for smaller ones (more, shorter blocks: the pass is
 // latency-bound when it cannot fill the 256 CUs). seg_len / segs: see the top of this section (0 / 1 = one segment with a
 // device-side count).
 
@@ -255,7 +255,9 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
   }
 }
 
-int gh_radix_items(size_t per_segment) { return per_segment <= ((size_t)1 << 21) ? 4 : 16; }
+// keys per thread: measured on the 8-view workload (98 k keys per segment / 3 M instances): 2 / 4 / 8 for the small class
+// gave 0.296 / 0.287 / 0.294 ms of binning, 4 / 8 / 16 for the middle class 0.298 / 0.287 / 0.294
+int gh_radix_items(size_t per_segment) { return per_segment <= ((size_t)1 << 21) ? 4 : (per_segment <= ((size_t)1 << 25) ? 8 : 16); }
 
 // Table words for sorting `segs` segments of `per_segment` elements (capacity).
 size_t gh_radix_table_words(size_t per_segment, int segs) {
@@ -268,7 +270,9 @@ size_t gh_radix_table_words(size_t cap) { return gh_radix_table_words(cap, 1); }
 void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                       int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s) {
   const size_t per_seg = seg_len ? seg_len : cap;
-  if (gh_radix_items(per_seg) == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
+  const int items = gh_radix_items(per_seg);
+  if (items == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
+  else if (items == 8) gh_radix_sort_t<8>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
   else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
 }
 
@@ -373,7 +377,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
 // Per sorted instance: tile ranges, the render record gathered from the Gaussian's 64-byte geometry line, and the
 // 16-bit mask of the tile's 4x4-pixel blocks the alpha >= 1/255 ellipse can reach (gh_block_mask16): the render
 // kernels test one bit instead of repeating the ellipse/rectangle test per wave, forward and backward.
-__global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+__global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
+    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                               const GhCounters* __restrict__ ctr, uint32_t cap, int gx, int tiles,
                                                               const float4* __restrict__ geom, uint32_t* __restrict__ sorted_slot,
                                                               uint2* __restrict__ ranges, float4* __restrict__ r0,
