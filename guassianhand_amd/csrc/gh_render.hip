@@ -132,6 +132,27 @@ __device__ __forceinline__ float gh_lane_fetch(float v, int src_lane_x4) {   // 
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane_x4, __builtin_bit_cast(int, v)));
 }
 
+// The (up to) four lowest / highest set bits of a wave-uniform hit mask, removed from the mask, as lane numbers in
+// 0..63 (an arbitrary valid lane when fewer than four bits are set: callers gate on the count taken beforehand).
+// s_ff1 / s_flbit + s_bitset0 (which uses the low 6 bits of its operand, so the -1 of an empty mask is harmless): two to
+// three scalar instructions per pick instead of the six of `ctz`, `mask &= mask - 1`, compare and select.
+__device__ __forceinline__ void gh_pop4_low(uint64_t& mask, int& j0, int& j1, int& j2, int& j3) {
+  asm("s_ff1_i32_b64 %1, %0\n\ts_bitset0_b64 %0, %1\n\t"
+      "s_ff1_i32_b64 %2, %0\n\ts_bitset0_b64 %0, %2\n\t"
+      "s_ff1_i32_b64 %3, %0\n\ts_bitset0_b64 %0, %3\n\t"
+      "s_ff1_i32_b64 %4, %0\n\ts_bitset0_b64 %0, %4"
+      : "+s"(mask), "=&s"(j0), "=&s"(j1), "=&s"(j2), "=&s"(j3));
+  j0 &= 63; j1 &= 63; j2 &= 63; j3 &= 63;
+}
+__device__ __forceinline__ void gh_pop4_high(uint64_t& mask, int& j0, int& j1, int& j2, int& j3) {
+  asm("s_flbit_i32_b64 %1, %0\n\ts_xor_b32 %1, %1, 63\n\ts_bitset0_b64 %0, %1\n\t"
+      "s_flbit_i32_b64 %2, %0\n\ts_xor_b32 %2, %2, 63\n\ts_bitset0_b64 %0, %2\n\t"
+      "s_flbit_i32_b64 %3, %0\n\ts_xor_b32 %3, %3, 63\n\ts_bitset0_b64 %0, %3\n\t"
+      "s_flbit_i32_b64 %4, %0\n\ts_xor_b32 %4, %4, 63\n\ts_bitset0_b64 %0, %4"
+      : "+s"(mask), "=&s"(j0), "=&s"(j1), "=&s"(j2), "=&s"(j3) : : "scc");
+  j0 &= 63; j1 &= 63; j2 &= 63; j3 &= 63;
+}
+
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
 template <bool ALPHA>
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, int blk,
@@ -142,10 +163,8 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
   while (mask) {
     // next four set bits, ascending (wave-uniform scalar work)
     const int nh = __builtin_popcountll(mask);                      // entries left in this batch (>= 1)
-    const int j0 = __builtin_ctzll(mask); mask &= mask - 1;
-    const int n1 = mask != 0; const int j1 = n1 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
-    const int n2 = mask != 0; const int j2 = n2 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
-    const int n3 = mask != 0; const int j3 = n3 ? __builtin_ctzll(mask) : j0; mask &= mask - 1;
+    int j0, j1, j2, j3;
+    gh_pop4_low(mask, j0, j1, j2, j3);
     // the four entry lanes travel as bytes of one scalar: a lane extracts its slot's with a single v_bfe
     const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
     const int src = (int)((packed4 >> slot8) & 0xFFu);              // 4 * entry lane = ds_bpermute address
@@ -421,10 +440,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     while (mask) {
       // next four set bits, descending (back to front); wave-uniform scalar work
       const int nh = __builtin_popcountll(mask);                     // entries left in this batch (>= 1)
-      const int j0 = 63 - __builtin_clzll(mask); mask &= ~(1ull << j0);
-      const int n1 = mask != 0; const int j1 = n1 ? 63 - __builtin_clzll(mask) : j0; if (n1) mask &= ~(1ull << j1);
-      const int n2 = mask != 0; const int j2 = n2 ? 63 - __builtin_clzll(mask) : j0; if (n2) mask &= ~(1ull << j2);
-      const int n3 = mask != 0; const int j3 = n3 ? 63 - __builtin_clzll(mask) : j0; if (n3) mask &= ~(1ull << j3);
+      int j0, j1, j2, j3;
+      gh_pop4_high(mask, j0, j1, j2, j3);
       const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
       const int src = (int)((packed4 >> slot8) & 0xFFu);            // one v_bfe: 4 * this slot's entry lane
       const int myj = src >> 2;
