@@ -132,17 +132,18 @@ __device__ __forceinline__ float gh_lane_fetch(float v, int src_lane_x4) {   // 
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane_x4, __builtin_bit_cast(int, v)));
 }
 
-// The (up to) four lowest / highest set bits of a wave-uniform hit mask, removed from the mask, as lane numbers in
-// 0..63 (an arbitrary valid lane when fewer than four bits are set: callers gate on the count taken beforehand).
+// The (up to) four lowest / highest set bits of a wave-uniform hit mask, removed from the mask, as lane numbers.
 // s_ff1 / s_flbit + s_bitset0 (which uses the low 6 bits of its operand, so the -1 of an empty mask is harmless): two to
 // three scalar instructions per pick instead of the six of `ctz`, `mask &= mask - 1`, compare and select.
+// With fewer than four bits set the trailing picks are -1 (low) / -64 (high): callers gate on the count taken beforehand,
+// and in the packed form (j0 | j1 << 8 | j2 << 16 | j3 << 24) << 2 such a value only spills into the bytes of LATER picks,
+// which are invalid too, so no masking is needed.
 __device__ __forceinline__ void gh_pop4_low(uint64_t& mask, int& j0, int& j1, int& j2, int& j3) {
   asm("s_ff1_i32_b64 %1, %0\n\ts_bitset0_b64 %0, %1\n\t"
       "s_ff1_i32_b64 %2, %0\n\ts_bitset0_b64 %0, %2\n\t"
       "s_ff1_i32_b64 %3, %0\n\ts_bitset0_b64 %0, %3\n\t"
       "s_ff1_i32_b64 %4, %0\n\ts_bitset0_b64 %0, %4"
       : "+s"(mask), "=&s"(j0), "=&s"(j1), "=&s"(j2), "=&s"(j3));
-  j0 &= 63; j1 &= 63; j2 &= 63; j3 &= 63;
 }
 __device__ __forceinline__ void gh_pop4_high(uint64_t& mask, int& j0, int& j1, int& j2, int& j3) {
   asm("s_flbit_i32_b64 %1, %0\n\ts_xor_b32 %1, %1, 63\n\ts_bitset0_b64 %0, %1\n\t"
@@ -150,7 +151,6 @@ __device__ __forceinline__ void gh_pop4_high(uint64_t& mask, int& j0, int& j1, i
       "s_flbit_i32_b64 %3, %0\n\ts_xor_b32 %3, %3, 63\n\ts_bitset0_b64 %0, %3\n\t"
       "s_flbit_i32_b64 %4, %0\n\ts_xor_b32 %4, %4, 63\n\ts_bitset0_b64 %0, %4"
       : "+s"(mask), "=&s"(j0), "=&s"(j1), "=&s"(j2), "=&s"(j3) : : "scc");
-  j0 &= 63; j1 &= 63; j2 &= 63; j3 &= 63;
 }
 
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
