@@ -149,8 +149,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t
     if (o0 > o1) o0 = o1;
   }
   float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t fnext = o0 < o1 ? inst_flag[o0] : 0u;           // 4 quadrant flag bytes of a tile instance
   for (uint32_t sidx = o0; sidx < o1; ++sidx) {
-    const uint32_t f = inst_flag[sidx];                      // 4 quadrant flag bytes of this tile instance
+    const uint32_t f = fnext;
+    fnext = sidx + 1 < o1 ? inst_flag[sidx + 1] : 0u;        // next instance's flags in flight behind this one's records
     if ((f >> (8 * q)) & 1u) {
       const GhF3* r = (const GhF3*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC_G);
       const GhF3 r0 = r[0], r1 = r[1], r2 = r[2];
