@@ -429,6 +429,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     st.Bs = fmaf(d2, (fc.z - c.w) * iT, fmaf(d1, (fc.y - c.z) * iT, d0 * ((fc.x - c.y) * iT)));
   }
   const int nb = (qend - seg_lo + GH_WAVE - 1) / GH_WAVE;
+  const uint32_t row3_slot_bit = lane >= 48 ? 1u << slot : 0u;     // the lanes that hold a slot's totals after the 16-pixel sums
   GhBatch cur, nxt;
   gh_load_batch(cur, r0, r1, r2, seg_lo + (nb - 1) * GH_WAVE + lane, qend);
   for (int k = nb - 1; k >= 0; --k) {
@@ -441,7 +442,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       // next four set bits, descending (back to front); wave-uniform scalar work
       const int nh = __builtin_popcountll(mask);                     // entries left in this batch (>= 1)
       int j0, j1, j2, j3;
+      const uint64_t before = mask;
       gh_pop4_high(mask, j0, j1, j2, j3);
+      const uint64_t picked = before ^ mask;                             // the (up to) four entries of this trip
       const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
       const int src = (int)((packed4 >> slot8) & 0xFFu);            // one v_bfe: 4 * this slot's entry lane
       const int myj = src >> 2;
@@ -516,13 +519,19 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
         v += gh_lane_fetch(v, (lane ^ 32) << 2);             // every row: bank b holds the total of value 4g + 3 - b, slot = lane & 3
         R[g] = v;
       }
-      // slots in which at least one pixel blended its entry get a partial record (wave-uniform bookkeeping)
-      uint64_t wm = 0;                                   // lanes of the slots that get a record (scalar arithmetic)
-      if (cm & 0x1111111111111111ull) { processed |= 1ull << j0; wm |= 0x1111000000000000ull; }
-      if (cm & 0x2222222222222222ull) { processed |= 1ull << j1; wm |= 0x2222000000000000ull; }
-      if (cm & 0x4444444444444444ull) { processed |= 1ull << j2; wm |= 0x4444000000000000ull; }
-      if (cm & 0x8888888888888888ull) { processed |= 1ull << j3; wm |= 0x8888000000000000ull; }
-      if ((wm >> lane) & 1ull) {                                        // row 3: lane 48 + 4b + slot holds values 3-b, 7-b (and 8 for b = 3)
+      // slots in which at least one pixel blended its entry get a partial record (wave-uniform bookkeeping, scalar):
+      // act = OR of the contribution ballot over the 16 pixels -> one bit per slot. Nearly always every picked entry is
+      // active, and then the processed set simply grows by the picked bits.
+      uint32_t act = (uint32_t)cm | (uint32_t)(cm >> 32);
+      act |= act >> 16; act |= act >> 8; act |= act >> 4; act &= 15u;
+      if (act == (nh >= 4 ? 15u : (1u << nh) - 1u)) processed |= picked;
+      else {
+        if (act & 1u) processed |= 1ull << j0;
+        if (act & 2u) processed |= 1ull << j1;
+        if (act & 4u) processed |= 1ull << j2;
+        if (act & 8u) processed |= 1ull << j3;
+      }
+      if (act & row3_slot_bit) {                                        // row 3: lane 48 + 4b + slot holds values 3-b, 7-b (and 8 for b = 3)
         float* pr = &s_part[buf][wid][myj][0];
         const int q0 = 3 - ((lane >> 2) & 3);
         pr[q0] = R[0];
