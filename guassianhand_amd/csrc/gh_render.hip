@@ -160,7 +160,8 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
   const uint32_t slot8 = (uint32_t)slot * 8u;
   const bool hit = (base + lane < total) && ((t.blocks >> blk) & 1u);
   uint64_t mask = gh_ballot(hit);
-  while (mask) {
+  bool finished = false;                                             // set (and the mask cleared) inside the rare stop branch, so
+  while (mask) {                                                     // the common path's loop control is one scalar compare
     // next four set bits, ascending (wave-uniform scalar work)
     const int nh = __builtin_popcountll(mask);                      // entries left in this batch (>= 1)
     int j0, j1, j2, j3;
@@ -196,6 +197,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
       blend = valid && ((qb & ((2u << slot) - 1u)) == 0u);         // no stop at or before this slot
       Tn = (qb & 1u) ? p.T : ((qb & 2u) ? P1 : ((qb & 4u) ? P2 : ((qb & 8u) ? P3 : P4)));   // T right before the stop
       if (qb) p.done = 1;
+      if (__all(p.done != 0)) { finished = true; mask = 0; }        // every pixel of the block is saturated: last trip
     }
     const float w = blend ? alpha * Pm : 0.0f;                     // C + c*0 == C exactly
     const float m0 = r * w, m1 = g * w, m2 = bl * w;
@@ -207,9 +209,8 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     // n_contrib: every lane remembers the last entry of ITS slot that was blended; the pixel's value is the maximum
     // over its four lanes, taken once after the walk.
     p.last = blend ? (uint32_t)(base + 1) + (uint32_t)(src >> 2) : p.last;   // per LANE (positions ascend); quad max at the end
-    if (sb && __all(p.done != 0)) return true;                     // every pixel of the block is saturated
   }
-  return false;
+  return finished;
 }
 
 // grid = 4 blocks per tile (one per 8x8 quadrant), 4 waves per block (one per 4x4 pixel block); no LDS, no barriers.
