@@ -228,7 +228,8 @@ def main():
                 local_step(sync=False).backward()
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: HIP calls of other threads (e.g. the RCCL watchdog's event queries) must not invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 g_loss = local_step(sync=False)
                 g_loss.backward()
             graph.replay()
