@@ -326,9 +326,10 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 // ------------------------------------------------------------------------------------------------
 // ---- backward: wave = 4x4 pixels x 4 depth slots, block = one 8x8 quadrant ----------------------------------
 // Same lane mapping as the forward (lane = 4*pixel + slot); entries are taken four per trip from the back.
-// Per pixel the reverse recurrence carries only (T, colour-behind B): after blending entry k,
-// B <- alpha_k*c_k + (1-alpha_k)*B, which is the oracle's lazily evaluated `accum` computed one step earlier on
-// the same operands. The recurrence walks the quad with quad_perm broadcasts; every lane keeps the state that
+// Per pixel the reverse recurrence carries only (T, Bs): Bs = dL/dpixel . (colour behind). The oracle's colour behind
+// obeys B <- alpha_k*c_k + (1-alpha_k)*B, which is linear, and dL/dalpha only needs d . B, so one scalar chain
+// Bs <- alpha_k*(d . c_k) + (1-alpha_k)*Bs replaces the per-channel ones; the mask channel (A = 1 - T_final) rides on the
+// background term. The recurrence walks the quad with quad_perm broadcasts; every lane keeps the state that
 // was current at ITS slot and then evaluates its nine partial gradients once. They are summed over the 16 pixels
 // of the slot (row_shr:4, row_shr:8, then xor-16 / xor-32 through the LDS crossbar) and the four waves of the
 // quadrant are combined through a double-buffered LDS stage, one barrier per 64 list entries, in fixed wave
