@@ -127,6 +127,17 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   keys_in += seg_off; vals_in += seg_off; keys_out += seg_off; vals_out += seg_off;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
+  // the block's keys: loads issued first, they do not depend on the digit bases computed below.
+  // Wave w owns keys [w*ITEMS*64, (w+1)*ITEMS*64) of the block's tile, visited as ITEMS rounds of 64 consecutive keys,
+  // so (round, lane) order == memory order.
+  uint32_t key[ITEMS];
+  const uint32_t wave_base = blk_base + wid * (ITEMS * GH_WAVE);
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const uint32_t idx = wave_base + r * GH_WAVE + lane;
+    key[r] = idx < n ? keys_in[idx] : ~0u;
+  }
+
   // digit base = exclusive scan over digits of tot[] + this block's row prefix
   {
     uint32_t v[DPT], sum = 0;
@@ -149,18 +160,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   }
   __syncthreads();
 
-  // Phase A: rank keys inside the wave. Wave w owns keys [w*ITEMS*64, (w+1)*ITEMS*64) of the block's tile,
-  // visited as ITEMS rounds of 64 consecutive keys, so (round, lane) order == memory order.
-  uint32_t key[ITEMS];
+  // Phase A: rank keys inside the wave.
   uint32_t rank[ITEMS];
-  const uint32_t wave_base = blk_base + wid * (ITEMS * GH_WAVE);
   volatile uint32_t* cnt = s_cnt[wid];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t idx = wave_base + r * GH_WAVE + lane;
     const bool valid = idx < n;
-    key[r] = valid ? keys_in[idx] : ~0u;
     const uint32_t dg = (key[r] >> shift) & dmask;
     uint64_t peers = gh_ballot(valid);
     for (int b = 0; b < nbit; ++b) {              // wave-uniform: one ballot per bit of this pass's digit
