@@ -59,12 +59,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t*
   const uint32_t base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
   if (base >= n) return;
   keys += (size_t)seg * seg_len;
+  uint32_t k[ITEMS];                                       // loads in flight while the counters are cleared
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const uint32_t idx = base + j * GH_BLOCK + threadIdx.x;
+    k[j] = idx < n ? keys[idx] : 0u;
+  }
   for (uint32_t d = threadIdx.x; d < ndig; d += GH_BLOCK) s_hist[d] = 0;
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const uint32_t idx = base + j * GH_BLOCK + threadIdx.x;
-    if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & dmask], 1u);
+    if (idx < n) atomicAdd(&s_hist[(k[j] >> shift) & dmask], 1u);
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < ndig; d += GH_BLOCK) table[((size_t)seg * ndig + d) * nblk + blockIdx.x] = s_hist[d];
@@ -130,12 +136,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   // the block's keys: loads issued first, they do not depend on the digit bases computed below.
   // Wave w owns keys [w*ITEMS*64, (w+1)*ITEMS*64) of the block's tile, visited as ITEMS rounds of 64 consecutive keys,
   // so (round, lane) order == memory order.
-  uint32_t key[ITEMS];
+  uint32_t key[ITEMS], val[ITEMS];
   const uint32_t wave_base = blk_base + wid * (ITEMS * GH_WAVE);
 #pragma unroll
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t idx = wave_base + r * GH_WAVE + lane;
     key[r] = idx < n ? keys_in[idx] : ~0u;
+    val[r] = idx < n ? vals_in[idx] : 0u;
   }
 
   // digit base = exclusive scan over digits of tot[] + this block's row prefix
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
       const uint32_t dg = (key[r] >> shift) & dmask;
       const uint32_t lpos = s_cnt[wid][dg] + rank[r];
       s_key[lpos] = key[r];
-      s_val[lpos] = vals_in[idx];
+      s_val[lpos] = val[r];
     }
   }
   __syncthreads();
@@ -311,10 +318,13 @@ __global__ __launch_bounds__(1024) void gh_scan_blocksums_kernel(uint32_t* __res
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (tid == 0) s_carry = 0;
   __syncthreads();
-  for (int base = 0; base < nblk; base += 1024) {
-    const int idx = base + tid;
-    const uint32_t v = idx < nblk ? block_sums[idx] : 0u;
-    uint32_t x = v;  // inclusive wave scan
+  for (int base = 0; base < nblk; base += 4096) {      // four consecutive sums per thread: 4096 per sweep (one sweep up to 1 M Gaussians)
+    const int i0 = base + tid * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = i0 + j < nblk ? block_sums[i0 + j] : 0u;
+    const uint32_t mine = (v[0] + v[1]) + (v[2] + v[3]);
+    uint32_t x = mine;  // inclusive wave scan of the per-thread sums
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
     if (lane == 63) s_w[wid] = x;
@@ -322,7 +332,9 @@ __global__ __launch_bounds__(1024) void gh_scan_blocksums_kernel(uint32_t* __res
     uint32_t woff = 0;
     for (int w = 0; w < wid; ++w) woff += s_w[w];
     const uint32_t carry = s_carry;
-    if (idx < nblk) block_sums[idx] = carry + woff + x - v;
+    uint32_t run = carry + woff + x - mine;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { if (i0 + j < nblk) block_sums[i0 + j] = run; run += v[j]; }
     __syncthreads();
     if (tid == 1023) s_carry = carry + woff + x;
     __syncthreads();
@@ -349,6 +361,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   float4* grec = geom + (size_t)n * 4;
   const uint32_t cnt = i < N ? tiles_touched[n] : 0u;
   const float4 g2 = grec[2];                            // rect + tile hit mask: issued before the scan, not after it
+  const uint32_t blk_off = block_offsets[blockIdx.x];
   uint32_t x = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   uint32_t woff = 0;
   for (int w = 0; w < wid; ++w) woff += s_w[w];
   if (i >= N) return;
-  uint32_t off = block_offsets[blockIdx.x] + woff + x - cnt;
+  uint32_t off = blk_off + woff + x - cnt;
   slot_begin[n] = off;
   if (cnt == 0) return;
   const uint32_t r = __float_as_uint(g2.y);
