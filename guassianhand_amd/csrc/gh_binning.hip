@@ -77,6 +77,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t*
 }
 
 // Pass part 2: one block per (digit, segment): exclusive scan of its row over the active blocks, row total -> tot.
+// Four consecutive row entries per thread: 1024 blocks per sweep (one sweep for the depth level, two for 3 M instances).
 template <int ITEMS>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ tot,
                                                                   const uint32_t* __restrict__ n_ptr, uint32_t cap, uint32_t seg_len,
@@ -90,10 +91,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __res
   uint32_t* row = table + rowi * nblk_cap;
   if (tid == 0) s_carry = 0;
   __syncthreads();
-  for (int base = 0; base < nblk; base += GH_BLOCK) {
-    const int idx = base + tid;
-    const uint32_t v = idx < nblk ? row[idx] : 0u;
-    uint32_t x = v;
+  for (int base = 0; base < nblk; base += 4 * GH_BLOCK) {
+    const int i0 = base + tid * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = i0 + j < nblk ? row[i0 + j] : 0u;
+    const uint32_t mine = (v[0] + v[1]) + (v[2] + v[3]);
+    uint32_t x = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
     if (lane == 63) s_w[wid] = x;
@@ -101,7 +105,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __res
     uint32_t woff = 0;
     for (int w = 0; w < wid; ++w) woff += s_w[w];
     const uint32_t carry = s_carry;
-    if (idx < nblk) row[idx] = carry + woff + x - v;
+    uint32_t run = carry + woff + x - mine;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { if (i0 + j < nblk) row[i0 + j] = run; run += v[j]; }
     __syncthreads();
     if (tid == GH_BLOCK - 1) s_carry = carry + woff + x;
     __syncthreads();
