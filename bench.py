@@ -125,7 +125,7 @@ def main():
 
     from guassianhand_amd import dist as ghdist
     from guassianhand_amd import rasterizer as R
-    from guassianhand_amd.loss import l1_mean_loss
+    from guassianhand_amd.loss import rendered_l1_loss
     from guassianhand_amd.scenes import make_scene, perturbed_target_xyz
     import torch.distributed as tdist
 
@@ -170,11 +170,12 @@ def main():
         """One pass of the hot path over this rank's views: forward, loss, backward. No collective."""
         for p in params.values():
             p.grad = None
-        img, _ = R.rasterize_views(cams, params["xyz"], params["opacity"], params["scaling"], params["rotation"],
-                                   params["shs"], H=H, W=W, use_rgb=s.use_rgb, sh_degree=s.sh_degree, sync=sync,
-                                   xyz_b=params.get("xyz_b"), opacity_b=params.get("opacity_b"),
-                                   color_w=params.get("color_w"), color_b=params.get("color_b"), **pv)
-        loss = l1_mean_loss(img, gt)                 # mean|img - gt| and dL/dimg in one fused pass (gh_l1_loss)
+        # render + loss as one autograd node: mean|img - gt| and dL/dimg from one fused pass (gh_l1_loss), dL/dloss applied
+        # inside the render backward (GhGrads.upstream_scale) instead of in an elementwise pass over the images
+        loss, _img, _ = rendered_l1_loss(cams, params["xyz"], params["opacity"], params["scaling"], params["rotation"],
+                                         params["shs"], gt, H=H, W=W, use_rgb=s.use_rgb, sh_degree=s.sh_degree, sync=sync,
+                                         xyz_b=params.get("xyz_b"), opacity_b=params.get("opacity_b"),
+                                         color_w=params.get("color_w"), color_b=params.get("color_b"), **pv)
         return loss
 
     def reduce_grads(loss):

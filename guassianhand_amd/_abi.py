@@ -44,7 +44,7 @@ class GhGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "dL_dimage", "dL_dalpha", "dL_dmeans3D", "dL_dmeans2D", "dL_dopacities", "dL_dscales", "dL_drotations",
         "dL_dshs", "dL_dcolors", "dL_dblend_xyz_b", "dL_dblend_opacity_b", "dL_dblend_color_w",
-        "dL_dblend_color_b")]
+        "dL_dblend_color_b", "upstream_scale")]
 
 
 LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "depth", "rect", "clamped",

@@ -143,7 +143,7 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
   char* ws = (char*)workspace;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
-  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, ws, L, s);
+  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, L, s);
   if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -39,7 +39,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha,
                           char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
-                          const float* dL_dalpha, char* ws, const GhLayout& L, hipStream_t s);
+                          const float* dL_dalpha, const float* upstream_scale, char* ws, const GhLayout& L, hipStream_t s);
 // LSD radix sort of (keys, vals) on bits [0, nbits): ceil(nbits/8) stable passes, element count read from device memory
 // (*n_ptr <= cap); pointers are swapped so that on return k_in / v_in hold the result. table: gh_radix_table_words(cap).
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,

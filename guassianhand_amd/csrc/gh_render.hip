@@ -363,8 +363,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const float4* __restrict__ r0, const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams,
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float4* __restrict__ ckpt_rgb, const float4* __restrict__ final_C,
-    const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, float* __restrict__ inst_grad,
-    uint8_t* __restrict__ inst_flag) {
+    const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, const float* __restrict__ upstream_scale,
+    float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag) {
   __shared__ float s_part[2][GH_BLOCK / GH_WAVE][GH_WAVE][GH_REC];    // [buffer][wave][entry][9]  (18 KB: 8 blocks per CU)
   __shared__ uint64_t s_mask[2][GH_BLOCK / GH_WAVE];                  // entries a wave wrote
   __shared__ int s_qlast;
@@ -401,6 +401,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const float* dimg = dL_dimage + (size_t)v * 3 * H * W + (size_t)y * W + x;
     d0 = dimg[0]; d1 = dimg[(size_t)H * W]; d2 = dimg[(size_t)2 * H * W];
     if (ALPHA) dM = dL_dalpha_img[pix];             // fused mask channel: colour 1, background 0
+    if (upstream_scale) {                           // dL/dloss of a scalar loss, applied here instead of in a pass of its own
+      const float us = upstream_scale[0];
+      d0 *= us; d1 *= us; d2 *= us; dM *= us;
+    }
   }
   // background term and (ALPHA) the mask channel: both are multiples of T_final / (1 - alpha_k)
   const float bg_dot = (bg[0] * d0 + bg[1] * d1 + bg[2] * d2) - dM;
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
 }
 
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
-                          const float* dL_dalpha, char* ws, const GhLayout& L, hipStream_t s) {
+                          const float* dL_dalpha, const float* upstream_scale, char* ws, const GhLayout& L, hipStream_t s) {
   if (g.cap == 0) return;
   // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (same n_contrib).
   // The work list (tile, depth segment) was written by the forward's last wave of every tile.
@@ -582,7 +586,7 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                        (const uint32_t*)(ws + L.sorted_slot), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
                        (const float2*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
                        (const uint32_t*)(ws + L.n_contrib), (const float4*)(ws + L.ckpt_rgb),
-                       (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, (float*)(ws + L.inst_grad),
+                       (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, upstream_scale, (float*)(ws + L.inst_grad),
                        (uint8_t*)(ws + L.inst_flag));
   };
   if (dL_dalpha) launch(gh_render_bwd_kernel<true>); else launch(gh_render_bwd_kernel<false>);

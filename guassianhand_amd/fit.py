@@ -178,9 +178,26 @@ class OneShotFit(nn.Module):
             grads = {k: torch.zeros_like(leaves[k]) for k in names}
         else:                                                      # graph B: rasteriser + image loss
             allv = len(mine) == n_total
-            out = self.render(w2cs if allv else w2cs[mine], Ks if allv else Ks[mine], H, W, bg, leaves, sync=sync)
             sel = (lambda t: t) if len(mine) == n_total else (lambda t: t[mine])
-            if "image_chw" in out and out["image_chw"].is_cuda:      # fused loss + gradients on the rasteriser's layouts
+            out = None
+            if self._default_render and self.color_w.is_cuda and allv:
+                # render + image loss as ONE autograd node (loss.rendered_fit_loss): dL/dloss is applied inside the render
+                # backward instead of in two elementwise passes over the images
+                from .camera import pack_cameras_from_w2c
+                from .loss import rendered_fit_loss
+                key = (w2cs.data_ptr(), Ks.data_ptr(), bg.data_ptr(), w2cs.shape[0], H, W, w2cs._version, Ks._version, bg._version)
+                if self._cams_key != key:
+                    self._cams, self._cams_key = pack_cameras_from_w2c(w2cs, Ks, H, W, bg), key
+                loss_img, _, _ = rendered_fit_loss(self._cams, self.gs.xyz, self.gs.opacity, self.gs.scaling, self.gs.rotation,
+                                                   self.gs.shs, gt_rgb, gt_mask, None if bbox_mask is None else bbox_mask.float(),
+                                                   scale=1.0 / n_total, H=H, W=W, use_rgb=self.use_rgb, sh_degree=self.sh_degree,
+                                                   xyz_b=leaves["xyz_b"], opacity_b=leaves["opacity_b"], color_w=leaves["color_w"],
+                                                   color_b=leaves["color_b"], sync=sync)
+            else:
+                out = self.render(w2cs if allv else w2cs[mine], Ks if allv else Ks[mine], H, W, bg, leaves, sync=sync)
+            if out is None:
+                pass
+            elif "image_chw" in out and out["image_chw"].is_cuda:    # fused loss + gradients on the rasteriser's layouts
                 from .loss import fit_image_loss
                 loss_img = fit_image_loss(out["image_chw"], out["alpha"], sel(gt_rgb), sel(gt_mask),
                                           None if bbox_mask is None else sel(bbox_mask).float(), scale=1.0 / n_total)

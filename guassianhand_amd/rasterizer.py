@@ -250,7 +250,9 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
 
 
 def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: bool = True,
-                    dL_dalpha: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                    dL_dalpha: Optional[torch.Tensor] = None, grad_scale: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """grad_scale: optional one-element device tensor multiplied into dL_dimage / dL_dalpha as the kernel reads them
+    (GhGrads.upstream_scale): the dL/dloss of a scalar loss whose image gradient was produced unscaled."""
     L = _lib.lib()
     t = ctx.tensors
     dev = t["means3D"].device
@@ -259,6 +261,7 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
         dL_dimage = torch.zeros(NV, 3, ctx.H, ctx.W, dtype=torch.float32, device=dev)
     g = dL_dimage.detach().to(torch.float32).reshape(NV, 3, ctx.H, ctx.W).contiguous()
     ga = None if dL_dalpha is None else dL_dalpha.detach().to(torch.float32).reshape(NV, ctx.H, ctx.W).contiguous()
+    gs = None if grad_scale is None else grad_scale.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
     mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
     R_ = ctx.rows                                  # rows of the per-Gaussian tensors (P, or NV*P for a pose batch)
     o = dict(means3D=mk(R_, 3), means2D=mk(NV, P, 3) if want_means2D else None, opacities=mk(R_), scales=mk(R_, 3),
@@ -272,7 +275,7 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
                       dL_dopacities=_ptr(o["opacities"]), dL_dscales=_ptr(o["scales"]), dL_drotations=_ptr(o["rotations"]),
                       dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]), dL_dblend_xyz_b=_ptr(o["xyz_b"]),
                       dL_dblend_opacity_b=_ptr(o["opacity_b"]), dL_dblend_color_w=_ptr(o["color_w"]),
-                      dL_dblend_color_b=_ptr(o["color_b"]))
+                      dL_dblend_color_b=_ptr(o["color_b"]), upstream_scale=_ptr(gs))
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev):
         bargs = (C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(),

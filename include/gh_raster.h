@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define GH_VERSION_MAJOR 0
-#define GH_VERSION_MINOR 1
+#define GH_VERSION_MINOR 2
 
 #define GH_TILE 16           /* tile edge in pixels (binning granularity; fixes which Gaussians a pixel sees) */
 #define GH_CAM_FLOATS 40     /* floats per camera record, see GhCamera */
@@ -126,6 +126,10 @@ typedef struct GhGrads {
   float* dL_dblend_opacity_b; /* (P,) */
   float* dL_dblend_color_w;   /* (48,) or (P,48) */
   float* dL_dblend_color_b;   /* (P,48), 16-byte aligned (rows are written as float4s) */
+  /* Optional device scalar that multiplies dL_dimage and dL_dalpha as they are read (NULL = 1): the upstream gradient of
+     a scalar loss whose image gradient was produced unscaled by the loss kernel (gh_l1_loss / gh_fit_loss), so that the
+     autograd product `dL/dimage * dL/dloss` needs no pass over the images of its own. */
+  const float* upstream_scale;
 } GhGrads;
 
 /* Byte offsets of the internal arrays inside the workspace (public so tests can inspect every stage). */

@@ -229,3 +229,44 @@ def test_pose_batch_equals_per_item_renders(dev, use_rgb):
         want = torch.cat([g[j] for g in per_grads])
         assert torch.equal(xs[j].grad, want), k
     assert torch.allclose(cw.grad, gw, rtol=1e-4, atol=1e-6) and torch.allclose(xb.grad, gx, rtol=1e-4, atol=1e-6)
+
+
+def test_rendered_loss_is_the_two_node_form_bit_for_bit(dev):
+    """Render + loss as one autograd node (GhGrads.upstream_scale applies dL/dloss inside the kernel) against
+    rasterize_views followed by the loss Function, with a non-trivial upstream factor."""
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.loss import fit_image_loss, l1_mean_loss, rendered_fit_loss, rendered_l1_loss
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=3, P=2500, use_rgb=True, blend=True)
+    s = sc.to(dev)
+    cams = s.cams().contiguous()
+    names = ("xyz", "opacity", "scaling", "rotation", "shs", "xyz_b", "opacity_b", "color_w", "color_b")
+    g = torch.Generator().manual_seed(5)
+    target = torch.rand(3, 3, sc.H, sc.W, generator=g).to(dev)
+    gt_rgb, gt_mask = torch.rand(3, sc.H, sc.W, 3, generator=g).to(dev), (torch.rand(3, sc.H, sc.W, generator=g) > 0.5).float().to(dev)
+
+    def leaves():
+        return {k: getattr(s, k).clone().requires_grad_(True) for k in names}
+
+    def args(p):
+        return (cams, p["xyz"], p["opacity"], p["scaling"], p["rotation"], p["shs"]), dict(
+            H=sc.H, W=sc.W, use_rgb=True, xyz_b=p["xyz_b"], opacity_b=p["opacity_b"], color_w=p["color_w"], color_b=p["color_b"])
+
+    for kind in ("l1", "fit"):
+        pa, pb = leaves(), leaves()
+        a_pos, a_kw = args(pa)
+        b_pos, b_kw = args(pb)
+        if kind == "l1":
+            img, _ = R.rasterize_views(*a_pos, **a_kw)
+            la = l1_mean_loss(img, target)
+            lb, img_b, _ = rendered_l1_loss(*b_pos, target, **b_kw)
+        else:
+            img, alpha, _ = R.rasterize_views(*a_pos, return_alpha=True, **a_kw)
+            la = fit_image_loss(img, alpha, gt_rgb, gt_mask, None, 10.0, 1.0, 0.5)
+            lb, img_b, alpha_b = rendered_fit_loss(*b_pos, gt_rgb, gt_mask, None, 10.0, 1.0, 0.5, **b_kw)
+            assert torch.equal(alpha_b, alpha.detach())
+        assert torch.equal(la.detach(), lb.detach()) and torch.equal(img_b, img.detach())
+        (3.0 * la).backward()
+        (3.0 * lb).backward()
+        for k in names:
+            assert torch.equal(pa[k].grad, pb[k].grad), (kind, k)
