@@ -123,6 +123,7 @@ class _RenderedLoss(torch.autograd.Function):
         else:
             raise ValueError(kind)
         ctx.rctx, ctx.dimg, ctx.dal, ctx.use_rgb = rctx, dimg, dal, use_rgb
+        ctx.set_materialize_grads(False)             # no image-sized zero tensors for the outputs that carry no gradient
         ctx.shapes = [None if t is None else t.shape for t in (xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b)]
         alpha = rctx.alpha if rctx.alpha is not None else image.new_zeros(0)
         ctx.mark_non_differentiable(image, alpha, radii)

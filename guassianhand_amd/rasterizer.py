@@ -330,6 +330,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape, scales.shape,
                       rotations.shape)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
         return image[0], radii[0]
 
     @staticmethod
@@ -381,6 +382,7 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.use_rgb = use_rgb
         ctx.shapes = [None if t is None else t.shape for t in (xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b)]
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)             # an unused output (image or alpha) arrives as None, not as a zero image
         alpha = rctx.alpha if want_alpha else image.new_zeros(0)
         if not want_alpha:
             ctx.mark_non_differentiable(alpha)
