@@ -193,13 +193,15 @@ def main():
         if world > 1 and not args.allreduce_grads:
             loss_sum = loss.detach().clone()
             work = tdist.all_reduce(loss_sum, op=tdist.ReduceOp.SUM, async_op=True)
-        loss.backward()
+        loss.backward(seed)
         if work is not None:
             work.wait()                              # stream-level dependency for RCCL (no host block); gloo blocks
             loss = loss_sum
         elif world > 1:
             loss = reduce_grads(loss)
         return loss
+
+    seed = torch.ones((), dtype=torch.float32, device=dev)      # dL/dloss, allocated once (backward() would fill a new one per step)
 
     def barrier():
         if world > 1:
@@ -226,13 +228,13 @@ def main():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                local_step(sync=False).backward()
+                local_step(sync=False).backward(seed)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             # thread_local: HIP calls of other threads (e.g. the RCCL watchdog's event queries) must not invalidate the capture
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 g_loss = local_step(sync=False)
-                g_loss.backward()
+                g_loss.backward(seed)
             graph.replay()
             torch.cuda.synchronize()
         except Exception as e:                           # capture is an optimisation of the enqueue path, never a requirement
@@ -276,7 +278,7 @@ def main():
     if not args.no_stage_timing:
         R.enable_stage_timing(True)
         for _ in range(args.steps):
-            local_step(sync=False).backward()
+            local_step(sync=False).backward(seed)
         stage_ms = R.stage_timing_summary()
         R.enable_stage_timing(False)
         R.check_overflow()
