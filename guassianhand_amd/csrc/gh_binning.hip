@@ -48,8 +48,9 @@ __device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w
   return woff + x - v;
 }
 
-// Pass part 1: per-block digit histogram -> table[digit][block].
-template <int ITEMS, int MAXD>
+// Pass part 1: per-block digit histogram -> table[digit][block]; SELF: -> table[block][digit] (the scatter kernel sums the
+// rows of the blocks before it itself, see there).
+template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
                                                                   uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
                                                                   uint32_t* __restrict__ table) {
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t*
     if (idx < n) atomicAdd(&s_hist[(k[j] >> shift) & dmask], 1u);
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < ndig; d += GH_BLOCK) table[((size_t)seg * ndig + d) * nblk + blockIdx.x] = s_hist[d];
+  for (uint32_t d = threadIdx.x; d < ndig; d += GH_BLOCK) {
+    if (SELF) table[((size_t)seg * nblk + blockIdx.x) * ndig + d] = s_hist[d];
+    else table[((size_t)seg * ndig + d) * nblk + blockIdx.x] = s_hist[d];
+  }
 }
 
 // Pass part 2: one block per (digit, segment): exclusive scan of its row over the active blocks, row total -> tot.
@@ -119,7 +123,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __res
 // ordered through an LDS prefix over their digit counts, so equal digits keep their input order. The tile is first
 // sorted into LDS and then written out, so that each digit run leaves as contiguous global segments.
 // Thread t owns the DPT = MAXD / GH_BLOCK consecutive digits [t*DPT, (t+1)*DPT) in the digit-indexed phases.
-template <int ITEMS, int MAXD>
+// SELF (segments of at most 128 blocks, e.g. the per-view depth sort): there is no scan kernel; the histogram table is
+// block-major and every block adds up the rows of the blocks before it (its prefix) and of all blocks (the digit totals)
+// with coalesced reads — one launch less per pass where the row scan was nothing but launch latency.
+template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
@@ -153,11 +160,27 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
 
   // digit base = exclusive scan over digits of tot[] + this block's row prefix
   {
-    uint32_t v[DPT], sum = 0;
+    uint32_t v[DPT], pre[DPT], sum = 0;
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
       const uint32_t d = (uint32_t)(tid * DPT + k);
-      v[k] = d < ndig ? tot[(size_t)seg * ndig + d] : 0u;
+      if (SELF) {
+        const uint32_t nact = (n + (uint32_t)(GH_BLOCK * ITEMS) - 1u) / (uint32_t)(GH_BLOCK * ITEMS);   // blocks that wrote a row
+        const uint32_t* col = table + (size_t)seg * nblk * ndig + d;
+        uint32_t t_all = 0, t_pre = 0;
+        if (d < ndig) {
+#pragma unroll 8
+          for (uint32_t b = 0; b < nact; ++b) {
+            const uint32_t c = col[(size_t)b * ndig];
+            t_all += c;
+            t_pre += b < blockIdx.x ? c : 0u;
+          }
+        }
+        v[k] = t_all; pre[k] = t_pre;
+      } else {
+        v[k] = d < ndig ? tot[(size_t)seg * ndig + d] : 0u;
+        pre[k] = d < ndig ? table[((size_t)seg * ndig + d) * nblk + blockIdx.x] : 0u;
+      }
       sum += v[k];
 #pragma unroll
       for (int w = 0; w < NW; ++w) s_cnt[w][d] = 0;
@@ -167,7 +190,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
       const uint32_t d = (uint32_t)(tid * DPT + k);
-      s_base[d] = run + (d < ndig ? table[((size_t)seg * ndig + d) * nblk + blockIdx.x] : 0u);
+      s_base[d] = run + pre[k];
       run += v[k];
     }
   }
@@ -266,10 +289,16 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
     const uint32_t ndig = dmask + 1u;
     uint32_t* tot = table + (size_t)segs * ndig * nblk;
     const dim3 gb(nblk, segs), gs(ndig, segs), blk(GH_BLOCK);
-    hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table);
-    hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
-    hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len, lo,
-                       dmask, hi - lo, table, tot);
+    if (nblk <= 128) {                                   // short segments: no scan kernel (see gh_radix_scatter_kernel)
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table);
+      hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
+                         lo, dmask, hi - lo, table, tot);
+    } else {
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table);
+      hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
+      hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
+                         lo, dmask, hi - lo, table, tot);
+    }
     uint32_t* t = k_in; k_in = k_out; k_out = t;
     t = v_in; v_in = v_out; v_out = t;
   }
