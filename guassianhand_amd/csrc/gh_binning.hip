@@ -345,65 +345,40 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_count_sorted_kernel(int N, const 
   if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
 }
 
-// Exclusive scan of the per-block tile counts (one block, carry loop) + instance total / overflow flag.
-__global__ __launch_bounds__(1024) void gh_scan_blocksums_kernel(uint32_t* __restrict__ block_sums, int nblk,
-                                                                  GhCounters* __restrict__ ctr, uint32_t cap) {
-  __shared__ uint32_t s_w[16];
-  __shared__ uint32_t s_carry;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < nblk; base += 4096) {      // four consecutive sums per thread: 4096 per sweep (one sweep up to 1 M Gaussians)
-    const int i0 = base + tid * 4;
-    uint32_t v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = i0 + j < nblk ? block_sums[i0 + j] : 0u;
-    const uint32_t mine = (v[0] + v[1]) + (v[2] + v[3]);
-    uint32_t x = mine;  // inclusive wave scan of the per-thread sums
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wid] = x;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += s_w[w];
-    const uint32_t carry = s_carry;
-    uint32_t run = carry + woff + x - mine;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { if (i0 + j < nblk) block_sums[i0 + j] = run; run += v[j]; }
-    __syncthreads();
-    if (tid == 1023) s_carry = carry + woff + x;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    const uint32_t total = s_carry;
-    ctr->num_rendered = total;
-    ctr->overflow = total > cap ? 1u : 0u;
-  }
-}
-
 // One thread per (view, Gaussian) IN DEPTH ORDER: block-local scan -> first emit slot of the Gaussian, then one
 // instance per tile of its rect that passes the exact ellipse/tile test (the same test that counted them in the
 // projection kernel), row-major: key = global tile id, payload = view*P+gaussian.
 // A Gaussian's instances occupy consecutive slots [slot_begin, slot_begin + tiles): the backward sums its records there.
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
-    const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ slot_begin, float4* __restrict__ geom,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
+    const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ slot_begin, float4* __restrict__ geom,
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr) {
+  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE], s_p[GH_BLOCK / GH_WAVE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = blockIdx.x * GH_BLOCK + tid;
   const uint32_t n = i < N ? perm[i] : 0u;
   float4* grec = geom + (size_t)n * 4;
   const uint32_t cnt = i < N ? tiles_touched[n] : 0u;
   const float4 g2 = grec[2];                            // rect + tile hit mask: issued before the scan, not after it
-  const uint32_t blk_off = block_offsets[blockIdx.x];
+  // first emit slot of this block = sum of the per-block instance counts of all blocks before it (gh_count_sorted_kernel):
+  // every block adds them up itself (a few thousand coalesced L2 reads) instead of waiting for a one-block scan kernel
+  uint32_t part = 0;
+  for (uint32_t b = tid; b < blockIdx.x; b += GH_BLOCK) part += block_sums[b];
+  part = gh_wave_sum_u32(part);
   uint32_t x = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
   if (lane == 63) s_w[wid] = x;
+  if (lane == 0) s_p[wid] = part;
   __syncthreads();
-  uint32_t woff = 0;
-  for (int w = 0; w < wid; ++w) woff += s_w[w];
+  uint32_t woff = 0, blk_off = 0, blk_sum = 0;
+#pragma unroll
+  for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { if (w < wid) woff += s_w[w]; blk_sum += s_w[w]; blk_off += s_p[w]; }
+  if (blockIdx.x == gridDim.x - 1 && tid == 0) {        // the last block knows the instance total D
+    const uint32_t total = blk_off + blk_sum;
+    ctr->num_rendered = total;
+    ctr->overflow = total > cap ? 1u : 0u;
+  }
   if (i >= N) return;
   uint32_t off = blk_off + woff + x - cnt;
   slot_begin[n] = off;
@@ -543,8 +518,6 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   const uint32_t* tiles_touched = (const uint32_t*)(ws + L.tiles_touched);
   hipLaunchKernelGGL(gh_count_sorted_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, perm, tiles_touched,
                      (uint32_t*)(ws + L.block_sums));
-  hipLaunchKernelGGL(gh_scan_blocksums_kernel, dim3(1), dim3(1024), 0, s, (uint32_t*)(ws + L.block_sums), nblk_pre, ctr, cap);
-  if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }
   // level 3: stable partition by tile id; an odd number of passes starts in the b buffers so the result is in *_a
   const int tile_passes = (g.tile_bits + 7) / 8;
   uint32_t* ka = (uint32_t*)(ws + L.keys_a); uint32_t* kb = (uint32_t*)(ws + L.keys_b);
@@ -553,7 +526,8 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* k_in = start_b ? kb : ka; uint32_t* k_out = start_b ? ka : kb;
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
-                     (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (float4*)(ws + L.geom), k_in, v_in);
+                     (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (float4*)(ws + L.geom), k_in, v_in, ctr);
+  if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }    // the emit kernel has written D (it stores nothing past cap)
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
   const int nblk_d = (int)((g.cap + GH_BLOCK - 1) / GH_BLOCK);
