@@ -87,12 +87,13 @@ def declare(lib: C.CDLL) -> None:
     lib.gh_uv_gather_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.gh_adam_reg_step.restype = C.c_int
     lib.gh_adam_reg_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float,
-                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
     lib.gh_l1_loss.restype = C.c_int
-    lib.gh_l1_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.gh_l1_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.gh_fit_loss.restype = C.c_int
     lib.gh_fit_loss.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [C.c_void_p] * 4 + \
-        [C.c_int, C.c_void_p]
+        [C.c_int, C.c_void_p, C.c_void_p]
     lib.gh_knn_workspace_bytes.restype = C.c_size_t
     lib.gh_knn_workspace_bytes.argtypes = [C.c_int]
     lib.gh_knn_indices.restype = C.c_int

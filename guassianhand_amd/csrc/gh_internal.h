@@ -216,7 +216,11 @@ __device__ __forceinline__ bool gh_block_hit(const float4& g0, const float4& g1,
   const float q2 = A * dx0 * dx0 + 2.0f * B * dx0 * ly + C * ly * ly;
   const float q3 = A * dx1 * dx1 + 2.0f * B * dx1 * uy + C * uy * uy;
   const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
-  const bool miss = !inside && (qmin * 0.9999f > thr);
+  // rounding of the (cancelling) terms of q: bounded by a few ulps of the largest term magnitude anywhere on the block,
+  // A mx^2 + 2|B| mx my + C my^2 with (mx, my) the largest offsets — matters for far off-screen centres of elongated conics
+  const float mx = fmaxf(fabsf(lx), fabsf(ux)), my = fmaxf(fabsf(ly), fabsf(uy));
+  const float mag = A * mx * mx + 2.0f * fabsf(B) * mx * my + C * my * my;
+  const bool miss = !inside && (qmin * 0.9999f - 1e-6f * mag > thr);
   return !miss;                                       // NaN compares false -> hit
 }
 // Exact tile culling (binning) and the per-instance 4x4-block mask (render kernels) are both this test:
@@ -234,6 +238,9 @@ __device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const floa
   const float sx = -B * rC, sy = -B * rA;            // dy* = sx * u on a vertical line, dx* = sy * v on a horizontal one
   const float Kx = A - B * B * rC, Ky = C - B * B * rA;
   const float ox = tx0 - g0.x, oy = ty0 - g0.y;      // tile origin relative to the centre
+  // rounding margin for the whole tile (see gh_block_hit): a few ulps of the largest term magnitude on it
+  const float mx = fmaxf(fabsf(ox), fabsf(ox + 15.0f)), my = fmaxf(fabsf(oy), fabsf(oy + 15.0f));
+  const float thr_m = thr + 1e-6f * (A * mx * mx + 2.0f * fabsf(B) * mx * my + C * my * my);
   float u[8], v[8], ux2[8], vy2[8], us[8], vs[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
@@ -243,7 +250,7 @@ __device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const floa
     us[k] = sx * u[k]; vs[k] = sy * v[k];
   }
   uint32_t m = 0;
-  bool nonfinite = !(thr == thr) || !(Kx == Kx) || !(Ky == Ky);
+  bool nonfinite = !(thr_m == thr_m) || !(Kx == Kx) || !(Ky == Ky);
 #pragma unroll
   for (int by = 0; by < 4; ++by) {
     const float ly = v[2 * by], uy = v[2 * by + 1];
@@ -258,7 +265,7 @@ __device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const floa
       const float q0 = C * d0 * d0 + ux2[2 * bx], q1 = C * d1 * d1 + ux2[2 * bx + 1];
       const float q2 = A * e0 * e0 + vy2[2 * by], q3 = A * e1 * e1 + vy2[2 * by + 1];
       const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
-      const bool miss = !inside && (qmin * 0.9999f > thr);                     // NaN compares false -> hit
+      const bool miss = !inside && (qmin * 0.9999f > thr_m);                   // NaN compares false -> hit
       m |= miss ? 0u : (1u << (by * 4 + bx));
     }
   }

@@ -6,9 +6,11 @@
 __global__ __launch_bounds__(GH_BLOCK) void gh_l1_loss_kernel(const float4* __restrict__ img, const float4* __restrict__ gt, size_t n4,
                                                                const float* __restrict__ img_tail, const float* __restrict__ gt_tail,
                                                                int n_tail, float grad_scale, float4* __restrict__ dimg,
-                                                               float* __restrict__ dimg_tail, float* __restrict__ partials) {
+                                                               float* __restrict__ dimg_tail, float* __restrict__ partials,
+                                                               const GhCounters* __restrict__ guard) {
   __shared__ float s_w[GH_BLOCK / GH_WAVE];
   float acc = 0.0f;
+  if (guard && guard->overflow) grad_scale = 0.0f;       // the image is invalid (instance overflow): no gradient leaves here
   auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };      // torch.sign: sign(0) = 0
   for (size_t i = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * GH_BLOCK) {
     const float4 a = img[i], b = gt[i];
@@ -28,18 +30,20 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_l1_loss_kernel(const float4* __re
 }
 
 // fixed-order sum of the block partials (one block), scaled: loss[0] = scale * sum
-__global__ __launch_bounds__(GH_BLOCK) void gh_partials_sum_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ out) {
+// guard (optional): when the forward that produced the images overflowed its instance capacity the loss is NaN
+__global__ __launch_bounds__(GH_BLOCK) void gh_partials_sum_kernel(const float* __restrict__ partials, int n, float scale, float* __restrict__ out,
+                                                                    const GhCounters* __restrict__ guard) {
   __shared__ float s_w[GH_BLOCK / GH_WAVE];
   float s = 0.0f;
   for (int i = threadIdx.x; i < n; i += GH_BLOCK) s += partials[i];
   s = gh_wave_sum_to63(s);
   if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = scale * (((s_w[0] + s_w[1]) + s_w[2]) + s_w[3]);
+  if (threadIdx.x == 0) out[0] = (guard && guard->overflow) ? __uint_as_float(0x7FC00000u) : scale * (((s_w[0] + s_w[1]) + s_w[2]) + s_w[3]);
 }
 
 extern "C" int gh_l1_loss(const float* image, const float* target, size_t n, float* loss_out, float* dL_dimage, float* partials,
-                          int n_partials, void* hip_stream) {
+                          int n_partials, const GhCounters* guard, void* hip_stream) {
   if (n == 0 || n_partials < 1 || !image || !target || !loss_out || !dL_dimage || !partials) return GH_ERR_INVALID_ARG;
   if ((((uintptr_t)image | (uintptr_t)target | (uintptr_t)dL_dimage) & 15) != 0) return GH_ERR_INVALID_ARG;   // float4 access
   (void)hipGetLastError();
@@ -48,8 +52,8 @@ extern "C" int gh_l1_loss(const float* image, const float* target, size_t n, flo
   const float inv = (float)(1.0 / (double)n);
   hipStream_t s = (hipStream_t)hip_stream;
   hipLaunchKernelGGL(gh_l1_loss_kernel, dim3((unsigned)n_partials), dim3(GH_BLOCK), 0, s, (const float4*)image, (const float4*)target, n4,
-                     image + n4 * 4, target + n4 * 4, tail, inv, (float4*)dL_dimage, dL_dimage + n4 * 4, partials);
-  hipLaunchKernelGGL(gh_partials_sum_kernel, dim3(1), dim3(GH_BLOCK), 0, s, partials, n_partials, inv, loss_out);
+                     image + n4 * 4, target + n4 * 4, tail, inv, (float4*)dL_dimage, dL_dimage + n4 * 4, partials, guard);
+  hipLaunchKernelGGL(gh_partials_sum_kernel, dim3(1), dim3(GH_BLOCK), 0, s, partials, n_partials, inv, loss_out, guard);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 
@@ -64,10 +68,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_fit_loss_kernel(const float* __re
                                                                 const float* __restrict__ gt_rgb, const float* __restrict__ gt_mask,
                                                                 const float* __restrict__ bbox, int NV, int HW, float k_l1, float k_m,
                                                                 float* __restrict__ dimage, float* __restrict__ dalpha,
-                                                                float* __restrict__ partials) {
+                                                                float* __restrict__ partials, const GhCounters* __restrict__ guard) {
   __shared__ float s_w[GH_BLOCK / GH_WAVE];
   float acc = 0.0f;
   const size_t npix = (size_t)NV * HW;
+  const float live = (guard && guard->overflow) ? 0.0f : 1.0f;   // instance overflow: invalid images, no gradient leaves here
   for (size_t i = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; i < npix; i += (size_t)gridDim.x * GH_BLOCK) {
     const size_t v = i / HW, p = i - v * HW;
     const bool in_box = bbox ? bbox[i] != 0.0f : true;
@@ -77,13 +82,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_fit_loss_kernel(const float* __re
     for (int c = 0; c < 3; ++c) {
       const float d = (in_box ? im[(size_t)c * HW] : 0.0f) - gt_rgb[i * 3 + c];
       acc += k_l1 * fabsf(d);
-      di[(size_t)c * HW] = in_box ? k_l1 * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) : 0.0f;
+      di[(size_t)c * HW] = in_box ? live * k_l1 * (d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f)) : 0.0f;
     }
     const float a = alpha[i];
     const float ac = fminf(fmaxf(a, -0.001f), 1.0f);
     const float e = ac - gt_mask[i];
     acc += k_m * e * e;
-    dalpha[i] = (a >= -0.001f && a <= 1.0f) ? 2.0f * k_m * e : 0.0f;      // torch.clamp passes the gradient on [min, max]
+    dalpha[i] = (a >= -0.001f && a <= 1.0f) ? live * 2.0f * k_m * e : 0.0f;      // torch.clamp passes the gradient on [min, max]
   }
   acc = gh_wave_sum_to63(acc);
   if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = acc;
@@ -93,14 +98,15 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_fit_loss_kernel(const float* __re
 
 extern "C" int gh_fit_loss(const float* image, const float* alpha, const float* gt_rgb, const float* gt_mask, const float* bbox,
                            int n_views, int H, int W, float lambda_l1, float lambda_mask, float scale, float* loss_out,
-                           float* dL_dimage, float* dL_dalpha, float* partials, int n_partials, void* hip_stream) {
+                           float* dL_dimage, float* dL_dalpha, float* partials, int n_partials, const GhCounters* guard,
+                           void* hip_stream) {
   if (n_views < 1 || H < 1 || W < 1 || n_partials < 1) return GH_ERR_INVALID_ARG;
   if (!image || !alpha || !gt_rgb || !gt_mask || !loss_out || !dL_dimage || !dL_dalpha || !partials) return GH_ERR_INVALID_ARG;
   (void)hipGetLastError();
   const int HW = H * W;
   hipStream_t s = (hipStream_t)hip_stream;
   hipLaunchKernelGGL(gh_fit_loss_kernel, dim3((unsigned)n_partials), dim3(GH_BLOCK), 0, s, image, alpha, gt_rgb, gt_mask, bbox,
-                     n_views, HW, scale * lambda_l1 / (3.0f * (float)HW), scale * lambda_mask / (float)HW, dL_dimage, dL_dalpha, partials);
-  hipLaunchKernelGGL(gh_partials_sum_kernel, dim3(1), dim3(GH_BLOCK), 0, s, partials, n_partials, 1.0f, loss_out);
+                     n_views, HW, scale * lambda_l1 / (3.0f * (float)HW), scale * lambda_mask / (float)HW, dL_dimage, dL_dalpha, partials, guard);
+  hipLaunchKernelGGL(gh_partials_sum_kernel, dim3(1), dim3(GH_BLOCK), 0, s, partials, n_partials, 1.0f, loss_out, guard);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

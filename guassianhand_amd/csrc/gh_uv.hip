@@ -115,14 +115,28 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_uv_gather_bwd_kernel(const int32_
 // regulariser gradient (l1*sign(p) + l2*2p) added to the accumulated image gradient, Adam update (torch.optim.Adam
 // semantics, no amsgrad / weight decay: infer_one_shot.py:345), and the gradient buffer is cleared for the next step.
 __global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                                float* __restrict__ v, size_t n, float lr_over_bc1, float inv_sqrt_bc2,
+                                                                float* __restrict__ v, size_t n, int host_step, float lr,
                                                                 float beta1, float beta2, float eps, float l1, float l2,
-                                                                float* __restrict__ partials /* [gridDim][2] */) {
+                                                                float* __restrict__ partials /* [gridDim][2] */,
+                                                                const GhCounters* __restrict__ guard, int32_t* __restrict__ step_state) {
   __shared__ float s_a[GH_BLOCK / GH_WAVE], s_b[GH_BLOCK / GH_WAVE];
+  // Device-side guard: a step whose render overflowed its instance capacity must not touch the parameters. The step count
+  // of the bias correction then lives on the device too (step_state, two words used alternately: every launch reads the
+  // word the previous launch wrote, so no thread of this launch can see its own launch's update).
+  const bool skip = guard && guard->overflow != 0u;
+  int t = host_step;
+  if (step_state) {
+    t = step_state[(host_step - 1) & 1] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) step_state[host_step & 1] = skip ? t - 1 : t;
+  }
+  // bias corrections in double, as torch.optim.Adam's Python arithmetic (once per thread, not per element)
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  const float lr_over_bc1 = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   float sa = 0.0f, sb = 0.0f;
   for (size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; idx < n; idx += (size_t)gridDim.x * GH_BLOCK) {
     const float pv = p[idx];
     sa += fabsf(pv); sb += pv * pv;
+    if (skip) { g[idx] = 0.0f; continue; }
     const float sgn = pv > 0.0f ? 1.0f : (pv < 0.0f ? -1.0f : 0.0f);
     const float gv = g[idx] + l1 * sgn + l2 * 2.0f * pv;
     const float mv = beta1 * m[idx] + (1.0f - beta1) * gv;
@@ -164,14 +178,12 @@ extern "C" int gh_uv_gather_backward(const int32_t* slot, const float* w, const 
 
 extern "C" int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, float lr,
                                 float beta1, float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials,
-                                void* hip_stream) {
+                                const GhCounters* guard, int32_t* step_state, void* hip_stream) {
   if (step < 1 || n_partials < 1) return GH_ERR_INVALID_ARG;
   if (n == 0) return GH_OK;
   if (!param || !grad || !exp_avg || !exp_avg_sq || !partials) return GH_ERR_INVALID_ARG;
   (void)hipGetLastError();
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(gh_adam_reg_kernel, dim3((unsigned)n_partials), dim3(GH_BLOCK), 0, (hipStream_t)hip_stream, param, grad,
-                     exp_avg, exp_avg_sq, n, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, reg_l1, reg_l2,
-                     partials);
+                     exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, reg_l1, reg_l2, partials, guard, step_state);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -75,7 +75,8 @@ class OneShotFit(nn.Module):
         self.lr0, self.epoch = lr, 0
         self.active = uv.is_cuda if active_texels is None else bool(active_texels)
         self._default_render = render_fn is None
-        self._cams, self._cams_key = None, None
+        self._cams, self._cams_src = None, None
+        self.keep_boundary_grads, self.boundary_grads, self.last_reg = False, None, None
         if render_fn is None:
             from .renderer import render_views
             render_fn = render_views
@@ -132,6 +133,20 @@ class OneShotFit(nn.Module):
         self.color_b_tex.copy_(ct[:, :self.cb_channels]); self.opacity_b_tex.copy_(ot)
 
     # -- pieces ----------------------------------------------------------------------------------------
+    def _packed_cameras(self, w2cs, Ks, H, W, bg) -> torch.Tensor:
+        """Packed camera records of the caller's (w2cs, Ks, bg). The cache holds STRONG references to the tensors it was
+        built from and is hit only by those very objects, unmodified (`is` + `_version`): a caller that allocates fresh
+        camera tensors every step (as the reference's training_step does with its batch) gets them repacked — an address
+        recycled by the caching allocator can never alias a stale entry."""
+        src = self._cams_src
+        if src is not None and src[0] is w2cs and src[1] is Ks and src[2] is bg and src[3] == (H, W) and \
+                src[4] == (w2cs._version, Ks._version, bg._version):
+            return self._cams
+        from .camera import pack_cameras_from_w2c
+        self._cams = pack_cameras_from_w2c(w2cs, Ks, H, W, bg)
+        self._cams_src = (w2cs, Ks, bg, (H, W), (w2cs._version, Ks._version, bg._version))
+        return self._cams
+
     def blend_values(self) -> Dict[str, torch.Tensor]:
         """Per-Gaussian blend values: the device UV lookup of renderer_one_shot.py:489-492 (gh_uv_sample_* /
         gh_uv_gather_*)."""
@@ -150,11 +165,7 @@ class OneShotFit(nn.Module):
     def render(self, w2cs, Ks, H, W, bg, blend: Dict[str, torch.Tensor], sync: bool = True):
         kw = {}
         if self._default_render:                                      # the camera records of a fit never change: pack them once
-            key = (w2cs.data_ptr(), Ks.data_ptr(), bg.data_ptr(), w2cs.shape[0], H, W, w2cs._version, Ks._version, bg._version)
-            if self._cams_key != key:
-                from .camera import pack_cameras_from_w2c
-                self._cams, self._cams_key = pack_cameras_from_w2c(w2cs, Ks, H, W, bg), key
-            kw["cams"] = self._cams
+            kw["cams"] = self._packed_cameras(w2cs, Ks, H, W, bg)
         return self.render_fn(self.gs, w2cs, Ks, H, W, bg, color_w=blend["color_w"], xyz_b=blend["xyz_b"],
                               color_b=blend["color_b"], opacity_b=blend["opacity_b"], use_rgb=self.use_rgb,
                               sh_degree=self.sh_degree, sync=sync, **kw)
@@ -183,12 +194,8 @@ class OneShotFit(nn.Module):
             if self._default_render and self.color_w.is_cuda and allv:
                 # render + image loss as ONE autograd node (loss.rendered_fit_loss): dL/dloss is applied inside the render
                 # backward instead of in two elementwise passes over the images
-                from .camera import pack_cameras_from_w2c
                 from .loss import rendered_fit_loss
-                key = (w2cs.data_ptr(), Ks.data_ptr(), bg.data_ptr(), w2cs.shape[0], H, W, w2cs._version, Ks._version, bg._version)
-                if self._cams_key != key:
-                    self._cams, self._cams_key = pack_cameras_from_w2c(w2cs, Ks, H, W, bg), key
-                loss_img, _, _ = rendered_fit_loss(self._cams, self.gs.xyz, self.gs.opacity, self.gs.scaling, self.gs.rotation,
+                loss_img, _, _ = rendered_fit_loss(self._packed_cameras(w2cs, Ks, H, W, bg), self.gs.xyz, self.gs.opacity, self.gs.scaling, self.gs.rotation,
                                                    self.gs.shs, gt_rgb, gt_mask, None if bbox_mask is None else bbox_mask.float(),
                                                    scale=1.0 / n_total, H=H, W=W, use_rgb=self.use_rgb, sh_degree=self.sh_degree,
                                                    xyz_b=leaves["xyz_b"], opacity_b=leaves["opacity_b"], color_w=leaves["color_w"],
@@ -198,9 +205,11 @@ class OneShotFit(nn.Module):
             if out is None:
                 pass
             elif "image_chw" in out and out["image_chw"].is_cuda:    # fused loss + gradients on the rasteriser's layouts
+                from . import rasterizer as R
                 from .loss import fit_image_loss
                 loss_img = fit_image_loss(out["image_chw"], out["alpha"], sel(gt_rgb), sel(gt_mask),
-                                          None if bbox_mask is None else sel(bbox_mask).float(), scale=1.0 / n_total)
+                                          None if bbox_mask is None else sel(bbox_mask).float(), scale=1.0 / n_total,
+                                          guard=R.last_guard() if self._default_render else None)
             else:
                 loss_img = fit_loss(out["comp_rgb"], out["comp_mask"], sel(gt_rgb), sel(gt_mask),
                                     None if bbox_mask is None else sel(bbox_mask)) / n_total
@@ -217,19 +226,29 @@ class OneShotFit(nn.Module):
             red["color_b"] = full
         else:
             loss_tot, red = ghdist.allreduce_grads(grads, loss_img.detach(), sorted(grads))
+        if self.keep_boundary_grads:                                  # tests: the reduced gradient block at the rasteriser boundary
+            self.boundary_grads = {k: v.detach().clone() for k, v in red.items()}
         if self.active:                                               # maps: scatter, then regulariser + Adam in one pass
             uv_gather_backward(red["color_b"], self.texels, self._adam["color_b"].grad)
             uv_gather_backward(red["opacity_b"], self.texels, self._adam["opacity_b"].grad)
             self._adam["color_w"].grad.copy_(red["color_w"])
             lr = self.lr0 * 0.5 ** sum(1 for m in MILESTONES if m <= self.epoch)
             sums = {}
+            guard = None
+            if self._default_render and self.color_w.is_cuda and mine:
+                # device-side overflow guard: if this step's render overflowed its instance capacity (sync-free / graph
+                # replay), the loss kernel has already emitted NaN + zero gradients and Adam leaves the parameters alone
+                from . import rasterizer as R
+                guard = R.last_guard()
             for k, a in self._adam.items():
                 a.lr = lr
-                sums[k] = a.step()
+                sums[k] = a.step(guard)
             Hm, Wm = self.map_hw
             reg = 100.0 * sums["color_b"][0] / (48 * Hm * Wm) + sums["opacity_b"][1] / (Hm * Wm)
+            self.last_reg = reg
             return loss_tot + reg
         reg = self.regulariser()                                      # identical on every rank: never reduced
+        self.last_reg = reg.detach()
         torch.autograd.backward([blend[k] for k in names] + [reg], [red[k] for k in names] + [torch.ones_like(reg)])
         self.opt.step()
         return loss_tot + reg.detach()

@@ -13,8 +13,9 @@ from . import _abi, _lib
 _N_PARTIALS = 1024
 
 
-def _l1_kernel(image, target):
-    """(mean|image - target|, its gradient w.r.t. image) from one pass (gh_l1_loss)."""
+def _l1_kernel(image, target, guard=None):
+    """(mean|image - target|, its gradient w.r.t. image) from one pass (gh_l1_loss). guard: device GhCounters of the
+    forward that rendered `image` (overflow -> loss NaN, zero gradient)."""
     if not image.is_cuda:
         raise RuntimeError("gh_l1_loss runs on a ROCm device only (there is no CPU path)")
     L = _lib.lib()
@@ -30,6 +31,7 @@ def _l1_kernel(image, target):
     with torch.cuda.device(a.device):
         rc = L.gh_l1_loss(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), n, C.c_void_p(loss.data_ptr()),
                           C.c_void_p(grad.data_ptr()), C.c_void_p(partials.data_ptr()), nblk,
+                          None if guard is None else C.c_void_p(guard.data_ptr()),
                           C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"gh_l1_loss failed: {_abi.status_name(rc)}")
@@ -55,7 +57,7 @@ def l1_mean_loss(image: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return _L1Mean.apply(image, target)
 
 
-def _fit_kernel(image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mloss, scale):
+def _fit_kernel(image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mloss, scale, guard=None):
     """(loss, dL/dimage, dL/dalpha) of the fit's image loss from one pass (gh_fit_loss)."""
     if not image.is_cuda:
         raise RuntimeError("gh_fit_loss runs on a ROCm device only (there is no CPU path)")
@@ -72,7 +74,8 @@ def _fit_kernel(image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mlos
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     with torch.cuda.device(im.device):
         rc = L.gh_fit_loss(p(im), p(al), p(gr), p(gm), p(bb), NV, H, W, float(lambda_l1), float(lambda_mloss), float(scale),
-                           p(loss), p(dimg), p(dal), p(partials), nblk, C.c_void_p(torch.cuda.current_stream(im.device).cuda_stream))
+                           p(loss), p(dimg), p(dal), p(partials), nblk, p(guard),
+                           C.c_void_p(torch.cuda.current_stream(im.device).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"gh_fit_loss failed: {_abi.status_name(rc)}")
     return loss, dimg, dal
@@ -80,23 +83,23 @@ def _fit_kernel(image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mlos
 
 class _FitImageLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mloss, scale):
-        loss, dimg, dal = _fit_kernel(image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mloss, scale)
+    def forward(ctx, image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mloss, scale, guard):
+        loss, dimg, dal = _fit_kernel(image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mloss, scale, guard)
         ctx.save_for_backward(dimg, dal)
         return loss
 
     @staticmethod
     def backward(ctx, g):
         dimg, dal = ctx.saved_tensors
-        return dimg * g, dal * g, None, None, None, None, None, None
+        return dimg * g, dal * g, None, None, None, None, None, None, None
 
 
 def fit_image_loss(image, alpha, gt_rgb, gt_mask, bbox_mask=None, lambda_l1: float = 10.0, lambda_mloss: float = 1.0,
-                   scale: float = 1.0) -> torch.Tensor:
+                   scale: float = 1.0, guard=None) -> torch.Tensor:
     """scale * sum over views of [lambda_l1 * L1(rgb, gt) + lambda_mloss * MSE(clip(alpha, -0.001, 1), gt_mask)] — the
     image part of the reference's fit loss (fit.fit_loss is the torch restatement) — on the rasteriser's own layouts:
     image (Nv,3,H,W), alpha (Nv,H,W); gt_rgb (Nv,H,W,3), gt_mask / bbox_mask (Nv,H,W). Differentiable w.r.t. image, alpha."""
-    return _FitImageLoss.apply(image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mloss, scale)
+    return _FitImageLoss.apply(image, alpha, gt_rgb, gt_mask, bbox_mask, lambda_l1, lambda_mloss, scale, guard)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -115,11 +118,12 @@ class _RenderedLoss(torch.autograd.Function):
                                               scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b, color_w=color_w,
                                               color_b=color_b, sync=sync, max_instances=max_instances,
                                               return_alpha=(kind == "fit"), per_view_gaussians=per_view, **kw)
+        guard = rctx.ws[:16]                          # device-side overflow guard: an overflowed render yields loss NaN, zero gradients
         if kind == "l1":
-            loss, dimg = _l1_kernel(image, spec[1])
+            loss, dimg = _l1_kernel(image, spec[1], guard)
             dal = None
         elif kind == "fit":
-            loss, dimg, dal = _fit_kernel(image, rctx.alpha, *spec[1:])
+            loss, dimg, dal = _fit_kernel(image, rctx.alpha, *spec[1:], guard=guard)
         else:
             raise ValueError(kind)
         ctx.rctx, ctx.dimg, ctx.dal, ctx.use_rgb = rctx, dimg, dal, use_rgb

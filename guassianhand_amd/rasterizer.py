@@ -55,6 +55,15 @@ _stage_timing = False
 _stage_events = []   # (stage name, start event, end event)
 
 
+_last_ws = None      # workspace of the most recent forward (its first 16 bytes are the GhCounters)
+
+
+def last_guard():
+    """Device view of the GhCounters of the most recent forward: the `guard` argument of gh_l1_loss / gh_fit_loss /
+    gh_adam_reg_step (device-side overflow guard). Holds that workspace alive until the next forward."""
+    return None if _last_ws is None else _last_ws[:16]
+
+
 def last_num_rendered() -> int:
     """Tile instances D of the most recent forward whose counters have been read back."""
     return _last_D
@@ -92,7 +101,7 @@ def _run_stages(fn, args, stages):
 
 
 _graph_mode = False
-_graph_counters = []   # device views of GhCounters of forwards issued in graph mode (read back by check_overflow)
+_graph_counters = {}   # workspace address -> device view of GhCounters of forwards issued in graph mode (read back by check_overflow)
 
 
 def set_graph_mode(on: bool) -> None:
@@ -112,7 +121,7 @@ def _initial_capacity(P: int, NV: int) -> int:
 def check_overflow(block: bool = True) -> None:
     """Verify every outstanding sync-free forward fitted its capacity (raises GhOverflowError)."""
     global _pending, _last_D
-    for counters, cap, key in _graph_counters:            # graph mode: workspaces are static, read them directly
+    for counters, cap, key in list(_graph_counters.values()):   # graph mode: workspaces are static, read them directly
         d = int(counters[0].item()) & 0xFFFFFFFF
         _last_D = d
         if d > cap:
@@ -157,7 +166,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha.
     per_view_gaussians (pose batch, the batch loop of GS3DRenderer.forward): every per-Gaussian tensor holds NV*P rows and
     view v renders rows [v*P, (v+1)*P) — NV different Gaussian sets in one launch sequence."""
-    global _last_D
+    global _last_D, _last_ws
     L = _lib.lib()
     dev = means3D.device
     if dev.type != "cuda":
@@ -220,6 +229,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         if rc != 0:
             raise RuntimeError(f"gh_forward failed: {_abi.status_name(rc)}")
         counters = ws[:16].view(torch.int32)
+        _last_ws = ws
         if sync:
             d = int(counters[0].item()) & 0xFFFFFFFF      # the one host read-back, as in the reference wrapper
             _last_D = d
@@ -231,8 +241,9 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             if max_instances is None and key not in _capacity:
                 _capacity[key] = max(int(d * 1.5) + 1024, 1 << 16)
         elif _graph_mode:
-            if len(_graph_counters) < 64:
-                _graph_counters.append((counters, cap, key))
+            # every captured workspace is registered (keyed by its address, so a workspace re-used by later captures is
+            # listed once); check_overflow() reads each of them
+            _graph_counters[ws.data_ptr()] = (counters, cap, key)
         else:
             host = torch.empty(4, dtype=torch.int32, pin_memory=True)
             host.copy_(counters, non_blocking=True)

@@ -10,6 +10,7 @@ the fit-loop host logic — go through torch's grid_sample, which the GPU test c
 from __future__ import annotations
 
 import ctypes as C
+from typing import Optional
 
 import torch
 import torch.nn.functional as F
@@ -166,8 +167,11 @@ class AdamReg:
         n = param.numel()
         self.n_partials = max(1, min(self.N_PARTIALS, (n + 255) // 256))
         self.partials = torch.zeros(self.n_partials, 2, dtype=torch.float32, device=param.device)
+        self.step_state = torch.zeros(2, dtype=torch.int32, device=param.device)   # steps actually applied (device side)
 
-    def step(self) -> torch.Tensor:
+    def step(self, guard: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """guard: device GhCounters of the render whose gradients are in `.grad` (rasterizer.last_guard()): when its
+        overflow flag is set the kernel leaves param / moments untouched and does not count the step."""
         self.t += 1
         L = _lib.lib()
         p = self.param
@@ -175,7 +179,8 @@ class AdamReg:
             rc = L.gh_adam_reg_step(C.c_void_p(p.data_ptr()), C.c_void_p(self.grad.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
                                     C.c_void_p(self.exp_avg_sq.data_ptr()), p.numel(), self.t, self.lr, self.betas[0], self.betas[1],
                                     self.eps, self.reg_l1, self.reg_l2, C.c_void_p(self.partials.data_ptr()), self.n_partials,
-                                    _stream(p))
+                                    None if guard is None else C.c_void_p(guard.data_ptr()),
+                                    C.c_void_p(self.step_state.data_ptr()), _stream(p))
         if rc != 0:
             raise RuntimeError(f"gh_adam_reg_step failed: {_abi.status_name(rc)}")
         return self.partials.sum(0)

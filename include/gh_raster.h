@@ -36,7 +36,7 @@ extern "C" {
 #endif
 
 #define GH_VERSION_MAJOR 0
-#define GH_VERSION_MINOR 2
+#define GH_VERSION_MINOR 3
 
 #define GH_TILE 16           /* tile edge in pixels (binning granularity; fixes which Gaussians a pixel sees) */
 #define GH_CAM_FLOATS 40     /* floats per camera record, see GhCamera */
@@ -247,18 +247,28 @@ int gh_uv_gather_backward(const int32_t* slot, const float* w, const float* dL_d
  * gradient of reg_l1*sum|param| + reg_l2*sum(param^2) (the regularisers of :514-518) folded in. `grad` is cleared
  * for the next accumulation. partials (n_partials,2) receives per-block sums of |param| and param^2 of the
  * PRE-update values (the regulariser value the loss of this step reports); n_partials is also the grid size.
+ *
+ * Device-side overflow guard (optional, NULL = none): `guard` points at the GhCounters of the forward whose gradients feed
+ * this step (the first bytes of its workspace). When guard->overflow is set the step is a no-op for param / exp_avg /
+ * exp_avg_sq (grad is still cleared, partials still written), so a sync-free or graph-replayed fit never steps on the
+ * invalid gradients of an overflowed render. With a guard the bias-correction step count must live on the device as well:
+ * `step_state` (two int32, zero-initialised by the caller, NULL = use `step`) holds the number of steps actually applied;
+ * `step` then only selects which of the two words is read (step-1)&1 and written step&1.
  */
 int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, float lr, float beta1,
-                     float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials, void* hip_stream);
+                     float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials,
+                     const GhCounters* guard, int32_t* step_state, void* hip_stream);
 
 /*
  * Image-loss consumer (the L1 term of utils.py:282-294 as bench.py / the fit loop use it):
  * loss_out[0] = mean|image - target| over n floats and dL_dimage = sign(image - target) / n (sign(0) = 0, as
  * torch.abs' backward) in one pass. image / target / dL_dimage must be 16-byte aligned; partials holds n_partials
  * floats of scratch (n_partials = grid size, e.g. 1024). Fixed-order sums: bitwise reproducible.
+ * guard (optional, NULL = none): GhCounters of the forward that produced `image`; when its overflow flag is set the image
+ * is invalid, so loss_out[0] = NaN and dL_dimage = 0 — nothing downstream can step on garbage (also gh_fit_loss).
  */
 int gh_l1_loss(const float* image, const float* target, size_t n, float* loss_out, float* dL_dimage, float* partials,
-               int n_partials, void* hip_stream);
+               int n_partials, const GhCounters* guard, void* hip_stream);
 
 /*
  * Image part of the one-shot fit loss for a stack of views (utils.py:180-252, :282-294; infer_one_shot.py:497, :507-510):
@@ -269,7 +279,7 @@ int gh_l1_loss(const float* image, const float* target, size_t n, float* loss_ou
  */
 int gh_fit_loss(const float* image, const float* alpha, const float* gt_rgb, const float* gt_mask, const float* bbox,
                 int n_views, int H, int W, float lambda_l1, float lambda_mask, float scale, float* loss_out,
-                float* dL_dimage, float* dL_dalpha, float* partials, int n_partials, void* hip_stream);
+                float* dL_dimage, float* dL_dalpha, float* partials, int n_partials, const GhCounters* guard, void* hip_stream);
 
 /*
  * Interaction mask of the interaction-aware step (infer_one_shot.py:247-250):

@@ -57,9 +57,11 @@ int main(int argc, char** argv) {
   GhDims dims = {P, NV, H, W, 0, 0, 1.0f, 0u, (int64_t)4 * P * NV + 1024};
   void* ws = nullptr;
   uint32_t D = 0;
-  for (int attempt = 0; attempt < 4; ++attempt) {        // the caller's capacity policy: grow and re-run on overflow
+  bool fits = false;
+  for (int attempt = 0; attempt < 4 && !fits; ++attempt) {   // the caller's capacity policy: grow and re-run on overflow
     const size_t ws_bytes = gh_workspace_bytes(&dims);
     if (!ws_bytes) return 3;
+    if (ws) { CHECK(hipFree(ws)); ws = nullptr; }       // the previous attempt's workspace (freed only when replaced)
     CHECK(hipMalloc(&ws, ws_bytes));
     const int rc = gh_forward(&dims, &in, &out, ws, ws_bytes, stream);
     if (rc != GH_OK) { std::fprintf(stderr, "gh_forward: %d\n", rc); return 3; }
@@ -67,10 +69,10 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpyAsync(&ctr, ws, sizeof ctr, hipMemcpyDeviceToHost, stream));
     CHECK(hipStreamSynchronize(stream));
     D = ctr.num_rendered;
-    if (!ctr.overflow) break;
-    CHECK(hipFree(ws));
-    dims.max_instances = (int64_t)D + D / 2 + 1024;
+    fits = !ctr.overflow;
+    if (!fits) dims.max_instances = (int64_t)D + D / 2 + 1024;
   }
+  if (!fits) { std::fprintf(stderr, "instance capacity still too small after 4 attempts (D = %u)\n", D); return 4; }
   std::printf("P %d views %d %dx%d instances %u workspace %zu bytes\n", P, NV, H, W, D, gh_workspace_bytes(&dims));
 
   GhGrads gr = {};

@@ -220,3 +220,44 @@ def test_fused_fit_loss_matches_torch_restatement(dev):
         assert float(l1) == pytest.approx(float(l2), rel=2e-6)
         assert torch.allclose(a1.grad, a2.grad, rtol=1e-5, atol=1e-9)
         assert torch.allclose(b1.grad, b2.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_device_side_overflow_guard_keeps_a_sync_free_fit_from_stepping_on_garbage(dev):
+    """with the instance capacity forced too small, a sync-free step must NOT move the parameters:
+    the loss kernel emits NaN + zero gradients and gh_adam_reg_step is a no-op that does not count the step (device-side
+    GhCounters.overflow guard). check_overflow() then raises and grows the capacity; the re-run step equals the step a
+    fit that never overflowed takes, bit for bit."""
+    from guassianhand_amd import fit as F
+    from guassianhand_amd import rasterizer as R
+    pb = tiny_fit_problem(P=600, n_views=4, hw=(64, 64), device=dev)
+    mk = lambda: F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"])
+    g = torch.Generator().manual_seed(3)
+    gt_rgb = torch.rand(4, 64, 64, 3, generator=g).to(dev)
+    gt_mask = (torch.rand(4, 64, 64, generator=g) > 0.5).float().to(dev)
+    args = (pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
+    ref = mk()
+    l_ref = float(ref.step(*args, sync=True))
+    key = (600, 4, 64, 64)
+    good_cap = R._capacity[key]
+    f = mk()
+    before = {k: a.param.clone() for k, a in f._adam.items()}
+    R.check_overflow()
+    R._capacity[key] = 64                                          # far below D
+    try:
+        l_bad = f.step(*args, sync=False)
+        assert torch.isnan(l_bad).item(), "an overflowed render must report a NaN loss, not a number"
+        for k, a in f._adam.items():
+            assert torch.equal(a.param, before[k]), k               # parameters untouched
+            assert float(a.exp_avg.abs().max()) == 0.0 and float(a.exp_avg_sq.abs().max()) == 0.0
+            assert int(a.step_state.max()) == 0                     # ... and the step was not counted
+        with pytest.raises(R.GhOverflowError):
+            R.check_overflow()
+        assert R._capacity[key] > 64
+    finally:
+        R._capacity[key] = max(R._capacity.get(key, 0), good_cap)
+    l_again = float(f.step(*args, sync=False))
+    R.check_overflow()
+    assert l_again == l_ref
+    for k in f._adam:
+        assert torch.equal(f._adam[k].param, ref._adam[k].param), k
+        assert int(f._adam[k].step_state.max()) == 1
