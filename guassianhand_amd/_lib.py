@@ -16,6 +16,9 @@ from . import _abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libgh_raster.so")
+# Profiling / ablation tooling only: load another build of the same C-ABI (tools/abl/*.so). Still a HIP library — there
+# is no CPU path behind this switch either.
+_OVERRIDE = os.environ.get("GH_RASTER_LIB")
 SOURCES = ("gh_api.hip", "gh_preprocess.hip", "gh_binning.hip", "gh_render.hip", "gh_uv.hip", "gh_sh.hip", "gh_knn.hip", "gh_loss.hip")
 HEADERS = ("gh_internal.h", os.path.join("..", "..", "include", "gh_raster.h"))
 # -ffp-contract=off: FMAs only where the source says fmaf() (arithmetic contract)
@@ -65,18 +68,19 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         import torch  # noqa: F401  (loads libamdhip64.so.7 into the process before our library binds to it)
-        if not os.path.exists(LIB_PATH):
+        path = _OVERRIDE or LIB_PATH
+        if not os.path.exists(path):
             raise GhLibraryError(
-                f"{LIB_PATH} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the rasteriser)")
         try:
-            L = C.CDLL(LIB_PATH)
+            L = C.CDLL(path)
         except OSError as e:  # pragma: no cover
-            raise GhLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+            raise GhLibraryError(f"cannot load {path}: {e}") from e
         _abi.declare(L)
         _lib = L
     return _lib
 
 
 def loaded_path() -> Optional[str]:
-    return LIB_PATH if _lib is not None else None
+    return (_OVERRIDE or LIB_PATH) if _lib is not None else None

@@ -324,40 +324,147 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// ---- backward: wave = 4x4 pixels x 4 depth slots, block = one 8x8 quadrant ----------------------------------
-// Same lane mapping as the forward (lane = 4*pixel + slot); entries are taken four per trip from the back.
-// Per pixel the reverse recurrence carries only (T, Bs): Bs = dL/dpixel . (colour behind). The oracle's colour behind
-// obeys B <- alpha_k*c_k + (1-alpha_k)*B, which is linear, and dL/dalpha only needs d . B, so one scalar chain
-// Bs <- alpha_k*(d . c_k) + (1-alpha_k)*Bs replaces the per-channel ones; the mask channel (A = 1 - T_final) rides on the
-// background term. The recurrence walks the quad with quad_perm broadcasts; every lane keeps the state that
-// was current at ITS slot and then evaluates its nine partial gradients once. They are summed over the 16 pixels
-// of the slot (row_shr:4, row_shr:8, then xor-16 / xor-32 through the LDS crossbar) and the four waves of the
-// quadrant are combined through a double-buffered LDS stage, one barrier per 64 list entries, in fixed wave
-// order: lane l of the flushing wave owns entry l and writes the quadrant's sub-record + flag byte.
-struct GhStateBwd { float T, Bs; };   // Bs = dL/dpixel . (colour behind), the only form the colour behind is needed in
+// ---- backward: wave = one 8x8 quadrant, lane = LIST ENTRY ------------------------------------------------
+// The forward's mapping (lane = 4*pixel + slot) pays for the sequential order of its recurrence with a crossbar fetch
+// of every entry value per trip and a 16-pixel reduction tree per gradient. The backward carries a 1e-3 tolerance, not
+// bit-exactness, so it uses the transposed mapping: the entries of a depth segment that can reach a 4x4 pixel block are
+// COMPACTED into the lanes (from the back of the list to the front), and the wave loops over the block's pixels:
+//   * the entry's record sits in the lane's own registers (no fetch at all); the pixel's values come from a 32-byte LDS
+//     record read with a broadcast address;
+//   * the reverse recurrence over the entries becomes two prefix scans per pixel (DPP row shifts + row broadcasts, no
+//     LDS): Q = running product of (1 - alpha) from the back, S = running sum of alpha*T*(d.c);
+//   * every lane accumulates the nine gradient moments of ITS entry over the pixels in registers: no cross-lane
+//     reduction, no atomics on HBM.
+// Batches are shape-adaptive: 64 entries x 1 pixel per iteration, or — for the remainder of a list — 32 entries x 2
+// pixels or 16 entries x 4 pixels (the entries replicated over the lane groups, the scans cut at the group borders), so a
+// short list does not idle three quarters of the wave (measured lane fill on the bench workload 62 % -> 88 %).
+// A wave owns one quadrant's four 4x4 blocks and walks them one after the other; the per-(entry, block) sums meet in a
+// wave-private LDS array (ds_add_f32 from one wave: program order, so the result is bitwise reproducible), and the wave
+// writes the quadrant's sub-record of every blended entry at the end. One wave per workgroup: no barriers, no cross-wave
+// traffic, a wave's registers and LDS are free the moment it is done.
 
-__device__ __forceinline__ float gh_slot_sum16(float v, int lane) {   // sum over the 16 pixels of this lane's slot
-  v += gh_dpp<0x114>(v);                                              // row_shr:4
-  v += gh_dpp<0x118>(v);                                              // row_shr:8 -> lanes 12..15 of each row: row sums
-  v += gh_lane_fetch(v, (lane ^ 16) << 2);
-  v += gh_lane_fetch(v, (lane ^ 32) << 2);                            // lanes 12..15 (+16k): totals per slot
+#define GH_BWD_ACC 128     // compact accumulator rows (entries of the segment that reach the quadrant) held in LDS at a time
+#define GH_PIX_DUMMY 64    // pixel record that blends nothing (padding of the 2- / 4-pixel iterations)
+
+// Inclusive prefix product / sum in lane order over groups of L = 64, 32 or 16 lanes: Kogge-Stone inside each row of 16
+// with DPP row shifts, then the row totals with row_bcast15 (L >= 32) and row_bcast31 (L = 64). Lanes without a source
+// lane keep their value (in place, bound_ctrl off). A VALU write followed by a DPP read needs two wait states (s_nop 1).
+#ifdef GH_ABL_NONOP
+#define GH_NOP ""
+#else
+#define GH_NOP "s_nop 1\n\t"
+#endif
+#define GH_SCAN_ROW(OP) \
+  GH_NOP OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
+  GH_NOP OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+  GH_NOP OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+  GH_NOP OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
+#define GH_SCAN_B15(OP) "\n\t" GH_NOP OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+#define GH_SCAN_B31(OP) "\n\t" GH_NOP OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+template <int L>
+__device__ __forceinline__ float gh_scan_mul(float v) {
+#ifdef GH_ABL_NOSCAN
+  return v;
+#endif
+  if (L == 64) asm(GH_SCAN_ROW("v_mul_f32_dpp") GH_SCAN_B15("v_mul_f32_dpp") GH_SCAN_B31("v_mul_f32_dpp") : "+v"(v));
+  else if (L == 32) asm(GH_SCAN_ROW("v_mul_f32_dpp") GH_SCAN_B15("v_mul_f32_dpp") : "+v"(v));
+  else asm(GH_SCAN_ROW("v_mul_f32_dpp") : "+v"(v));
+  return v;
+}
+template <int L>
+__device__ __forceinline__ float gh_scan_add(float v) {
+#ifdef GH_ABL_NOSCAN
+  return v;
+#endif
+  if (L == 64) asm(GH_SCAN_ROW("v_add_f32_dpp") GH_SCAN_B15("v_add_f32_dpp") GH_SCAN_B31("v_add_f32_dpp") : "+v"(v));
+  else if (L == 32) asm(GH_SCAN_ROW("v_add_f32_dpp") GH_SCAN_B15("v_add_f32_dpp") : "+v"(v));
+  else asm(GH_SCAN_ROW("v_add_f32_dpp") : "+v"(v));
   return v;
 }
 
-// r[q] += row_shr:4, then += row_shr:8, for nine values: lanes 12..15 of every row end up with the row's sums per slot.
-// Assembly because the compiler splits four of the eighteen fused DPP adds into v_mov_dpp + v_add. The two steps of a
-// value are nine instructions apart (VALU write -> DPP read needs two wait states); s_nop covers the producer of r[8].
-__device__ __forceinline__ void gh_row_sum9(float (&r)[9]) {
-#define GH_RS(N, SH) "v_add_f32_dpp %" #N ", %" #N ", %" #N " row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-  asm("s_nop 1\n\t"
-      GH_RS(0, 4) GH_RS(1, 4) GH_RS(2, 4) GH_RS(3, 4) GH_RS(4, 4) GH_RS(5, 4) GH_RS(6, 4) GH_RS(7, 4) GH_RS(8, 4)
-      GH_RS(0, 8) GH_RS(1, 8) GH_RS(2, 8) GH_RS(3, 8) GH_RS(4, 8) GH_RS(5, 8) GH_RS(6, 8) GH_RS(7, 8) GH_RS(8, 8)
-      : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]));
-#undef GH_RS
+struct GhBwdEntry {            // one list entry in the lane's registers
+  float4 a, b;                 // (px, py, A, B), (C, opacity, r, g)
+  float cb;                    // b
+  int pos;                     // list position inside the tile
+};
+
+// One batch: cnt <= L entries (lane % L = index from the back), 64 / L pixels per iteration. am: the block's pixels that
+// blend into the batch (bit i = pixel i of the block); pix_base: LDS record index of the block's pixel 0.
+// Adds the lane's nine sums into acc[9]; returns the ballot of lanes whose entry some pixel blended.
+template <int L>
+__device__ __forceinline__ uint64_t gh_bwd_batch(const GhBwdEntry& e, bool valid, uint32_t am, int pix_base, int lane,
+                                                 float4* s_pix, float (&acc)[9]) {
+  constexpr int NPX = GH_WAVE / L;
+  const uint32_t slot8 = (uint32_t)(lane / L) * 8u;
+  const bool seg_last = (lane % L) == L - 1;
+  uint64_t anyc = 0;
+  // pixel records of the next iteration are fetched while the current one is computed
+  auto pick = [&](uint32_t& m) -> uint32_t {                 // next NPX pixels as bytes (record indices), padded with the dummy
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < NPX; ++i) {
+      const int j = m ? pix_base + __builtin_ctz(m) : GH_PIX_DUMMY;
+      m &= m - 1u;
+      packed |= (uint32_t)j << (8 * i);
+    }
+    return packed;
+  };
+  uint32_t pidx = (pick(am) >> slot8) & 0xFFu;
+  float4 c0 = s_pix[2 * pidx], c1 = s_pix[2 * pidx + 1];
+  bool more = true;
+  while (more) {
+    const uint32_t pcur = pidx;
+    const float4 p0 = c0, p1 = c1;                               // (T, B, d0, d1), (d2, last, px, py) of this lane's pixel
+    more = am != 0u;
+    pidx = (pick(am) >> slot8) & 0xFFu;                          // all dummy once the mask is empty
+    c0 = s_pix[2 * pidx]; c1 = s_pix[2 * pidx + 1];
+    // alpha exactly as the forward evaluated it (same expression, same gh_exp): the same entries count as blended
+    const float dx = e.a.x - p1.z, dy = e.a.y - p1.w;
+    const float power = -0.5f * (e.a.z * dx * dx + e.b.x * dy * dy) - e.a.w * dx * dy;
+#ifdef GH_ABL_NOEXP
+    const float G = fminf(power, 0.0f) + 1.0f;
+#else
+    const float G = gh_exp(fminf(power, 0.0f));
+#endif
+    const float alpha = fminf(0.99f, e.b.y * G);
+    const bool contrib = valid && (e.pos < __float_as_int(p1.y)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+    anyc |= gh_ballot(contrib);
+    const float ae = contrib ? alpha : 0.0f;                    // entries the pixel did not blend: factor 1, weight 0
+    const float m1 = 1.0f - ae;
+    // Q_l = product of (1 - alpha) over this entry and everything behind it in the batch:
+    // T in front of the entry = (T behind the batch) / Q_l
+    const float Q = gh_scan_mul<L>(m1);
+#ifdef GH_ABL_NORCP
+    const float Tk = p0.x * Q;
+#else
+    const float Tk = p0.x * __builtin_amdgcn_rcpf(Q);
+#endif
+    const float ec = fmaf(p1.x, e.cb, fmaf(p0.w, e.b.w, p0.z * e.b.z));      // d . c of this entry
+    const float w = ae * Tk;                                               // the forward's blend weight alpha * T
+    const float we = w * ec;
+    const float S = gh_scan_add<L>(we) + p0.y;         // d . (colour blended at or behind this entry) + background / mask term
+    // dL/dalpha_k = T_k (d . c_k) - (d . colour strictly behind + background / mask term) / (1 - alpha_k)
+#ifdef GH_ABL_NORCP
+    const float dLda = Tk * ec - m1 * (S - we);
+#else
+    const float dLda = Tk * ec - __builtin_amdgcn_rcpf(m1) * (S - we);
+#endif
+    const float h = contrib ? G * dLda : 0.0f;        // raw moments of h = G dL/dalpha; opacity / conic factors are applied
+    const float hx = h * dx, hy = h * dy;             // once per (view, Gaussian) by gh_preprocess_bwd_kernel
+    acc[0] += hx; acc[1] += hy;
+    acc[2] = fmaf(hx, dx, acc[2]); acc[3] = fmaf(hx, dy, acc[3]); acc[4] = fmaf(hy, dy, acc[4]);
+    acc[5] += h;
+    acc[6] = fmaf(w, p0.z, acc[6]); acc[7] = fmaf(w, p0.w, acc[7]); acc[8] = fmaf(w, p1.x, acc[8]);
+    // state in front of the batch: the group's last lane holds the totals (lanes past the count: factor 1, weight 0)
+#ifndef GH_ABL_NOSTATE
+    if (seg_last) *(float2*)&s_pix[2 * pcur] = make_float2(Tk, S);
+#endif
+  }
+  return anyc;
 }
 
 template <bool ALPHA>
-__global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
+__global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ items, const GhCounters* __restrict__ ctr,
     const uint32_t* __restrict__ sorted_slot,
     const float4* __restrict__ r0, const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams,
@@ -365,27 +472,24 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
     const float4* __restrict__ ckpt_rgb, const float4* __restrict__ final_C,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, const float* __restrict__ upstream_scale,
     float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag) {
-  __shared__ float s_part[2][GH_BLOCK / GH_WAVE][GH_WAVE][GH_REC];    // [buffer][wave][entry][9]  (18 KB: 8 blocks per CU)
-  __shared__ uint64_t s_mask[2][GH_BLOCK / GH_WAVE];                  // entries a wave wrote
-  __shared__ int s_qlast;
-  int v, tx, ty;
+  __shared__ float s_acc[GH_BWD_ACC * GH_REC];            // [compact quadrant entry][9]
+  __shared__ float4 s_pix[2 * (GH_WAVE + 1)];             // per pixel (T, B, d0, d1), (d2, last, px, py); last record = dummy
+  __shared__ uint16_t s_q[4 * GH_SEGMENT];                // compacted entry lists of the four blocks: raw | compact << 8
+  __shared__ uint8_t s_f[GH_BWD_ACC];                     // 1 where some pixel of the quadrant blended the entry
   const uint32_t n_items = ctr->reserved[1];             // written by the forward; the grid is sized for the list's capacity
   uint32_t item_idx, quad_u;
-  gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);
+  gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);       // the four quadrants of an item share an XCD (L2)
   if (item_idx >= n_items) return;
   const uint2 item = items[n_items - 1u - item_idx];     // (tile, depth segment): the tiles the forward finished last go first
-  const int tile = (int)item.x;
+  const int tile = (int)item.x, quad = (int)quad_u;
   const int seg_lo = (int)item.y * GH_SEGMENT, seg_hi = seg_lo + GH_SEGMENT;
-  const int quad = (int)quad_u;
+  int v, tx, ty;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int slot = lane & 3, pi = lane >> 2;
-  const uint32_t slot8 = (uint32_t)slot * 8u;
-  const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (wid & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (wid >> 1) * 4;
-  const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
+  const int lane = threadIdx.x;
+  // pixel state: one pixel per lane, lane = 16 * block + 4 * row + column
+  const int lb = lane >> 4, lp = lane & 15;
+  const int x = tx * GH_TILE + (quad & 1) * 8 + (lb & 1) * 4 + (lp & 3), y = ty * GH_TILE + (quad >> 1) * 8 + (lb >> 1) * 4 + (lp >> 2);
   const bool inside = x < W && y < H;
-  const float pxf = (float)x, pyf = (float)y;
-  const int blk = ((quad >> 1) * 2 + (wid >> 1)) * 4 + (quad & 1) * 2 + (wid & 1);
   const uint2 range = ranges[tile];
   if (range.y == range.x) return;
   r0 += range.x; r1 += range.x; r2 += range.x;
@@ -406,180 +510,193 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_bwd_kernel(
       d0 *= us; d1 *= us; d2 *= us; dM *= us;
     }
   }
-  // background term and (ALPHA) the mask channel: both are multiples of T_final / (1 - alpha_k)
-  const float bg_dot = (bg[0] * d0 + bg[1] * d1 + bg[2] * d2) - dM;
-  int wave_last = last;                    // list positions >= wave_last were blended by no pixel of this 4x4 block
+  int qlast = last;                        // list positions >= qlast were blended by no pixel of this quadrant
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(wave_last, o); wave_last = t > wave_last ? t : wave_last; }
-  if (tid == 0) s_qlast = 0;
-  __syncthreads();
-  if (lane == 0) atomicMax(&s_qlast, wave_last);
-  __syncthreads();
-  const int qlast = s_qlast;               // ... by no pixel of the quadrant
-  if (qlast <= seg_lo) return;             // block-uniform: the quadrant blended nothing inside this depth segment
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(qlast, o); qlast = t > qlast ? t : qlast; }
+  if (qlast <= seg_lo) return;             // wave-uniform: the quadrant blended nothing inside this depth segment
   const int qend = qlast < seg_hi ? qlast : seg_hi;
+  const int nb = (qend - seg_lo + GH_WAVE - 1) / GH_WAVE;             // raw batches of 64 list entries in the segment (1..4)
+  int blast = last;                        // ... by no pixel of the lane's 4x4 block (max over the DPP row)
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { int t = __shfl_xor(blast, o); blast = t > blast ? t : blast; }
 
-  // State behind the segment. A pixel whose last blended entry lies inside (or before) the segment starts from
-  // (T_final, nothing behind), as the unsegmented walk does. A pixel that blends entries behind the cut starts from
-  // the forward's own state at the cut: T = transmittance in front of entry seg_hi, colour behind it =
-  // (final colour - colour accumulated in front of the cut) / T  — exact T instead of T_final divided back up.
-  GhStateBwd st;
-  st.T = T_final; st.Bs = 0.0f;
+  // Per-pixel state behind the segment, ABSOLUTE form: T = transmittance in front of list position `cut`, B = d . (colour
+  // blended at positions >= cut) + the background / mask term T_final * (bg . d - dM); both enter dL/dalpha_k as
+  // -(...) / (1 - alpha_k). A pixel whose last blended entry lies inside (or before) the segment starts from (T_final,
+  // nothing behind); one that blends entries behind the cut starts from the forward's own state at the cut (exact T).
+  float vT = T_final;
+  float vB = T_final * ((bg[0] * d0 + bg[1] * d1 + bg[2] * d2) - dM);
   if (inside && last > seg_hi) {
     const size_t ck = ((size_t)(range.x / GH_SEGMENT) + (size_t)tile + (size_t)item.y) * 256 +
                       (size_t)((y - ty * GH_TILE) * GH_TILE + (x - tx * GH_TILE));
     const float4 c = ckpt_rgb[ck];
     const float4 fc = final_C[((size_t)v * H + y) * W + x];
-    const float iT = 1.0f / c.x;           // > 1e-4: the pixel was still open at the cut
-    st.T = c.x;
-    st.Bs = fmaf(d2, (fc.z - c.w) * iT, fmaf(d1, (fc.y - c.z) * iT, d0 * ((fc.x - c.y) * iT)));
+    vT = c.x;
+    vB += fmaf(d2, fc.z - c.w, fmaf(d1, fc.y - c.z, d0 * (fc.x - c.y)));
   }
-  const int nb = (qend - seg_lo + GH_WAVE - 1) / GH_WAVE;
-  const uint32_t row3_slot_bit = lane >= 48 ? 1u << slot : 0u;     // the lanes that hold a slot's totals after the 16-pixel sums
-  GhBatch cur, nxt;
-  gh_load_batch(cur, r0, r1, r2, seg_lo + (nb - 1) * GH_WAVE + lane, qend);
-  for (int k = nb - 1; k >= 0; --k) {
-    const int buf = k & 1;
-    const int sbase = seg_lo + k * GH_WAVE;
-    gh_load_batch(nxt, r0, r1, r2, seg_lo + (k > 0 ? (k - 1) * GH_WAVE : 0) + lane, qend);   // next batch in flight
-    uint64_t processed = 0;
-    uint64_t mask = gh_ballot((sbase + lane < wave_last) && ((cur.blocks >> blk) & 1u));
-    while (mask) {
-      // next four set bits, descending (back to front); wave-uniform scalar work
-      const int nh = __builtin_popcountll(mask);                     // entries left in this batch (>= 1)
-      int j0, j1, j2, j3;
-      const uint64_t before = mask;
-      gh_pop4_high(mask, j0, j1, j2, j3);
-      const uint64_t picked = before ^ mask;                             // the (up to) four entries of this trip
-      const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
-      const int src = (int)((packed4 >> slot8) & 0xFFu);            // one v_bfe: 4 * this slot's entry lane
-      const int myj = src >> 2;
-      const bool have = slot < nh;
-      const float gpx = gh_lane_fetch(cur.a.x, src), gpy = gh_lane_fetch(cur.a.y, src), cA = gh_lane_fetch(cur.a.z, src);
-      const float cB = gh_lane_fetch(cur.a.w, src), cC = gh_lane_fetch(cur.b.x, src), op = gh_lane_fetch(cur.b.y, src);
-      const float cr = gh_lane_fetch(cur.b.z, src), cg = gh_lane_fetch(cur.b.w, src), cbl = gh_lane_fetch(cur.cb, src);
-      const float dx = gpx - pxf, dy = gpy - pyf;
-      const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-      const float G = gh_exp(fminf(power, 0.0f));
-      const float alpha = fminf(0.99f, op * G);
-      const bool contrib = have && (sbase + myj < last) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-      const uint64_t cm = gh_ballot(contrib);
-      if (cm == 0) continue;                                           // wave-uniform: nothing blended by this block
-      // 1/(1-alpha): v_rcp_f32 (<= 1 ulp). Gradients carry a 1e-3 rtol; only the forward is bit-exact.
-      // Reverse recurrence over the quad as DPP-fused prefix products / affine updates, in exact processing order:
-      //   T <- T * f,  B <- B * m + a   with (f, m, a) = (1/(1-alpha), 1-alpha, alpha*c) where the pixel blended the
-      //   entry and (1, 1, 0) otherwise (x*1 and x+0 leave the state bit-identical). One select does it all: with the
-      //   EFFECTIVE alpha = 0 for pixels that did not blend the entry, m = 1, f = rcp(1) = 1 and a = 0 fall out exactly.
-      const float ae = contrib ? alpha : 0.0f;
-      const float m = 1.0f - ae;
-      const float inv1ma = __builtin_amdgcn_rcpf(m);      // v_rcp_f32 (<= 1 ulp; exact for 1). Gradients carry a 1e-3 rtol.
-      const float f = inv1ma;
-      // The three colour channels only ever enter dL/dalpha through their dot product with dL/dpixel, and the recurrence
-      // of the colour behind is linear, so ONE scalar chain carries Bs = d . B:  Bs <- Bs * m + ae * (d . c).
-      const float e = fmaf(d2, cbl, fmaf(d1, cg, d0 * cr));                             // d . c of this lane's entry
-      const float ace = ae * e;
-      const float T1 = st.T * gh_quad_bcast<0>(f), T2 = T1 * gh_quad_bcast<1>(f), T3 = T2 * gh_quad_bcast<2>(f),
-                  T4 = T3 * gh_quad_bcast<3>(f);
-      const float mTn = gh_slot_select(T1, T2, T3, T4);                                  // T right after this lane's entry
-      float mBs;
+  s_pix[2 * lane] = make_float4(vT, vB, d0, d1);
+  s_pix[2 * lane + 1] = make_float4(d2, __int_as_float(last), (float)x, (float)y);
+  if (lane == 0) {
+    s_pix[2 * GH_PIX_DUMMY] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+    s_pix[2 * GH_PIX_DUMMY + 1] = make_float4(0.0f, __int_as_float(0), 0.0f, 0.0f);       // last = 0: blends nothing
+  }
+  int bl4[4];                                                  // per block: first list position no pixel of it blended
+#pragma unroll
+  for (int b = 0; b < 4; ++b) bl4[b] = __builtin_amdgcn_readlane(blast, 16 * b);
+
+  // 4x4-block masks of the segment's entries: lane l holds entries l, l + 64, l + 128, l + 192 of the segment
+  const uint32_t quad_bits = 0x33u << (8 * (quad >> 1) + 2 * (quad & 1));          // the quadrant's four blocks in the entry masks
+  uint32_t mk[GH_SEGMENT / GH_WAVE];
+  int qcnt[GH_SEGMENT / GH_WAVE];                                                   // entries per raw batch that reach the quadrant
+#pragma unroll
+  for (int k = 0; k < GH_SEGMENT / GH_WAVE; ++k) {
+    const int pos = seg_lo + k * GH_WAVE + lane;
+    mk[k] = (k < nb && pos < qend) ? (__float_as_uint(r2[pos].y) & quad_bits) : 0u;
+    qcnt[k] = __popcll(gh_ballot(mk[k] != 0u));
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // Chunks of consecutive raw batches, from the back, whose entries fit the accumulator rows (nearly always the whole segment)
+  int k_hi = nb - 1;
+  while (k_hi >= 0) {
+    int k_lo = k_hi, rows = 0;
+#pragma unroll
+    for (int k = GH_SEGMENT / GH_WAVE - 1; k >= 0; --k)
+      if (k <= k_hi && k == k_lo && (k == k_hi || rows + qcnt[k] <= GH_BWD_ACC)) { rows += qcnt[k]; k_lo = k - 1; }
+    k_lo += 1;                                                  // chunk = raw batches [k_lo, k_hi], `rows` accumulator rows
+    // compact row of each of the lane's entries inside the chunk
+    int crow[GH_SEGMENT / GH_WAVE];
+    {
+      int base = 0;
+#pragma unroll
+      for (int k = 0; k < GH_SEGMENT / GH_WAVE; ++k) {
+        crow[k] = 0;
+        if (k >= k_lo && k <= k_hi) {
+          const uint64_t qm = gh_ballot(mk[k] != 0u);
+          crow[k] = base + __popcll(qm & ((1ull << lane) - 1ull));
+          base += __popcll(qm);
+        }
+      }
+    }
+    for (int i = lane; i < rows * GH_REC; i += GH_WAVE) s_acc[i] = 0.0f;
+    for (int i = lane; i < rows; i += GH_WAVE) s_f[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- compaction: per block, the entries that can reach it, from the back of the list to the front
+    int nh0 = 0, nh1 = 0, nh2 = 0, nh3 = 0;                    // entries per block (scalars: a dynamically indexed array would live in scratch)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int bl = bl4[b];
+      const int bend = bl < seg_hi ? bl : seg_hi;
+      const int bit = ((quad >> 1) * 2 + (b >> 1)) * 4 + (quad & 1) * 2 + (b & 1);      // the block's bit in the entry masks
+      int nhit = 0;
+#pragma unroll
+      for (int k = GH_SEGMENT / GH_WAVE - 1; k >= 0; --k) {
+        if (k < k_lo || k > k_hi) continue;
+        const bool hit = ((mk[k] >> bit) & 1u) && (seg_lo + k * GH_WAVE + lane < bend);      // bend <= chunk start: no hits
+        const uint64_t hm = gh_ballot(hit);
+        if (hit) ((volatile uint16_t*)s_q)[b * GH_SEGMENT + nhit + __popcll((hm >> lane) >> 1)] = (uint16_t)((k * GH_WAVE + lane) | (crow[k] << 8));
+        nhit += __popcll(hm);
+      }
+      if (b == 0) nh0 = nhit; else if (b == 1) nh1 = nhit; else if (b == 2) nh2 = nhit; else nh3 = nhit;
+    }
+    auto nh = [&](int b) { return b == 0 ? nh0 : (b == 1 ? nh1 : (b == 2 ? nh2 : nh3)); };
+    __builtin_amdgcn_wave_barrier();
+    // ---- batches: a flat walk over (block, offset) with ONE BATCH OF LOOKAHEAD — the next batch's records are gathered
+    // while the current one is computed (a wave has a handful of dependent memory round trips, not one per batch)
+    struct Batch { int b, j0, L, cnt, ci; bool valid; uint32_t am; GhBwdEntry e; };
+    auto first_block = [&](int b) { while (b < 4 && nh(b) == 0) ++b; return b; };
+    auto fetch = [&](Batch& t, int b, int j0) {
+      t.b = b; t.j0 = j0;
+      if (b >= 4) return;
+      const int rem = nh(b) - j0;
+      // batch shape: 64 lanes x 1 pixel, or for short remainders 32 x 2 / 16 x 4 (rem in (32, 48] goes as 32 + a 16-lane batch)
+#ifdef GH_ABL_L64
+      t.L = 64;
+#else
+      t.L = rem > 48 ? 64 : (rem > 16 ? 32 : 16);
+#endif
+      t.cnt = rem < t.L ? rem : t.L;
+      const int el = lane & (t.L - 1);
+      t.valid = el < t.cnt;
+      const uint32_t qe = t.valid ? (uint32_t)((volatile uint16_t*)s_q)[b * GH_SEGMENT + j0 + el] : 0u;
+      t.ci = (int)(qe >> 8);
+      t.e.pos = seg_lo + (int)(qe & 0xFFu);
+      t.e.a = r0[t.e.pos]; t.e.b = r1[t.e.pos]; t.e.cb = r2[t.e.pos].x;
+      const int minpos = __builtin_amdgcn_readlane(t.e.pos, t.cnt - 1);       // front-most entry of the batch
+      t.am = (uint32_t)(gh_ballot(last > minpos) >> (16 * b)) & 0xFFFFu;      // pixels of the block that blend into the batch
+    };
+    Batch cur, nxt;
+    fetch(cur, first_block(0), 0);
+    while (cur.b < 4) {
       {
-        float b1, b2, b3, b4;
-        gh_quad_affine4(st.Bs, m, ace, b1, b2, b3, b4);
-        mBs = gh_slot_select(st.Bs, b1, b2, b3);                                         // d . (colour behind this lane's entry)
-        st.Bs = b4;
+        int nb_ = cur.b, nj = cur.j0 + cur.cnt;
+        if (nj >= nh(nb_)) { nb_ = first_block(nb_ + 1); nj = 0; }
+        fetch(nxt, nb_, nj);
       }
-      st.T = T4;
-      // the mask channel A = 1 - T_final has dA/dalpha_k = T_final / (1 - alpha_k): it rides on the background term
-      float dL_dalpha = (e - mBs) * mTn;
-      dL_dalpha += (-T_final * inv1ma) * bg_dot;
-      // pixels that did not blend the entry contribute nothing: every partial below is a product with dL_dalpha or
-      // dchannel_dcolor (all other factors are finite), so zeroing these two replaces nine selects
-      dL_dalpha = contrib ? dL_dalpha : 0.0f;
-      // Raw pixel moments of h = G * dL/dalpha; opacity and conic factors are constant per instance and are applied
-      // after all sums, once per (view, Gaussian), by gh_preprocess_bwd_kernel (the 0.99 clamp is straight-through,
-      // App. A.4-2): 6 multiplies here instead of 20.
-      const float h = G * dL_dalpha;
-      const float hx = h * dx, hy = h * dy;
-      const float dchannel_dcolor = ae * mTn;
-      float r[9];
-      r[0] = hx; r[1] = hy;
-      r[2] = hx * dx; r[3] = hx * dy; r[4] = hy * dy;
-      r[5] = h;
-      r[6] = dchannel_dcolor * d0; r[7] = dchannel_dcolor * d1; r[8] = dchannel_dcolor * d2;
-      // Sum every value over the 16 pixels of each slot. In-row half with DPP: lanes 12..15 of each row then hold the row's
-      // sums for slots 0..3. Before the cross-row half (the LDS crossbar, by far the most expensive step) four values are
-      // PACKED into one register — value 4g+1 / +2 / +3 moves to lanes 8..11 / 4..7 / 0..3 of its row with bank-masked
-      // row shifts — so the xor-16 / xor-32 butterfly runs 3 times per trip instead of 9.
-      gh_row_sum9(r);
-      float R[3];
+      float acc[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      uint64_t anyc = 0;
+#ifdef GH_ABL_NOBODY
+      if (false) {
+#else
+      if (cur.am) {
+#endif
+        if (cur.L == 64) anyc = gh_bwd_batch<64>(cur.e, cur.valid, cur.am, 16 * cur.b, lane, s_pix, acc);
+        else if (cur.L == 32) anyc = gh_bwd_batch<32>(cur.e, cur.valid, cur.am, 16 * cur.b, lane, s_pix, acc);
+        else anyc = gh_bwd_batch<16>(cur.e, cur.valid, cur.am, 16 * cur.b, lane, s_pix, acc);
+      }
+      // The lane groups of a 32- / 16-lane batch hold partial sums of the SAME entries (different pixels): fold them into
+      // group 0 (fixed order). Then plain read-modify-write of the entry's accumulator row: the wave owns the rows and the
+      // entries of a batch are distinct (LDS float atomics cost 0.19 ms of a 0.36 ms kernel when this was ds_add_f32).
+      if (cur.L < 64) {
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        int pk = __builtin_bit_cast(int, r[4 * g]);
-        if (g < 2) {
-          pk = __builtin_amdgcn_update_dpp(pk, __builtin_bit_cast(int, r[4 * g + 1]), 0x104, 0xF, 0x4, false);   // row_shl:4  -> bank 2
-          pk = __builtin_amdgcn_update_dpp(pk, __builtin_bit_cast(int, r[4 * g + 2]), 0x108, 0xF, 0x2, false);   // row_shl:8  -> bank 1
-          pk = __builtin_amdgcn_update_dpp(pk, __builtin_bit_cast(int, r[4 * g + 3]), 0x10C, 0xF, 0x1, false);   // row_shl:12 -> bank 0
+        for (int q = 0; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 32);
+        anyc |= (anyc >> 32) | (anyc << 32);
+        if (cur.L < 32) {
+#pragma unroll
+          for (int q = 0; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 16);
+          anyc |= ((anyc >> 16) & 0x0000FFFF0000FFFFull) | ((anyc << 16) & 0xFFFF0000FFFF0000ull);
         }
-        float v = __builtin_bit_cast(float, pk);
-        v += gh_lane_fetch(v, (lane ^ 16) << 2);
-        v += gh_lane_fetch(v, (lane ^ 32) << 2);             // every row: bank b holds the total of value 4g + 3 - b, slot = lane & 3
-        R[g] = v;
       }
-      // slots in which at least one pixel blended its entry get a partial record (wave-uniform bookkeeping, scalar):
-      // act = OR of the contribution ballot over the 16 pixels -> one bit per slot. Nearly always every picked entry is
-      // active, and then the processed set simply grows by the picked bits.
-      uint32_t act = (uint32_t)cm | (uint32_t)(cm >> 32);
-      act |= act >> 16; act |= act >> 8; act |= act >> 4; act &= 15u;
-      if (act == (nh >= 4 ? 15u : (1u << nh) - 1u)) processed |= picked;
-      else {
-        if (act & 1u) processed |= 1ull << j0;
-        if (act & 2u) processed |= 1ull << j1;
-        if (act & 4u) processed |= 1ull << j2;
-        if (act & 8u) processed |= 1ull << j3;
+#ifdef GH_ABL_NOADD
+      if (false) {
+#else
+      if (lane < cur.L && ((anyc >> lane) & 1ull)) {                 // lane's entry was blended by some pixel of the block
+#endif
+        float* d = s_acc + cur.ci * GH_REC;
+#pragma unroll
+        for (int q = 0; q < GH_REC; ++q) d[q] += acc[q];
+        ((volatile uint8_t*)s_f)[cur.ci] = 1;
       }
-      if (act & row3_slot_bit) {                                        // row 3: lane 48 + 4b + slot holds values 3-b, 7-b (and 8 for b = 3)
-        float* pr = &s_part[buf][wid][myj][0];
-        const int q0 = 3 - ((lane >> 2) & 3);
-        pr[q0] = R[0];
-        pr[4 + q0] = R[1];
-        if (lane >= 60) pr[8] = R[2];
+      __builtin_amdgcn_wave_barrier();
+      cur = nxt;
+    }
+    // ---- the quadrant's sub-record of every entry some pixel blended, at the instance's emit slot
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < GH_SEGMENT / GH_WAVE; ++k) {
+      if (k < k_lo || k > k_hi) continue;
+      if (mk[k] != 0u && ((volatile uint8_t*)s_f)[crow[k]]) {
+        const float* s9 = s_acc + crow[k] * GH_REC;
+        const uint32_t sl = slots[seg_lo + k * GH_WAVE + lane];
+        GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC_G);
+        rec[0] = GhF3{s9[0], s9[1], s9[2]};
+        rec[1] = GhF3{s9[3], s9[4], s9[5]};
+        rec[2] = GhF3{s9[6], s9[7], s9[8]};
+        inst_flag[(size_t)sl * 4 + quad] = 1;
       }
     }
-    if (lane == 0) s_mask[buf][wid] = processed;
-    __syncthreads();
-    if (wid == (k & 3)) {                       // flush batch k: lane l owns entry l; fixed wave order => reproducible
-      const int pos = sbase + lane;
-      if (pos < qend) {
-        float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        bool any = false;
-#pragma unroll
-        for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) {
-          if ((s_mask[buf][w] >> lane) & 1ull) {
-            any = true;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) s9[q] += s_part[buf][w][lane][q];
-          }
-        }
-        if (any) {
-          const uint32_t sl = slots[pos];
-          GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC_G);
-          rec[0] = GhF3{s9[0], s9[1], s9[2]};
-          rec[1] = GhF3{s9[3], s9[4], s9[5]};
-          rec[2] = GhF3{s9[6], s9[7], s9[8]};
-          inst_flag[(size_t)sl * 4 + quad] = 1;
-        }
-      }
-    }
-    cur = nxt;
+    __builtin_amdgcn_wave_barrier();
+    k_hi = k_lo - 1;
   }
 }
 
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, const float* upstream_scale, char* ws, const GhLayout& L, hipStream_t s) {
   if (g.cap == 0) return;
-  // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (same n_contrib).
-  // The work list (tile, depth segment) was written by the forward's last wave of every tile.
-  const dim3 grid(4 * (unsigned)g.n_items), block(GH_BLOCK);      // capacity of the work list; surplus blocks exit at once
+  // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (they depend on the forward's
+  // n_contrib only). The work list (tile, depth segment) was written by the forward's last wave of every tile.
+  const dim3 grid(4 * (unsigned)g.n_items), block(GH_WAVE);      // capacity of the work list x 4 quadrants; surplus waves exit at once
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(ws + L.ranges), (const uint2*)(ws + L.bwd_items),
                        (const GhCounters*)(ws + L.counters),

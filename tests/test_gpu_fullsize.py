@@ -100,12 +100,16 @@ def test_config3_full_size_fit_step_matches_oracle_driven_step(dev):
         f.opacity_b_tex.copy_((0.02 * torch.randn(f.opacity_b_tex.shape, generator=g)).to(dev))
     blend = {k: v.detach().cpu() for k, v in f.blend_values().items()}
     assert blend["color_b"].shape == (P, 3) and blend["opacity_b"].shape == (P, 1)
+    with torch.no_grad():
+        mine = f.render(s.w2c, s.K, H, W, s.bg, f.blend_values())
+        img_g, alpha_g = mine["image_chw"].cpu(), mine["alpha"].cpu()
     f.keep_boundary_grads = True
     loss = float(f.step(s.w2c, s.K, H, W, s.bg, gt_rgb, gt_mask, sync=True))
     got = {k: v.detach().cpu() for k, v in f.boundary_grads.items()}
 
     # the same step on the C oracle, the reference's way: per view an RGB pass and a mask pass (colour 1, bg 0)
-    cams = sc.cams()
+    from guassianhand_amd.camera import pack_cameras_from_w2c
+    cams = pack_cameras_from_w2c(s.w2c, s.K, H, W, s.bg).cpu()     # the device-packed records (tan / atan2 differ by 1 ulp on the host)
     cb48 = torch.zeros(P, 48)
     cb48[:, :3] = blend["color_b"]
     gt_rgb_c, gt_mask_c = gt_rgb.cpu(), gt_mask.cpu()
@@ -119,6 +123,7 @@ def test_config3_full_size_fit_step_matches_oracle_driven_step(dev):
         cam0[:, 37:40] = 0.0
         msk = OracleRender(cam0, sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=H, W=W, colors_precomp=torch.ones(P, 3),
                            xyz_b=blend["xyz_b"], opacity_b=blend["opacity_b"])
+        assert torch.equal(rgb.image[0], img_g[v]) and torch.equal(msk.image[0, 0], alpha_g[v]), v     # forward: bit-exact
         img = rgb.image[0].permute(1, 2, 0).double()                 # (H,W,3)
         alpha = msk.image[0].double().mean(0)                         # infer_one_shot.py:497
         d = img - gt_rgb_c[v].double()
@@ -136,4 +141,7 @@ def test_config3_full_size_fit_step_matches_oracle_driven_step(dev):
     for k in ("color_w", "color_b", "opacity_b"):
         a, b = got[k].reshape(want[k].shape).double(), want[k]
         assert rel_l2(a, b) <= 1e-5, (k, rel_l2(a, b))
-        assert max_rel(a, b) <= 1e-3, (k, max_rel(a, b))
+        rel = ((a - b).abs() / (b.abs() + 1e-3 * b.abs().max())).reshape(-1)
+        worst = torch.topk(rel, min(5, rel.numel())).indices
+        assert max_rel(a, b) <= 1e-3, (k, max_rel(a, b), [(int(i), float(a.reshape(-1)[i]), float(b.reshape(-1)[i])) for i in worst],
+                                       float(b.abs().max()))
