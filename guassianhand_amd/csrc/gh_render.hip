@@ -339,7 +339,7 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 // pixels or 16 entries x 4 pixels (the entries replicated over the lane groups, the scans cut at the group borders), so a
 // short list does not idle three quarters of the wave (measured lane fill on the bench workload 62 % -> 88 %).
 // A wave owns one quadrant's four 4x4 blocks and walks them one after the other; the per-(entry, block) sums meet in a
-// wave-private LDS array (ds_add_f32 from one wave: program order, so the result is bitwise reproducible), and the wave
+// wave-private LDS array (plain read-modify-write in program order, so the result is bitwise reproducible), and the wave
 // writes the quadrant's sub-record of every blended entry at the end. One wave per workgroup: no barriers, no cross-wave
 // traffic, a wave's registers and LDS are free the moment it is done.
 
@@ -389,35 +389,37 @@ struct GhBwdEntry {            // one list entry in the lane's registers
 };
 
 // One batch: cnt <= L entries (lane % L = index from the back), 64 / L pixels per iteration. am: the block's pixels that
-// blend into the batch (bit i = pixel i of the block); pix_base: LDS record index of the block's pixel 0.
-// Adds the lane's nine sums into acc[9]; returns the ballot of lanes whose entry some pixel blended.
+// blend into the batch (bit i = pixel i of the block, wave-uniform); pix_base: LDS record index of the block's pixel 0.
+// Adds the lane's nine sums into acc[9]; returns whether some pixel blended the lane's entry.
 template <int L>
-__device__ __forceinline__ uint64_t gh_bwd_batch(const GhBwdEntry& e, bool valid, uint32_t am, int pix_base, int lane,
-                                                 float4* s_pix, float (&acc)[9]) {
+__device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, uint32_t am_in, int pix_base, int lane,
+                                             float4* s_pix, float (&acc)[9]) {
   constexpr int NPX = GH_WAVE / L;
+  uint32_t am = (uint32_t)__builtin_amdgcn_readfirstlane((int)am_in);
   const uint32_t slot8 = (uint32_t)(lane / L) * 8u;
   const bool seg_last = (lane % L) == L - 1;
-  uint64_t anyc = 0;
-  // pixel records of the next iteration are fetched while the current one is computed
-  auto pick = [&](uint32_t& m) -> uint32_t {                 // next NPX pixels as bytes (record indices), padded with the dummy
+  bool any = false;
+  // record index of this lane's next pixel: the next NPX set bits of am, padded with the dummy. Scalar instructions written
+  // out (s_ff1 + s_bitset0, which uses the low 5 bits of its operand, so the -1 of an empty mask is harmless): the mask
+  // stays in an SGPR across the loop instead of being walked with vector instructions.
+  auto pick = [&]() -> uint32_t {
+    int j[NPX];
+    if (NPX == 1) asm("s_ff1_i32_b32 %1, %0\n\ts_bitset0_b32 %0, %1" : "+s"(am), "=&s"(j[0]));
+    else if (NPX == 2) asm("s_ff1_i32_b32 %1, %0\n\ts_bitset0_b32 %0, %1\n\ts_ff1_i32_b32 %2, %0\n\ts_bitset0_b32 %0, %2"
+                           : "+s"(am), "=&s"(j[0]), "=&s"(j[NPX > 1 ? 1 : 0]));
+    else asm("s_ff1_i32_b32 %1, %0\n\ts_bitset0_b32 %0, %1\n\ts_ff1_i32_b32 %2, %0\n\ts_bitset0_b32 %0, %2\n\t"
+             "s_ff1_i32_b32 %3, %0\n\ts_bitset0_b32 %0, %3\n\ts_ff1_i32_b32 %4, %0\n\ts_bitset0_b32 %0, %4"
+             : "+s"(am), "=&s"(j[0]), "=&s"(j[NPX > 1 ? 1 : 0]), "=&s"(j[NPX > 2 ? 2 : 0]), "=&s"(j[NPX > 3 ? 3 : 0]));
     uint32_t packed = 0;
 #pragma unroll
-    for (int i = 0; i < NPX; ++i) {
-      const int j = m ? pix_base + __builtin_ctz(m) : GH_PIX_DUMMY;
-      m &= m - 1u;
-      packed |= (uint32_t)j << (8 * i);
-    }
-    return packed;
+    for (int i = 0; i < NPX; ++i) packed |= (uint32_t)(j[i] < 0 ? GH_PIX_DUMMY : pix_base + j[i]) << (8 * i);
+    return NPX == 1 ? packed : ((packed >> slot8) & 0xFFu);
   };
-  uint32_t pidx = (pick(am) >> slot8) & 0xFFu;
-  float4 c0 = s_pix[2 * pidx], c1 = s_pix[2 * pidx + 1];
-  bool more = true;
-  while (more) {
+  uint32_t pidx = pick();
+  float4 p0 = s_pix[2 * pidx], p1 = s_pix[2 * pidx + 1];        // (T, B, d0, d1), (d2, last, px, py) of this lane's pixel
+  bool more;
+  do {
     const uint32_t pcur = pidx;
-    const float4 p0 = c0, p1 = c1;                               // (T, B, d0, d1), (d2, last, px, py) of this lane's pixel
-    more = am != 0u;
-    pidx = (pick(am) >> slot8) & 0xFFu;                          // all dummy once the mask is empty
-    c0 = s_pix[2 * pidx]; c1 = s_pix[2 * pidx + 1];
     // alpha exactly as the forward evaluated it (same expression, same gh_exp): the same entries count as blended
     const float dx = e.a.x - p1.z, dy = e.a.y - p1.w;
     const float power = -0.5f * (e.a.z * dx * dx + e.b.x * dy * dy) - e.a.w * dx * dy;
@@ -428,39 +430,34 @@ __device__ __forceinline__ uint64_t gh_bwd_batch(const GhBwdEntry& e, bool valid
 #endif
     const float alpha = fminf(0.99f, e.b.y * G);
     const bool contrib = valid && (e.pos < __float_as_int(p1.y)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
-    anyc |= gh_ballot(contrib);
+    any |= contrib;
     const float ae = contrib ? alpha : 0.0f;                    // entries the pixel did not blend: factor 1, weight 0
     const float m1 = 1.0f - ae;
     // Q_l = product of (1 - alpha) over this entry and everything behind it in the batch:
     // T in front of the entry = (T behind the batch) / Q_l
     const float Q = gh_scan_mul<L>(m1);
-#ifdef GH_ABL_NORCP
-    const float Tk = p0.x * Q;
-#else
     const float Tk = p0.x * __builtin_amdgcn_rcpf(Q);
-#endif
     const float ec = fmaf(p1.x, e.cb, fmaf(p0.w, e.b.w, p0.z * e.b.z));      // d . c of this entry
     const float w = ae * Tk;                                               // the forward's blend weight alpha * T
     const float we = w * ec;
-    const float S = gh_scan_add<L>(we) + p0.y;         // d . (colour blended at or behind this entry) + background / mask term
+    acc[6] = fmaf(w, p0.z, acc[6]); acc[7] = fmaf(w, p0.w, acc[7]); acc[8] = fmaf(w, p1.x, acc[8]);
+    const float sB = p0.y;
+    // the pixel records of the next iteration land while the second half of this one is computed
+    more = am != 0u;
+    pidx = pick();                                               // all dummy once the mask is empty
+    p0 = s_pix[2 * pidx]; p1 = s_pix[2 * pidx + 1];
+    const float S = gh_scan_add<L>(we) + sB;          // d . (colour blended at or behind this entry) + background / mask term
     // dL/dalpha_k = T_k (d . c_k) - (d . colour strictly behind + background / mask term) / (1 - alpha_k)
-#ifdef GH_ABL_NORCP
-    const float dLda = Tk * ec - m1 * (S - we);
-#else
     const float dLda = Tk * ec - __builtin_amdgcn_rcpf(m1) * (S - we);
-#endif
     const float h = contrib ? G * dLda : 0.0f;        // raw moments of h = G dL/dalpha; opacity / conic factors are applied
     const float hx = h * dx, hy = h * dy;             // once per (view, Gaussian) by gh_preprocess_bwd_kernel
     acc[0] += hx; acc[1] += hy;
     acc[2] = fmaf(hx, dx, acc[2]); acc[3] = fmaf(hx, dy, acc[3]); acc[4] = fmaf(hy, dy, acc[4]);
     acc[5] += h;
-    acc[6] = fmaf(w, p0.z, acc[6]); acc[7] = fmaf(w, p0.w, acc[7]); acc[8] = fmaf(w, p1.x, acc[8]);
     // state in front of the batch: the group's last lane holds the totals (lanes past the count: factor 1, weight 0)
-#ifndef GH_ABL_NOSTATE
     if (seg_last) *(float2*)&s_pix[2 * pcur] = make_float2(Tk, S);
-#endif
-  }
-  return anyc;
+  } while (more);
+  return any;
 }
 
 template <bool ALPHA>
@@ -474,7 +471,7 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
     float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag) {
   __shared__ float s_acc[GH_BWD_ACC * GH_REC];            // [compact quadrant entry][9]
   __shared__ float4 s_pix[2 * (GH_WAVE + 1)];             // per pixel (T, B, d0, d1), (d2, last, px, py); last record = dummy
-  __shared__ uint16_t s_q[4 * GH_SEGMENT];                // compacted entry lists of the four blocks: raw | compact << 8
+  __shared__ uint16_t s_q[GH_SEGMENT];                    // compacted entry list of the block being walked: raw | compact << 8
   __shared__ uint8_t s_f[GH_BWD_ACC];                     // 1 where some pixel of the quadrant blended the entry
   const uint32_t n_items = ctr->reserved[1];             // written by the forward; the grid is sized for the list's capacity
   uint32_t item_idx, quad_u;
@@ -540,9 +537,6 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
     s_pix[2 * GH_PIX_DUMMY] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
     s_pix[2 * GH_PIX_DUMMY + 1] = make_float4(0.0f, __int_as_float(0), 0.0f, 0.0f);       // last = 0: blends nothing
   }
-  int bl4[4];                                                  // per block: first list position no pixel of it blended
-#pragma unroll
-  for (int b = 0; b < 4; ++b) bl4[b] = __builtin_amdgcn_readlane(blast, 16 * b);
 
   // 4x4-block masks of the segment's entries: lane l holds entries l, l + 64, l + 128, l + 192 of the segment
   const uint32_t quad_bits = 0x33u << (8 * (quad >> 1) + 2 * (quad & 1));          // the quadrant's four blocks in the entry masks
@@ -582,94 +576,76 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
     for (int i = lane; i < rows; i += GH_WAVE) s_f[i] = 0;
     __builtin_amdgcn_wave_barrier();
 
-    // ---- compaction: per block, the entries that can reach it, from the back of the list to the front
-    int nh0 = 0, nh1 = 0, nh2 = 0, nh3 = 0;                    // entries per block (scalars: a dynamically indexed array would live in scratch)
-#pragma unroll
+#pragma unroll 1
     for (int b = 0; b < 4; ++b) {
-      const int bl = bl4[b];
+      const int bl = __builtin_amdgcn_readlane(blast, 16 * b);          // first list position no pixel of the block blended
+      if (bl <= seg_lo + k_lo * GH_WAVE) continue;                     // the block blended nothing inside this chunk
       const int bend = bl < seg_hi ? bl : seg_hi;
       const int bit = ((quad >> 1) * 2 + (b >> 1)) * 4 + (quad & 1) * 2 + (b & 1);      // the block's bit in the entry masks
+      // ---- compaction: the entries that can reach the block, from the back of the list to the front
       int nhit = 0;
 #pragma unroll
       for (int k = GH_SEGMENT / GH_WAVE - 1; k >= 0; --k) {
         if (k < k_lo || k > k_hi) continue;
-        const bool hit = ((mk[k] >> bit) & 1u) && (seg_lo + k * GH_WAVE + lane < bend);      // bend <= chunk start: no hits
+        const bool hit = ((mk[k] >> bit) & 1u) && (seg_lo + k * GH_WAVE + lane < bend);
         const uint64_t hm = gh_ballot(hit);
-        if (hit) ((volatile uint16_t*)s_q)[b * GH_SEGMENT + nhit + __popcll((hm >> lane) >> 1)] = (uint16_t)((k * GH_WAVE + lane) | (crow[k] << 8));
+        if (hit) ((volatile uint16_t*)s_q)[nhit + __popcll((hm >> lane) >> 1)] = (uint16_t)((k * GH_WAVE + lane) | (crow[k] << 8));
         nhit += __popcll(hm);
       }
-      if (b == 0) nh0 = nhit; else if (b == 1) nh1 = nhit; else if (b == 2) nh2 = nhit; else nh3 = nhit;
-    }
-    auto nh = [&](int b) { return b == 0 ? nh0 : (b == 1 ? nh1 : (b == 2 ? nh2 : nh3)); };
-    __builtin_amdgcn_wave_barrier();
-    // ---- batches: a flat walk over (block, offset) with ONE BATCH OF LOOKAHEAD — the next batch's records are gathered
-    // while the current one is computed (a wave has a handful of dependent memory round trips, not one per batch)
-    struct Batch { int b, j0, L, cnt, ci; bool valid; uint32_t am; GhBwdEntry e; };
-    auto first_block = [&](int b) { while (b < 4 && nh(b) == 0) ++b; return b; };
-    auto fetch = [&](Batch& t, int b, int j0) {
-      t.b = b; t.j0 = j0;
-      if (b >= 4) return;
-      const int rem = nh(b) - j0;
-      // batch shape: 64 lanes x 1 pixel, or for short remainders 32 x 2 / 16 x 4 (rem in (32, 48] goes as 32 + a 16-lane batch)
-#ifdef GH_ABL_L64
-      t.L = 64;
-#else
-      t.L = rem > 48 ? 64 : (rem > 16 ? 32 : 16);
-#endif
-      t.cnt = rem < t.L ? rem : t.L;
-      const int el = lane & (t.L - 1);
-      t.valid = el < t.cnt;
-      const uint32_t qe = t.valid ? (uint32_t)((volatile uint16_t*)s_q)[b * GH_SEGMENT + j0 + el] : 0u;
-      t.ci = (int)(qe >> 8);
-      t.e.pos = seg_lo + (int)(qe & 0xFFu);
-      t.e.a = r0[t.e.pos]; t.e.b = r1[t.e.pos]; t.e.cb = r2[t.e.pos].x;
-      const int minpos = __builtin_amdgcn_readlane(t.e.pos, t.cnt - 1);       // front-most entry of the batch
-      t.am = (uint32_t)(gh_ballot(last > minpos) >> (16 * b)) & 0xFFFFu;      // pixels of the block that blend into the batch
-    };
-    Batch cur, nxt;
-    fetch(cur, first_block(0), 0);
-    while (cur.b < 4) {
-      {
-        int nb_ = cur.b, nj = cur.j0 + cur.cnt;
-        if (nj >= nh(nb_)) { nb_ = first_block(nb_ + 1); nj = 0; }
-        fetch(nxt, nb_, nj);
-      }
-      float acc[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-      uint64_t anyc = 0;
-#ifdef GH_ABL_NOBODY
-      if (false) {
-#else
-      if (cur.am) {
-#endif
-        if (cur.L == 64) anyc = gh_bwd_batch<64>(cur.e, cur.valid, cur.am, 16 * cur.b, lane, s_pix, acc);
-        else if (cur.L == 32) anyc = gh_bwd_batch<32>(cur.e, cur.valid, cur.am, 16 * cur.b, lane, s_pix, acc);
-        else anyc = gh_bwd_batch<16>(cur.e, cur.valid, cur.am, 16 * cur.b, lane, s_pix, acc);
-      }
-      // The lane groups of a 32- / 16-lane batch hold partial sums of the SAME entries (different pixels): fold them into
-      // group 0 (fixed order). Then plain read-modify-write of the entry's accumulator row: the wave owns the rows and the
-      // entries of a batch are distinct (LDS float atomics cost 0.19 ms of a 0.36 ms kernel when this was ds_add_f32).
-      if (cur.L < 64) {
-#pragma unroll
-        for (int q = 0; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 32);
-        anyc |= (anyc >> 32) | (anyc << 32);
-        if (cur.L < 32) {
-#pragma unroll
-          for (int q = 0; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 16);
-          anyc |= ((anyc >> 16) & 0x0000FFFF0000FFFFull) | ((anyc << 16) & 0xFFFF0000FFFF0000ull);
-        }
-      }
-#ifdef GH_ABL_NOADD
-      if (false) {
-#else
-      if (lane < cur.L && ((anyc >> lane) & 1ull)) {                 // lane's entry was blended by some pixel of the block
-#endif
-        float* d = s_acc + cur.ci * GH_REC;
-#pragma unroll
-        for (int q = 0; q < GH_REC; ++q) d[q] += acc[q];
-        ((volatile uint8_t*)s_f)[cur.ci] = 1;
-      }
       __builtin_amdgcn_wave_barrier();
-      cur = nxt;
+#pragma unroll 1
+      for (int j0 = 0; j0 < nhit;) {
+        const int rem = nhit - j0;
+        // batch shape: 64 lanes x 1 pixel, or for short remainders 32 x 2 / 16 x 4 (rem in (32, 48] goes as 32 + a 16-lane batch)
+#ifdef GH_ABL_L64
+        const int L = 64;
+#else
+        const int L = rem > 48 ? 64 : (rem > 16 ? 32 : 16);
+#endif
+        const int cnt = rem < L ? rem : L;
+        const int el = lane & (L - 1);
+        const bool valid = el < cnt;
+        const uint32_t qe = valid ? (uint32_t)((volatile uint16_t*)s_q)[j0 + el] : 0u;
+        const int ci = (int)(qe >> 8);
+        GhBwdEntry e;
+        e.pos = seg_lo + (int)(qe & 0xFFu);
+        e.a = r0[e.pos]; e.b = r1[e.pos]; e.cb = r2[e.pos].x;
+        const int minpos = __builtin_amdgcn_readlane(e.pos, cnt - 1);     // front-most entry of the batch
+        const uint32_t am = (uint32_t)(gh_ballot(last > minpos) >> (16 * b)) & 0xFFFFu;     // pixels of the block that blend into the batch
+        float acc[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        bool any = false;
+#ifdef GH_ABL_NOBODY
+        if (false) {
+#else
+        if (am) {
+#endif
+          if (L == 64) any = gh_bwd_batch<64>(e, valid, am, 16 * b, lane, s_pix, acc);
+          else if (L == 32) any = gh_bwd_batch<32>(e, valid, am, 16 * b, lane, s_pix, acc);
+          else any = gh_bwd_batch<16>(e, valid, am, 16 * b, lane, s_pix, acc);
+        }
+        // The lane groups of a 32- / 16-lane batch hold partial sums of the SAME entries (different pixels): fold them into
+        // group 0 (fixed order). Then plain read-modify-write of the entry's accumulator row: the wave owns the rows and the
+        // entries of a batch are distinct (LDS float atomics cost 0.19 ms of a 0.36 ms kernel when this was ds_add_f32).
+        int anyi = any ? 1 : 0;
+        if (L < 64) {
+#pragma unroll
+          for (int q = 0; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 32);
+          anyi |= __shfl_xor(anyi, 32);
+          if (L < 32) {
+#pragma unroll
+            for (int q = 0; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 16);
+            anyi |= __shfl_xor(anyi, 16);
+          }
+        }
+        if (lane < L && anyi) {                                       // lane's entry was blended by some pixel of the block
+          float* d = s_acc + ci * GH_REC;
+#pragma unroll
+          for (int q = 0; q < GH_REC; ++q) d[q] += acc[q];
+          ((volatile uint8_t*)s_f)[ci] = 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        j0 += cnt;
+      }
     }
     // ---- the quadrant's sub-record of every entry some pixel blended, at the instance's emit slot
     __builtin_amdgcn_wave_barrier();
