@@ -7,22 +7,29 @@
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
-    GhInputs in, int P, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
+    GhInputs in, int P, int NV, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
     const float4* __restrict__ sh_rgb, float4* __restrict__ geom, float* __restrict__ depth,
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk) {
-  const int n = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
-  if (n == 0) {                                        // counters: reserved[0] = element count of the level-1 (depth) sort
+  if (t == 0) {                                        // counters: reserved[0] = element count of the level-1 (depth) sort
     ctr->num_rendered = 0; ctr->overflow = 0; ctr->reserved[0] = (uint32_t)N; ctr->reserved[1] = 0;
   }
-  if (n < T) { ranges[n] = make_uint2(0u, 0u); tile_walk[n] = 0u; tile_walk[T + n] = 0u; }   // per-tile state of the later stages
-  if (n < N) {
+  if (t < T) { ranges[t] = make_uint2(0u, 0u); tile_walk[t] = 0u; tile_walk[T + t] = 0u; }   // per-tile state of the later stages
+  if (t < N) {
     uint32_t dkey = 0xFFFFFFFFu;                        // culled Gaussians sort behind everything and emit nothing
     unsigned rect_bits = 0;
-    const int v = n / P;
-    const int i = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? n : n - v * P;     // row of the attribute arrays (pose batch: own rows per view)
+    // Thread -> (Gaussian row i, view v). Shared Gaussians: GAUSSIAN-major, the NV views of a row in adjacent lanes, so the
+    // row's attributes (and its 192-byte blend rows) reach the wave once per Gaussian instead of once per (view, Gaussian)
+    // — the views' loads of one row coalesce into one request. Every per-(view, Gaussian) output is a whole 64-byte line or
+    // a 4-byte element of a view-major array (n = v * P + i): consecutive rows of a view stay adjacent in memory.
+    // Pose batch (own rows per view): n = t, row = n.
+    int v, i;
+    if (flags & GH_FLAG_PER_VIEW_GAUSSIANS) { v = t / P; i = t; }
+    else { i = t / NV; v = t - i * NV; }
+    const int n = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : v * P + i;
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     int radius = 0;
     GhGeo e;
@@ -108,7 +115,7 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
     return;
   }
   int nblk = ((g.N > T ? g.N : T) + GH_BLOCK - 1) / GH_BLOCK;
-  hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.N, g.H, g.W, g.gx, g.gy,
+  hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.NV, g.N, g.H, g.W, g.gx, g.gy,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (const float4*)(ws + L.sh_rgb), (float4*)(ws + L.geom),
                      (float*)(ws + L.depth),
                      (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
