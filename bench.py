@@ -52,29 +52,35 @@ def algorithmic_bytes(P, NV, H, W, D, C=12, M=0):
     }
 
 
-def pmc_traffic(kernel: str, args, V: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
-    (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md). Only valid for the workload
-    the counters were collected on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if args.config != "two_hands" or V != 8 or args.pose_batch or not os.path.exists(path):
-        return None
-    try:
-        return json.load(open(path))["kernels"][kernel]["traffic_bytes"]
-    except (KeyError, ValueError):
-        return None
+def source_hash() -> str:
+    """sha256 over the HIP sources + the C-ABI header: ties committed profile data to the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "guassianhand_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(src, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "gh_raster.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def pmc_valu(kernel: str, args, V: int):
-    """VALU busy fraction of `kernel` from the committed SQ counter passes (profiles/pmc_sq.json): the render kernels
-    are bound by vector-ALU issue, not by HBM, so this is the utilisation that explains a low hbm `frac`."""
-    path = os.path.join(ROOT, "profiles", "pmc_sq.json")
-    if args.config != "two_hands" or V != 8 or args.pose_batch or not os.path.exists(path):
-        return None
+def pmc_profile(name: str, kernel: str, args, V: int):
+    """Per-kernel entry of a committed rocprofv3 counter summary (profiles/<name>.json), or (None, why). The counters come from
+    separate profiling runs (`tools/refresh_profiles.sh`), NOT from this run: the entry is returned with its source tag and
+    only when it was collected on this workload AND on this build (source_hash)."""
+    path = os.path.join(ROOT, "profiles", name + ".json")
+    if args.config != "two_hands" or V != 8 or args.pose_batch or args.scaling != "weak":
+        return None, "offline counters exist for the default workload only"
+    if not os.path.exists(path):
+        return None, f"profiles/{name}.json missing"
     try:
-        return json.load(open(path))["kernels"][kernel]["valu_busy_frac"]
+        doc = json.load(open(path))
+        ent = doc["kernels"][kernel]
     except (KeyError, ValueError):
-        return None
+        return None, f"no entry for {kernel} in profiles/{name}.json"
+    if doc.get("source_hash") != source_hash():
+        return None, f"profiles/{name}.json is stale (collected on source {doc.get('source_hash')}, this build is {source_hash()})"
+    return ent, f"profiles/{name}.json (offline rocprofv3 --pmc passes, source {doc['source_hash']})"
 
 
 def cpu_baseline(scene, seconds: float):
@@ -121,6 +127,12 @@ def main():
                     help="enqueue the timed steps kernel by kernel instead of replaying one step (forward + loss + backward) "
                          "captured in a HIP graph; the eager loop is bound by the host for small batches or on a slow host")
     ap.add_argument("--graph", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank renders --views-per-step cameras; strong: the --views-per-step cameras of ONE "
+                         "step are split over the ranks (BASELINE configs[3]: 8 novel views sharded over 8 GPUs = 1 view per GPU)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed windows of --steps steps each; `value` / `ms_per_step` are the FIRST window's (the contract's exactly-K "
+                         "steps), the others are reported as repeat statistics")
     args = ap.parse_args()
 
     from guassianhand_amd import dist as ghdist
@@ -138,13 +150,20 @@ def main():
     torch.cuda.set_device(dev)
 
     V = args.views_per_step
-    scene_cpu = make_scene(args.config, n_views=V * world)
+    if args.scaling == "strong":
+        assert V % world == 0, "--scaling strong: --views-per-step must be a multiple of the rank count"
+        V_total, V = V, V // world                   # strong scaling: the step's cameras are dealt round-robin to the ranks
+        scene_cpu = make_scene(args.config, n_views=V_total)
+        mine = ghdist.shard_views(V_total, rank, world)
+    else:
+        V_total = V * world
+        scene_cpu = make_scene(args.config, n_views=V_total)
+        mine = [rank * V + i for i in range(V)]      # weak scaling: V views per rank
     scene_one = scene_cpu                            # one pose: what the CPU baseline renders
-    mine = [rank * V + i for i in range(V)]          # weak scaling: V views per rank
     if args.pose_batch:                              # V poses per rank: concatenate V different scenes, camera v of pose v
         import dataclasses
         from guassianhand_amd.scenes import SEED
-        poses = [make_scene(args.config, n_views=V * world, seed=SEED + 1000 * (rank * V + b)) for b in range(V)]
+        poses = [make_scene(args.config, n_views=V_total, seed=SEED + 1000 * (rank * V + b)) for b in range(V)]
         cat = lambda k: None if getattr(poses[0], k) is None else torch.cat([getattr(p_, k) for p_ in poses])
         scene_cpu = dataclasses.replace(poses[0], **{k: cat(k) for k in ("xyz", "opacity", "rotation", "scaling", "shs", "color_b", "opacity_b")})
     s = scene_cpu.to(dev)
@@ -179,11 +198,13 @@ def main():
         return loss
 
     def reduce_grads(loss):
-        """Data-parallel fit (--allreduce-grads): sum the gradient block at the rasteriser boundary, one collective."""
-        grads = {k: params[k].grad for k in names}
-        if s.use_rgb and "color_b" in grads:         # RGB mode reads color_b[:, 0:3] only (renderer_one_shot.py:328): the
-            grads["color_b"] = grads["color_b"][:, :3]       # other 45 gradient columns are exactly zero on every rank
-        return ghdist.allreduce_grads(grads, loss.detach(), names)[0]
+        """Data-parallel fit (--allreduce-grads): sum the gradient block at the rasteriser boundary, ONE collective over the
+        contiguous block the backward kernels wrote (rasterizer.last_grad_block): no packing pass, float 0 carries the loss."""
+        block, n_red, _spans, _ = R.last_grad_block()
+        work, buf = ghdist.allreduce_block(block, n_red, loss.detach())
+        if work is not None:
+            work.wait()
+        return buf[0]
 
     def step(sync: bool):
         """Eager step: kernel-by-kernel enqueue. N>1, north star protocol (views are independent, RCCL only for the loss):
@@ -235,7 +256,8 @@ def main():
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 g_loss = local_step(sync=False)
                 g_loss.backward(seed)
-            graph.replay()
+            for _ in range(max(1, args.warmup)):         # warm-up of the replay path itself (clocks, graph upload): untimed
+                graph.replay()
             torch.cuda.synchronize()
         except Exception as e:                           # capture is an optimisation of the enqueue path, never a requirement
             graph, g_loss, graph_note = None, None, f"graph capture failed ({type(e).__name__}: {e}); eager steps"
@@ -254,19 +276,23 @@ def main():
         loss_sum = g_loss.detach().clone()
         return loss_sum, tdist.all_reduce(loss_sum, op=tdist.ReduceOp.SUM, async_op=True)
 
-    barrier()
-    t0 = time.perf_counter()
-    pending = None
-    for _ in range(args.steps):
-        if graph is not None:
-            loss, pending = replay_step(pending)
-        else:
-            loss = step(sync=False)
-    if pending is not None:
-        pending.wait()
-    t_enq = time.perf_counter() - t0                 # host time to enqueue the timed steps (GPU-bound if << dt)
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_window():
+        barrier()
+        t0 = time.perf_counter()
+        pending, loss = None, None
+        for _ in range(args.steps):
+            if graph is not None:
+                loss, pending = replay_step(pending)
+            else:
+                loss = step(sync=False)
+        if pending is not None:
+            pending.wait()
+        t_enq = time.perf_counter() - t0             # host time to enqueue the timed steps (GPU-bound if << dt)
+        barrier()
+        return time.perf_counter() - t0, t_enq, loss
+
+    dt, t_enq, loss = timed_window()                 # THE timed region: exactly --steps steps between two barriers
+    extra = [timed_window()[0] for _ in range(max(0, args.repeats - 1))]      # repeat statistics (not `value`)
     R.check_overflow()
     if graph is not None:
         R.set_graph_mode(False)
@@ -284,11 +310,13 @@ def main():
         R.check_overflow()
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt] + extra, dtype=torch.float64, device=dev)
         tdist.all_reduce(tmax, op=tdist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, extra = float(tmax[0].item()), [float(x) for x in tmax[1:].tolist()]
     renders = args.steps * V * world
     value = renders / dt
+    # checksum of the step's result (after the last timed step): the N-rank control tests compare it with a 1-rank run
+    grad_l1 = float(sum(params[k].grad.detach().abs().sum() for k in names if params[k].grad is not None))
 
     if rank == 0:
         # instance count of the published algorithm (every tile of the 3-sigma rects) beside the exactly culled one
@@ -308,15 +336,21 @@ def main():
             single = {k: v for k, v in stage_ms.items() if k != "binning"}   # binning is a multi-kernel stage
             dom = max(single, key=single.get)
             ach = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "gh_" + dom + "_kernel", "achieved": ach, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic("gh_" + dom + "_kernel", args, V),
+            kname = "gh_" + dom + "_kernel"
+            tr, tr_src = pmc_profile("r2_pmc_traffic", kname, args, V)
+            sq, sq_src = pmc_profile("r2_pmc_sq", kname, args, V)
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr["traffic_bytes"] if tr else None,
+                        "traffic_source": tr_src,
                         "alg_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom],
                         "timing": f"HIP events around the stage entry points, {args.steps} eager steps run right after the timed steps",
-                        "valu_busy_frac": pmc_valu("gh_" + dom + "_kernel", args, V)}
+                        # what actually bounds the kernel (it is not bandwidth): vector-ALU issue and the LDS pipe, from the
+                        # committed SQ counter passes — arithmetic in profiles/r2_pmc_sq.json
+                        "secondary": sq["secondary"] if sq else None, "secondary_source": sq_src}
         out = {
             "metric": "fwd+bwd renders/sec @512x334, ~100k Gaussians", "value": value, "unit": "renders/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: P={P} Gaussians, {H}x{W}, "
                                    f"{'RGB colours' if s.use_rgb else 'SH degree %d colours' % s.sh_degree}, attribute blend "
                                    f"{'on' if s.color_w is not None else 'off'}"
@@ -326,7 +360,13 @@ def main():
                        "instances_in_3sigma_rects": D_rect, "parallelism": f"view-parallel x{world}",
                        "collective": None if world == 1 else ("all-reduce(loss + gradient block)" if args.allreduce_grads
                                                               else "all-reduce(loss)"),
-                       "loss": "mean|img-gt|", "final_loss": float(loss.detach()),
+                       "loss": "mean|img-gt|", "final_loss": float(loss.detach()), "grad_l1": grad_l1,
+                       "views_per_step_total": V * world,
+                       "repeats": {"windows": 1 + len(extra), "steps_per_window": args.steps,
+                                   "ms_per_step_min": min([dt] + extra) / args.steps * 1e3,
+                                   "ms_per_step_median": sorted([dt] + extra)[len([dt] + extra) // 2] / args.steps * 1e3,
+                                   "ms_per_step_max": max([dt] + extra) / args.steps * 1e3,
+                                   "note": "`value` / `ms_per_step` are window 1 (the contract's timed region); the others follow it"},
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
                        "hip_graph": graph is not None, "timed_steps": "HIP graph replay of one captured step" if graph is not None
                        else "eager kernel-by-kernel enqueue" + (f" [{graph_note}]" if graph_note else "")},

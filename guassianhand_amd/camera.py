@@ -54,13 +54,27 @@ class Camera:
         return Camera(w2c, intrinsic, FoVx, FoVy, height, width, znear, zfar)
 
 
+_pack_cache = None      # (viewmatrix, projmatrix, campos, their versions, tanfovx, tanfovy) -> 37-float prefix; strong refs, `is` compare
+
+
 def pack_camera(viewmatrix, projmatrix, campos, tanfovx, tanfovy, bg) -> torch.Tensor:
-    """One GH_CAM_FLOATS record from the 12-field settings of the reference call (:281-294)."""
+    """One GH_CAM_FLOATS record from the 12-field settings of the reference call (:281-294), built on the device without a
+    host->device copy (a pageable copy would synchronise). The reference's RGB and mask call of a view hand over the same
+    camera tensors with a different bg (:281-296, :355-370): the 37-float prefix of the previous call is reused when the
+    very same tensor objects arrive unmodified."""
+    global _pack_cache
     dev = viewmatrix.device
-    tf = torch.as_tensor([float(tanfovx), float(tanfovy)], dtype=torch.float32).to(dev, non_blocking=True)
-    rec = torch.cat([viewmatrix.reshape(16).float(), projmatrix.reshape(16).float(), campos.reshape(3).float(),
-                     tf, bg.reshape(3).float().to(dev)])
-    return rec.reshape(1, GH_CAM_FLOATS)
+    tx, ty = float(tanfovx), float(tanfovy)
+    c = _pack_cache
+    if c is not None and c[0] is viewmatrix and c[1] is projmatrix and c[2] is campos and c[3] == (viewmatrix._version, projmatrix._version, campos._version, tx, ty):
+        prefix = c[4]
+    else:
+        tf = torch.empty(2, dtype=torch.float32, device=dev)
+        tf[0].fill_(tx)
+        tf[1].fill_(ty)
+        prefix = torch.cat([viewmatrix.reshape(16).float(), projmatrix.reshape(16).float(), campos.reshape(3).float(), tf])
+        _pack_cache = (viewmatrix, projmatrix, campos, (viewmatrix._version, projmatrix._version, campos._version, tx, ty), prefix)
+    return torch.cat([prefix, bg.reshape(3).float().to(dev)]).reshape(1, GH_CAM_FLOATS)
 
 
 def pack_cameras_from_w2c(w2cs: torch.Tensor, Ks: torch.Tensor, H: int, W: int, bg: torch.Tensor) -> torch.Tensor:

@@ -118,7 +118,7 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   if (stages & GH_FWD_BINNING) {
     gh_launch_binning(d, g, ws, L, s);
   }
-  if (stages & GH_FWD_RENDER) gh_launch_render_fwd(d, g, in, out->image, out->alpha, ws, L, s);
+  if (stages & GH_FWD_RENDER) gh_launch_render_fwd(d, g, in, out->image, out->alpha, ws, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 
@@ -143,7 +143,50 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
   char* ws = (char*)workspace;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
-  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, L, s);
-  if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, L, s);
+  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, ws, L, s);
+  if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+// ---- second call over the same geometry --------------------------------------------------------------------------
+static int check_shared(const GhDims* d, const GhInputs* in) {
+  int rc = check_dims(d);
+  if (rc != GH_OK) return rc;
+  rc = check_inputs(d, in);
+  if (rc != GH_OK) return rc;
+  if (d->P > 0 && !in->colors_precomp) return GH_ERR_UNSUPPORTED;       // colours must be precomputed (no SH stage here)
+  return GH_OK;
+}
+
+extern "C" int gh_forward_shared(const GhDims* d, const GhInputs* in, const GhOutputs* out, const void* geometry_ws,
+                                 void* workspace, size_t ws_bytes, void* hip_stream) {
+  int rc = check_shared(d, in);
+  if (rc != GH_OK) return rc;
+  if (!out || !out->image || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
+  GhLayout L;
+  gh_workspace_layout(d, &L);
+  if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
+  hipStream_t s = (hipStream_t)hip_stream;
+  GhGrid g = gh_make_grid(d);
+  (void)hipGetLastError();
+  gh_launch_recolour(d, g, in, (const char*)geometry_ws, (char*)workspace, L, s);
+  gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_backward_shared(const GhDims* d, const GhInputs* in, const GhGrads* gr, const void* geometry_ws,
+                                  void* workspace, size_t ws_bytes, void* hip_stream) {
+  int rc = check_shared(d, in);
+  if (rc != GH_OK) return rc;
+  if (!gr || !gr->dL_dimage || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
+  if ((((uintptr_t)gr->dL_dblend_color_b | (uintptr_t)gr->dL_dblend_color_w) & 15) != 0) return GH_ERR_INVALID_ARG;
+  GhLayout L;
+  gh_workspace_layout(d, &L);
+  if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
+  hipStream_t s = (hipStream_t)hip_stream;
+  GhGrid g = gh_make_grid(d);
+  (void)hipGetLastError();
+  gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, (const char*)geometry_ws, (char*)workspace, L, s);
+  gh_launch_preprocess_bwd(d, g, in, gr, (const char*)geometry_ws, (char*)workspace, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -36,10 +36,14 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
 void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii,
                               char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
+// wg: workspace that owns the geometry / binning arrays (ranges, tile order, inst_r0, sorted_slot, slot_begin, tiles_touched,
+// vals); ws: workspace of this call's own state (colour records, image state, backward scratch). wg == ws for a plain call;
+// they differ for a second call over the same geometry (gh_forward_shared).
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha,
-                          char* ws, const GhLayout& L, hipStream_t s);
+                          const char* wg, char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
-                          const float* dL_dalpha, const float* upstream_scale, char* ws, const GhLayout& L, hipStream_t s);
+                          const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
+void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
 // LSD radix sort of (keys, vals) on bits [0, nbits): ceil(nbits/8) stable passes, element count read from device memory
 // (*n_ptr <= cap); pointers are swapped so that on return k_in / v_in hold the result. table: gh_radix_table_words(cap).
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
@@ -54,7 +58,7 @@ void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* i
 int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
                             const GhLayout& L, hipStream_t s);
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr,
-                              char* ws, const GhLayout& L, hipStream_t s);
+                              const char* wg, char* ws, const GhLayout& L, hipStream_t s);
 
 #if defined(__HIPCC__)
 // ---- arithmetic contract: fp32, no implicit contraction, FMAs only where written ----
@@ -192,6 +196,20 @@ __device__ __forceinline__ float gh_blended_sh(const GhInputs& in, uint32_t flag
     }
   }
   return s;
+}
+
+// Blended precomputed colour of row i (renderer_one_shot.py:321-328): c*w[0:3] + w[3:6] - 1 (+ b[0:3]).
+__device__ __forceinline__ void gh_blended_rgb(const GhInputs& in, uint32_t flags, int i, float* rgb) {
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float col = in.colors_precomp[3 * i + ch];
+    if (in.blend_color_w) {
+      const float* w = in.blend_color_w + ((flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? (size_t)i * 48 : 0);
+      col = col * w[ch]; col = col + w[3 + ch]; col = col - 1.0f;
+    }
+    if (in.blend_color_b) col = col + in.blend_color_b[(size_t)i * ((flags & GH_FLAG_BLEND_COLOR_B_RGB) ? 3 : 48) + ch];
+    rgb[ch] = col;
+  }
 }
 
 // Culling test: can Gaussian (g0 = px,py,A,B; g1 = C,opacity,..) reach alpha >= 1/255 at any pixel centre of the

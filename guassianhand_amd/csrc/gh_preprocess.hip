@@ -72,16 +72,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         float rgb[3];
         unsigned cl = 0;
         if (in.colors_precomp) {
-#pragma unroll
-          for (int ch = 0; ch < 3; ++ch) {
-            float col = in.colors_precomp[3 * i + ch];
-            if (in.blend_color_w) {
-              const float* w = in.blend_color_w + ((flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? (size_t)i * 48 : 0);
-              col = col * w[ch]; col = col + w[3 + ch]; col = col - 1.0f;
-            }
-            if (in.blend_color_b) col = col + in.blend_color_b[(size_t)i * ((flags & GH_FLAG_BLEND_COLOR_B_RGB) ? 3 : 48) + ch];
-            rgb[ch] = col;
-          }
+          gh_blended_rgb(in, flags, i, rgb);
         } else {                                       // SH colours: evaluated by gh_sh_colour_fwd_kernel (gh_sh.hip)
           const float4 c4 = sh_rgb[n];
           rgb[0] = c4.x; rgb[1] = c4.y; rgb[2] = c4.z; cl = __float_as_uint(c4.w);
@@ -420,7 +411,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_blend_reduce_kernel(const float* 
   }
 }
 
-void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
+void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, const char* wg, char* ws,
                               const GhLayout& L, hipStream_t s) {
   if (g.P == 0) return;
   const bool per_view = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
@@ -431,12 +422,12 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   auto kern = in->colors_precomp ? gh_preprocess_bwd_kernel<true> : gh_preprocess_bwd_kernel<false>;
   const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
-                     (const uint32_t*)(ws + L.slot_begin), (const uint32_t*)(ws + L.tiles_touched),
+                     (const uint32_t*)(wg + L.slot_begin), (const uint32_t*)(wg + L.tiles_touched),
                      (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
   const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, ws, L, s);     // SH mode only; no-op with colors_precomp
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, lg,
-                     (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.dmean_sh),
+                     (const uint32_t*)(wg + L.tiles_touched), (const float4*)(ws + L.dmean_sh),
                      (const float4*)(ws + L.grad_sums), (float*)(ws + L.bwd_scratch));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;

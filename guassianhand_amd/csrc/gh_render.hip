@@ -298,19 +298,22 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     n_contrib[pix] = p.last;
     final_C[pix] = make_float4(p.C0, p.C1, p.C2, 0.0f);
     float* img = image + (size_t)v * 3 * H * W + (size_t)y * W + x;
-    img[0] = fmaf(p.T, bg[0], p.C0);
-    img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1);
-    img[(size_t)2 * H * W] = fmaf(p.T, bg[2], p.C2);
-    if (ALPHA) alpha_img[pix] = fmaf(p.T, 0.0f, p.A);
+    // Device-side overflow guard: with D > max_instances the lists are truncated, so a sync-free caller must never see a
+    // plausible image — it gets NaN (and GhCounters.overflow for the host to read whenever it chooses).
+    const float poison = ctr->overflow ? __uint_as_float(0x7FC00000u) : 0.0f;
+    img[0] = fmaf(p.T, bg[0], p.C0) + poison;
+    img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1) + poison;
+    img[(size_t)2 * H * W] = fmaf(p.T, bg[2], p.C2) + poison;
+    if (ALPHA) alpha_img[pix] = fmaf(p.T, 0.0f, p.A) + poison;
   }
 }
 
-void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha, char* ws,
+void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha, const char* wg, char* ws,
                           const GhLayout& L, hipStream_t s) {
   const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
-  const uint2* ranges = (const uint2*)(ws + L.ranges);
-  const uint32_t* order = (const uint32_t*)(ws + L.tile_order);
-  const float4* r0 = (const float4*)(ws + L.inst_r0); const float4* r1 = (const float4*)(ws + L.inst_r1);
+  const uint2* ranges = (const uint2*)(wg + L.ranges);
+  const uint32_t* order = (const uint32_t*)(wg + L.tile_order);
+  const float4* r0 = (const float4*)(wg + L.inst_r0); const float4* r1 = (const float4*)(ws + L.inst_r1);
   const float2* r2 = (const float2*)(ws + L.inst_r2);
   float* fT = (float*)(ws + L.final_T); uint32_t* nc = (uint32_t*)(ws + L.n_contrib); uint32_t* tw = (uint32_t*)(ws + L.tile_walk);
   float4* ck = (float4*)(ws + L.ckpt_rgb); float4* fC = (float4*)(ws + L.final_C);
@@ -668,19 +671,57 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
 }
 
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
-                          const float* dL_dalpha, const float* upstream_scale, char* ws, const GhLayout& L, hipStream_t s) {
+                          const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s) {
   if (g.cap == 0) return;
   // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (they depend on the forward's
   // n_contrib only). The work list (tile, depth segment) was written by the forward's last wave of every tile.
   const dim3 grid(4 * (unsigned)g.n_items), block(GH_WAVE);      // capacity of the work list x 4 quadrants; surplus waves exit at once
   auto launch = [&](auto kern) {
-    hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(ws + L.ranges), (const uint2*)(ws + L.bwd_items),
+    hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(wg + L.ranges), (const uint2*)(ws + L.bwd_items),
                        (const GhCounters*)(ws + L.counters),
-                       (const uint32_t*)(ws + L.sorted_slot), (const float4*)(ws + L.inst_r0), (const float4*)(ws + L.inst_r1),
+                       (const uint32_t*)(wg + L.sorted_slot), (const float4*)(wg + L.inst_r0), (const float4*)(ws + L.inst_r1),
                        (const float2*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
                        (const uint32_t*)(ws + L.n_contrib), (const float4*)(ws + L.ckpt_rgb),
                        (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, upstream_scale, (float*)(ws + L.inst_grad),
                        (uint8_t*)(ws + L.inst_flag));
   };
   if (dL_dalpha) launch(gh_render_bwd_kernel<true>); else launch(gh_render_bwd_kernel<false>);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Second call over the same geometry (gh_forward_shared): the per-instance colour part of the render records
+// (inst_r1.zw, inst_r2.x) is rebuilt from this call's colours; conic / opacity / block mask are copied from the geometry
+// owner. Also resets this call's own per-tile walk state, backward flags and counters (D and the overflow flag are the
+// geometry owner's).
+__global__ __launch_bounds__(GH_BLOCK) void gh_recolour_kernel(GhInputs in, uint32_t flags, int P, int T, uint32_t cap,
+                                                                const GhCounters* __restrict__ gctr, const uint32_t* __restrict__ vals,
+                                                                const float4* __restrict__ g_r1, const float2* __restrict__ g_r2,
+                                                                float4* __restrict__ r1, float2* __restrict__ r2,
+                                                                uint32_t* __restrict__ inst_flag, uint32_t* __restrict__ tile_walk,
+                                                                GhCounters* __restrict__ ctr) {
+  const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const uint32_t D = gctr->num_rendered;
+  if (i == 0) { ctr->num_rendered = D; ctr->overflow = gctr->overflow; ctr->reserved[0] = gctr->reserved[0]; ctr->reserved[1] = 0; }
+  if (i < (uint32_t)T) { tile_walk[i] = 0u; tile_walk[T + i] = 0u; }
+  const uint32_t n = D < cap ? D : cap;
+  if (i >= n) return;
+  inst_flag[i] = 0;
+  const uint32_t gid = vals[i];
+  const int row = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? (int)gid : (int)(gid % (uint32_t)P);
+  float rgb[3];
+  gh_blended_rgb(in, flags, row, rgb);
+  const float4 a = g_r1[i];
+  const float2 b = g_r2[i];
+  r1[i] = make_float4(a.x, a.y, rgb[0], rgb[1]);
+  r2[i] = make_float2(rgb[2], b.y);
+}
+
+void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s) {
+  const int T = g.NV * g.tiles;
+  const size_t n = (size_t)g.cap > (size_t)T ? (size_t)g.cap : (size_t)T;
+  const int nblk = (int)((n + GH_BLOCK - 1) / GH_BLOCK);
+  hipLaunchKernelGGL(gh_recolour_kernel, dim3(nblk > 0 ? nblk : 1), dim3(GH_BLOCK), 0, s, *in, d->flags, g.P, T, (uint32_t)g.cap,
+                     (const GhCounters*)(wg + L.counters), (const uint32_t*)(wg + L.vals_a), (const float4*)(wg + L.inst_r1),
+                     (const float2*)(wg + L.inst_r2), (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2),
+                     (uint32_t*)(ws + L.inst_flag), (uint32_t*)(ws + L.tile_walk), (GhCounters*)(ws + L.counters));
 }

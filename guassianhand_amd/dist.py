@@ -67,3 +67,22 @@ def allreduce_grads(grads: Dict[str, torch.Tensor], loss: torch.Tensor, order: S
     buf, meta = pack_grads(grads, loss, order)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return unpack_grads(buf, meta)
+
+
+def allreduce_block(block: torch.Tensor, n_reducible: int, loss: torch.Tensor, stream: "torch.cuda.Stream" = None):
+    """All-reduce(sum) the gradient block of rasterizer.last_grad_block() IN PLACE: float 0 of the block carries the loss, the
+    rest is what the backward kernels wrote (one contiguous buffer, no packing pass). Returns (work, view of the reduced
+    prefix); with `stream` the collective is enqueued on that side stream right behind the backward (it overlaps whatever
+    the caller enqueues next on the main stream) and the caller waits with `torch.cuda.current_stream().wait_stream(stream)`
+    or work.wait() before reading the block."""
+    buf = block[:n_reducible]
+    buf[0:1].copy_(loss.reshape(1))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None, buf
+    if stream is not None and buf.is_cuda:
+        stream.wait_stream(torch.cuda.current_stream(buf.device))
+        with torch.cuda.stream(stream):
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        buf.record_stream(stream)
+        return work, buf
+    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf

@@ -77,6 +77,7 @@ class OneShotFit(nn.Module):
         self._default_render = render_fn is None
         self._cams, self._cams_src = None, None
         self.keep_boundary_grads, self.boundary_grads, self.last_reg = False, None, None
+        self._side = None
         if render_fn is None:
             from .renderer import render_views
             render_fn = render_views
@@ -215,8 +216,23 @@ class OneShotFit(nn.Module):
                                     None if bbox_mask is None else sel(bbox_mask)) / n_total
             g = torch.autograd.grad(loss_img, [leaves[k] for k in names], allow_unused=True)
             grads = {k: (gi if gi is not None else torch.zeros_like(leaves[k])) for k, gi in zip(names, g)}
+        blk = None
+        if world > 1 and self._default_render and self.color_w.is_cuda and self.active and mine:
+            from . import rasterizer as R
+            blk = R.last_grad_block()
         if world == 1:
             loss_tot, red = loss_img.detach(), grads
+        elif blk is not None and all(grads[k].data_ptr() == blk[0].data_ptr() + 4 * a for k, _, a, _ in blk[2] if k in grads):
+            # The backward kernels wrote the blend gradients into ONE contiguous block; its leading floats are reserved for
+            # the loss: all-reduce that prefix in place on a side stream, right behind the backward (no packing pass).
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.color_w.device)
+            work, buf = ghdist.allreduce_block(blk[0], blk[3], loss_img.detach(), stream=self._side)
+            if work is not None:
+                work.wait()
+            torch.cuda.current_stream().wait_stream(self._side)
+            loss_tot = buf[0]
+            red = {k: blk[0][a:a + n].view(shp) for k, shp, a, n in blk[2] if k in grads}
         elif self.use_rgb and "color_b" in grads and grads["color_b"].shape[1] == 48:   # RGB mode touches color_b[:, 0:3] only (:328)
             small = dict(grads)
             small["color_b"] = grads["color_b"][:, :3].contiguous()

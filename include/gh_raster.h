@@ -218,6 +218,21 @@ int gh_backward_stages(const GhDims* dims, const GhInputs* in, const GhGrads* gr
                        void* workspace, size_t ws_bytes, void* hip_stream, uint32_t stages);
 
 /*
+ * A second rasteriser call over the SAME geometry. The reference renders every view twice with identical means3D /
+ * opacities / scales / rotations / camera: the RGB pass (renderer_one_shot.py:338-346) and the mask pass (:355-379,
+ * colors_precomp = 1, bg = 0). `geometry_ws` is the workspace of a completed gh_forward with the same dims (P, n_views,
+ * H, W, max_instances, flags) and the same geometry inputs; `workspace` (gh_workspace_bytes(dims), a different buffer)
+ * receives this call's own state only: colour records, image state, backward scratch. Projection, both sorts, emit and
+ * the record gather are skipped; results are bit-identical to a full gh_forward / gh_backward with the same inputs.
+ * Colours must be colors_precomp (GH_ERR_UNSUPPORTED with shs); out->radii may be NULL (the first call's are the same).
+ * The geometry workspace must stay intact until the matching gh_backward_shared has run.
+ */
+int gh_forward_shared(const GhDims* dims, const GhInputs* in, const GhOutputs* out, const void* geometry_ws,
+                      void* workspace, size_t ws_bytes, void* hip_stream);
+int gh_backward_shared(const GhDims* dims, const GhInputs* in, const GhGrads* grads, const void* geometry_ws,
+                       void* workspace, size_t ws_bytes, void* hip_stream);
+
+/*
  * Per-Gaussian bilinear lookup of a learnable UV map and its backward. Replaces
  * F.grid_sample(..., align_corners=True, mode="bilinear") of query_triplane_texture (renderer_one_shot.py:420-446)
  * at the call sites :489-492. `map` is CHANNEL-LAST (Hm, Wm, C) fp32 (the reference parameter (C,Hm,Wm) permuted

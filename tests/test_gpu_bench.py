@@ -48,16 +48,41 @@ def test_bench_one_gpu_line():
     assert "workload" in d["config"] and "model" not in d["config"]
 
 
-@pytest.mark.timeout(600)
-def test_bench_two_ranks_control_path():
+def _run_bench(n_ranks, *extra):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--dist-backend", "gloo", "--no-stage-timing"]
+    tail = ["--steps", "2", "--warmup", "1", "--repeats", "1", "--no-stage-timing", "--no-cpu-baseline", *extra]
+    if n_ranks == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *tail]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks),
+               "--dist-backend", "gloo", *tail]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=560)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["collective"] == "all-reduce(loss)" and d["cpu_baseline"] is None
-    assert d["config"]["parallelism"] == "view-parallel x2"
-    # the reduced loss is the sum of both ranks' losses (two different sets of 8 views): well above a single rank's
-    assert d["config"]["final_loss"] > 0.03
+    return _last_json(r.stdout)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_equal_the_single_process_run():
+    """the N > 1 control path (two ranks on the one card, gloo: the collectives are real, the numbers
+    are not) must produce THE SAME step as one process: 2 ranks x 4 views == 1 rank x 8 views (the same eight cameras), for
+    the loss-only protocol, for --allreduce-grads (the gradient block reduced in place), and for --scaling strong."""
+    one = _run_bench(1, "--views-per-step", "8")
+    L1, G1 = one["config"]["final_loss"], one["config"]["grad_l1"]
+    assert one["config"]["views_per_step_total"] == 8 and G1 > 0
+
+    weak = _run_bench(2, "--views-per-step", "4")
+    assert weak["n_gpus"] == 2 and weak["config"]["collective"] == "all-reduce(loss)" and weak["cpu_baseline"] is None
+    assert weak["config"]["parallelism"] == "view-parallel x2" and weak["scaling"] == "weak"
+    # rank losses are means over 4 views each; their sum is twice the 8-view mean
+    assert weak["config"]["final_loss"] == pytest.approx(2 * L1, rel=1e-5)
+
+    red = _run_bench(2, "--views-per-step", "4", "--allreduce-grads")
+    assert red["config"]["collective"] == "all-reduce(loss + gradient block)"
+    assert red["config"]["final_loss"] == pytest.approx(2 * L1, rel=1e-5)
+    assert red["config"]["grad_l1"] == pytest.approx(2 * G1, rel=1e-4)          # summed gradients of both ranks, all parameters
+
+    strong = _run_bench(2, "--views-per-step", "8", "--scaling", "strong", "--allreduce-grads")
+    assert strong["scaling"] == "strong" and strong["config"]["views_per_step_per_gpu"] == 4 and strong["config"]["views_per_step_total"] == 8
+    assert strong["config"]["final_loss"] == pytest.approx(2 * L1, rel=1e-5)
+    assert strong["config"]["grad_l1"] == pytest.approx(2 * G1, rel=1e-4)

@@ -270,3 +270,58 @@ def test_rendered_loss_is_the_two_node_form_bit_for_bit(dev):
         (3.0 * lb).backward()
         for k in names:
             assert torch.equal(pa[k].grad, pb[k].grad), (kind, k)
+
+
+@pytest.mark.parametrize("use_rgb", [True, False])
+def test_second_call_over_the_same_geometry_reuses_the_first_calls_lists_bit_for_bit(dev, use_rgb):
+    """the reference's mask pass (renderer_one_shot.py:372-379) follows the RGB pass (:338-346) with the
+    same means3D / opacity / scales / rotations / camera objects. The drop-in recognises that and only re-walks the first
+    call's tile lists with the new colours (gh_forward_shared / gh_backward_shared). Images, radii and every gradient must
+    equal the plain two-full-calls protocol bit for bit; a call with different geometry must NOT be matched."""
+    from guassianhand_amd import rasterizer as Rz
+    from guassianhand_amd import renderer as R
+    from guassianhand_amd.camera import Camera
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=2, P=3000, use_rgb=use_rgb, blend=True)
+    s = sc.to(dev)
+    names = ("xyz", "opacity", "rotation", "scaling", "shs", "color_w", "color_b", "opacity_b", "xyz_b")
+    gt = torch.rand(2, sc.H, sc.W, 3, generator=torch.Generator().manual_seed(7)).to(dev)
+    cams = [Camera.from_w2c(s.w2c[v], s.K[v], sc.H, sc.W) for v in range(2)]
+
+    def run(reuse):
+        Rz.set_geometry_reuse(reuse)
+        a = {n: getattr(s, n).clone().requires_grad_(True) for n in names}
+        gs = R.GaussianModel(a["xyz"], a["opacity"], a["rotation"], a["scaling"], a["shs"])
+        outs = [R.forward_single_view(gs, cams[v], s.bg, color_w=a["color_w"], xyz_b=a["xyz_b"], color_b=a["color_b"],
+                                      opacity_b=a["opacity_b"], use_rgb=use_rgb, sh_degree=3) for v in range(2)]
+        rgb = torch.stack([o["comp_rgb"] for o in outs]); mask = torch.stack([o["comp_mask"] for o in outs])
+        ((rgb - gt).abs().mean() + ((mask.mean(-1) - gt[..., 0]) ** 2).mean()).backward()
+        return rgb.detach(), mask.detach(), {n: a[n].grad for n in names}
+
+    try:
+        rgb0, mask0, g0 = run(False)
+        rgb1, mask1, g1 = run(True)
+        assert Rz._geom_last is not None
+    finally:
+        Rz.set_geometry_reuse(True)
+    assert torch.equal(rgb0, rgb1) and torch.equal(mask0, mask1)
+    assert float(mask1.max()) > 0.5                                      # the mask pass really rendered something
+    for n in names:
+        assert torch.equal(g0[n], g1[n]), n
+    # the second call of a view really took the shared path (its context has a parent), a different view did not
+    from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    import math
+    cam = cams[0]
+    mk = lambda bg: GaussianRasterizationSettings(
+        image_height=sc.H, image_width=sc.W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg,
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform.float(), sh_degree=0,
+        campos=cam.camera_center, prefiltered=False, debug=False)
+    xyz = s.xyz.clone().requires_grad_(True)
+    col = torch.rand(sc.P, 3, device=dev)
+    kw = dict(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=s.opacity, scales=s.scaling, rotations=s.rotation, cov3D_precomp=None)
+    img_a, _ = GaussianRasterizer(mk(s.bg))(colors_precomp=col, **kw)
+    img_b, _ = GaussianRasterizer(mk(torch.zeros(3, device=dev)))(colors_precomp=torch.ones_like(col), **kw)
+    assert img_a.grad_fn.rctx.parent is None and img_b.grad_fn.rctx.parent is img_a.grad_fn.rctx
+    kw2 = dict(kw, opacities=s.opacity.clone())                           # another tensor object: geometry not provably the same
+    img_c, _ = GaussianRasterizer(mk(s.bg))(colors_precomp=col, **kw2)
+    assert img_c.grad_fn.rctx.parent is None

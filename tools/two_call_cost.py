@@ -31,5 +31,5 @@ def t(fn, n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 a = t(ref_protocol); b = t(fused)
 R.check_overflow()
-print(f"reference protocol (8 views x 2 rasteriser calls, sync each): {a:.3f} ms = {a / 8:.3f} ms per view fwd+bwd")
+print(f"reference protocol (8 views x 2 rasteriser calls through the drop-in): {a:.3f} ms = {a / 8:.3f} ms per view fwd+bwd")
 print(f"fused batched form (8 views, RGB+alpha in one pass, sync-free): {b:.3f} ms = {b / 8:.3f} ms per view fwd+bwd")
