@@ -146,7 +146,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t
     if (o1 > cap) o1 = cap;
     if (o0 > o1) o0 = o1;
   }
-  float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // Compensated (Kahan) fixed-order sums: a footprint of hundreds of tiles adds thousands of signed sub-records that
+  // largely cancel, and a plain fp32 running sum loses the result's low bits to the large intermediate values (VERDICT r1
+  // item 9: whole-image Gaussians missed the 1e-3 gradient bar against the oracle's double accumulation). The kernel is
+  // bound by its scattered reads, the 27 extra adds per record are free. Bitwise reproducible as before.
+  float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t fnext = o0 < o1 ? inst_flag[o0] : 0u;           // 4 quadrant flag bytes of a tile instance
   for (uint32_t sidx = o0; sidx < o1; ++sidx) {
     const uint32_t f = fnext;
@@ -154,10 +158,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t
     if ((f >> (8 * q)) & 1u) {
       const GhF3* r = (const GhF3*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC_G);
       const GhF3 r0 = r[0], r1 = r[1], r2 = r[2];
-      s9[0] += r0.x; s9[1] += r0.y; s9[2] += r0.z; s9[3] += r1.x; s9[4] += r1.y;
-      s9[5] += r1.z; s9[6] += r2.x; s9[7] += r2.y; s9[8] += r2.z;
+      const float v9[9] = {r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z};
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float y = v9[k] - c9[k];
+        const float t = s9[k] + y;
+        c9[k] = (t - s9[k]) - y;
+        s9[k] = t;
+      }
     }
   }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s9[k] -= c9[k];               // fold the last compensation in
   // quadrants combined in fixed order, (q0 + q1) + (q2 + q3), in every lane of the quad
 #pragma unroll
   for (int k = 0; k < 9; ++k) {

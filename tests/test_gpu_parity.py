@@ -111,8 +111,9 @@ def compare(sc, dev, check_stages=True, grad_l2=1e-5, grad_rtol=GRAD_RTOL, check
     for k in og:
         assert bool(torch.isfinite(g[k]).all()), k
         if check_grads:
+            rtol = grad_rtol.get(k, GRAD_RTOL) if isinstance(grad_rtol, dict) else grad_rtol
             assert rel_l2(g[k].cpu(), og[k]) <= grad_l2, k
-            assert max_rel(g[k].cpu(), og[k]) <= grad_rtol, k
+            assert max_rel(g[k].cpu(), og[k]) <= rtol, (k, max_rel(g[k].cpu(), og[k]))
     print(f"instances: {D} after exact tile culling, {orc.num_rendered} in the 3-sigma rects")
     orc.close()
     return D
@@ -239,10 +240,13 @@ def test_culling_is_conservative_for_thin_faint_and_border_gaussians(dev):
     sc.xyz[k, 1] = (((k // 33) % 33) * 4 - 64 + 0.5).float() / 325.0
     sc.xyz[k, 2] = 0.0
     sc.xyz[5000:5200, 0] += 0.5                                                   # far outside the frustum
-    # The subject here is the FORWARD (bit-exact, asserted inside compare). Gradients w.r.t. the 3e-5 m axes of 1000:1
-    # needles are ill-conditioned in fp32 (cancellation in dSigma -> dscale), so the order of the fp32 pixel sums shows
-    # up at ~2e-3 of the entry scale; every well-conditioned scene keeps the 1e-3 bar (all other tests).
-    compare(sc, dev, grad_l2=1e-4, grad_rtol=5e-3)
+    # The subject here is the FORWARD (bit-exact, asserted inside compare). Every gradient keeps the 1e-3 bar except
+    # dL/dscales: the chain rule dSigma2D -> dSigma3D -> dscale of a 1000:1 needle subtracts terms ~(s_max / s_min)^2 = 1e6
+    # times larger than the result for the 3e-5 m axes, in fp32 on BOTH sides (the oracle's per-Gaussian stage is fp32 as
+    # well; only its pixel sums are double). The two sides' nine per-Gaussian sums agree to ~1e-7 relative (fp32 eps), which
+    # that cancellation amplifies to 1.8e-3 of the entry scale (measured, round 2; 5e-3 before the compensated record
+    # sums). A bar of 1e-3 here would need the per-Gaussian chain rule in double on the GPU.
+    compare(sc, dev, grad_l2=1e-4, grad_rtol={"scales": 3e-3})
 
 
 def test_frustum_clamp_edge_gradients(dev):
@@ -326,7 +330,7 @@ def test_footprints_larger_than_the_64_tile_hit_mask(dev):
     # The subject is the instance lists and the (bit-exact) forward. A whole-image Gaussian's gradient is a signed sum
     # of 1.7e5 pixel terms that largely cancel: fp32 partial sums vs the oracle's double accumulation differ by up to a
     # few % on the near-cancelled components (rel-L2 stays <= 2e-4); well-conditioned scenes keep the 1e-3 bar.
-    D = compare(sc, dev, grad_l2=2e-4, grad_rtol=5e-2)
+    D = compare(sc, dev, grad_l2=2e-4, grad_rtol=GRAD_RTOL)
     assert D > 20000
 
 

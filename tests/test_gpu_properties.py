@@ -196,4 +196,4 @@ def test_randomised_parity_sweep(dev):
             sc.color_b = None
         if rnd.random() < 0.3 and sc.opacity_b is not None:
             sc.opacity_b = None
-        compare(sc, dev, grad_l2=1e-4, grad_rtol=5e-3)
+        compare(sc, dev, grad_l2=1e-4)                     # gradient bar: GRAD_RTOL = 1e-3 (BASELINE.json)
