@@ -68,6 +68,8 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->sh_scratch = take(sh_mode ? ((N * 16 + GH_BLOCK - 1) / GH_BLOCK + 1) * 64 * 4 : 0);   // sized for the pose-batch row count
   L->grad_sums = take(N * 48);
   L->bwd_scratch = take((2 * nblk_pre + 2) * 64 * 4);     // per-block partials of the chain-rule kernel (<= 2N lanes)
+  const size_t nblk_proj = (((N > (size_t)g.NV * g.tiles ? N : (size_t)g.NV * g.tiles)) + GH_BLOCK - 1) / GH_BLOCK;
+  L->key_bits = take((nblk_proj + 1) * 8);                // (OR, AND) of the visible depth keys per projection block
   L->total_bytes = off;
   return GH_OK;
 }

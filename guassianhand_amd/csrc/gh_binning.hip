@@ -48,13 +48,36 @@ __device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w
   return woff + x - v;
 }
 
+// Bits in which at least two (relevant) keys differ, from the per-producer-block (OR, AND) of the key bits
+// (gh_preprocess_fwd_kernel; key_bits[n_bits] receives the word). Computed ONCE, by block (0, 0) of the first pass's histogram
+// kernel; every later pass reads the word: a pass whose digit has no varying bit is the identity (its histogram kernel exits,
+// its scatter kernel copies). Keys that were left out of the (OR, AND) — Gaussians that emit no instance — may land anywhere.
+__device__ __forceinline__ void gh_store_varying_bits(uint2* __restrict__ key_bits, int n_bits) {
+  __shared__ uint32_t s_or[GH_BLOCK / GH_WAVE], s_and[GH_BLOCK / GH_WAVE];
+  uint32_t o = 0u, a = 0xFFFFFFFFu;
+  for (int i = threadIdx.x; i < n_bits; i += GH_BLOCK) { const uint2 b = key_bits[i]; o |= b.x; a &= b.y; }
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) { o |= __shfl_xor(o, k); a &= __shfl_xor(a, k); }
+  if ((threadIdx.x & 63) == 0) { s_or[threadIdx.x >> 6] = o; s_and[threadIdx.x >> 6] = a; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    key_bits[n_bits].x = (s_or[0] | s_or[1] | s_or[2] | s_or[3]) & ~(s_and[0] & s_and[1] & s_and[2] & s_and[3]);
+  __syncthreads();
+}
+__device__ __forceinline__ bool gh_digit_varies(const uint2* __restrict__ key_bits, int n_bits, int shift, uint32_t dmask) {
+  return !key_bits || shift == 0 || ((key_bits[n_bits].x >> shift) & dmask) != 0u;      // shift 0 is the producing pass
+}
+
 // Pass part 1: per-block digit histogram -> table[digit][block]; SELF: -> table[block][digit] (the scatter kernel sums the
 // rows of the blocks before it itself, see there).
 template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
                                                                   uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
-                                                                  uint32_t* __restrict__ table) {
+                                                                  uint32_t* __restrict__ table, const uint2* __restrict__ key_bits,
+                                                                  int n_bits) {
   __shared__ uint32_t s_hist[MAXD];
+  if (key_bits && shift == 0 && blockIdx.x == 0 && blockIdx.y == 0) gh_store_varying_bits((uint2*)key_bits, n_bits);
+  if (!gh_digit_varies(key_bits, n_bits, shift, dmask)) return;       // the scatter of this pass is a plain copy
   const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
   const uint32_t seg = blockIdx.y, nblk = gridDim.x, ndig = dmask + 1u;
   const uint32_t base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
@@ -130,7 +153,7 @@ template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
-    int nbit, const uint32_t* __restrict__ table, const uint32_t* __restrict__ tot) {
+    int nbit, const uint32_t* __restrict__ table, const uint32_t* __restrict__ tot, const uint2* __restrict__ key_bits, int n_bits) {
   constexpr int DPT = MAXD / GH_BLOCK;
   constexpr int NW = GH_BLOCK / GH_WAVE;
   __shared__ uint32_t s_base[MAXD];                        // global base of (digit, this block)
@@ -141,10 +164,19 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
   const uint32_t seg = blockIdx.y, nblk = gridDim.x, ndig = dmask + 1u;
   const uint32_t blk_base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
+  const bool varies = gh_digit_varies(key_bits, n_bits, shift, dmask);
   if (blk_base >= n) return;
   const size_t seg_off = (size_t)seg * seg_len;
   keys_in += seg_off; vals_in += seg_off; keys_out += seg_off; vals_out += seg_off;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (!varies) {                                   // every key carries the same digit: the stable scatter is the identity
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+      const uint32_t idx = blk_base + r * GH_BLOCK + tid;
+      if (idx < n) { keys_out[idx] = keys_in[idx]; vals_out[idx] = vals_in[idx]; }
+    }
+    return;
+  }
 
   // the block's keys: loads issued first, they do not depend on the digit bases computed below.
   // Wave w owns keys [w*ITEMS*64, (w+1)*ITEMS*64) of the block's tile, visited as ITEMS rounds of 64 consecutive keys,
@@ -277,7 +309,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
 
 template <int ITEMS>
 static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr,
-                            uint32_t cap, int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s) {
+                            uint32_t cap, int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s,
+                            const uint2* key_bits, int n_bits) {
   const size_t per_seg = seg_len ? seg_len : cap;
   const int nblk = (int)((per_seg + GH_BLOCK * ITEMS - 1) / (GH_BLOCK * ITEMS));
   if (nblk == 0 || segs == 0) return;
@@ -290,14 +323,14 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
     uint32_t* tot = table + (size_t)segs * ndig * nblk;
     const dim3 gb(nblk, segs), gs(ndig, segs), blk(GH_BLOCK);
     if (nblk <= 128) {                                   // short segments: no scan kernel (see gh_radix_scatter_kernel)
-      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table);
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits);
       hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
-                         lo, dmask, hi - lo, table, tot);
+                         lo, dmask, hi - lo, table, tot, key_bits, n_bits);
     } else {
-      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table);
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits);
       hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
       hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
-                         lo, dmask, hi - lo, table, tot);
+                         lo, dmask, hi - lo, table, tot, key_bits, n_bits);
     }
     uint32_t* t = k_in; k_in = k_out; k_out = t;
     t = v_in; v_in = v_out; v_out = t;
@@ -317,17 +350,17 @@ size_t gh_radix_table_words(size_t per_segment, int segs) {
 size_t gh_radix_table_words(size_t cap) { return gh_radix_table_words(cap, 1); }
 
 void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
-                      int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s) {
+                      int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s, const uint2* key_bits, int n_bits) {
   const size_t per_seg = seg_len ? seg_len : cap;
   const int items = gh_radix_items(per_seg);
-  if (items == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
-  else if (items == 8) gh_radix_sort_t<8>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
-  else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s);
+  if (items == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
+  else if (items == 8) gh_radix_sort_t<8>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
+  else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
 }
 
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                    int nbits, uint32_t* table, hipStream_t s) {
-  gh_radix_sort_ex(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, 0u, 1, table, s);
+  gh_radix_sort_ex(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, 0u, 1, table, s, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,7 +544,10 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   // level 1: depth order of every view's Gaussians (keys / payload written by the preprocess kernel): NV segments of P
   uint32_t* dk_in = (uint32_t*)(ws + L.depth_keys_a); uint32_t* dk_out = (uint32_t*)(ws + L.depth_keys_b);
   uint32_t* dv_in = (uint32_t*)(ws + L.depth_vals_a); uint32_t* dv_out = (uint32_t*)(ws + L.depth_vals_b);
-  gh_radix_sort_ex(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, 32, (uint32_t)g.P, g.NV, table, s);
+  const int T = g.NV * g.tiles;
+  const int n_proj_blocks = ((g.N > T ? g.N : T) + GH_BLOCK - 1) / GH_BLOCK;          // grid of gh_preprocess_fwd_kernel
+  gh_radix_sort_ex(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, 32, (uint32_t)g.P, g.NV, table, s,
+                   (const uint2*)(ws + L.key_bits), n_proj_blocks);
   const uint32_t* perm = dv_in;                       // 4 passes: the result is back in the *_a buffers
 
   // level 2: emit in depth order

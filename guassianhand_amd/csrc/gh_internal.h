@@ -51,8 +51,10 @@ void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*
 size_t gh_radix_table_words(size_t cap);
 // General form: `segs` independent segments of exactly seg_len elements each (seg_len = 0: one segment, count from *n_ptr).
 // table: gh_radix_table_words(per-segment capacity, segs).
+// key_bits / n_bits: optional per-producer-block (OR, AND) of the key bits: a pass whose digit no two keys differ in is a copy.
 void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
-                      int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s);
+                      int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s, const uint2* key_bits = nullptr,
+                      int n_bits = 0);
 size_t gh_radix_table_words(size_t per_segment, int segs);
 void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, char* ws, const GhLayout& L, hipStream_t s);
 int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,

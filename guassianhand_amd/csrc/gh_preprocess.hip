@@ -11,9 +11,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     const float4* __restrict__ sh_rgb, float4* __restrict__ geom, float* __restrict__ depth,
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
-    int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk) {
+    int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk,
+    uint2* __restrict__ key_bits) {
+  __shared__ uint2 s_bits[GH_BLOCK / GH_WAVE];
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
+  uint32_t k_or = 0u, k_and = 0xFFFFFFFFu;              // bits of this thread's depth key if its Gaussian emits instances
   if (t == 0) {                                        // counters: reserved[0] = element count of the level-1 (depth) sort
     ctr->num_rendered = 0; ctr->overflow = 0; ctr->reserved[0] = (uint32_t)N; ctr->reserved[1] = 0;
   }
@@ -94,7 +97,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     depth_key[n] = dkey;
     depth_val[n] = (uint32_t)n;
     if (radii) radii[n] = radius;
+    if (tiles > 0) { k_or = dkey; k_and = dkey; }     // only Gaussians that emit instances need to be in depth order
   }
+  // (OR, AND) of the block's keys: the depth sort skips a digit no two keys differ in (views at ~1 m: the top byte)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { k_or |= __shfl_xor(k_or, o); k_and &= __shfl_xor(k_and, o); }
+  if ((threadIdx.x & 63) == 0) s_bits[threadIdx.x >> 6] = make_uint2(k_or, k_and);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    key_bits[blockIdx.x] = make_uint2(s_bits[0].x | s_bits[1].x | s_bits[2].x | s_bits[3].x,
+                                      s_bits[0].y & s_bits[1].y & s_bits[2].y & s_bits[3].y);
 }
 
 void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii, char* ws,
@@ -111,7 +123,7 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                      (float*)(ws + L.depth),
                      (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii,
-                     T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk));
+                     T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk), (uint2*)(ws + L.key_bits));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -172,6 +172,8 @@ typedef struct GhLayout {
   size_t sh_scratch;     /* float[ceil(P/16)][64] block partials of the global colour-weight gradient (SH mode) */
   size_t grad_sums;      /* float4[n_views*P][3] per-(view,Gaussian) sums of the sub-records: dpx dpy dA dB | dC do dr dg | db */
   size_t bwd_scratch;    /* blend-parameter reduction scratch */
+  size_t key_bits;       /* uint2[projection blocks] (OR, AND) over the depth-key bits of the block's visible Gaussians: a depth-sort
+                            pass whose digit is the same in every key (OR & ~AND has no bit in it) degenerates to a copy */
 } GhLayout;
 
 /* Library version: major<<16 | minor. */
