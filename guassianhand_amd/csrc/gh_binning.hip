@@ -485,52 +485,42 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   r0[i] = a; r1[i] = b; r2[i] = make_float2(cb, __uint_as_float(m));
 }
 
-// Longest-processing-time-first launch order for the render kernels: a counting sort of the tiles by list
-// length (256 buckets of 16 entries, longest first). Workgroups are dispatched in blockIdx order, so the heavy
-// tiles start at t=0 and the light / empty ones fill in behind them instead of forming the tail.
-// One block; the order inside a bucket is arbitrary (it only affects scheduling, never results).
-// The key is the tile's list length. (The backward's order comes from the forward itself: gh_render_fwd_kernel.)
-__global__ __launch_bounds__(1024) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int ntiles,
-                                                              uint32_t* __restrict__ order) {
+// Longest-processing-time-first launch order for the render kernels: a counting sort of the tiles by list length (256
+// buckets of 16 entries, longest first). Workgroups are dispatched in blockIdx order, so the heavy tiles start at t = 0 and
+// the light / empty ones fill in behind them instead of forming the tail. One block PER VIEW sorts that view's tiles; the
+// global order interleaves the views rank by rank (order[r * NV + v] = view v's r-th heaviest tile), which is the merged
+// order up to differences between the views' r-th tiles. The order only affects scheduling, never results; the order
+// inside a bucket is arbitrary. (The backward's order comes from the forward itself: gh_render_fwd_kernel.)
+__global__ __launch_bounds__(GH_BLOCK) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int tiles, int NV,
+                                                                  uint32_t* __restrict__ order) {
   __shared__ uint32_t s_cnt[256];
-  __shared__ uint32_t s_w[4];
-  const int tid = threadIdx.x;
-  if (tid < 256) s_cnt[tid] = 0;
+  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
+  const int tid = threadIdx.x, v = blockIdx.x;
+  ranges += (size_t)v * tiles;
+  s_cnt[tid] = 0;
   __syncthreads();
-  for (int t = tid; t < ntiles; t += 1024) {
+  for (int t = tid; t < tiles; t += GH_BLOCK) {
     const uint2 r = ranges[t];
-    const uint32_t len = r.y - r.x;
-    uint32_t b = (len + 15u) >> 4; b = b > 255u ? 255u : b;
+    uint32_t b = (r.y - r.x + 15u) >> 4; b = b > 255u ? 255u : b;
     atomicAdd(&s_cnt[255u - b], 1u);                 // bucket 0 = longest lists
   }
   __syncthreads();
-  // exclusive scan of the 256 counters by the first 4 waves
-  const int lane = tid & 63, wid = tid >> 6;
-  uint32_t v = 0, x = 0;
-  if (tid < 256) {
-    v = s_cnt[tid];
-    x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wid] = x;
-  }
+  uint32_t total;
+  const uint32_t c = s_cnt[tid];
+  const uint32_t pre = gh_block_excl_scan(c, s_w, &total);
   __syncthreads();
-  if (tid < 256) {
-    uint32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += s_w[w];
-    s_cnt[tid] = woff + x - v;
-  }
+  s_cnt[tid] = pre;
   __syncthreads();
-  for (int t = tid; t < ntiles; t += 1024) {
+  for (int t = tid; t < tiles; t += GH_BLOCK) {
     const uint2 r = ranges[t];
-    const uint32_t len = r.y - r.x;
-    uint32_t b = (len + 15u) >> 4; b = b > 255u ? 255u : b;
-    order[atomicAdd(&s_cnt[255u - b], 1u)] = (uint32_t)t;
+    uint32_t b = (r.y - r.x + 15u) >> 4; b = b > 255u ? 255u : b;
+    const uint32_t rank = atomicAdd(&s_cnt[255u - b], 1u);
+    order[(size_t)rank * NV + v] = (uint32_t)(v * tiles + t);
   }
 }
 
 static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
-  hipLaunchKernelGGL(gh_tile_order_kernel, dim3(1), dim3(1024), 0, s, (const uint2*)(ws + L.ranges), g.NV * g.tiles,
+  hipLaunchKernelGGL(gh_tile_order_kernel, dim3(g.NV), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges), g.tiles, g.NV,
                      (uint32_t*)(ws + L.tile_order));
 }
 

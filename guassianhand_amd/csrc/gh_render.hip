@@ -352,11 +352,7 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 // Inclusive prefix product / sum in lane order over groups of L = 64, 32 or 16 lanes: Kogge-Stone inside each row of 16
 // with DPP row shifts, then the row totals with row_bcast15 (L >= 32) and row_bcast31 (L = 64). Lanes without a source
 // lane keep their value (in place, bound_ctrl off). A VALU write followed by a DPP read needs two wait states (s_nop 1).
-#ifdef GH_ABL_NONOP
-#define GH_NOP ""
-#else
 #define GH_NOP "s_nop 1\n\t"
-#endif
 #define GH_SCAN_ROW(OP) \
   GH_NOP OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t" \
   GH_NOP OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
@@ -366,9 +362,6 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 #define GH_SCAN_B31(OP) "\n\t" GH_NOP OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
 template <int L>
 __device__ __forceinline__ float gh_scan_mul(float v) {
-#ifdef GH_ABL_NOSCAN
-  return v;
-#endif
   if (L == 64) asm(GH_SCAN_ROW("v_mul_f32_dpp") GH_SCAN_B15("v_mul_f32_dpp") GH_SCAN_B31("v_mul_f32_dpp") : "+v"(v));
   else if (L == 32) asm(GH_SCAN_ROW("v_mul_f32_dpp") GH_SCAN_B15("v_mul_f32_dpp") : "+v"(v));
   else asm(GH_SCAN_ROW("v_mul_f32_dpp") : "+v"(v));
@@ -376,9 +369,6 @@ __device__ __forceinline__ float gh_scan_mul(float v) {
 }
 template <int L>
 __device__ __forceinline__ float gh_scan_add(float v) {
-#ifdef GH_ABL_NOSCAN
-  return v;
-#endif
   if (L == 64) asm(GH_SCAN_ROW("v_add_f32_dpp") GH_SCAN_B15("v_add_f32_dpp") GH_SCAN_B31("v_add_f32_dpp") : "+v"(v));
   else if (L == 32) asm(GH_SCAN_ROW("v_add_f32_dpp") GH_SCAN_B15("v_add_f32_dpp") : "+v"(v));
   else asm(GH_SCAN_ROW("v_add_f32_dpp") : "+v"(v));
@@ -426,11 +416,7 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     // alpha exactly as the forward evaluated it (same expression, same gh_exp): the same entries count as blended
     const float dx = e.a.x - p1.z, dy = e.a.y - p1.w;
     const float power = -0.5f * (e.a.z * dx * dx + e.b.x * dy * dy) - e.a.w * dx * dy;
-#ifdef GH_ABL_NOEXP
-    const float G = fminf(power, 0.0f) + 1.0f;
-#else
     const float G = gh_exp(fminf(power, 0.0f));
-#endif
     const float alpha = fminf(0.99f, e.b.y * G);
     const bool contrib = valid && (e.pos < __float_as_int(p1.y)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
     any |= contrib;
@@ -600,11 +586,7 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
       for (int j0 = 0; j0 < nhit;) {
         const int rem = nhit - j0;
         // batch shape: 64 lanes x 1 pixel, or for short remainders 32 x 2 / 16 x 4 (rem in (32, 48] goes as 32 + a 16-lane batch)
-#ifdef GH_ABL_L64
-        const int L = 64;
-#else
         const int L = rem > 48 ? 64 : (rem > 16 ? 32 : 16);
-#endif
         const int cnt = rem < L ? rem : L;
         const int el = lane & (L - 1);
         const bool valid = el < cnt;
@@ -617,11 +599,7 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
         const uint32_t am = (uint32_t)(gh_ballot(last > minpos) >> (16 * b)) & 0xFFFFu;     // pixels of the block that blend into the batch
         float acc[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         bool any = false;
-#ifdef GH_ABL_NOBODY
-        if (false) {
-#else
         if (am) {
-#endif
           if (L == 64) any = gh_bwd_batch<64>(e, valid, am, 16 * b, lane, s_pix, acc);
           else if (L == 32) any = gh_bwd_batch<32>(e, valid, am, 16 * b, lane, s_pix, acc);
           else any = gh_bwd_batch<16>(e, valid, am, 16 * b, lane, s_pix, acc);
