@@ -10,6 +10,7 @@
 #define GH_BLOCK 256                 // 4 waves: one 8x8 pixel quadrant of a 16x16 tile per wave
 #define GH_REC 9                     // LDS stride (floats) of a partial gradient record: 18 KB per block keeps 8 blocks per CU
 #define GH_REC_G 9                   // floats per (instance, quadrant) sub-record in HBM: packed, three 12-byte accesses
+#define GH_FINE_TILES 2048           // launches of at most this many tiles run the backward with one wave per 4x4 block
 
 struct GhF3 { float x, y, z; };      // 12-byte access (global_load/store_dwordx3)
 

@@ -449,8 +449,11 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
   return any;
 }
 
-template <bool ALPHA>
-__global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
+// NW = waves per workgroup. 1: a wave walks the quadrant's four blocks one after the other. 4 (small launches: one or two
+// views leave most of the 256 CUs idle and the longest quadrant IS the kernel): the quadrant's four blocks run in four
+// waves of one workgroup, each with its own accumulator rows, and are combined in fixed wave order behind one barrier.
+template <bool ALPHA, int NW>
+__global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ items, const GhCounters* __restrict__ ctr,
     const uint32_t* __restrict__ sorted_slot,
     const float4* __restrict__ r0, const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams,
@@ -458,10 +461,14 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
     const float4* __restrict__ ckpt_rgb, const float4* __restrict__ final_C,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, const float* __restrict__ upstream_scale,
     float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag) {
-  __shared__ float s_acc[GH_BWD_ACC * GH_REC];            // [compact quadrant entry][9]
+  __shared__ float s_acc_all[NW][GH_BWD_ACC * GH_REC];    // per wave: [compact quadrant entry][9]
   __shared__ float4 s_pix[2 * (GH_WAVE + 1)];             // per pixel (T, B, d0, d1), (d2, last, px, py); last record = dummy
-  __shared__ uint16_t s_q[GH_SEGMENT];                    // compacted entry list of the block being walked: raw | compact << 8
-  __shared__ uint8_t s_f[GH_BWD_ACC];                     // 1 where some pixel of the quadrant blended the entry
+  __shared__ uint16_t s_q_all[NW][GH_SEGMENT];            // per wave: compacted entry list of the block being walked: raw | compact << 8
+  __shared__ uint8_t s_f_all[NW][GH_BWD_ACC];             // per wave: 1 where some pixel of its block(s) blended the entry
+  const int wv = NW == 1 ? 0 : (int)(threadIdx.x >> 6);
+  float* s_acc = s_acc_all[wv];
+  uint16_t* s_q = s_q_all[wv];
+  uint8_t* s_f = s_f_all[wv];
   const uint32_t n_items = ctr->reserved[1];             // written by the forward; the grid is sized for the list's capacity
   uint32_t item_idx, quad_u;
   gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);       // the four quadrants of an item share an XCD (L2)
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
   const int seg_lo = (int)item.y * GH_SEGMENT, seg_hi = seg_lo + GH_SEGMENT;
   int v, tx, ty;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   // pixel state: one pixel per lane, lane = 16 * block + 4 * row + column
   const int lb = lane >> 4, lp = lane & 15;
   const int x = tx * GH_TILE + (quad & 1) * 8 + (lb & 1) * 4 + (lp & 3), y = ty * GH_TILE + (quad >> 1) * 8 + (lb >> 1) * 4 + (lp >> 2);
@@ -520,8 +527,10 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
     vT = c.x;
     vB += fmaf(d2, fc.z - c.w, fmaf(d1, fc.y - c.z, d0 * (fc.x - c.y)));
   }
-  s_pix[2 * lane] = make_float4(vT, vB, d0, d1);
-  s_pix[2 * lane + 1] = make_float4(d2, __int_as_float(last), (float)x, (float)y);
+  if (NW == 1 || lb == wv) {                           // (NW = 4: every wave owns the records of its own block's pixels)
+    s_pix[2 * lane] = make_float4(vT, vB, d0, d1);
+    s_pix[2 * lane + 1] = make_float4(d2, __int_as_float(last), (float)x, (float)y);
+  }
   if (lane == 0) {
     s_pix[2 * GH_PIX_DUMMY] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
     s_pix[2 * GH_PIX_DUMMY + 1] = make_float4(0.0f, __int_as_float(0), 0.0f, 0.0f);       // last = 0: blends nothing
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
     __builtin_amdgcn_wave_barrier();
 
 #pragma unroll 1
-    for (int b = 0; b < 4; ++b) {
+    for (int b = NW == 1 ? 0 : wv; b < (NW == 1 ? 4 : wv + 1); ++b) {
       const int bl = __builtin_amdgcn_readlane(blast, 16 * b);          // first list position no pixel of the block blended
       if (bl <= seg_lo + k_lo * GH_WAVE) continue;                     // the block blended nothing inside this chunk
       const int bend = bl < seg_hi ? bl : seg_hi;
@@ -629,12 +638,23 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
       }
     }
     // ---- the quadrant's sub-record of every entry some pixel blended, at the instance's emit slot
-    __builtin_amdgcn_wave_barrier();
+    if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
 #pragma unroll
     for (int k = 0; k < GH_SEGMENT / GH_WAVE; ++k) {
-      if (k < k_lo || k > k_hi) continue;
-      if (mk[k] != 0u && ((volatile uint8_t*)s_f)[crow[k]]) {
-        const float* s9 = s_acc + crow[k] * GH_REC;
+      if (k < k_lo || k > k_hi || (NW > 1 && (k & (NW - 1)) != wv)) continue;      // NW = 4: raw batch k is flushed by wave k
+      if (mk[k] == 0u) continue;
+      float s9[GH_REC] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+      bool any = false;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {                     // fixed wave order: bitwise reproducible
+        if (((volatile uint8_t*)s_f_all[w])[crow[k]]) {
+          any = true;
+          const float* a9 = s_acc_all[w] + crow[k] * GH_REC;
+#pragma unroll
+          for (int q = 0; q < GH_REC; ++q) s9[q] += a9[q];
+        }
+      }
+      if (any) {
         const uint32_t sl = slots[seg_lo + k * GH_WAVE + lane];
         GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC_G);
         rec[0] = GhF3{s9[0], s9[1], s9[2]};
@@ -643,7 +663,7 @@ __global__ __launch_bounds__(GH_WAVE) void gh_render_bwd_kernel(
         inst_flag[(size_t)sl * 4 + quad] = 1;
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    if (NW == 1) __builtin_amdgcn_wave_barrier(); else __syncthreads();
     k_hi = k_lo - 1;
   }
 }
@@ -653,7 +673,8 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   if (g.cap == 0) return;
   // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (they depend on the forward's
   // n_contrib only). The work list (tile, depth segment) was written by the forward's last wave of every tile.
-  const dim3 grid(4 * (unsigned)g.n_items), block(GH_WAVE);      // capacity of the work list x 4 quadrants; surplus waves exit at once
+  const bool small = (size_t)g.NV * g.tiles <= GH_FINE_TILES;    // few tiles: four waves per quadrant (one per 4x4 block)
+  const dim3 grid(4 * (unsigned)g.n_items), block(small ? 4 * GH_WAVE : GH_WAVE);   // capacity of the work list x 4 quadrants; surplus workgroups exit at once
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(wg + L.ranges), (const uint2*)(ws + L.bwd_items),
                        (const GhCounters*)(ws + L.counters),
@@ -663,7 +684,8 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                        (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, upstream_scale, (float*)(ws + L.inst_grad),
                        (uint8_t*)(ws + L.inst_flag));
   };
-  if (dL_dalpha) launch(gh_render_bwd_kernel<true>); else launch(gh_render_bwd_kernel<false>);
+  if (small) { if (dL_dalpha) launch(gh_render_bwd_kernel<true, 4>); else launch(gh_render_bwd_kernel<false, 4>); }
+  else { if (dL_dalpha) launch(gh_render_bwd_kernel<true, 1>); else launch(gh_render_bwd_kernel<false, 1>); }
 }
 
 // ------------------------------------------------------------------------------------------------
