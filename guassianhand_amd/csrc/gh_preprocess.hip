@@ -163,20 +163,32 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t
   // item 9: whole-image Gaussians missed the 1e-3 gradient bar against the oracle's double accumulation). The kernel is
   // bound by its scattered reads, the 27 extra adds per record are free. Bitwise reproducible as before.
   float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  uint32_t fnext = o0 < o1 ? inst_flag[o0] : 0u;           // 4 quadrant flag bytes of a tile instance
-  for (uint32_t sidx = o0; sidx < o1; ++sidx) {
-    const uint32_t f = fnext;
-    fnext = sidx + 1 < o1 ? inst_flag[sidx + 1] : 0u;        // next instance's flags in flight behind this one's records
-    if ((f >> (8 * q)) & 1u) {
-      const GhF3* r = (const GhF3*)(inst_grad + ((size_t)sidx * 4 + q) * GH_REC_G);
-      const GhF3 r0 = r[0], r1 = r[1], r2 = r[2];
-      const float v9[9] = {r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z};
+  // Four instances per trip: their flag words (4 quadrant flag bytes each), then the flagged sub-records, are all requested
+  // before the first is used — the loop is a chain of dependent scattered reads otherwise (flag -> record, instance after
+  // instance), and most Gaussians have no more than four instances.
+  for (uint32_t base = o0; base < o1; base += 4) {
+    bool has[4];
+    GhF3 r[4][3];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const float y = v9[k] - c9[k];
-        const float t = s9[k] + y;
-        c9[k] = (t - s9[k]) - y;
-        s9[k] = t;
+    for (int i = 0; i < 4; ++i) has[i] = base + i < o1 && ((inst_flag[base + i] >> (8 * q)) & 1u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (has[i]) {
+        const GhF3* p = (const GhF3*)(inst_grad + ((size_t)(base + i) * 4 + q) * GH_REC_G);
+        r[i][0] = p[0]; r[i][1] = p[1]; r[i][2] = p[2];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (has[i]) {
+        const float v9[9] = {r[i][0].x, r[i][0].y, r[i][0].z, r[i][1].x, r[i][1].y, r[i][1].z, r[i][2].x, r[i][2].y, r[i][2].z};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float y = v9[k] - c9[k];
+          const float t = s9[k] + y;
+          c9[k] = (t - s9[k]) - y;
+          s9[k] = t;
+        }
       }
     }
   }
