@@ -174,6 +174,28 @@ def clear_workspace_pool() -> None:
     _ws_pool.clear()
 
 
+def _raw_stream(dev: torch.device) -> int:
+    """Handle of the caller's current stream on `dev` (the torch.cuda.current_stream() object costs ~10 us of host time)."""
+    return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+class _OnDevice:
+    """`with torch.cuda.device(dev)` only when `dev` is not already current (the context manager costs ~10 us per call)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev: torch.device):
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.ctx = None if torch.cuda.current_device() == idx else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -262,8 +284,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                             _ptr(t["rotations"]), None, _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
                             _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
         out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha))
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _raw_stream(dev)
+        with _OnDevice(dev):
             rc = L.gh_forward_shared(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(g0.ws.data_ptr()),
                                      C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
         if rc != 0:
@@ -287,8 +309,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                             _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
                             _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
         out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha))
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        stream = _raw_stream(dev)
+        with _OnDevice(dev):
             fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
             if _stage_timing:
                 rc = _run_stages(L.gh_forward_stages, fargs, (("preprocess_fwd", _abi.GH_FWD_PREPROCESS),
@@ -385,8 +407,8 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
                       dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]), dL_dblend_xyz_b=_ptr(o["xyz_b"]),
                       dL_dblend_opacity_b=_ptr(o["opacity_b"]), dL_dblend_color_w=_ptr(o["color_w"]),
                       dL_dblend_color_b=_ptr(o["color_b"]), upstream_scale=_ptr(gs))
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    with torch.cuda.device(dev):
+    stream = _raw_stream(dev)
+    with _OnDevice(dev):
         bargs = (C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(),
                  C.c_void_p(stream))
         if ctx.parent is not None:
