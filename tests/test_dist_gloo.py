@@ -48,7 +48,21 @@ def _worker(rank, world, port, q):
         loss = l if loss is None else loss + l
         grads = g if grads is None else {k: grads[k] + g[k] for k in g}
     order = sorted(grads)
+    # (a) the packing form (CPU / gloo tensors), (b) the in-place form over ONE contiguous block laid out like
+    # rasterizer.last_grad_block(): [4 caller floats | parts at 16-byte boundaries], float 0 = loss
+    off, spans = 4, []
+    for k in order:
+        spans.append((k, grads[k].shape, off, grads[k].numel()))
+        off += (grads[k].numel() + 3) & ~3
+    block = torch.zeros(off)
+    for k, shp, a, n in spans:
+        block[a:a + n] = grads[k].reshape(-1)
+    work, buf = ghdist.allreduce_block(block, off, loss)
+    if work is not None:
+        work.wait()
+    loss_b, grads_b = buf[0].clone(), {k: buf[a:a + n].view(shp).clone() for k, shp, a, n in spans}
     loss, grads = ghdist.allreduce_grads(grads, loss, order)
+    assert torch.equal(loss_b, loss.reshape(()).float()) and all(torch.equal(grads_b[k], grads[k]) for k in order)
     if rank == 0:
         q.put((float(loss), {k: v.numpy().copy() for k, v in grads.items()}))
     dist.barrier()
