@@ -314,6 +314,21 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
   const size_t per_seg = seg_len ? seg_len : cap;
   const int nblk = (int)((per_seg + GH_BLOCK * ITEMS - 1) / (GH_BLOCK * ITEMS));
   if (nblk == 0 || segs == 0) return;
+  // Small single-segment sorts of 9 or 10 key bits (the tile partition of ONE 512x334 view: 672 tiles) run as ONE pass with
+  // 1024 digits: a small launch is bound by the latency of its kernels, not by bandwidth, and three launches beat six
+  // (at 8 views the wide pass cost what the two narrow ones cost — DESIGN.md, round 1).
+  if (ITEMS == 4 && segs == 1 && nbits > 8 && nbits <= 10 && !key_bits) {
+    const uint32_t dmask = (1u << nbits) - 1u, ndig = dmask + 1u;
+    uint32_t* tot = table + (size_t)ndig * nblk;
+    const dim3 gb(nblk, 1), gs(ndig, 1), blk(GH_BLOCK);
+    hipLaunchKernelGGL((gh_radix_hist_kernel<4, 1024, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, 0, dmask, table, key_bits, n_bits);
+    hipLaunchKernelGGL(gh_radix_scan_kernel<4>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
+    hipLaunchKernelGGL((gh_radix_scatter_kernel<4, 1024, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
+                       0, dmask, nbits, table, tot, key_bits, n_bits);
+    uint32_t* t = k_in; k_in = k_out; k_out = t;
+    t = v_in; v_in = v_out; v_out = t;
+    return;
+  }
   const int passes = (nbits + 7) / 8;
   for (int p = 0; p < passes; ++p) {
     // spread the bits evenly over the passes (e.g. 13 bits -> 6 + 7)
@@ -344,10 +359,16 @@ int gh_radix_items(size_t per_segment) { return per_segment <= ((size_t)1 << 21)
 // Table words for sorting `segs` segments of `per_segment` elements (capacity).
 size_t gh_radix_table_words(size_t per_segment, int segs) {
   const size_t tile = (size_t)GH_BLOCK * gh_radix_items(per_segment);
-  return (size_t)segs * 256 * ((per_segment + tile - 1) / tile) + (size_t)segs * 256;
+  return (size_t)segs * 1024 * ((per_segment + tile - 1) / tile) + (size_t)segs * 1024;      // up to 1024 digits per pass
 }
 
 size_t gh_radix_table_words(size_t cap) { return gh_radix_table_words(cap, 1); }
+
+// Passes gh_radix_sort runs for `nbits` key bits on one segment of capacity `cap` (callers pick the start buffer by its parity).
+int gh_radix_passes(size_t cap, int nbits) {
+  if (gh_radix_items(cap) == 4 && nbits > 8 && nbits <= 10) return 1;
+  return (nbits + 7) / 8;
+}
 
 void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                       int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s, const uint2* key_bits, int n_bits) {
@@ -545,7 +566,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   hipLaunchKernelGGL(gh_count_sorted_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, perm, tiles_touched,
                      (uint32_t*)(ws + L.block_sums));
   // level 3: stable partition by tile id; an odd number of passes starts in the b buffers so the result is in *_a
-  const int tile_passes = (g.tile_bits + 7) / 8;
+  const int tile_passes = gh_radix_passes((size_t)g.cap, g.tile_bits);
   uint32_t* ka = (uint32_t*)(ws + L.keys_a); uint32_t* kb = (uint32_t*)(ws + L.keys_b);
   uint32_t* va = (uint32_t*)(ws + L.vals_a); uint32_t* vb = (uint32_t*)(ws + L.vals_b);
   const bool start_b = (tile_passes & 1) != 0;

@@ -50,6 +50,7 @@ void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, co
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                    int nbits, uint32_t* table, hipStream_t s);
 size_t gh_radix_table_words(size_t cap);
+int gh_radix_passes(size_t cap, int nbits);
 // General form: `segs` independent segments of exactly seg_len elements each (seg_len = 0: one segment, count from *n_ptr).
 // table: gh_radix_table_words(per-segment capacity, segs).
 // key_bits / n_bits: optional per-producer-block (OR, AND) of the key bits: a pass whose digit no two keys differ in is a copy.
