@@ -6,7 +6,9 @@
 // blob: int32 P, NV, H, W; float cams[NV*40], means3D[P*3], opacities[P], scales[P*3], rotations[P*4], colors[P*3],
 //       dL_dimage[NV*3*H*W]
 // out:  float image[NV*3*H*W]; int32 radii[NV*P]; uint32 D; float dmeans3D[P*3], dopacities[P], dscales[P*3],
-//       drotations[P*4], dcolors[P*3]
+//       drotations[P*4], dcolors[P*3];
+//       then the SECOND call over the same geometry (gh_forward_shared / gh_backward_shared with colour 1, the reference's
+//       mask pass, renderer_one_shot.py:372-379): float mask_image[NV*3*H*W], float dopacities_mask[P]
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -75,6 +77,23 @@ int main(int argc, char** argv) {
   if (!fits) { std::fprintf(stderr, "instance capacity still too small after 4 attempts (D = %u)\n", D); return 4; }
   std::printf("P %d views %d %dx%d instances %u workspace %zu bytes\n", P, NV, H, W, D, gh_workspace_bytes(&dims));
 
+  // second call over the same geometry (the first workspace must stay intact until both backwards have run)
+  std::vector<float> ones((size_t)P * 3, 1.0f);
+  GhInputs in2 = in;
+  in2.colors_precomp = to_device(ones);
+  float* image2; void* ws2 = nullptr;
+  const size_t ws_bytes = gh_workspace_bytes(&dims);
+  CHECK(hipMalloc((void**)&image2, (size_t)NV * 3 * H * W * 4));
+  CHECK(hipMalloc(&ws2, ws_bytes));
+  GhOutputs out2 = {image2, nullptr, nullptr};
+  int rc2 = gh_forward_shared(&dims, &in2, &out2, ws, ws2, ws_bytes, stream);
+  if (rc2 != GH_OK) { std::fprintf(stderr, "gh_forward_shared: %d\n", rc2); return 3; }
+  GhGrads gr2 = {};
+  gr2.dL_dimage = d_dimg;
+  CHECK(hipMalloc((void**)&gr2.dL_dopacities, (size_t)P * 4));
+  rc2 = gh_backward_shared(&dims, &in2, &gr2, ws, ws2, ws_bytes, stream);
+  if (rc2 != GH_OK) { std::fprintf(stderr, "gh_backward_shared: %d\n", rc2); return 3; }
+
   GhGrads gr = {};
   gr.dL_dimage = d_dimg;
   CHECK(hipMalloc((void**)&gr.dL_dmeans3D, (size_t)P * 3 * 4)); CHECK(hipMalloc((void**)&gr.dL_dopacities, (size_t)P * 4));
@@ -95,6 +114,7 @@ int main(int argc, char** argv) {
   std::fwrite(&D, 4, 1, o);
   wr(gr.dL_dmeans3D, (size_t)P * 12); wr(gr.dL_dopacities, (size_t)P * 4); wr(gr.dL_dscales, (size_t)P * 12);
   wr(gr.dL_drotations, (size_t)P * 16); wr(gr.dL_dcolors, (size_t)P * 12);
+  wr(image2, (size_t)NV * 3 * H * W * 4); wr(gr2.dL_dopacities, (size_t)P * 4);
   std::fclose(o);
   std::printf("ok\n");
   return 0;

@@ -58,6 +58,8 @@ def test_cpp_driver_matches_python_host_and_oracle(tmp_path, gh_lib_path):
     grads = {"means3D": take(P * 3, np.float32).reshape(P, 3), "opacities": take(P, np.float32),
              "scales": take(P * 3, np.float32).reshape(P, 3), "rotations": take(P * 4, np.float32).reshape(P, 4),
              "colors_precomp": take(P * 3, np.float32).reshape(P, 3)}
+    mask_image = take(2 * 3 * H * W, np.float32).reshape(2, 3, H, W)
+    mask_dop = take(P, np.float32)
     assert off == raw.size
 
     # the same call through the Python host (ctypes + torch memory): identical bits
@@ -69,6 +71,11 @@ def test_cpp_driver_matches_python_host_and_oracle(tmp_path, gh_lib_path):
     assert torch.equal(image, img_p.cpu()) and torch.equal(radii, radii_p.cpu())
     for k, v in grads.items():
         assert torch.equal(v, g_p[k].cpu().reshape(v.shape)), k
+    # the shared-geometry second call (colour 1) == a full call with colour 1 through the Python host, bit for bit
+    ones = torch.ones(P, 3, device=dev)
+    img_m, _, ctx_m = raster_forward(cams.to(dev), s.xyz, s.opacity, s.scaling, s.rotation, H=H, W=W, colors_precomp=ones)
+    g_m = raster_backward(ctx_m, dimg.to(dev), want_means2D=False)
+    assert torch.equal(mask_image, img_m.cpu()) and torch.equal(mask_dop, g_m["opacities"].cpu())
     # and the oracle
     orc = OracleRender(cams, sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=H, W=W, colors_precomp=cols, debug=True)
     assert torch.equal(image, orc.image) and torch.equal(radii, orc.radii) and 0 < D <= orc.num_rendered
