@@ -403,17 +403,35 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_count_sorted_kernel(int N, const 
 // instance per tile of its rect that passes the exact ellipse/tile test (the same test that counted them in the
 // projection kernel), row-major: key = global tile id, payload = view*P+gaussian.
 // A Gaussian's instances occupy consecutive slots [slot_begin, slot_begin + tiles): the backward sums its records there.
+// The instances are written by the WAVE, not by their Gaussian's lane: the 64 Gaussians of a wave own one contiguous run of
+// slots; lane l of trip j takes slot 64 j + l of the run, finds its Gaussian (binary search over the wave's prefix sums in
+// LDS) and the tile (the k-th set bit of the Gaussian's hit mask) — coalesced stores and ceil(run / 64) trips, where one
+// lane per Gaussian ran max(tiles) trips with the other lanes idle. Rects larger than the 64-bit hit mask (rare, huge
+// footprints) are still walked by their own lane.
+__device__ __forceinline__ uint32_t gh_kth_set_bit(uint32_t lo, uint32_t hi, uint32_t k) {
+  uint32_t c = (uint32_t)__popc(lo), w = lo, pos = 0;
+  if (k >= c) { k -= c; w = hi; pos = 32; }
+  c = (uint32_t)__popc(w & 0xFFFFu); if (k >= c) { k -= c; w >>= 16; pos += 16; }
+  c = (uint32_t)__popc(w & 0xFFu);   if (k >= c) { k -= c; w >>= 8;  pos += 8; }
+  c = (uint32_t)__popc(w & 0xFu);    if (k >= c) { k -= c; w >>= 4;  pos += 4; }
+  c = (uint32_t)__popc(w & 0x3u);    if (k >= c) { k -= c; w >>= 2;  pos += 2; }
+  return pos + ((k >= (w & 1u)) ? 1u : 0u);
+}
+
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ slot_begin, float4* __restrict__ geom,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr) {
-  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE], s_p[GH_BLOCK / GH_WAVE];
+  constexpr int NW = GH_BLOCK / GH_WAVE;
+  __shared__ uint32_t s_w[NW], s_p[NW];
+  __shared__ uint32_t s_end[NW][GH_WAVE];               // per wave: inclusive prefix of the lanes' instance counts
+  __shared__ uint4 s_g[NW][GH_WAVE];                    // (rect, hit mask lo, hi, n); rect = 0: not written by the wave
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = blockIdx.x * GH_BLOCK + tid;
   const uint32_t n = i < N ? perm[i] : 0u;
   float4* grec = geom + (size_t)n * 4;
-  const uint32_t cnt = i < N ? tiles_touched[n] : 0u;
-  const float4 g2 = grec[2];                            // rect + tile hit mask: issued before the scan, not after it
+  const uint32_t cnt = i < N ? __float_as_uint(grec[3].x) : 0u;   // instance count, rect + tile hit mask: one 64-byte line
+  const float4 g2 = grec[2];
   // first emit slot of this block = sum of the per-block instance counts of all blocks before it (gh_count_sorted_kernel):
   // every block adds them up itself (a few thousand coalesced L2 reads) instead of waiting for a one-block scan kernel
   uint32_t part = 0;
@@ -422,37 +440,53 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   uint32_t x = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+  const uint32_t r = __float_as_uint(g2.y);
+  const int minx = r & 255, miny = (r >> 8) & 255, maxx = (r >> 16) & 255, maxy = r >> 24;
+  const bool small = (maxx - minx) * (maxy - miny) <= 64;               // the projection kernel kept the hit mask
+  s_end[wid][lane] = x;
+  s_g[wid][lane] = make_uint4(small && cnt ? r : 0u, __float_as_uint(g2.z), __float_as_uint(g2.w), n);
   if (lane == 63) s_w[wid] = x;
   if (lane == 0) s_p[wid] = part;
   __syncthreads();
   uint32_t woff = 0, blk_off = 0, blk_sum = 0;
 #pragma unroll
-  for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { if (w < wid) woff += s_w[w]; blk_sum += s_w[w]; blk_off += s_p[w]; }
+  for (int w = 0; w < NW; ++w) { if (w < wid) woff += s_w[w]; blk_sum += s_w[w]; blk_off += s_p[w]; }
   if (blockIdx.x == gridDim.x - 1 && tid == 0) {        // the last block knows the instance total D
     const uint32_t total = blk_off + blk_sum;
     ctr->num_rendered = total;
     ctr->overflow = total > cap ? 1u : 0u;
   }
-  if (i >= N) return;
-  uint32_t off = blk_off + woff + x - cnt;
-  slot_begin[n] = off;
-  if (cnt == 0) return;
-  const uint32_t r = __float_as_uint(g2.y);
-  const int minx = r & 255, miny = (r >> 8) & 255, maxx = (r >> 16) & 255, maxy = r >> 24;
+  const uint32_t wave_base = blk_off + woff, wave_total = s_w[wid];
+  if (i < N) slot_begin[n] = wave_base + x - cnt;
+  // the wave's run of slots, 64 per trip
+  for (uint32_t j = 0; j < wave_total; j += GH_WAVE) {
+    const uint32_t sl = j + (uint32_t)lane;
+    if (sl >= wave_total) break;                        // (only the last trip is partial)
+    uint32_t o = 0;                                     // owner = number of lanes whose run ends at or before sl
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) if (s_end[wid][o + step - 1] <= sl) o += step;
+    const uint4 g = s_g[wid][o];
+    if (g.x == 0u) continue;                            // a large rect: written by its own lane below
+    const uint32_t k = sl - (o ? s_end[wid][o - 1] : 0u);
+    const uint32_t bit = gh_kth_set_bit(g.y, g.z, k);
+    const uint32_t mnx = g.x & 255u, mny = (g.x >> 8) & 255u, wdt = ((g.x >> 16) & 255u) - mnx;
+    const uint32_t dy = (uint32_t)(((float)bit + 0.5f) * __frcp_rn((float)wdt)), dx = bit - dy * wdt;
+    const uint32_t slot = wave_base + sl;
+    if (slot < cap) {
+      keys[slot] = (g.w / (uint32_t)P) * (uint32_t)tiles + (mny + dy) * (uint32_t)gx + (mnx + dx);
+      vals[slot] = g.w;                                  // the emit slot is recomputed from (n, tile) after the sort
+    }
+  }
+  if (i >= N || cnt == 0 || small) return;
+  uint32_t off = wave_base + x - cnt;
   const uint32_t vbase = (n / (uint32_t)P) * (uint32_t)tiles;
-  const bool small = (maxx - minx) * (maxy - miny) <= 64;               // the projection kernel kept the hit mask
-  const unsigned long long hitmask = ((unsigned long long)__float_as_uint(g2.w) << 32) | __float_as_uint(g2.z);
-  float4 g0 = make_float4(0, 0, 0, 0), g1 = g0;
-  if (!small) { g0 = grec[0]; g1 = make_float4(grec[1].x, grec[1].y, 0.0f, 0.0f); }   // (C, opacity): the projection kernel's operands
-  int bit = 0;
+  const float4 g0 = grec[0], g1 = make_float4(grec[1].x, grec[1].y, 0.0f, 0.0f);   // (C, opacity): the projection kernel's operands
   for (int ty = miny; ty < maxy; ++ty)
-    for (int tx = minx; tx < maxx; ++tx, ++bit) {
-      const bool h = small ? ((hitmask >> bit) & 1ull) != 0
-                           : gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
-      if (!h) continue;
+    for (int tx = minx; tx < maxx; ++tx) {
+      if (!gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1))) continue;
       if (off < cap) {
         keys[off] = vbase + (uint32_t)(ty * gx + tx);
-        vals[off] = n;                                   // the emit slot is recomputed from (n, tile) after the sort
+        vals[off] = n;
       }
       ++off;
     }

@@ -218,39 +218,42 @@ __device__ __forceinline__ void gh_blended_rgb(const GhInputs& in, uint32_t flag
 
 // Culling test: can Gaussian (g0 = px,py,A,B; g1 = C,opacity,..) reach alpha >= 1/255 at any pixel centre of the
 // block [qx0, qx0+ext] x [qy0, qy0+ext]?  alpha >= 1/255  <=>  q(d) = A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o).
-// q is convex, so its minimum over the rectangle is 0 if the centre is inside, otherwise it lies on one of the
-// four edges (a clamped 1-D parabola each): an exact ellipse/rectangle intersection up to rounding. The threshold
-// carries a margin for the approximate log / rcp; anything non-finite answers "hit". A false "hit" only costs
+// For a positive definite conic q is convex with its minimum 0 at the centre and grows along every ray from it, so its
+// minimum over the rectangle lies on an edge that FACES the centre: on the vertical line dx = clamp(0, lx, ux) or the
+// horizontal line dy = clamp(0, ly, uy) (the near edges; a line through the centre when the centre's coordinate is inside
+// the range — then the point found is inside the rectangle and at most ties the minimum; centre inside: q = 0). Each line
+// is a clamped 1-D parabola: an exact ellipse/rectangle intersection up to rounding, from two edges instead of four.
+// A conic that is not positive definite (a determinant that rounded to <= 0: needle-shaped covariances) or anything
+// non-finite answers "hit". The threshold carries a margin for the approximate log / rcp. A false "hit" only costs
 // time and a false "miss" is impossible within the margin: the exact per-pixel tests of App. A.3 still decide.
 __device__ __forceinline__ bool gh_block_hit(const float4& g0, const float4& g1, float qx0, float qy0, float ext) {
   const float o = g1.y;
   if (!(o >= 1.0f / 255.0f)) return false;          // alpha = min(.99, o*exp(p<=0)) <= o < 1/255 everywhere
   const float thr = 2.0f * (__logf(255.0f * o) * 1.0001f + 1e-3f);
   const float A = g0.z, B = g0.w, C = g1.x;
+  if (!(C > 0.0f && A * C - B * B > 0.0f)) return true;
   const float lx = qx0 - g0.x, ux = lx + ext, ly = qy0 - g0.y, uy = ly + ext;   // offset ranges of the block
-  const bool inside = (lx <= 0.0f) && (ux >= 0.0f) && (ly <= 0.0f) && (uy >= 0.0f);
   const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
-  // vertical edges dx = lx / ux: best dy = clamp(-B dx / C); horizontal edges dy = ly / uy: best dx = clamp(-B dy / A)
-  const float dy0 = fminf(fmaxf(-B * lx * rC, ly), uy), dy1 = fminf(fmaxf(-B * ux * rC, ly), uy);
-  const float dx0 = fminf(fmaxf(-B * ly * rA, lx), ux), dx1 = fminf(fmaxf(-B * uy * rA, lx), ux);
-  const float q0 = A * lx * lx + 2.0f * B * lx * dy0 + C * dy0 * dy0;
-  const float q1 = A * ux * ux + 2.0f * B * ux * dy1 + C * dy1 * dy1;
-  const float q2 = A * dx0 * dx0 + 2.0f * B * dx0 * ly + C * ly * ly;
-  const float q3 = A * dx1 * dx1 + 2.0f * B * dx1 * uy + C * uy * uy;
-  const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
+  const float xn = fminf(fmaxf(0.0f, lx), ux), yn = fminf(fmaxf(0.0f, ly), uy);  // the lines facing the centre
+  // on dx = xn the best dy = clamp(-B xn / C); on dy = yn the best dx = clamp(-B yn / A)
+  const float dyb = fminf(fmaxf(-B * xn * rC, ly), uy), dxb = fminf(fmaxf(-B * yn * rA, lx), ux);
+  const float q0 = A * xn * xn + 2.0f * B * xn * dyb + C * dyb * dyb;
+  const float q1 = A * dxb * dxb + 2.0f * B * dxb * yn + C * yn * yn;
+  const float qmin = fminf(q0, q1);
   // rounding of the (cancelling) terms of q: bounded by a few ulps of the largest term magnitude anywhere on the block,
   // A mx^2 + 2|B| mx my + C my^2 with (mx, my) the largest offsets — matters for far off-screen centres of elongated conics
   const float mx = fmaxf(fabsf(lx), fabsf(ux)), my = fmaxf(fabsf(ly), fabsf(uy));
   const float mag = A * mx * mx + 2.0f * fabsf(B) * mx * my + C * my * my;
-  const bool miss = !inside && (qmin * 0.9999f - 1e-6f * mag > thr);
+  const bool miss = qmin * 0.9999f - 1e-6f * mag > thr;
   return !miss;                                       // NaN compares false -> hit
 }
 // Exact tile culling (binning) and the per-instance 4x4-block mask (render kernels) are both this test:
 //   tile (tx, ty):            gh_block_hit(g0, g1, 16 tx, 16 ty, 15)
 //   block (bx, by) of a tile: gh_block_hit(g0, g1, 16 tx + 4 bx, 16 ty + 4 by, 3)   -> bit by*4 + bx
 // Same decision as 16 gh_block_hit(.., 3) calls, with the per-line terms shared: on the vertical line dx = u the
-// parabola in dy is C (dy - dy*)^2 + (A - B^2/C) u^2 with dy* = -B u / C, so an edge costs a clamp, a subtract and an
-// fma (and symmetrically for horizontal lines). The margin of the threshold absorbs the different rounding.
+// parabola in dy is C (dy - dy*)^2 + (A - B^2/C) u^2 with dy* = -B u / C, so a line costs a clamp, a subtract and an
+// fma (and symmetrically for horizontal lines); the facing line of a block depends on its column (row) only.
+// The margin of the threshold absorbs the different rounding.
 __device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const float4& g1, float tx0, float ty0) {
   const float o = g1.y;
   if (!(o >= 1.0f / 255.0f)) return 0u;
@@ -262,36 +265,29 @@ __device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const floa
   const float ox = tx0 - g0.x, oy = ty0 - g0.y;      // tile origin relative to the centre
   // rounding margin for the whole tile (see gh_block_hit): a few ulps of the largest term magnitude on it
   const float mx = fmaxf(fabsf(ox), fabsf(ox + 15.0f)), my = fmaxf(fabsf(oy), fabsf(oy + 15.0f));
-  const float thr_m = thr + 1e-6f * (A * mx * mx + 2.0f * fabsf(B) * mx * my + C * my * my);
-  float u[8], v[8], ux2[8], vy2[8], us[8], vs[8];
+  const float thr_m = (thr + 1e-6f * (A * mx * mx + 2.0f * fabsf(B) * mx * my + C * my * my)) * 1.0002f;   // (q * 0.9999 > t)
+  if (!(C > 0.0f && A * C - B * B > 0.0f && Kx > 0.0f && Ky > 0.0f && thr_m == thr_m)) return 0xFFFFu;    // not convex / non-finite
+  float lo_x[4], hi_x[4], lo_y[4], hi_y[4], us[4], vs[4], ux2[4], vy2[4];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    u[k] = ox + (float)((k >> 1) * 4 + (k & 1) * 3);  // x lines 0,3,4,7,8,11,12,15
-    v[k] = oy + (float)((k >> 1) * 4 + (k & 1) * 3);
-    ux2[k] = Kx * u[k] * u[k]; vy2[k] = Ky * v[k] * v[k];
-    us[k] = sx * u[k]; vs[k] = sy * v[k];
+  for (int k = 0; k < 4; ++k) {
+    lo_x[k] = ox + (float)(4 * k); hi_x[k] = ox + (float)(4 * k + 3);         // pixel-centre offsets of block column k
+    lo_y[k] = oy + (float)(4 * k); hi_y[k] = oy + (float)(4 * k + 3);
+    const float xn = fminf(fmaxf(0.0f, lo_x[k]), hi_x[k]), yn = fminf(fmaxf(0.0f, lo_y[k]), hi_y[k]);   // facing lines
+    us[k] = sx * xn; vs[k] = sy * yn;
+    ux2[k] = Kx * xn * xn; vy2[k] = Ky * yn * yn;
   }
   uint32_t m = 0;
-  bool nonfinite = !(thr_m == thr_m) || !(Kx == Kx) || !(Ky == Ky);
 #pragma unroll
   for (int by = 0; by < 4; ++by) {
-    const float ly = v[2 * by], uy = v[2 * by + 1];
 #pragma unroll
     for (int bx = 0; bx < 4; ++bx) {
-      const float lx = u[2 * bx], hx = u[2 * bx + 1];
-      const bool inside = (lx <= 0.0f) && (hx >= 0.0f) && (ly <= 0.0f) && (uy >= 0.0f);
-      const float d0 = fminf(fmaxf(us[2 * bx], ly), uy) - us[2 * bx];          // vertical edges
-      const float d1 = fminf(fmaxf(us[2 * bx + 1], ly), uy) - us[2 * bx + 1];
-      const float e0 = fminf(fmaxf(vs[2 * by], lx), hx) - vs[2 * by];          // horizontal edges
-      const float e1 = fminf(fmaxf(vs[2 * by + 1], lx), hx) - vs[2 * by + 1];
-      const float q0 = C * d0 * d0 + ux2[2 * bx], q1 = C * d1 * d1 + ux2[2 * bx + 1];
-      const float q2 = A * e0 * e0 + vy2[2 * by], q3 = A * e1 * e1 + vy2[2 * by + 1];
-      const float qmin = fminf(fminf(q0, q1), fminf(q2, q3));
-      const bool miss = !inside && (qmin * 0.9999f > thr_m);                   // NaN compares false -> hit
-      m |= miss ? 0u : (1u << (by * 4 + bx));
+      const float d = fminf(fmaxf(us[bx], lo_y[by]), hi_y[by]) - us[bx];       // vertical line of column bx within row by
+      const float e = fminf(fmaxf(vs[by], lo_x[bx]), hi_x[bx]) - vs[by];       // horizontal line of row by within column bx
+      const float qmin = fminf(fmaf(C * d, d, ux2[bx]), fmaf(A * e, e, vy2[by]));
+      m |= (qmin > thr_m) ? 0u : (1u << (by * 4 + bx));                         // NaN compares false -> hit
     }
   }
-  return nonfinite ? 0xFFFFu : m;
+  return m;
 }
 
 // wave64 ballot of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0/1 integer first)

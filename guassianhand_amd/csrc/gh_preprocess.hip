@@ -86,12 +86,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         // .y = packed tile rect, .zw = tile hit mask: the post-sort gather reads one line
         grec[2] = make_float4(rgb[2], __uint_as_float((unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24)),
                               __uint_as_float((unsigned)hitmask), __uint_as_float((unsigned)(hitmask >> 32)));
-        grec[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // completes the 64-byte line (full-line write)
         depth[n] = e.tz;
         dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
         clamped[n] = (uint8_t)cl;
       }
     }
+    // .x = instance count: the emit kernel, which walks the Gaussians in depth order, finds it in the line it reads anyway
+    // (written for every Gaussian: a culled one keeps a stale line from an earlier call apart from this count of 0)
+    geom[(size_t)n * 4 + 3] = make_float4(__uint_as_float(tiles), 0.0f, 0.0f, 0.0f);
     tiles_touched[n] = tiles;
     rect[n] = rect_bits;                               // 3-sigma tile rect of every projected Gaussian (0 = none)
     depth_key[n] = dkey;

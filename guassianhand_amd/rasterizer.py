@@ -149,23 +149,24 @@ def check_overflow(block: bool = True) -> None:
 
 
 # Workspace pool: a forward takes its workspace from here and the context gives it back when it dies (after its backward,
-# or when a no-grad caller drops it), so steady-state calls allocate nothing. Keyed by (device, bytes); all work of one
-# device runs on the caller's current stream, which orders a workspace's next use behind its previous one.
-_ws_pool: Dict[Tuple[int, int], list] = {}
+# or when a no-grad caller drops it), so steady-state calls allocate nothing. Keyed by (device, stream, bytes): a workspace
+# only ever returns to the stream that used it last, and that stream orders its next use behind the previous one (callers
+# that render on several streams at once — e.g. two half-batches overlapped in one captured graph — get one set per stream).
+_ws_pool: Dict[Tuple[int, int, int], list] = {}
 _WS_POOL_DEPTH = 4
 
 
-def _ws_acquire(dev: torch.device, nbytes: int) -> torch.Tensor:
-    free = _ws_pool.get((dev.index or 0, nbytes))
+def _ws_acquire(dev: torch.device, nbytes: int, stream: int) -> torch.Tensor:
+    free = _ws_pool.get((dev.index or 0, stream, nbytes))
     if free:
         return free.pop()
     return torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
 
-def _ws_release(ws: Optional[torch.Tensor]) -> None:
+def _ws_release(ws: Optional[torch.Tensor], stream: int) -> None:
     if ws is None:
         return
-    free = _ws_pool.setdefault((ws.device.index or 0, ws.numel()), [])
+    free = _ws_pool.setdefault((ws.device.index or 0, stream, ws.numel()), [])
     if len(free) < _WS_POOL_DEPTH:
         free.append(ws)
 
@@ -216,7 +217,7 @@ class _Ctx:
 
     def __del__(self):
         try:
-            _ws_release(getattr(self, "ws", None))
+            _ws_release(getattr(self, "ws", None), getattr(self, "stream", 0))
         except Exception:                      # interpreter shutdown
             pass
 
@@ -277,14 +278,14 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         cap = int(g0.dims.max_instances)
         dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
         nbytes = L.gh_workspace_bytes(C.byref(dims))
-        ws = _ws_acquire(dev, nbytes)
+        stream = _raw_stream(dev)
+        ws = _ws_acquire(dev, nbytes, stream)
         image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
         alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
         inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
                             _ptr(t["rotations"]), None, _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
                             _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
         out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha))
-        stream = _raw_stream(dev)
         with _OnDevice(dev):
             rc = L.gh_forward_shared(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(g0.ws.data_ptr()),
                                      C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
@@ -293,7 +294,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         _last_ws = ws
         ctx = _Ctx()
         ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
-        ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii = b_rgb, rows, alpha, g0, g0.radii
+        ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
         return image, g0.radii, ctx           # same geometry, same radii; an overflow is the first call's (NaN image here too)
     while True:
         cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))
@@ -301,7 +302,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         nbytes = L.gh_workspace_bytes(C.byref(dims))
         if nbytes == 0:
             raise RuntimeError("gh_workspace_bytes rejected the dimensions")
-        ws = _ws_acquire(dev, nbytes)
+        stream = _raw_stream(dev)
+        ws = _ws_acquire(dev, nbytes, stream)
         image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
         radii = torch.empty(NV, P, dtype=torch.int32, device=dev)
         alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
@@ -309,7 +311,6 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                             _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
                             _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
         out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha))
-        stream = _raw_stream(dev)
         with _OnDevice(dev):
             fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
             if _stage_timing:
@@ -353,7 +354,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
     ctx.b_rgb, ctx.rows = b_rgb, rows
-    ctx.alpha, ctx.parent, ctx.radii = alpha, None, radii
+    ctx.alpha, ctx.parent, ctx.radii, ctx.stream = alpha, None, radii, stream
     return image, radii, ctx
 
 
@@ -408,6 +409,7 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
                       dL_dblend_opacity_b=_ptr(o["opacity_b"]), dL_dblend_color_w=_ptr(o["color_w"]),
                       dL_dblend_color_b=_ptr(o["color_b"]), upstream_scale=_ptr(gs))
     stream = _raw_stream(dev)
+    ctx.stream = stream                            # the workspace goes back to the pool of the stream that used it last
     with _OnDevice(dev):
         bargs = (C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(),
                  C.c_void_p(stream))
