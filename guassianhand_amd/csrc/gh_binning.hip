@@ -435,7 +435,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   // first emit slot of this block = sum of the per-block instance counts of all blocks before it (gh_count_sorted_kernel):
   // every block adds them up itself (a few thousand coalesced L2 reads) instead of waiting for a one-block scan kernel
   uint32_t part = 0;
-  for (uint32_t b = tid; b < blockIdx.x; b += GH_BLOCK) part += block_sums[b];
+  const uint32_t blk = blockIdx.x;
+  for (uint32_t b = tid; b < blk; b += 4 * GH_BLOCK) {
+    const uint32_t b1 = b + GH_BLOCK, b2 = b + 2 * GH_BLOCK, b3 = b + 3 * GH_BLOCK;    // four loads in flight per trip
+    const uint32_t v0 = block_sums[b], v1 = b1 < blk ? block_sums[b1] : 0u, v2 = b2 < blk ? block_sums[b2] : 0u,
+                   v3 = b3 < blk ? block_sums[b3] : 0u;
+    part += (v0 + v1) + (v2 + v3);
+  }
   part = gh_wave_sum_u32(part);
   uint32_t x = cnt;
 #pragma unroll
@@ -503,7 +509,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
                                                               uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
-  const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
+  // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
+  // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
+  // right, a tile row apart for the one below — so its geometry line is found in the XCD's own L2 again instead of being
+  // fetched by whichever XCD the neighbouring block happened to land on. (Placement only matters for speed; the grid is a
+  // multiple of 8 blocks, so every (group, position) below the chunk length exists.)
+  const uint32_t chunk = ((n + GH_BLOCK - 1) / GH_BLOCK + 7u) >> 3;
+  if ((blockIdx.x >> 3) >= chunk) return;
+  const uint32_t i = ((blockIdx.x & 7u) * chunk + (blockIdx.x >> 3)) * GH_BLOCK + threadIdx.x;
   if (i >= n) return;
   inst_flag[i] = 0;                                    // quadrant flags of the backward's sub-records (emit slots 0 .. D-1)
   const uint32_t t = keys[i];
@@ -612,7 +625,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
   const int nblk_d = (int)((g.cap + GH_BLOCK - 1) / GH_BLOCK);
-  hipLaunchKernelGGL(gh_ranges_kernel, dim3(nblk_d), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,
+  hipLaunchKernelGGL(gh_ranges_kernel, dim3((nblk_d + 7) & ~7), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,
                      (const float4*)(ws + L.geom), (uint32_t*)(ws + L.sorted_slot),
                      (uint2*)(ws + L.ranges), (float4*)(ws + L.inst_r0),
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
