@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every rank renders --views-per-step cameras; strong: the --views-per-step cameras of ONE "
                          "step are split over the ranks (BASELINE configs[3]: 8 novel views sharded over 8 GPUs = 1 view per GPU)")
+    ap.add_argument("--split-streams", default="off", choices=["off", "on", "auto"],
+                    help="GH_FLAG_SPLIT_STREAMS: render the step's views as two halves on two HIP streams inside the library "
+                         "(bit-identical results); auto = from 4 views per rank up")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of --steps steps each; `value` / `ms_per_step` are the FIRST window's (the contract's exactly-K "
                          "steps), the others are reported as repeat statistics")
@@ -149,6 +152,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    R.set_split_streams({"off": False, "on": True, "auto": "auto"}[args.split_streams])
     V = args.views_per_step
     if args.scaling == "strong":
         assert V % world == 0, "--scaling strong: --views-per-step must be a multiple of the rank count"
@@ -322,7 +326,8 @@ def main():
         # instance count of the published algorithm (every tile of the 3-sigma rects) beside the exactly culled one
         with torch.no_grad():
             col = dict(colors_precomp=s.shs.reshape(-1, 3)) if s.use_rgb else dict(shs=s.shs, sh_degree=s.sh_degree)
-            _, _, rctx = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=H, W=W, sync=True, **col, **blend, **pv)
+            _, _, rctx = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=H, W=W, sync=True, split_streams=False,
+                                           **col, **blend, **pv)
             rect = R.workspace_views(rctx)["rect"].long()
             D_rect = int((((rect >> 16 & 255) - (rect & 255)) * ((rect >> 24 & 255) - (rect >> 8 & 255))).sum())
             del rctx
@@ -368,6 +373,7 @@ def main():
                                    "ms_per_step_max": max([dt] + extra) / args.steps * 1e3,
                                    "note": "`value` / `ms_per_step` are window 1 (the contract's timed region); the others follow it"},
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+                       "split_streams": bool(V >= 2 and (R._split_policy is True or (R._split_policy == "auto" and V >= 4))),
                        "hip_graph": graph is not None, "timed_steps": "HIP graph replay of one captured step" if graph is not None
                        else "eager kernel-by-kernel enqueue" + (f" [{graph_note}]" if graph_note else "")},
             "roofline": roofline, "stages": stages,

@@ -8,6 +8,7 @@ GH_CAM_FLOATS = 40
 GH_FLAG_BLEND_W_PER_GAUSSIAN = 1
 GH_FLAG_BLEND_COLOR_B_RGB = 2
 GH_FLAG_PER_VIEW_GAUSSIANS = 4
+GH_FLAG_SPLIT_STREAMS = 8
 
 GH_OK = 0
 GH_ERR_INVALID_ARG = -1
@@ -50,7 +51,7 @@ class GhGrads(C.Structure):
 LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "depth", "rect", "clamped",
                  "tiles_touched", "slot_begin", "depth_keys_a", "depth_keys_b", "depth_vals_a", "depth_vals_b",
                  "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "sorted_slot", "inst_r0", "inst_r1", "inst_r2",
-                 "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "key_bits")
+                 "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "half_counters", "key_bits")
 
 
 class GhLayout(C.Structure):

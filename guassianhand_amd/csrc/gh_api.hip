@@ -2,6 +2,8 @@
 // No allocation, no synchronisation, no host read-back: everything is enqueued on the caller's stream.
 #include "gh_internal.h"
 
+#include <mutex>
+
 static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 static int check_dims(const GhDims* d) {
@@ -18,6 +20,34 @@ static int check_dims(const GhDims* d) {
 }
 
 extern "C" int gh_version(void) { return (GH_VERSION_MAJOR << 16) | GH_VERSION_MINOR; }
+
+// ---- GH_FLAG_SPLIT_STREAMS: the two halves of the views -----------------------------------------------------------
+static bool gh_split_on(const GhDims* d) { return (d->flags & GH_FLAG_SPLIT_STREAMS) && d->n_views >= 2 && d->P > 0; }
+
+// Dims of half h (0 / 1): views [0, NV/2) / [NV/2, NV), a share of the instance capacity proportional to the views
+// (multiple of 64 slots). *v0 / *cap0: first view / first instance slot of the half.
+static GhDims gh_half_dims(const GhDims* d, int h, int* v0, size_t* cap0) {
+  const int nva = d->n_views / 2;
+  const size_t capa = ((size_t)d->max_instances * (size_t)nva / (size_t)d->n_views) & ~(size_t)63;
+  GhDims o = *d;
+  o.flags &= ~GH_FLAG_SPLIT_STREAMS;
+  o.n_views = h ? d->n_views - nva : nva;
+  o.max_instances = h ? (int64_t)((size_t)d->max_instances - capa) : (int64_t)capa;
+  *v0 = h ? nva : 0;
+  *cap0 = h ? capa : 0;
+  return o;
+}
+
+static size_t gh_sort_table_words(const GhGrid& g) {
+  const size_t tab_n = gh_radix_table_words((size_t)g.P, g.NV);          // per-view depth sort: NV segments of P keys
+  const size_t tab_d = gh_radix_table_words((size_t)g.cap);
+  return tab_n > tab_d ? tab_n : tab_d;
+}
+
+static size_t gh_proj_blocks(const GhGrid& g) {                          // grid of gh_preprocess_fwd_kernel
+  const size_t N = (size_t)g.N, T = (size_t)g.NV * g.tiles;
+  return ((N > T ? N : T) + GH_BLOCK - 1) / GH_BLOCK;
+}
 
 extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   int rc = check_dims(d);
@@ -38,7 +68,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->depth_keys_b = take(N * 4);
   L->depth_vals_a = take(N * 4);
   L->depth_vals_b = take(N * 4);
-  L->block_sums = take((nblk_pre + 1) * 4);
+  L->block_sums = take((nblk_pre + 3) * 4);               // (+2: the halves of a split call keep one spare entry each)
   L->keys_a = take(cap * 4);
   L->keys_b = take(cap * 4);
   L->vals_a = take(cap * 4);
@@ -47,14 +77,19 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->inst_r0 = take(cap * 16);
   L->inst_r1 = take(cap * 16);
   L->inst_r2 = take(cap * 8);
-  const size_t tab_n = gh_radix_table_words((size_t)g.P, g.NV);          // per-view depth sort: NV segments of P keys
-  const size_t tab_d = gh_radix_table_words((size_t)g.cap);
-  L->sort_tables = take((tab_n > tab_d ? tab_n : tab_d) * 4);
+  size_t tab = gh_sort_table_words(g);
+  if (gh_split_on(d)) {                                   // each half sorts with tables of its own
+    int v0; size_t c0;
+    const GhDims da = gh_half_dims(d, 0, &v0, &c0), db = gh_half_dims(d, 1, &v0, &c0);
+    const size_t both = gh_sort_table_words(gh_make_grid(&da)) + gh_sort_table_words(gh_make_grid(&db));
+    if (both > tab) tab = both;
+  }
+  L->sort_tables = take(tab * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
   L->tile_walk = take((size_t)g.NV * g.tiles * 8);       // walked entries [T] + completion counters [T]; directly after
                                                          // ranges: all cleared by one memset when there is nothing to project
   L->tile_order = take((size_t)g.NV * g.tiles * 4);
-  const size_t n_items = (size_t)g.NV * g.tiles + cap / GH_SEGMENT + 2;       // backward work items / checkpoint slots
+  const size_t n_items = (size_t)g.NV * g.tiles + cap / GH_SEGMENT + 4;       // backward work items / checkpoint slots (2 + 2 spare per half)
   L->bwd_items = take(n_items * 8);
   L->ckpt_rgb = take(n_items * 256 * 16);
   L->final_C = take(pix * 16);
@@ -68,8 +103,9 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->sh_scratch = take(sh_mode ? ((N * 16 + GH_BLOCK - 1) / GH_BLOCK + 1) * 64 * 4 : 0);   // sized for the pose-batch row count
   L->grad_sums = take(N * 48);
   L->bwd_scratch = take((2 * nblk_pre + 2) * 64 * 4);     // per-block partials of the chain-rule kernel (<= 2N lanes)
-  const size_t nblk_proj = (((N > (size_t)g.NV * g.tiles ? N : (size_t)g.NV * g.tiles)) + GH_BLOCK - 1) / GH_BLOCK;
-  L->key_bits = take((nblk_proj + 1) * 8);                // (OR, AND) of the visible depth keys per projection block
+  L->half_counters = take(512);
+  L->key_bits = take((gh_proj_blocks(g) + 4) * 8);        // (OR, AND) of the visible depth keys per projection block (+1 word; two
+                                                          // halves: + 1 block of rounding + 1 word each)
   L->total_bytes = off;
   return GH_OK;
 }
@@ -93,6 +129,100 @@ static int check_inputs(const GhDims* d, const GhInputs* in) {
   return GH_OK;
 }
 
+// The half's view of the workspace: every array that is indexed by (view, Gaussian), tile or pixel keeps its place in the
+// whole call's array (view-major), the per-instance arrays of the second half start at its first slot, and the few arrays
+// with another shape (scan scratch, sort tables, work list, key bits, counters) are cut in two.
+struct GhHalf {
+  GhDims d; GhGrid g; GhLayout L; GhInputs in;
+  int v0;
+};
+
+static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* in, GhHalf hv[2]) {
+  const GhGrid gf = gh_make_grid(d);
+  const bool per_view = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
+  const bool sh_mode = d->M != 0;
+  size_t blk_a = 0, items_a = 0, tab_a = 0, proj_a = 0;
+  for (int h = 0; h < 2; ++h) {
+    GhHalf& H = hv[h];
+    size_t cap0;
+    H.d = gh_half_dims(d, h, &H.v0, &cap0);
+    H.g = gh_make_grid(&H.d);
+    H.g.total_tiles = gf.total_tiles;
+    const size_t n0 = (size_t)H.v0 * gf.P, t0 = (size_t)H.v0 * gf.tiles, p0 = (size_t)H.v0 * gf.H * gf.W;
+    GhLayout& o = H.L;
+    o = L;
+    o.counters = L.half_counters + (size_t)h * 256;
+    o.geom += n0 * 64; o.depth += n0 * 4; o.rect += n0 * 4; o.clamped += n0; o.tiles_touched += n0 * 4; o.slot_begin += n0 * 4;
+    o.depth_keys_a += n0 * 4; o.depth_keys_b += n0 * 4; o.depth_vals_a += n0 * 4; o.depth_vals_b += n0 * 4;
+    o.block_sums += h ? (blk_a + 1) * 4 : 0;
+    o.keys_a += cap0 * 4; o.keys_b += cap0 * 4; o.vals_a += cap0 * 4; o.vals_b += cap0 * 4; o.sorted_slot += cap0 * 4;
+    o.inst_r0 += cap0 * 16; o.inst_r1 += cap0 * 16; o.inst_r2 += cap0 * 8;
+    o.sort_tables += h ? tab_a * 4 : 0;
+    o.ranges += t0 * 8; o.tile_walk += t0 * 8; o.tile_order += t0 * 4;
+    o.bwd_items += h ? items_a * 8 : 0; o.ckpt_rgb += h ? items_a * 256 * 16 : 0;
+    o.final_C += p0 * 16; o.final_T += p0 * 4; o.n_contrib += p0 * 4;
+    o.inst_grad += cap0 * 4 * GH_REC_G * 4; o.inst_flag += cap0 * 4;
+    if (sh_mode) { o.sh_rgb += n0 * 16; o.dmean_sh += n0 * 16; }
+    o.grad_sums += n0 * 48;
+    o.key_bits += h ? (proj_a + 1) * 8 : 0;
+    if (h == 0) {
+      blk_a = ((size_t)H.g.N + GH_BLOCK - 1) / GH_BLOCK; items_a = (size_t)H.g.n_items; tab_a = gh_sort_table_words(H.g);
+      proj_a = gh_proj_blocks(H.g);
+    }
+    H.in = *in;
+    H.in.cams = in->cams + (size_t)H.v0 * GH_CAM_FLOATS;
+    if (per_view) {                                       // pose batch: the half's own rows of every per-Gaussian array
+      const size_t r0 = n0;
+      H.in.means3D = in->means3D + r0 * 3; H.in.opacities = in->opacities + r0;
+      H.in.scales = in->scales + r0 * 3; H.in.rotations = in->rotations + r0 * 4;
+      if (in->shs) H.in.shs = in->shs + r0 * (size_t)d->M * 3;
+      if (in->colors_precomp) H.in.colors_precomp = in->colors_precomp + r0 * 3;
+      if (in->blend_opacity_b) H.in.blend_opacity_b = in->blend_opacity_b + r0;
+      if (in->blend_color_w && (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN)) H.in.blend_color_w = in->blend_color_w + r0 * 48;
+      if (in->blend_color_b) H.in.blend_color_b = in->blend_color_b + r0 * ((d->flags & GH_FLAG_BLEND_COLOR_B_RGB) ? 3 : 48);
+    }
+  }
+}
+
+// The library's own stream and fork / join events, one set per device, created on first use.
+struct GhSide { hipStream_t s2 = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+static GhSide* gh_side() {
+  static GhSide sides[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  GhSide& S = sides[dev];
+  if (!S.ok) {
+    if (hipStreamCreateWithFlags(&S.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&S.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&S.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    S.ok = true;
+  }
+  return &S;
+}
+static bool gh_fork(GhSide* S, hipStream_t s) {
+  return hipEventRecord(S->fork, s) == hipSuccess && hipStreamWaitEvent(S->s2, S->fork, 0) == hipSuccess;
+}
+static bool gh_join(GhSide* S, hipStream_t s) {
+  return hipEventRecord(S->join, S->s2) == hipSuccess && hipStreamWaitEvent(s, S->join, 0) == hipSuccess;
+}
+
+// Counters of the whole call from the halves': D = sum, overflow = either, reserved[0] = the max_instances that would have
+// given every half a share large enough.
+__global__ void gh_merge_counters_kernel(const GhCounters* __restrict__ a, const GhCounters* __restrict__ b,
+                                         GhCounters* __restrict__ out, uint32_t nv, uint32_t nva) {
+  const unsigned long long da = a->num_rendered, db = b->num_rendered, nvb = nv - nva;
+  unsigned long long need_a = (da * nv + nva - 1) / nva + 64ull * nv, need_b = (db * nv + nvb - 1) / nvb + 64ull * nv;
+  unsigned long long need = need_a > need_b ? need_a : need_b;
+  if (need > 0xFFFFFFFFull) need = 0xFFFFFFFFull;
+  const unsigned long long tot = da + db;
+  out->num_rendered = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;
+  out->overflow = (a->overflow | b->overflow) ? 1u : 0u;
+  out->reserved[0] = (uint32_t)need;
+  out->reserved[1] = 0u;
+}
+
 extern "C" int gh_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, void* workspace,
                           size_t ws_bytes, void* hip_stream) {
   return gh_forward_stages(d, in, out, workspace, ws_bytes, hip_stream, GH_FWD_ALL);
@@ -112,6 +242,30 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   char* ws = (char*)workspace;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
+  if (gh_split_on(d)) {
+    GhSide* S = gh_side();
+    if (!S) return GH_ERR_LAUNCH;
+    GhHalf hv[2];
+    gh_make_halves(d, L, in, hv);
+    if (!gh_fork(S, s)) return GH_ERR_LAUNCH;
+    for (int h = 0; h < 2; ++h) {
+      const GhHalf& H = hv[h];
+      hipStream_t sh = h ? S->s2 : s;
+      const size_t pix0 = (size_t)H.v0 * g.H * g.W;
+      if (stages & GH_FWD_PREPROCESS) {
+        gh_launch_sh_colour_fwd(&H.d, H.g, &H.in, ws, H.L, sh);
+        gh_launch_preprocess_fwd(&H.d, H.g, &H.in, out->radii ? out->radii + (size_t)H.v0 * g.P : nullptr, ws, H.L, sh);
+      }
+      if (stages & GH_FWD_BINNING) gh_launch_binning(&H.d, H.g, ws, H.L, sh);
+      if (stages & GH_FWD_RENDER)
+        gh_launch_render_fwd(&H.d, H.g, &H.in, out->image + pix0 * 3, out->alpha ? out->alpha + pix0 : nullptr, ws, ws, H.L, sh);
+    }
+    if (!gh_join(S, s)) return GH_ERR_LAUNCH;
+    hipLaunchKernelGGL(gh_merge_counters_kernel, dim3(1), dim3(1), 0, s, (const GhCounters*)(ws + hv[0].L.counters),
+                       (const GhCounters*)(ws + hv[1].L.counters), (GhCounters*)(ws + L.counters), (uint32_t)d->n_views,
+                       (uint32_t)hv[0].d.n_views);
+    return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+  }
   if (stages & GH_FWD_PREPROCESS) {
     // the projection kernel also resets the counters and the per-tile state (ranges, tile_walk) of the later stages
     gh_launch_sh_colour_fwd(d, g, in, ws, L, s);
@@ -145,6 +299,27 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
   char* ws = (char*)workspace;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
+  if (gh_split_on(d)) {
+    // the halves walk their lists and sum their sub-records side by side; the chain rule then runs once over all views
+    // (every per-(view, Gaussian) sum sits where the unsplit call puts it)
+    GhSide* S = gh_side();
+    if (!S) return GH_ERR_LAUNCH;
+    GhHalf hv[2];
+    gh_make_halves(d, L, in, hv);
+    if (!gh_fork(S, s)) return GH_ERR_LAUNCH;
+    for (int h = 0; h < 2; ++h) {
+      const GhHalf& H = hv[h];
+      hipStream_t sh = h ? S->s2 : s;
+      const size_t pix0 = (size_t)H.v0 * g.H * g.W;
+      if (stages & GH_BWD_RENDER)
+        gh_launch_render_bwd(&H.d, H.g, &H.in, gr->dL_dimage + pix0 * 3, gr->dL_dalpha ? gr->dL_dalpha + pix0 : nullptr,
+                             gr->upstream_scale, ws, ws, H.L, sh);
+      if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(&H.d, H.g, &H.in, gr, ws, ws, H.L, sh, GH_PBWD_RECORD_SUM);
+    }
+    if (!gh_join(S, s)) return GH_ERR_LAUNCH;
+    if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s, GH_PBWD_CHAIN);
+    return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+  }
   if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, ws, L, s);
   if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
@@ -157,6 +332,7 @@ static int check_shared(const GhDims* d, const GhInputs* in) {
   rc = check_inputs(d, in);
   if (rc != GH_OK) return rc;
   if (d->P > 0 && !in->colors_precomp) return GH_ERR_UNSUPPORTED;       // colours must be precomputed (no SH stage here)
+  if (d->flags & GH_FLAG_SPLIT_STREAMS) return GH_ERR_UNSUPPORTED;
   return GH_OK;
 }
 

@@ -19,6 +19,8 @@ struct GhGrid {
   int tile_bits, n_pass;
   int64_t cap;                        // max_instances
   int n_items;                        // capacity of the backward work list: NV*tiles + cap/GH_SEGMENT + 2
+  int64_t total_tiles;                // tiles of the whole call (a half of a GH_FLAG_SPLIT_STREAMS call keeps the full call's
+                                      // kernel variants, so that its results are the unsplit call's bit for bit)
 };
 
 static inline GhGrid gh_make_grid(const GhDims* d) {
@@ -30,6 +32,7 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
   g.tile_bits = tb; g.n_pass = 4 + (tb + 7) / 8;   // level-1 depth passes + level-3 tile passes
   g.cap = d->max_instances;
   g.n_items = (int)((size_t)g.NV * g.tiles + (size_t)g.cap / GH_SEGMENT + 2);
+  g.total_tiles = (int64_t)g.NV * g.tiles;
   return g;
 }
 
@@ -61,8 +64,13 @@ size_t gh_radix_table_words(size_t per_segment, int segs);
 void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, char* ws, const GhLayout& L, hipStream_t s);
 int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
                             const GhLayout& L, hipStream_t s);
+// parts: GH_PBWD_RECORD_SUM (fixed-order sums of the render backward's sub-records, per (view, Gaussian)) and / or
+// GH_PBWD_CHAIN (SH colour backward, chain rule, blend-parameter reductions)
+#define GH_PBWD_RECORD_SUM 1
+#define GH_PBWD_CHAIN 2
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr,
-                              const char* wg, char* ws, const GhLayout& L, hipStream_t s);
+                              const char* wg, char* ws, const GhLayout& L, hipStream_t s,
+                              int parts = GH_PBWD_RECORD_SUM | GH_PBWD_CHAIN);
 
 #if defined(__HIPCC__)
 // ---- arithmetic contract: fp32, no implicit contraction, FMAs only where written ----

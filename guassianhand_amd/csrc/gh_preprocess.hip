@@ -450,7 +450,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_blend_reduce_kernel(const float* 
 }
 
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, const char* wg, char* ws,
-                              const GhLayout& L, hipStream_t s) {
+                              const GhLayout& L, hipStream_t s, int parts) {
   if (g.P == 0) return;
   const bool per_view = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   const int rows = per_view ? g.N : g.P;
@@ -459,9 +459,11 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   int nblk = (int)((((size_t)rows << lg) + GH_BLOCK - 1) / GH_BLOCK);   // <= 2 N / 256 + 1: bwd_scratch holds 64 floats per block
   auto kern = in->colors_precomp ? gh_preprocess_bwd_kernel<true> : gh_preprocess_bwd_kernel<false>;
   const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
-  hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
-                     (const uint32_t*)(wg + L.slot_begin), (const uint32_t*)(wg + L.tiles_touched),
-                     (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
+  if (parts & GH_PBWD_RECORD_SUM)
+    hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
+                       (const uint32_t*)(wg + L.slot_begin), (const uint32_t*)(wg + L.tiles_touched),
+                       (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
+  if (!(parts & GH_PBWD_CHAIN)) return;
   const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, ws, L, s);     // SH mode only; no-op with colors_precomp
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, lg,

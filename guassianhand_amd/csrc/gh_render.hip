@@ -673,7 +673,7 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   if (g.cap == 0) return;
   // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (they depend on the forward's
   // n_contrib only). The work list (tile, depth segment) was written by the forward's last wave of every tile.
-  const bool small = (size_t)g.NV * g.tiles <= GH_FINE_TILES;    // few tiles: four waves per quadrant (one per 4x4 block)
+  const bool small = g.total_tiles <= GH_FINE_TILES;    // few tiles: four waves per quadrant (one per 4x4 block)
   const dim3 grid(4 * (unsigned)g.n_items), block(small ? 4 * GH_WAVE : GH_WAVE);   // capacity of the work list x 4 quadrants; surplus workgroups exit at once
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(wg + L.ranges), (const uint2*)(ws + L.bwd_items),

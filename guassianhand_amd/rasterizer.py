@@ -117,6 +117,24 @@ def set_graph_mode(on: bool) -> None:
         _graph_counters.clear()
 
 
+_split_policy = False       # False | True | "auto"
+_SPLIT_AUTO_MIN_VIEWS = 4
+
+
+def set_split_streams(mode) -> None:
+    """Module policy for calls that do not say (split_streams=None): False = one stream, True = split whenever n_views >= 2,
+    "auto" = split from 4 views up (GH_FLAG_SPLIT_STREAMS; results are bit-identical either way)."""
+    global _split_policy
+    if mode not in (False, True, "auto"):
+        raise ValueError("set_split_streams: False, True or 'auto'")
+    _split_policy = mode
+
+
+def capacity_key(P: int, NV: int, H: int, W: int, split: bool = False):
+    """Key of the learned instance capacity of a call shape (tests / tools)."""
+    return (P, NV, H, W, bool(split))
+
+
 def _initial_capacity(P: int, NV: int) -> int:
     return max(1 << 16, 8 * P * NV)
 
@@ -125,8 +143,11 @@ def check_overflow(block: bool = True) -> None:
     """Verify every outstanding sync-free forward fitted its capacity (raises GhOverflowError)."""
     global _pending, _last_D
     for counters, cap, key in list(_graph_counters.values()):   # graph mode: workspaces are static, read them directly
-        d = int(counters[0].item()) & 0xFFFFFFFF
+        c4 = counters.tolist()
+        d = c4[0] & 0xFFFFFFFF
         _last_D = d
+        if key[-1]:                                    # split call: the capacity that would have sufficed for both halves
+            d = c4[2] & 0xFFFFFFFF
         if d > cap:
             _capacity[key] = max(_capacity.get(key, 0), int(d * 1.5) + 1024)
             raise GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside a captured graph")
@@ -137,8 +158,10 @@ def check_overflow(block: bool = True) -> None:
             continue
         ev.synchronize()
         d = int(host[0]) & 0xFFFFFFFF
-        _free_slots.append((host, ev))
         _last_D = d
+        if key[-1]:
+            d = int(host[2]) & 0xFFFFFFFF
+        _free_slots.append((host, ev))
         if d > cap:
             _capacity[key] = max(_capacity.get(key, 0), int(d * 1.5) + 1024)
             bad = (d, cap)
@@ -225,14 +248,18 @@ class _Ctx:
 def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None, colors_precomp=None,
                    sh_degree: int = 0, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
                    color_b=None, max_instances: Optional[int] = None, sync: Optional[bool] = True, return_alpha: bool = False,
-                   per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None):
+                   per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None,
+                   split_streams: Optional[bool] = None):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
     with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha.
     per_view_gaussians (pose batch, the batch loop of GS3DRenderer.forward): every per-Gaussian tensor holds NV*P rows and
     view v renders rows [v*P, (v+1)*P) — NV different Gaussian sets in one launch sequence.
     geometry_of: context of an earlier forward with the SAME means3D / opacities / scales / rotations / cameras (apart from
     bg): this call re-uses its projection and tile lists (gh_forward_shared) and only walks the lists with its own colours —
-    the reference's mask pass after the RGB pass of a view. Colours must be colors_precomp."""
+    the reference's mask pass after the RGB pass of a view. Colours must be colors_precomp.
+    split_streams (GH_FLAG_SPLIT_STREAMS, n_views >= 2): the views run as two halves on two HIP streams inside the library
+    (forked from / joined into the current stream, graph-capturable); bit-identical images, radii and gradients.
+    None = the module policy (set_split_streams)."""
     global _last_D, _last_ws
     L = _lib.lib()
     dev = means3D.device
@@ -253,6 +280,11 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             raise ValueError("per_view_gaussians: the Gaussian tensors must hold n_views * P rows")
         flags |= _abi.GH_FLAG_PER_VIEW_GAUSSIANS
     P = rows // NV if per_view_gaussians else rows
+    if split_streams is None:
+        split_streams = _split_policy is True or (_split_policy == "auto" and NV >= _SPLIT_AUTO_MIN_VIEWS)
+    split = bool(split_streams) and NV >= 2 and P > 0 and geometry_of is None and not _stage_timing
+    if split:
+        flags |= _abi.GH_FLAG_SPLIT_STREAMS
     wpg = False
     if t["color_w"] is not None:
         if t["color_w"].numel() == 48:
@@ -269,10 +301,10 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             b_rgb = True
         elif t["color_b"].numel() != rows * 48:
             raise ValueError("color_b must have P*48 elements (or P*3 with colors_precomp)")
-    key = (P, NV, H, W)
+    key = (P, NV, H, W, split)
     if geometry_of is not None:
         g0 = geometry_of
-        if shs is not None or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (P, NV, H, W, rows) or \
+        if shs is not None or (g0.dims.flags & _abi.GH_FLAG_SPLIT_STREAMS) or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (P, NV, H, W, rows) or \
                 (g0.dims.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) != (flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS):
             raise ValueError("geometry_of: the second call must have the first one's shapes and precomputed colours")
         cap = int(g0.dims.max_instances)
@@ -328,8 +360,11 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             if not sync:
                 check_overflow(block=False)               # surfaces an overflow of an earlier sync-free call as soon as it is known
         if sync:
-            d = int(counters[0].item()) & 0xFFFFFFFF      # the one host read-back, as in the reference wrapper
+            c4 = counters.tolist()                        # the one host read-back, as in the reference wrapper
+            d = c4[0] & 0xFFFFFFFF
             _last_D = d
+            if split:                                      # the capacity that gives each half of the views a large enough share
+                d = c4[2] & 0xFFFFFFFF
             if d > cap:
                 if max_instances is not None:
                     raise GhOverflowError(f"tile instances D={d} exceed max_instances={cap}")
@@ -444,6 +479,8 @@ def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
     L = _lib.lib()
     lay = _abi.GhLayout()
     L.gh_workspace_layout(C.byref(ctx.dims), C.byref(lay))
+    if ctx.dims.flags & _abi.GH_FLAG_SPLIT_STREAMS:
+        raise ValueError("workspace_views: a split call keeps two sets of per-instance arrays; render with split_streams=False")
     ws, N, cap = ctx.ws, ctx.NV * ctx.P, int(ctx.dims.max_instances)
     gx, gy = (ctx.W + 15) // 16, (ctx.H + 15) // 16
     pix = ctx.NV * ctx.H * ctx.W

@@ -59,6 +59,14 @@ typedef enum GhStatus {
                                          [v*P, (v+1)*P) only (its own pose); color_w (48,), xyz_b stay shared */
 #define GH_FLAG_BLEND_COLOR_B_RGB 2u    /* colors_precomp mode only: blend_color_b and dL_dblend_color_b are (P,3), the
                                            three columns of the (P,48) view that renderer_one_shot.py:328 reads */
+#define GH_FLAG_SPLIT_STREAMS 8u        /* n_views >= 2: the views are rendered as two independent halves (views [0, n/2) and
+                                           [n/2, n)), the second on a HIP stream of the library's own, forked from and joined
+                                           back into the caller's stream inside every call (graph-capturable): the drain of one
+                                           half's kernels is filled with the other half's work. Images, radii and gradients
+                                           are bit-identical to the unsplit call. Each half gets its share of max_instances
+                                           (proportional to its views): GhCounters.overflow is set when either half exceeds
+                                           its share, and GhCounters.reserved[0] holds the max_instances that would have
+                                           sufficed. Not available for gh_forward_shared / gh_backward_shared. */
 
 /*
  * One camera, GH_CAM_FLOATS consecutive floats in DEVICE memory (built by the caller without a host sync):
@@ -107,7 +115,7 @@ typedef struct GhOutputs {
 typedef struct GhCounters {
   uint32_t num_rendered; /* D: tile instances emitted (before clamping to max_instances) */
   uint32_t overflow;     /* 1 if D > max_instances: image/gradients are invalid, re-run with a larger workspace */
-  uint32_t reserved[2];
+  uint32_t reserved[2];  /* [0] after a GH_FLAG_SPLIT_STREAMS forward: the max_instances that would have sufficed */
 } GhCounters;
 
 /* Upstream gradient + outputs of gh_backward. Any output pointer may be NULL (that gradient is skipped). */
@@ -172,6 +180,9 @@ typedef struct GhLayout {
   size_t sh_scratch;     /* float[ceil(P/16)][64] block partials of the global colour-weight gradient (SH mode) */
   size_t grad_sums;      /* float4[n_views*P][3] per-(view,Gaussian) sums of the sub-records: dpx dpy dA dB | dC do dr dg | db */
   size_t bwd_scratch;    /* blend-parameter reduction scratch */
+  size_t half_counters;  /* GhCounters[2], 256 bytes apart: the counters of the two halves of a GH_FLAG_SPLIT_STREAMS call (every
+                            per-view / per-tile / per-pixel array keeps its place; a half's per-instance arrays start at its
+                            share of max_instances) */
   size_t key_bits;       /* uint2[projection blocks] (OR, AND) over the depth-key bits of the block's visible Gaussians: a depth-sort
                             pass whose digit is the same in every key (OR & ~AND has no bit in it) degenerates to a copy */
 } GhLayout;

@@ -43,7 +43,17 @@ def half_step(params, views):
     return loss
 
 
-def run(nsplit):
+def fwd_only(params, views):
+    for p in params.values():
+        p.grad = None
+    loss, _, _ = rendered_l1_loss(views[0], params["xyz"], params["opacity"], params["scaling"], params["rotation"],
+                                  params["shs"], views[1], H=H, W=W, use_rgb=s.use_rgb, sh_degree=s.sh_degree,
+                                  sync=False, xyz_b=params["xyz_b"], opacity_b=params["opacity_b"], color_w=params["color_w"],
+                                  color_b=params["color_b"])
+    return loss
+
+
+def run(nsplit, stagger=False, midjoin=False):
     per = 8 // nsplit
     groups = [(cams[i * per:(i + 1) * per].contiguous(), gt[i * per:(i + 1) * per].contiguous()) for i in range(nsplit)]
     plist = [mk_params() for _ in groups]
@@ -65,14 +75,33 @@ def run(nsplit):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
         cur = torch.cuda.current_stream()
-        for st in streams:
-            st.wait_stream(cur)
-        for st, g, p in zip(streams, groups[1:], plist[1:]):
-            with torch.cuda.stream(st):
-                half_step(p, g)
-        half_step(plist[0], groups[0])
-        for st in streams:
-            cur.wait_stream(st)
+        if midjoin:                                   # both halves join after the forward + loss, fork again for the backward
+            streams[0].wait_stream(cur)
+            with torch.cuda.stream(streams[0]):
+                lossB = fwd_only(plist[1], groups[1])
+            lossA = fwd_only(plist[0], groups[0])
+            cur.wait_stream(streams[0])
+            streams[0].wait_stream(cur)
+            with torch.cuda.stream(streams[0]):
+                lossB.backward(seed)
+            lossA.backward(seed)
+            cur.wait_stream(streams[0])
+        elif stagger:                                   # B starts when A's forward is done: B's binning under A's backward
+            lossA = fwd_only(plist[0], groups[0])
+            streams[0].wait_stream(cur)
+            with torch.cuda.stream(streams[0]):
+                half_step(plist[1], groups[1])
+            lossA.backward(seed)
+            cur.wait_stream(streams[0])
+        else:
+            for st in streams:
+                st.wait_stream(cur)
+            for st, g, p in zip(streams, groups[1:], plist[1:]):
+                with torch.cuda.stream(st):
+                    half_step(p, g)
+            half_step(plist[0], groups[0])
+            for st in streams:
+                cur.wait_stream(st)
     for _ in range(5):
         graph.replay()
     torch.cuda.synchronize()
@@ -85,8 +114,7 @@ def run(nsplit):
         best = min(best, (time.perf_counter() - t0) / 20 * 1e3)
     R.set_graph_mode(False)
     R.check_overflow()
-    print(f"{nsplit} stream(s) x {per} views: {best:.3f} ms per 8-view step", flush=True)
+    print(f"{nsplit} stream(s) x {per} views{' (staggered)' if stagger else ''}{' (join after forward)' if midjoin else ''}: {best:.3f} ms per 8-view step", flush=True)
 
 
-for n in (1, 2, 4, 1):
-    run(n)
+run(1); run(2); run(2, midjoin=True); run(2); run(2, midjoin=True); run(1)
