@@ -421,11 +421,12 @@ __device__ __forceinline__ uint32_t gh_kth_set_bit(uint32_t lo, uint32_t hi, uin
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ slot_begin, float4* __restrict__ geom,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr) {
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP) {
   constexpr int NW = GH_BLOCK / GH_WAVE;
   __shared__ uint32_t s_w[NW], s_p[NW];
   __shared__ uint32_t s_end[NW][GH_WAVE];               // per wave: inclusive prefix of the lanes' instance counts
   __shared__ uint4 s_g[NW][GH_WAVE];                    // (rect, hit mask lo, hi, n); rect = 0: not written by the wave
+  __shared__ uint32_t s_vb[NW][GH_WAVE];                // first global tile id of the Gaussian's view
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = blockIdx.x * GH_BLOCK + tid;
   const uint32_t n = i < N ? perm[i] : 0u;
@@ -451,6 +452,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   const bool small = (maxx - minx) * (maxy - miny) <= 64;               // the projection kernel kept the hit mask
   s_end[wid][lane] = x;
   s_g[wid][lane] = make_uint4(small && cnt ? r : 0u, __float_as_uint(g2.z), __float_as_uint(g2.w), n);
+  const uint32_t vbase = (rP > 0.0f ? gh_div_small(n, (uint32_t)P, rP) : n / (uint32_t)P) * (uint32_t)tiles;   // per Gaussian, not per instance
+  s_vb[wid][lane] = vbase;
   if (lane == 63) s_w[wid] = x;
   if (lane == 0) s_p[wid] = part;
   __syncthreads();
@@ -479,13 +482,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     const uint32_t dy = (uint32_t)(((float)bit + 0.5f) * __frcp_rn((float)wdt)), dx = bit - dy * wdt;
     const uint32_t slot = wave_base + sl;
     if (slot < cap) {
-      keys[slot] = (g.w / (uint32_t)P) * (uint32_t)tiles + (mny + dy) * (uint32_t)gx + (mnx + dx);
+      keys[slot] = s_vb[wid][o] + (mny + dy) * (uint32_t)gx + (mnx + dx);
       vals[slot] = g.w;                                  // the emit slot is recomputed from (n, tile) after the sort
     }
   }
   if (i >= N || cnt == 0 || small) return;
   uint32_t off = wave_base + x - cnt;
-  const uint32_t vbase = (n / (uint32_t)P) * (uint32_t)tiles;
   const float4 g0 = grec[0], g1 = make_float4(grec[1].x, grec[1].y, 0.0f, 0.0f);   // (C, opacity): the projection kernel's operands
   for (int ty = miny; ty < maxy; ++ty)
     for (int tx = minx; tx < maxx; ++tx) {
@@ -507,7 +509,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               const float4* __restrict__ geom, uint32_t* __restrict__ sorted_slot,
                                                               uint2* __restrict__ ranges, float4* __restrict__ r0,
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
-                                                              uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin) {
+                                                              uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin,
+                                                              float rtiles, float rgx) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
   // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
@@ -532,7 +535,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   const uint32_t slot0 = slot_begin[gid];            // first emit slot (4-byte gather from an L2-sized array; keeping it
                                                      // in the geometry line cost the emit kernel a scattered line write)
   const float cb = c.x;
-  const uint32_t tl = t % (uint32_t)tiles, ty = tl / (uint32_t)gx, tx = tl - ty * (uint32_t)gx;
+  uint32_t tl, ty;                                     // tile inside the view, its row
+  if (rtiles > 0.0f) { tl = t - gh_div_small(t, (uint32_t)tiles, rtiles) * (uint32_t)tiles; ty = gh_div_small(tl, (uint32_t)gx, rgx); }
+  else { tl = t % (uint32_t)tiles; ty = tl / (uint32_t)gx; }
+  const uint32_t tx = tl - ty * (uint32_t)gx;
   // emit slot of (gid, tile): the Gaussian's instances were emitted row-major over the HIT tiles of its rect
   const uint32_t r = __float_as_uint(c.y);
   const uint32_t minx = r & 255u, miny = (r >> 8) & 255u, maxx = (r >> 16) & 255u, maxy = r >> 24;
@@ -620,7 +626,8 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* k_in = start_b ? kb : ka; uint32_t* k_out = start_b ? ka : kb;
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
-                     (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (float4*)(ws + L.geom), k_in, v_in, ctr);
+                     (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (float4*)(ws + L.geom), k_in, v_in, ctr,
+                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f);
   if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }    // the emit kernel has written D (it stores nothing past cap)
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
@@ -629,6 +636,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (const float4*)(ws + L.geom), (uint32_t*)(ws + L.sorted_slot),
                      (uint2*)(ws + L.ranges), (float4*)(ws + L.inst_r0),
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
-                     (const uint32_t*)(ws + L.slot_begin));
+                     (const uint32_t*)(ws + L.slot_begin),
+                     (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx);   // gh_div_small's range
   gh_launch_tile_order(g, ws, L, s);
 }

@@ -298,6 +298,15 @@ __device__ __forceinline__ uint32_t gh_block_mask16(const float4& g0, const floa
   return m;
 }
 
+// t / d for t < 2^24 and a quotient below 2^21 (tile ids, Gaussian indices inside a launch): an fp32 estimate with rd = 1 / d and
+// one correction step — the integer division the compiler emits for a run-time divisor costs ~40 instructions.
+__device__ __forceinline__ uint32_t gh_div_small(uint32_t t, uint32_t d, float rd) {
+  uint32_t q = (uint32_t)((float)t * rd);
+  const uint32_t r = t - q * d;                        // wraps below zero when the estimate is one too large
+  if ((int32_t)r < 0) q -= 1u; else if (r >= d) q += 1u;
+  return q;
+}
+
 // wave64 ballot of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0/1 integer first)
 __device__ __forceinline__ uint64_t gh_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 

@@ -68,13 +68,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_fit_loss_kernel(const float* __re
                                                                 const float* __restrict__ gt_rgb, const float* __restrict__ gt_mask,
                                                                 const float* __restrict__ bbox, int NV, int HW, float k_l1, float k_m,
                                                                 float* __restrict__ dimage, float* __restrict__ dalpha,
-                                                                float* __restrict__ partials, const GhCounters* __restrict__ guard) {
+                                                                float* __restrict__ partials, const GhCounters* __restrict__ guard,
+                                                                float rHW) {
   __shared__ float s_w[GH_BLOCK / GH_WAVE];
   float acc = 0.0f;
   const size_t npix = (size_t)NV * HW;
   const float live = (guard && guard->overflow) ? 0.0f : 1.0f;   // instance overflow: invalid images, no gradient leaves here
   for (size_t i = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; i < npix; i += (size_t)gridDim.x * GH_BLOCK) {
-    const size_t v = i / HW, p = i - v * HW;
+    const size_t v = rHW > 0.0f ? (size_t)gh_div_small((uint32_t)i, (uint32_t)HW, rHW) : i / HW, p = i - v * HW;   // (no 64-bit division per pixel)
     const bool in_box = bbox ? bbox[i] != 0.0f : true;
     const float* im = image + v * 3 * HW + p;
     float* di = dimage + v * 3 * HW + p;
@@ -106,7 +107,8 @@ extern "C" int gh_fit_loss(const float* image, const float* alpha, const float* 
   const int HW = H * W;
   hipStream_t s = (hipStream_t)hip_stream;
   hipLaunchKernelGGL(gh_fit_loss_kernel, dim3((unsigned)n_partials), dim3(GH_BLOCK), 0, s, image, alpha, gt_rgb, gt_mask, bbox,
-                     n_views, HW, scale * lambda_l1 / (3.0f * (float)HW), scale * lambda_mask / (float)HW, dL_dimage, dL_dalpha, partials, guard);
+                     n_views, HW, scale * lambda_l1 / (3.0f * (float)HW), scale * lambda_mask / (float)HW, dL_dimage, dL_dalpha, partials, guard,
+                     (long long)n_views * HW < (1ll << 24) ? 1.0f / (float)HW : 0.0f);
   hipLaunchKernelGGL(gh_partials_sum_kernel, dim3(1), dim3(GH_BLOCK), 0, s, partials, n_partials, 1.0f, loss_out, guard);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk,
-    uint2* __restrict__ key_bits) {
+    uint2* __restrict__ key_bits, float rdiv) {
   __shared__ uint2 s_bits[GH_BLOCK / GH_WAVE];
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
@@ -30,8 +30,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     // a 4-byte element of a view-major array (n = v * P + i): consecutive rows of a view stay adjacent in memory.
     // Pose batch (own rows per view): n = t, row = n.
     int v, i;
-    if (flags & GH_FLAG_PER_VIEW_GAUSSIANS) { v = t / P; i = t; }
-    else { i = t / NV; v = t - i * NV; }
+    // (rdiv = 1 / divisor where gh_div_small's range allows it: a run-time integer division costs ~40 instructions)
+    if (flags & GH_FLAG_PER_VIEW_GAUSSIANS) { v = rdiv > 0.0f ? (int)gh_div_small((uint32_t)t, (uint32_t)P, rdiv) : t / P; i = t; }
+    else { i = rdiv > 0.0f ? (int)gh_div_small((uint32_t)t, (uint32_t)NV, rdiv) : t / NV; v = t - i * NV; }
     const int n = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : v * P + i;
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     int radius = 0;
@@ -125,7 +126,8 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                      (float*)(ws + L.depth),
                      (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii,
-                     T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk), (uint2*)(ws + L.key_bits));
+                     T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk), (uint2*)(ws + L.key_bits),
+                     g.N < (1 << 24) ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,12 +40,12 @@ __device__ __forceinline__ void gh_sh_chain_step(float bk, float s0, float s1, f
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in, int P, int N, int sh_degree, int M,
-                                                                     uint32_t flags, float4* __restrict__ sh_rgb) {
+                                                                     uint32_t flags, float4* __restrict__ sh_rgb, float rP) {
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   const int n = t >> 4, k = t & 15;
   const bool live = n < N;
   const int nn = live ? n : 0;
-  const int v = nn / P;
+  const int v = rP > 0.0f ? (int)gh_div_small((uint32_t)nn, (uint32_t)P, rP) : nn / P;
   const int i = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? nn : nn - v * P;
   const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
   float mx = in.means3D[3 * i], my = in.means3D[3 * i + 1], mz = in.means3D[3 * i + 2];
@@ -193,7 +193,7 @@ void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* i
   if (g.N == 0 || !in->shs) return;
   const size_t threads = (size_t)g.N * 16;
   hipLaunchKernelGGL(gh_sh_colour_fwd_kernel, dim3((unsigned)((threads + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0, s, *in, g.P,
-                     g.N, d->sh_degree, d->M, d->flags, (float4*)(ws + L.sh_rgb));
+                     g.N, d->sh_degree, d->M, d->flags, (float4*)(ws + L.sh_rgb), g.N < (1 << 24) && g.P > 0 ? 1.0f / (float)g.P : 0.0f);
 }
 
 // returns the number of scratch blocks written (0 when the global colour-weight reduction is not needed)

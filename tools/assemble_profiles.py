@@ -11,7 +11,7 @@ shutil.copy(f"{O}/pmc_fetch_write_8views.csv", f"profiles/{tag}_pmc_fetch_write_
 for n in ("bench_default", "bench_1view", "bench_two_hands_hd_sh3", "bench_two_hands_hd_sh3_pose_batch32"):
     if os.path.exists(f"{O}/{n}.json"):
         shutil.copy(f"{O}/{n}.json", f"profiles/{tag}_{n}.json")
-for n in ("two_call_cost.txt", "valu_rate.txt"):
+for n in ("two_call_cost.txt", "valu_rate.txt", "dropin_host_breakdown.txt", "fit_step_profile.txt"):
     if os.path.exists(f"{O}/{n}") and os.path.getsize(f"{O}/{n}") > 0:
         shutil.copy(f"{O}/{n}", f"profiles/{tag}_{n}")
 rows = list(csv.DictReader(open(f"{O}/kernel_stats.csv")))

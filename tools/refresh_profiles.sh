@@ -4,7 +4,6 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
 mkdir -p $O
-echo "== bench default" && timeout 300 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo "== bench 1 view" && timeout 300 python3 bench.py --views-per-step 1 --no-cpu-baseline > $O/bench_1view.json 2> $O/bench_1view.err || exit 1
 echo "== bench hd sh3" && timeout 300 python3 bench.py --config two_hands_hd --no-cpu-baseline > $O/bench_two_hands_hd_sh3.json 2> $O/bench_hd.err || exit 1
 echo "== bench hd sh3 pose batch 32" && timeout 400 python3 bench.py --config two_hands_hd --pose-batch --views-per-step 32 --steps 5 --warmup 2 --repeats 3 --no-cpu-baseline > $O/bench_two_hands_hd_sh3_pose_batch32.json 2> $O/bench_hd_pb.err || exit 1
@@ -29,4 +28,11 @@ for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_
   rm -rf $O/pmc_$tag
 done
 python3 -c "import bench; print(bench.source_hash())" > $O/source_hash.txt
+echo "== host breakdown of the drop-in, fit step"
+timeout 300 python3 tools/dropin_time.py 2> /dev/null | grep -v amdgpu.ids > $O/dropin_host_breakdown.txt
+timeout 300 python3 tools/fit_profile.py 2> /dev/null | grep -v amdgpu.ids > $O/fit_step_profile.txt
+# the default bench line last: it quotes the counter summaries of THIS build (profiles/<tag>_pmc_*.json, written here on the box
+# by the assemble step; run tools/assemble_profiles.py again at home to pick up the bench line itself)
+python3 tools/assemble_profiles.py $TAG > /dev/null || exit 1
+echo "== bench default" && timeout 300 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo done
