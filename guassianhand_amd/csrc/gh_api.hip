@@ -185,7 +185,9 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
 }
 
 // The library's own stream and fork / join events, one set per device, created on first use.
-struct GhSide { hipStream_t s2 = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+// `call` is held for the whole of a split call: the events are re-recorded by every call, so two host threads must not
+// interleave their fork / join pairs (split calls of one device are enqueued one after the other; they still overlap on the GPU).
+struct GhSide { hipStream_t s2 = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; std::mutex call; };
 static GhSide* gh_side() {
   static GhSide sides[64];
   static std::mutex mu;
@@ -245,6 +247,7 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   if (gh_split_on(d)) {
     GhSide* S = gh_side();
     if (!S) return GH_ERR_LAUNCH;
+    std::lock_guard<std::mutex> one_call(S->call);
     GhHalf hv[2];
     gh_make_halves(d, L, in, hv);
     if (!gh_fork(S, s)) return GH_ERR_LAUNCH;
@@ -304,6 +307,7 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
     // (every per-(view, Gaussian) sum sits where the unsplit call puts it)
     GhSide* S = gh_side();
     if (!S) return GH_ERR_LAUNCH;
+    std::lock_guard<std::mutex> one_call(S->call);
     GhHalf hv[2];
     gh_make_halves(d, L, in, hv);
     if (!gh_fork(S, s)) return GH_ERR_LAUNCH;

@@ -360,3 +360,34 @@ def test_culling_margins_hold_for_extreme_anisotropy_and_far_offscreen_centres(d
     # footprints: the chain rule of a 3000:1 needle hundreds of sigma off screen cancels to nothing in fp32 on either side
     # (the oracle's fp32 per-Gaussian stage included); gradients are only required to be finite.
     compare(sc, dev, check_grads=False)
+
+
+def test_conics_that_are_not_positive_definite_are_never_culled(dev):
+    """Needles tens of metres long lying across the image at ~45 degrees: a c and b^2 of the dilated 2-D covariance agree to
+    more digits than fp32 holds, so `det = a c - b^2` comes out with a random sign (the reference only skips det == 0,
+    App. A.1-5). With det < 0 the conic is indefinite and `alpha >= 1/255` holds on two unbounded wedges; the convexity
+    argument of the culling tests does not apply, so gh_block_hit / gh_block_mask16 answer "hit" for every tile / block of
+    the rect. The forward must stay bit-equal to the oracle, which has no culling."""
+    import math
+    from guassianhand_amd.rasterizer import raster_forward, workspace_views
+    from guassianhand_amd.scenes import make_scene
+    from tests.helpers import scene_kwargs
+    sc = make_scene("random1k", n_views=1, P=1500)
+    g = torch.Generator().manual_seed(31)
+    n = 1200
+    sc.xyz[:n, :2] = 0.15 * (torch.rand(n, 2, generator=g) - 0.5)
+    sc.xyz[:n, 2] = 0.05 * torch.randn(n, generator=g)
+    L = 20.0 * 10 ** torch.rand(n, generator=g)                                    # 20 .. 200 m (6,500 .. 65,000 px at f = 325)
+    sc.scaling[:n] = torch.stack([L, L * 1e-6, torch.full((n,), 1e-6)], 1)
+    phi = math.pi / 4 + 0.5 * (torch.rand(n, generator=g) - 0.5)
+    sc.rotation[:n] = torch.stack([torch.cos(phi / 2), torch.zeros(n), torch.zeros(n), torch.sin(phi / 2)], 1)
+    sc.opacity[:n] = 0.02 + 0.5 * torch.rand(n, 1, generator=g)
+    s = sc.to(dev)
+    kw, bl = scene_kwargs(s)
+    _, _, ctx = raster_forward(s.cams(), s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W, **kw, **bl)
+    wv = workspace_views(ctx)
+    inst = wv["tiles_touched"][:n] > 0
+    A, B, C = wv["g0"][:n, 2], wv["g0"][:n, 3], wv["g1"][:n, 0]
+    not_pd = inst & ~((C > 0) & (A * C - B * B > 0))
+    assert int(not_pd.sum()) >= 50, "the scene no longer produces indefinite conics"
+    compare(sc, dev, check_grads=False)
