@@ -121,14 +121,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(float* __restrict
                                                                 const GhCounters* __restrict__ guard, int32_t* __restrict__ step_state) {
   __shared__ float s_a[GH_BLOCK / GH_WAVE], s_b[GH_BLOCK / GH_WAVE];
   // Device-side guard: a step whose render overflowed its instance capacity must not touch the parameters. The step count
-  // of the bias correction then lives on the device too (step_state, two words used alternately: every launch reads the
-  // word the previous launch wrote, so no thread of this launch can see its own launch's update).
+  // of the bias correction then lives on the device too: step_state[0] = steps applied so far, read by every block when it
+  // starts; the block that FINISHES last (a ticket in step_state[1]) writes the new count — every other block has read the old
+  // one by then. No host value changes from launch to launch, so a captured step replays correctly.
   const bool skip = guard && guard->overflow != 0u;
   int t = host_step;
-  if (step_state) {
-    t = step_state[(host_step - 1) & 1] + 1;
-    if (blockIdx.x == 0 && threadIdx.x == 0) step_state[host_step & 1] = skip ? t - 1 : t;
-  }
+  if (step_state) t = __hip_atomic_load(&step_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   // bias corrections in double, as torch.optim.Adam's Python arithmetic (once per thread, not per element)
   const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
   const float lr_over_bc1 = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
@@ -150,6 +148,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(float* __restrict
   if (threadIdx.x == 0 && partials) {
     partials[2 * blockIdx.x] = ((s_a[0] + s_a[1]) + s_a[2]) + s_a[3];
     partials[2 * blockIdx.x + 1] = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3];
+  }
+  if (threadIdx.x == 0 && step_state) {
+    const int ticket = __hip_atomic_fetch_add(&step_state[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (int)gridDim.x - 1) {                  // the last block out: nobody is left to read the old count
+      __hip_atomic_store(&step_state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&step_state[0], skip ? t - 1 : t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 

@@ -273,3 +273,67 @@ class OneShotFit(nn.Module):
         self.epoch += 1
         if not self.active:
             self.sched.step()
+
+    def captured(self, w2cs, Ks, H: int, W: int, bg, gt_rgb, gt_mask, bbox_mask=None) -> "CapturedFitStep":
+        """The step on these (fixed) cameras and targets as a replayable HIP graph: see CapturedFitStep."""
+        return CapturedFitStep(self, (w2cs, Ks, H, W, bg, gt_rgb, gt_mask, bbox_mask))
+
+
+class CapturedFitStep:
+    """One fit step (lookup -> render -> loss -> backward -> scatter -> regulariser + Adam) captured in a HIP graph and
+    replayed: ~45 kernel launches become one graph launch, so the step runs at the speed of the GPU however slow the host is
+    (the fit of infer_one_shot.py repeats the same cameras and targets every step). Requirements: active-texel mode, the default
+    renderer, one process (collectives stay outside graphs), tensors that stay in place. Construction runs TWO regular steps
+    (one sizes the instance capacity, one warms the capture stream up); every `replay()` is one more step and returns its
+    loss (a device tensor that the next replay overwrites). The learning rate is a kernel argument: when the epoch count moves
+    it across a milestone, the next replay re-captures (no extra step). Nothing on the host can see an instance-capacity
+    overflow inside a replay; the device-side guard turns such a step into a no-op with a NaN loss, and `check()` (a host
+    read-back) raises GhOverflowError with the capacity raised — construct a new CapturedFitStep then."""
+
+    def __init__(self, fit: OneShotFit, args):
+        if not (fit.active and fit._default_render and fit.color_w.is_cuda):
+            raise ValueError("CapturedFitStep needs the active-texel mode and the default renderer on a ROCm device")
+        if ghdist.dist.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise ValueError("CapturedFitStep is single-process: the gradient all-reduce of a sharded fit stays outside graphs")
+        self.fit, self.args = fit, args
+        self.graph, self.loss, self.lr = None, None, None
+        fit.step(*args, sync=True)                                   # sizes the instance capacity (a regular step)
+        from . import rasterizer as R
+        R.check_overflow()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fit.step(*args, sync=False)                              # warm-up of the capture path (a regular step)
+        torch.cuda.current_stream().wait_stream(side)
+        self._capture()
+
+    def _lr(self) -> float:
+        return self.fit.lr0 * 0.5 ** sum(1 for m in MILESTONES if m <= self.fit.epoch)
+
+    def _capture(self) -> None:
+        from . import rasterizer as R
+        R.set_graph_mode(True)
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss = self.fit.step(*self.args, sync=False)    # (capturing enqueues nothing: this is not a step)
+            self.counters = list(R._graph_counters.values())
+        finally:
+            R.set_graph_mode(False)
+        self.lr = self._lr()
+
+    def replay(self) -> torch.Tensor:
+        if self._lr() != self.lr:
+            self._capture()
+        self.graph.replay()
+        return self.loss
+
+    def check(self) -> None:
+        """Host read-back of the captured render's counters: raises rasterizer.GhOverflowError if a replay overflowed."""
+        from . import rasterizer as R
+        for counters, cap, key in self.counters:
+            c4 = counters.tolist()
+            d = (c4[2] if key[-1] else c4[0]) & 0xFFFFFFFF
+            if d > cap:
+                R._capacity[key] = max(R._capacity.get(key, 0), int(d * 1.5) + 1024)
+                raise R.GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside the captured fit step")

@@ -280,8 +280,10 @@ int gh_uv_gather_backward(const int32_t* slot, const float* w, const float* dL_d
  * this step (the first bytes of its workspace). When guard->overflow is set the step is a no-op for param / exp_avg /
  * exp_avg_sq (grad is still cleared, partials still written), so a sync-free or graph-replayed fit never steps on the
  * invalid gradients of an overflowed render. With a guard the bias-correction step count must live on the device as well:
- * `step_state` (two int32, zero-initialised by the caller, NULL = use `step`) holds the number of steps actually applied;
- * `step` then only selects which of the two words is read (step-1)&1 and written step&1.
+ * `step_state` (two int32, zero-initialised by the caller, NULL = use `step`): [0] = the number of steps actually applied, read
+ * by every block as it starts and advanced by the block that finishes last ([1] is that launch's ticket counter, 0 between
+ * launches); `step` is then ignored apart from the >= 1 check, so a captured (hipGraph) step replays with the right bias
+ * correction.
  */
 int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int step, float lr, float beta1,
                      float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials,

@@ -262,3 +262,40 @@ def test_device_side_overflow_guard_keeps_a_sync_free_fit_from_stepping_on_garba
         # (the texel scatter of gh_uv_gather_backward uses float atomics: equal up to their order noise)
         assert torch.allclose(f._adam[k].param, ref._adam[k].param, rtol=1e-4, atol=1e-6), k
         assert int(f._adam[k].step_state.max()) == 1
+
+
+def test_captured_fit_step_replays_the_eager_fit(dev):
+    """fit.CapturedFitStep: the whole step as one HIP graph. Its replays must take exactly the steps the eager loop takes —
+    parameters, Adam moments and losses — across a learning-rate milestone (re-capture) and with the step count of
+    the bias correction living on the device (gh_adam_reg_step's step_state)."""
+    from guassianhand_amd import fit as F
+    from guassianhand_amd import rasterizer as R
+    pb = tiny_fit_problem(P=600, n_views=4, hw=(64, 64), device=dev)
+    mk = lambda: F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"])
+    g = torch.Generator().manual_seed(5)
+    gt_rgb = torch.rand(4, 64, 64, 3, generator=g).to(dev)
+    gt_mask = (torch.rand(4, 64, 64, generator=g) > 0.5).float().to(dev)
+    args = (pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
+    steps_per_epoch, n_steps = 3, 12                                   # epochs 0..3: the milestone at epoch 2 halves the rate
+    eager, losses_e = mk(), []
+    for i in range(n_steps):
+        losses_e.append(float(eager.step(*args, sync=(i == 0))))
+        if (i + 1) % steps_per_epoch == 0:
+            eager.end_epoch()
+    R.check_overflow()
+    f = mk()
+    cap = f.captured(*args)                                            # two regular steps
+    losses_c = []
+    for i in range(2, n_steps):
+        if i % steps_per_epoch == 0:
+            f.end_epoch()
+        losses_c.append(float(cap.replay()))
+    cap.check()
+    # (the texel scatter of the lookup's backward adds with float atomics: equal up to the order of those sums)
+    assert losses_c == pytest.approx(losses_e[2:], rel=1e-5)
+    for k in eager._adam:
+        a, b = eager._adam[k], f._adam[k]
+        for x, y in ((a.param, b.param), (a.exp_avg, b.exp_avg), (a.exp_avg_sq, b.exp_avg_sq)):
+            assert torch.allclose(x, y, rtol=1e-4, atol=1e-7), k
+        assert int(b.step_state[0]) == n_steps and int(b.step_state[1]) == 0
+        assert int(a.step_state[0]) == n_steps
