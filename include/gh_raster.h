@@ -146,7 +146,7 @@ typedef struct GhLayout {
   size_t counters;       /* GhCounters */
   size_t geom;           /* float4[n_views*P][4]: one 64-byte line per Gaussian:
                             (px, py, conicA, conicB) (conicC, opacity, r, g) (b, rect bits, tile hit mask lo, hi)
-                            (-, -, -, -) */
+                            (tiles_touched, -, -, -) */
   size_t depth;          /* float [n_views*P] */
   size_t rect;           /* uint32[n_views*P]  minx | miny<<8 | maxx<<16 | maxy<<24 (tile units) */
   size_t clamped;        /* uint8 [n_views*P]  SH colour clamp flags (bit ch) */
