@@ -156,8 +156,12 @@ __device__ __forceinline__ void gh_pop4_high(uint64_t& mask, int& j0, int& j1, i
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
 template <bool ALPHA>
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, int blk,
-                                               float pxf, float pyf, GhPixelFwd& p) {
+                                               float pxf, float pyf, GhPixelFwd& p, float4* __restrict__ s_col) {
   const uint32_t slot8 = (uint32_t)slot * 8u;
+  // the batch's colours and opacities go through wave-private LDS memory (one 16-byte store per lane and batch, one
+  // broadcast 16-byte load per trip) instead of four crossbar fetches per trip: they are needed after the exponential,
+  // off the front of the trip's dependency chain, where the geometry's five fetches stay
+  s_col[lane] = make_float4(t.b.z, t.b.w, t.cb, t.b.y);            // (r, g, b, opacity)
   const bool hit = (base + lane < total) && ((t.blocks >> blk) & 1u);
   uint64_t mask = gh_ballot(hit);
   bool finished = false;                                             // set (and the mask cleared) inside the rare stop branch, so
@@ -171,8 +175,9 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const int src = (int)((packed4 >> slot8) & 0xFFu);              // 4 * entry lane = ds_bpermute address
     const bool have = slot < nh;
     const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
-    const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src), op = gh_lane_fetch(t.b.y, src);
-    const float r = gh_lane_fetch(t.b.z, src), g = gh_lane_fetch(t.b.w, src), bl = gh_lane_fetch(t.cb, src);
+    const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src);
+    const float4 col = s_col[src >> 2];
+    const float r = col.x, g = col.y, bl = col.z, op = col.w;
     const float dx = gpx - pxf, dy = gpy - pyf;
     const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
     const float alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
@@ -242,6 +247,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   // (disjoint between tiles because floor(a+b) >= floor(a) + floor(b)); pixel = row-major index inside the tile
   const size_t ck0 = ((size_t)(range.x / GH_SEGMENT) + (size_t)tile) * 256 + (size_t)((y - ty * GH_TILE) * GH_TILE + (x - tx * GH_TILE));
 
+  __shared__ float4 s_col_all[GH_BLOCK / GH_WAVE][GH_WAVE];
+  float4* s_col = s_col_all[wid];
   GhPixelFwd p;
   p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.done = inside ? 0 : 1;
   if (total > 0 && !__all(p.done != 0)) {
@@ -250,10 +257,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     gh_load_batch(A, r0, r1, r2, lane, total);
     for (int base = 0; base < total; base += 2 * GH_WAVE) {
       gh_load_batch(B, r0, r1, r2, base + GH_WAVE + lane, total);
-      if (gh_fwd_consume<ALPHA>(A, base, total, lane, slot, blk, pxf, pyf, p)) break;
+      if (gh_fwd_consume<ALPHA>(A, base, total, lane, slot, blk, pxf, pyf, p, s_col)) break;
       if (base + GH_WAVE >= total) break;
       gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
-      if (gh_fwd_consume<ALPHA>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p)) break;
+      if (gh_fwd_consume<ALPHA>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p, s_col)) break;
       const int next = base + 2 * GH_WAVE;              // wave-uniform: a checkpoint every GH_SEGMENT entries (rare)
       if ((next % GH_SEGMENT) == 0 && next < total && inside && slot == 0) {
         const size_t ck = ck0 + (size_t)(next / GH_SEGMENT - 1) * 256;
