@@ -107,3 +107,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "gh_oracle" not in txt, f
+
+
+def test_python_mirror_follows_the_header_field_by_field():
+    """GhLayout's field order and the GH_FLAG_* values of the ctypes mirror are read off include/gh_raster.h."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = open(os.path.join(root, "include", "gh_raster.h")).read()
+    body = h[h.index("typedef struct GhLayout"):h.index("} GhLayout;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in re.findall(r"size_t\s+([^;]+);", body):
+        fields += [f.strip() for f in decl.split(",")]
+    assert tuple(fields) == tuple(_abi.LAYOUT_FIELDS)
+    flags = dict(re.findall(r"#define (GH_FLAG_[A-Z_]+) (\d+)u", h))
+    for name, val in flags.items():
+        if name != "GH_FLAG_NONE":
+            assert getattr(_abi, name) == int(val), name
