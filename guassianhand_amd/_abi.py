@@ -111,6 +111,11 @@ def declare(lib: C.CDLL) -> None:
     lib.gh_forward_stages.argtypes = lib.gh_forward.argtypes + [C.c_uint32]
     lib.gh_backward_stages.restype = C.c_int
     lib.gh_backward_stages.argtypes = lib.gh_backward.argtypes + [C.c_uint32]
+    lib.gh_select_workspace_bytes.restype = C.c_size_t
+    lib.gh_select_workspace_bytes.argtypes = [C.c_int]
+    lib.gh_select_rows.restype = C.c_int
+    lib.gh_select_rows.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + \
+                                  [C.c_void_p, C.c_size_t, C.c_void_p]
 
 
 GH_FWD_PREPROCESS, GH_FWD_BINNING, GH_FWD_RENDER, GH_FWD_ALL = 1, 2, 4, 7
@@ -119,4 +124,5 @@ GH_BWD_RENDER, GH_BWD_PREPROCESS, GH_BWD_ALL = 1, 2, 3
 EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_forward", "gh_backward",
                     "gh_forward_stages", "gh_backward_stages", "gh_forward_shared", "gh_backward_shared", "gh_uv_sample_forward", "gh_uv_sample_backward",
                     "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_adam_reg_step",
-                    "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss", "gh_fit_loss")
+                    "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss", "gh_fit_loss",
+                    "gh_select_workspace_bytes", "gh_select_rows")

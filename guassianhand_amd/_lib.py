@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libgh_raster.so")
 # Profiling / ablation tooling only: load another build of the same C-ABI (tools/abl/*.so). Still a HIP library — there
 # is no CPU path behind this switch either.
 _OVERRIDE = os.environ.get("GH_RASTER_LIB")
-SOURCES = ("gh_api.hip", "gh_preprocess.hip", "gh_binning.hip", "gh_render.hip", "gh_uv.hip", "gh_sh.hip", "gh_knn.hip", "gh_loss.hip")
+SOURCES = ("gh_api.hip", "gh_preprocess.hip", "gh_binning.hip", "gh_render.hip", "gh_uv.hip", "gh_sh.hip", "gh_knn.hip", "gh_loss.hip", "gh_select.hip")
 HEADERS = ("gh_internal.h", os.path.join("..", "..", "include", "gh_raster.h"))
 # -ffp-contract=off: FMAs only where the source says fmaf() (arithmetic contract)
 # -fno-slp-vectorize: keeps the DPP butterflies as v_add_f32_dpp instead of v_mov_dpp + v_pk_add_f32

@@ -3,7 +3,7 @@
 Same names, argument meaning and outputs as the reference for the part of `GS3DRenderer` that sits on
 the hot path: `GaussianModel` (:114-119), the GSLayer activations (:191-214), `forward_single_view`
 (:259-382: settings, attribute blend, RGB pass + mask pass) and the per-view loop of
-`forward_single_batch` (:494-510). The feature networks above it (attention, MLPs, UV lookups) are out
+`forward_single_batch` (:494-510) with its Gaussian selection (:468-477, `select_gaussians`). The feature networks above it (attention, MLPs, UV lookups) are out
 of scope and stay in the reference.
 
 Two execution forms, identical results:
@@ -66,6 +66,57 @@ def gs_activations(raw: Dict[str, torch.Tensor], pts: torch.Tensor, *, use_rgb: 
     shs = torch.reshape(shs, (shs.shape[0], -1, 3))
     return GaussianModel(xyz=xyz, opacity=torch.sigmoid(raw["opacity"]), rotation=F.normalize(raw["rotation"]),
                          scaling=scaling, shs=shs)
+
+
+class _SelectRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, score, points, features, lo, hi):
+        import ctypes as C
+        from . import _abi, _lib
+        L = _lib.lib()
+        dev = points.device
+        if dev.type != "cuda":
+            raise RuntimeError("select_gaussians needs tensors on a ROCm device (no CPU fallback)")
+        N, Cf = points.shape[0], features.shape[1]
+        sc = score.detach().reshape(-1).float().contiguous()
+        pts, feat = points.detach().float().contiguous(), features.detach().float().contiguous()
+        out = [torch.empty(N, 3, device=dev), torch.empty(N, Cf, device=dev), torch.empty(N, 3, device=dev), torch.empty(N, Cf, device=dev)]
+        idx = [torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)]
+        counts = torch.empty(2, dtype=torch.int32, device=dev)
+        nws = L.gh_select_workspace_bytes(N)
+        ws = torch.empty(max(nws, 8), dtype=torch.uint8, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(dev):
+            rc = L.gh_select_rows(p(sc), N, float(lo), float(hi), p(pts), p(feat), Cf, p(out[0]), p(out[1]), p(out[2]), p(out[3]),
+                                  p(idx[0]), p(idx[1]), p(counts), p(ws), ws.numel(),
+                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"gh_select_rows failed: {_abi.status_name(rc)}")
+        nv, nc = counts.tolist()                                  # the one host read-back (the reference makes four)
+        ctx.shape = (N, Cf)
+        ctx.save_for_backward(idx[0][:nv], idx[1][:nc])
+        return out[0][:nv], out[1][:nv], out[2][:nc], out[3][:nc]
+
+    @staticmethod
+    def backward(ctx, g_vp, g_vf, g_cp, g_cf):
+        iv, ic = ctx.saved_tensors
+        N, Cf = ctx.shape
+        gp = torch.zeros(N, 3, device=iv.device)
+        gf = torch.zeros(N, Cf, device=iv.device)
+        for g, i, dst in ((g_vp, iv, gp), (g_cp, ic, gp), (g_vf, iv, gf), (g_cf, ic, gf)):
+            if g is not None and i.numel():
+                dst.index_add_(0, i.long(), g.float())            # indices are unique within each of the two sets
+        return None, gp, gf, None, None
+
+
+def select_gaussians(if_gs_valid: torch.Tensor, query_points: torch.Tensor, gs_hidden_features: torch.Tensor,
+                     threshold_low: float = 0.1, threshold_high: float = 0.9):
+    """The Gaussian selection of forward_single_batch (renderer_one_shot.py:468-473) on the device: returns
+    (query_points_valid, gs_hidden_features_valid, query_points_copied, gs_hidden_features_copied) — the rows whose validity
+    score exceeds threshold_low, and (again) those above threshold_high, in index order, exactly what the four boolean-mask
+    indexings of the reference produce, with ONE host read-back (the two counts) instead of four (`gh_select_rows`).
+    The caller continues like the reference: refine the copied positions, concatenate (:474-477)."""
+    return _SelectRows.apply(if_gs_valid, query_points, gs_hidden_features, threshold_low, threshold_high)
 
 
 def forward_single_view(gs: GaussianModel, viewpoint_camera: Camera, background_color: torch.Tensor, ret_mask: bool = True,

@@ -329,6 +329,24 @@ int gh_knn_indices(const float* points, int N, int K, int32_t* idx_out, float* d
 int gh_knn_mismatch_mask(const int32_t* idx_a, const int32_t* idx_b, int N, int K, int min_same, uint8_t* mask_out,
                          void* hip_stream);
 
+/*
+ * Gaussian selection of forward_single_batch (renderer_one_shot.py:468-477): with s = if_gs_valid.squeeze(1),
+ *     query_points_valid  = query_points[s > threshold_low]        gs_hidden_features_valid  = gs_hidden_features[s > threshold_low]
+ *     query_points_copied = query_points[s > threshold_high]       gs_hidden_features_copied = gs_hidden_features[s > threshold_high]
+ * (the reference then refines the copied positions with a network and concatenates valid ++ copied, :474-477).
+ * score (N,), points (N,3), features (N,C) fp32 row-major. The kept rows are written in index order to valid_points /
+ * valid_features and copied_points / copied_features (each with room for N rows; only the first counts[0] / counts[1] rows
+ * are written), their source indices to valid_index / copied_index (int32, optional, NULL = skip), and counts[0..1]
+ * (device memory) receive the two row counts: one read-back where the reference's four boolean-mask indexings make four,
+ * or none for a caller that works on the padded outputs. NaN scores are dropped (the comparison is false), as in the reference.
+ * workspace: gh_select_workspace_bytes(N) bytes. All work is enqueued on hip_stream.
+ */
+size_t gh_select_workspace_bytes(int N);
+int gh_select_rows(const float* score, int N, float threshold_low, float threshold_high, const float* points,
+                   const float* features, int C, float* valid_points, float* valid_features, float* copied_points,
+                   float* copied_features, int32_t* valid_index, int32_t* copied_index, uint32_t* counts, void* workspace,
+                   size_t ws_bytes, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

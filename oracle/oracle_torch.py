@@ -201,3 +201,15 @@ def blend_attributes(xyz, opacity, shs, *, use_rgb: bool, color_w=None, xyz_b=No
         if color_b is not None:
             out_shs = out_shs * color_w.view(-1, 16, 3) + color_b.view(-1, 16, 3)
     return means3D, op, colors_precomp, out_shs
+
+
+def select_gaussians_reference(if_gs_valid, query_points, gs_hidden_features, threshold_low: float = 0.1, threshold_high: float = 0.9):
+    """Restatement of tgs/models/renderer_one_shot.py:468-473 (forward_single_batch): the validity prune and the rows that
+    are duplicated, by boolean-mask indexing exactly as the reference writes it. Returns (query_points_valid,
+    gs_hidden_features_valid, query_points_copied, gs_hidden_features_copied)."""
+    s = if_gs_valid.squeeze(1)
+    query_points_valid = query_points[s > threshold_low]
+    gs_hidden_features_valid = gs_hidden_features[s > threshold_low]
+    query_points_copied = query_points[s > threshold_high]
+    gs_hidden_features_copied = gs_hidden_features[s > threshold_high]
+    return query_points_valid, gs_hidden_features_valid, query_points_copied, gs_hidden_features_copied
