@@ -39,14 +39,19 @@ __device__ __forceinline__ void gh_sh_chain_step(float bk, float s0, float s1, f
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in, int P, int N, int sh_degree, int M,
-                                                                     uint32_t flags, float4* __restrict__ sh_rgb, float rP) {
+__global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in, int P, int NV, int N, int sh_degree, int M,
+                                                                     uint32_t flags, float4* __restrict__ sh_rgb, float rdiv,
+                                                                     int wide) {
+  // One lane per (view, Gaussian): direction, basis, then the fma chain over the coefficients IN ORDER (bit-identical to the
+  // oracle's sequential sum). Round 1 spread a (view, Gaussian) over 16 lanes (lane = coefficient, coalesced 192-byte rows, the
+  // chain through row broadcasts): every lane evaluated the whole basis, 500 instructions per FOUR rows. Here a lane reads
+  // its Gaussian's coefficients itself; with the Gaussian-major order below the views of a Gaussian sit in adjacent lanes,
+  // so a wave's load touches 64 / n_views rows, each fetched once (pose batch: 64 rows per load, still 10x fewer instructions).
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
-  const int n = t >> 4, k = t & 15;
-  const bool live = n < N;
-  const int nn = live ? n : 0;
-  const int v = rP > 0.0f ? (int)gh_div_small((uint32_t)nn, (uint32_t)P, rP) : nn / P;
-  const int i = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? nn : nn - v * P;
+  if (t >= N) return;
+  int v, i, n;
+  if (flags & GH_FLAG_PER_VIEW_GAUSSIANS) { v = rdiv > 0.0f ? (int)gh_div_small((uint32_t)t, (uint32_t)P, rdiv) : t / P; i = t; n = t; }
+  else { i = rdiv > 0.0f ? (int)gh_div_small((uint32_t)t, (uint32_t)NV, rdiv) : t / NV; v = t - i * NV; n = v * P + i; }
   const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
   float mx = in.means3D[3 * i], my = in.means3D[3 * i + 1], mz = in.means3D[3 * i + 2];
   if (in.blend_xyz_b) { mx = mx + in.blend_xyz_b[0]; my = my + in.blend_xyz_b[1]; mz = mz + in.blend_xyz_b[2]; }
@@ -58,26 +63,55 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in,
   for (int j = 0; j < 16; ++j) Bv[j] = 0.0f;
   int nb = gh_sh_basis(sh_degree, dx, dy, dz, Bv);
   if (nb > M) nb = M;
-  const float bk = gh_pick16(Bv, k);
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-  if (live && k < nb) {
-    s0 = gh_blended_sh(in, flags, M, i, k, 0); s1 = gh_blended_sh(in, flags, M, i, k, 1); s2 = gh_blended_sh(in, flags, M, i, k, 2);
-  }
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;          // acc = fmaf(B_k, sh_k, acc) for k = 0 .. nb-1, in order
-  gh_sh_chain_step<0>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<1>(bk, s0, s1, s2, nb, a0, a1, a2);
-  gh_sh_chain_step<2>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<3>(bk, s0, s1, s2, nb, a0, a1, a2);
-  gh_sh_chain_step<4>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<5>(bk, s0, s1, s2, nb, a0, a1, a2);
-  gh_sh_chain_step<6>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<7>(bk, s0, s1, s2, nb, a0, a1, a2);
-  gh_sh_chain_step<8>(bk, s0, s1, s2, nb, a0, a1, a2);   gh_sh_chain_step<9>(bk, s0, s1, s2, nb, a0, a1, a2);
-  gh_sh_chain_step<10>(bk, s0, s1, s2, nb, a0, a1, a2);  gh_sh_chain_step<11>(bk, s0, s1, s2, nb, a0, a1, a2);
-  gh_sh_chain_step<12>(bk, s0, s1, s2, nb, a0, a1, a2);  gh_sh_chain_step<13>(bk, s0, s1, s2, nb, a0, a1, a2);
-  gh_sh_chain_step<14>(bk, s0, s1, s2, nb, a0, a1, a2);  gh_sh_chain_step<15>(bk, s0, s1, s2, nb, a0, a1, a2);
+  if (wide) {                                      // M == 16 and 16-byte aligned arrays (checked by the launcher)
+    // 48 coefficients = 192 contiguous, 16-byte aligned bytes: twelve 16-byte loads per array; element e = 3 k + channel
+    const float4* sh4 = (const float4*)(in.shs + (size_t)i * 48);
+    const float4* b4 = in.blend_color_b ? (const float4*)(in.blend_color_b + (size_t)i * 48) : nullptr;
+    const float4* w4 = in.blend_color_w ? (const float4*)(in.blend_color_w + ((flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? (size_t)i * 48 : 0))
+                                        : nullptr;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      if (4 * j < 3 * nb) {                        // nb is uniform over the launch (degree / M)
+        const float4 sv = sh4[j];
+        float e[4] = {sv.x, sv.y, sv.z, sv.w};
+        if (w4) {                                  // the blend of gh_blended_sh, element by element (same operations)
+          const float4 wv = w4[j];
+          const float w[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) e[q] = e[q] * w[q];
+          if (b4) {
+            const float4 bv = b4[j];
+            const float b[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { e[q] = e[q] * w[q]; e[q] = e[q] + b[q]; }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int el = 4 * j + q;                // compile-time after unrolling
+          if (el < 3 * nb) acc[el % 3] = fmaf(Bv[el / 3], e[q], acc[el % 3]);
+        }
+      }
+    }
+    a0 = acc[0]; a1 = acc[1]; a2 = acc[2];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < nb) {
+        a0 = fmaf(Bv[k], gh_blended_sh(in, flags, M, i, k, 0), a0);
+        a1 = fmaf(Bv[k], gh_blended_sh(in, flags, M, i, k, 1), a1);
+        a2 = fmaf(Bv[k], gh_blended_sh(in, flags, M, i, k, 2), a2);
+      }
+    }
+  }
   a0 = a0 + 0.5f; a1 = a1 + 0.5f; a2 = a2 + 0.5f;
   unsigned cl = 0;
   if (a0 < 0.0f) { cl |= 1u; a0 = 0.0f; }
   if (a1 < 0.0f) { cl |= 2u; a1 = 0.0f; }
   if (a2 < 0.0f) { cl |= 4u; a2 = 0.0f; }
-  if (live && k == 0) sh_rgb[n] = make_float4(a0, a1, a2, __uint_as_float(cl));
+  sh_rgb[n] = make_float4(a0, a1, a2, __uint_as_float(cl));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -191,9 +225,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd_kernel(
 
 void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, char* ws, const GhLayout& L, hipStream_t s) {
   if (g.N == 0 || !in->shs) return;
-  const size_t threads = (size_t)g.N * 16;
+  const size_t threads = (size_t)g.N;
   hipLaunchKernelGGL(gh_sh_colour_fwd_kernel, dim3((unsigned)((threads + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0, s, *in, g.P,
-                     g.N, d->sh_degree, d->M, d->flags, (float4*)(ws + L.sh_rgb), g.N < (1 << 24) && g.P > 0 ? 1.0f / (float)g.P : 0.0f);
+                     g.NV, g.N, d->sh_degree, d->M, d->flags, (float4*)(ws + L.sh_rgb),
+                     g.N < (1 << 24) && g.P > 0 ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f,
+                     (d->M == 16 && (((uintptr_t)in->shs | (uintptr_t)in->blend_color_w | (uintptr_t)in->blend_color_b) & 15) == 0) ? 1 : 0);
 }
 
 // returns the number of scratch blocks written (0 when the global colour-weight reduction is not needed)
