@@ -38,16 +38,112 @@ __device__ __forceinline__ void gh_sh_chain_step(float bk, float s0, float s1, f
   if (K < nb) { a0 = n0; a1 = n1; a2 = n2; }        // nb is wave-uniform (degree / M)
 }
 
+// Blended coefficients of row i, e[3 k + channel] for k < nb (others 0): gh_blended_sh element by element; `wide` (M == 16 and
+// 16-byte aligned arrays): twelve 16-byte loads per array.
+__device__ __forceinline__ void gh_blended_row(const GhInputs& in, uint32_t flags, int M, int i, int nb, int wide, float* e) {
+#pragma unroll
+  for (int q = 0; q < 48; ++q) e[q] = 0.0f;
+  if (wide) {
+    const float4* sh4 = (const float4*)(in.shs + (size_t)i * 48);
+    const float4* b4 = in.blend_color_b ? (const float4*)(in.blend_color_b + (size_t)i * 48) : nullptr;
+    const float4* w4 = in.blend_color_w ? (const float4*)(in.blend_color_w + ((flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? (size_t)i * 48 : 0))
+                                        : nullptr;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      if (4 * j < 3 * nb) {                        // nb is uniform over the launch (degree / M)
+        const float4 sv = sh4[j];
+        float x[4] = {sv.x, sv.y, sv.z, sv.w};
+        if (w4) {
+          const float4 wv = w4[j];
+          const float w[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[q] = x[q] * w[q];
+          if (b4) {
+            const float4 bv = b4[j];
+            const float b[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { x[q] = x[q] * w[q]; x[q] = x[q] + b[q]; }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (4 * j + q < 3 * nb) e[4 * j + q] = x[q];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < nb) { e[3 * k] = gh_blended_sh(in, flags, M, i, k, 0); e[3 * k + 1] = gh_blended_sh(in, flags, M, i, k, 1); e[3 * k + 2] = gh_blended_sh(in, flags, M, i, k, 2); }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in, int P, int NV, int N, int sh_degree, int M,
                                                                      uint32_t flags, float4* __restrict__ sh_rgb, float rdiv,
-                                                                     int wide) {
+                                                                     int wide, int staged) {
   // One lane per (view, Gaussian): direction, basis, then the fma chain over the coefficients IN ORDER (bit-identical to the
   // oracle's sequential sum). Round 1 spread a (view, Gaussian) over 16 lanes (lane = coefficient, coalesced 192-byte rows, the
   // chain through row broadcasts): every lane evaluated the whole basis, 500 instructions per FOUR rows. Here a lane reads
   // its Gaussian's coefficients itself; with the Gaussian-major order below the views of a Gaussian sit in adjacent lanes,
   // so a wave's load touches 64 / n_views rows, each fetched once (pose batch: 64 rows per load, still 10x fewer instructions).
+  extern __shared__ float s_rows[];                // staged: [256][49] blended coefficients of the block's 256 rows
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (staged) {
+    // Pose batch: every lane has a row of its own, so per-lane row loads would touch 64 different 192-byte rows per
+    // instruction. The block's 256 rows are contiguous: blend them with coalesced loads into LDS (row stride 49 words:
+    // conflict-free when lane l then reads row l).
+    const size_t e0 = (size_t)blockIdx.x * GH_BLOCK * 48;
+    const size_t e_end = (size_t)N * 48;
+    const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
+    if (wide) {                                    // 16-byte pieces: 12 per row, 12 per thread, all loads in flight at once
+      const float4* sh4 = (const float4*)in.shs + e0 / 4;
+      const float4* b4 = in.blend_color_b ? (const float4*)in.blend_color_b + e0 / 4 : nullptr;
+      const float4* w4 = in.blend_color_w ? (const float4*)in.blend_color_w + (wpg ? e0 / 4 : 0) : nullptr;
+      const int n4 = (int)((e_end - e0 < (size_t)GH_BLOCK * 48 ? e_end - e0 : (size_t)GH_BLOCK * 48) / 4);
+      float4 sv[12], wv[12], bv[12];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int q4 = threadIdx.x + GH_BLOCK * j;
+        const int c4 = q4 % 12;
+        sv[j] = q4 < n4 ? sh4[q4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (w4) wv[j] = wpg ? (q4 < n4 ? w4[q4] : sv[j]) : w4[c4];
+        if (b4) bv[j] = q4 < n4 ? b4[q4] : sv[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 12; ++j) {
+        const int q4 = threadIdx.x + GH_BLOCK * j;
+        const int row = q4 / 12, c4 = q4 - row * 12;
+        float x[4] = {sv[j].x, sv[j].y, sv[j].z, sv[j].w};
+        if (w4) {
+          const float w[4] = {wv[j].x, wv[j].y, wv[j].z, wv[j].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[q] = x[q] * w[q];
+          if (b4) {
+            const float b[4] = {bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { x[q] = x[q] * w[q]; x[q] = x[q] + b[q]; }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_rows[row * 49 + c4 * 4 + q] = x[q];
+      }
+    } else
+#pragma unroll 8
+    for (int idx = threadIdx.x; idx < GH_BLOCK * 48; idx += GH_BLOCK) {
+      const size_t ge = e0 + (size_t)idx;
+      const int row = idx / 48, el = idx - row * 48;
+      float x = 0.0f;
+      if (ge < e_end) {
+        x = in.shs[ge];
+        if (in.blend_color_w) {
+          const float w = in.blend_color_w[wpg ? ge : (size_t)el];
+          x = x * w;
+          if (in.blend_color_b) { x = x * w; x = x + in.blend_color_b[ge]; }
+        }
+      }
+      s_rows[row * 49 + el] = x;
+    }
+    __syncthreads();
+  }
   if (t >= N) return;
   int v, i, n;
   if (flags & GH_FLAG_PER_VIEW_GAUSSIANS) { v = rdiv > 0.0f ? (int)gh_div_small((uint32_t)t, (uint32_t)P, rdiv) : t / P; i = t; n = t; }
@@ -64,7 +160,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in,
   int nb = gh_sh_basis(sh_degree, dx, dy, dz, Bv);
   if (nb > M) nb = M;
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;          // acc = fmaf(B_k, sh_k, acc) for k = 0 .. nb-1, in order
-  if (wide) {                                      // M == 16 and 16-byte aligned arrays (checked by the launcher)
+  if (staged) {
+    const float* e = s_rows + threadIdx.x * 49;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < nb) { a0 = fmaf(Bv[k], e[3 * k], a0); a1 = fmaf(Bv[k], e[3 * k + 1], a1); a2 = fmaf(Bv[k], e[3 * k + 2], a2); }
+    }
+  } else if (wide) {                               // M == 16 and 16-byte aligned arrays (checked by the launcher)
     // 48 coefficients = 192 contiguous, 16-byte aligned bytes: twelve 16-byte loads per array; element e = 3 k + channel
     const float4* sh4 = (const float4*)(in.shs + (size_t)i * 48);
     const float4* b4 = in.blend_color_b ? (const float4*)(in.blend_color_b + (size_t)i * 48) : nullptr;
@@ -223,19 +325,172 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd_kernel(
   }
 }
 
+// Backward, two phases in one workgroup (n_views <= 256; the kernel above serves larger view counts):
+//   1. one lane per (view, Gaussian) of the block's G = 256 / n_views Gaussians (Gaussian-major; pose batch: G = 256 rows with one
+//      view each): masked dL/drgb, direction, basis and its gradient ONCE per (view, Gaussian) — the 16-lane form evaluates them
+//      in every one of its 16 lanes —, the position gradient through the view direction (dmean_sh), and (basis, dL/drgb) left
+//      in LDS;
+//   2. one lane per (Gaussian, coefficient): the sums over the views of basis_k * dL/drgb in view order (registers), then the
+//      blend's chain rule and coalesced stores of dL/dshs, dL/dcolor_b, dL/dcolor_w, as before.
+__global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
+    GhInputs in, GhGrads gr, int P, int NV, int sh_degree, int M, uint32_t flags, int G, int wide, int staged, float rdiv,
+    const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ sh_rgb, const float4* __restrict__ gsum,
+    float4* __restrict__ dmean_sh, float* __restrict__ scratch) {
+  extern __shared__ float s_rows[];                     // staged (pose batch, M == 16): [256][49] blended coefficients
+  __shared__ float s_B[GH_BLOCK][17];                   // basis of pair p (0 where the pair contributes nothing), padded rows
+  __shared__ float s_g[GH_BLOCK][3];                    // masked dL/drgb of pair p
+  __shared__ float s_cw[GH_BLOCK / 16][48];
+  const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
+  const int nv = per_view ? 1 : NV;                     // views per row of the attribute arrays
+  const int rows = per_view ? NV * P : P;
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * G;                      // first row of this block
+  if (staged) {                                         // G == 256 rows, one per lane: blend them with coalesced loads (see the forward)
+    const size_t e0 = (size_t)row0 * 48, e_end = (size_t)rows * 48;
+    const bool wpg_s = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
+    for (int idx = tid; idx < GH_BLOCK * 48; idx += GH_BLOCK) {
+      const size_t ge = e0 + (size_t)idx;
+      const int row = idx / 48, el = idx - row * 48;
+      float x = 0.0f;
+      if (ge < e_end) {
+        x = in.shs[ge];
+        if (in.blend_color_w) {
+          const float w = in.blend_color_w[wpg_s ? ge : (size_t)el];
+          x = x * w;
+          if (in.blend_color_b) { x = x * w; x = x + in.blend_color_b[ge]; }
+        }
+      }
+      s_rows[row * 49 + el] = x;
+    }
+    __syncthreads();
+  }
+  // ---- phase 1 ----
+  {
+    const int il = rdiv > 0.0f ? (int)gh_div_small((uint32_t)tid, (uint32_t)nv, rdiv) : tid / nv, vv = tid - il * nv;
+    const int i = row0 + il;
+    const bool live = il < G && i < rows;
+    float Bv[16], g[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) Bv[j] = 0.0f;
+    bool vis = false;
+    if (live) {
+      const int v = per_view ? i / P : vv;
+      const size_t n = per_view ? (size_t)i : (size_t)v * P + i;
+      vis = tiles_touched[n] != 0;
+      if (vis) {
+        const float4 r1 = gsum[n * 3 + 1]; const float4 r2 = gsum[n * 3 + 2];
+        const unsigned cl = __float_as_uint(sh_rgb[n].w);
+        g[0] = (cl & 1u) ? 0.0f : r1.z; g[1] = (cl & 2u) ? 0.0f : r1.w; g[2] = (cl & 4u) ? 0.0f : r2.x;
+        float mx = in.means3D[3 * i], my = in.means3D[3 * i + 1], mz = in.means3D[3 * i + 2];
+        if (in.blend_xyz_b) { mx = mx + in.blend_xyz_b[0]; my = my + in.blend_xyz_b[1]; mz = mz + in.blend_xyz_b[2]; }
+        const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
+        const float dx = mx - cam[32], dy = my - cam[33], dz = mz - cam[34];
+        const float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+        const float ux = dx / len, uy = dy / len, uz = dz / len;
+        float dBx[16], dBy[16], dBz[16], e[48];
+        int nb = gh_sh_basis(sh_degree, ux, uy, uz, Bv);
+        if (nb > M) nb = M;
+        gh_sh_basis_grad(sh_degree, ux, uy, uz, dBx, dBy, dBz);
+        if (staged) {
+#pragma unroll
+          for (int q = 0; q < 48; ++q) e[q] = q < 3 * nb ? s_rows[tid * 49 + q] : 0.0f;
+        } else gh_blended_row(in, flags, M, i, nb, wide, e);
+        float dd0 = 0.0f, dd1 = 0.0f, dd2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k < nb) {
+            const float sg = e[3 * k] * g[0] + e[3 * k + 1] * g[1] + e[3 * k + 2] * g[2];   // sum_ch sh'_k[ch] * dL/drgb[ch]
+            dd0 += dBx[k] * sg; dd1 += dBy[k] * sg; dd2 += dBz[k] * sg;
+          } else Bv[k] = 0.0f;
+        }
+        const float dot = ux * dd0 + uy * dd1 + uz * dd2;                                    // backward of d / |d|
+        dmean_sh[n] = make_float4((dd0 - ux * dot) / len, (dd1 - uy * dot) / len, (dd2 - uz * dot) / len, 0.0f);
+      } else {
+        dmean_sh[n] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_B[tid][k] = vis ? Bv[k] : 0.0f;
+    s_g[tid][0] = g[0]; s_g[tid][1] = g[1]; s_g[tid][2] = g[2];
+  }
+  __syncthreads();
+  // ---- phase 2 ----
+  const int k = tid & 15, grp = tid >> 4;
+  const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
+  const bool has_w = in.blend_color_w != nullptr, has_b = in.blend_color_b != nullptr;
+  float cw[3] = {0.0f, 0.0f, 0.0f};                                         // this lane's part of the global (48,) weight gradient
+  for (int il = grp; il < G; il += GH_BLOCK / 16) {
+    const int i = row0 + il;
+    if (i >= rows || k >= M) continue;
+    float raw[3], wv[3] = {1.0f, 1.0f, 1.0f};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      raw[ch] = in.shs[((size_t)i * M + k) * 3 + ch];
+      if (has_w) wv[ch] = in.blend_color_w[(wpg ? (size_t)i * 48 : 0) + k * 3 + ch];
+    }
+    float dsh[3] = {0.0f, 0.0f, 0.0f}, dcb[3] = {0.0f, 0.0f, 0.0f}, dcw[3] = {0.0f, 0.0f, 0.0f};
+    for (int vv = 0; vv < nv; ++vv) {                                        // views in order, as the sequential sum
+      const int p = il * nv + vv;
+      const float bk = s_B[p][k];
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float gk = bk * s_g[p][ch];                                    // dL/d(blended coefficient)
+        dcb[ch] += gk;
+        if (has_w) {
+          dsh[ch] += has_b ? gk * wv[ch] * wv[ch] : gk * wv[ch];
+          dcw[ch] += has_b ? gk * 2.0f * raw[ch] * wv[ch] : gk * raw[ch];
+        } else dsh[ch] += gk;
+      }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      if (gr.dL_dshs) gr.dL_dshs[((size_t)i * M + k) * 3 + ch] = dsh[ch];
+      if (has_b && gr.dL_dblend_color_b) gr.dL_dblend_color_b[(size_t)i * 48 + k * 3 + ch] = dcb[ch];
+      if (has_w && wpg && gr.dL_dblend_color_w) gr.dL_dblend_color_w[(size_t)i * 48 + k * 3 + ch] = dcw[ch];
+      cw[ch] += dcw[ch];
+    }
+  }
+  if (has_w && !wpg && gr.dL_dblend_color_w) {         // global (48,) weights: fixed-order block partials
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) s_cw[grp][k * 3 + ch] = cw[ch];
+    __syncthreads();
+    if (tid < 64) {
+      float sum = 0.0f;
+      if (tid < 48) for (int r = 0; r < GH_BLOCK / 16; ++r) sum += s_cw[r][tid];
+      scratch[(size_t)blockIdx.x * 64 + tid] = sum;
+    }
+  }
+}
+
 void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, char* ws, const GhLayout& L, hipStream_t s) {
   if (g.N == 0 || !in->shs) return;
   const size_t threads = (size_t)g.N;
-  hipLaunchKernelGGL(gh_sh_colour_fwd_kernel, dim3((unsigned)((threads + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0, s, *in, g.P,
+  const int staged = ((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) && d->M == 16) ? 1 : 0;       // rows of 48 coefficients, one per lane
+  hipLaunchKernelGGL(gh_sh_colour_fwd_kernel, dim3((unsigned)((threads + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK),
+                     staged ? GH_BLOCK * 49 * sizeof(float) : 0, s, *in, g.P,
                      g.NV, g.N, d->sh_degree, d->M, d->flags, (float4*)(ws + L.sh_rgb),
                      g.N < (1 << 24) && g.P > 0 ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f,
-                     (d->M == 16 && (((uintptr_t)in->shs | (uintptr_t)in->blend_color_w | (uintptr_t)in->blend_color_b) & 15) == 0) ? 1 : 0);
+                     (d->M == 16 && (((uintptr_t)in->shs | (uintptr_t)in->blend_color_w | (uintptr_t)in->blend_color_b) & 15) == 0) ? 1 : 0,
+                     staged);
 }
 
 // returns the number of scratch blocks written (0 when the global colour-weight reduction is not needed)
 int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws, const GhLayout& L,
                             hipStream_t s) {
   if (g.P == 0 || !in->shs) return 0;
+  const bool per_view_rows = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
+  const bool wpg2 = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
+  if (per_view_rows || g.NV <= GH_BLOCK) {               // two-phase kernel: one lane per (view, Gaussian), then per coefficient
+    const int nv = per_view_rows ? 1 : g.NV, G = GH_BLOCK / nv;
+    const int rows = per_view_rows ? g.N : g.P;
+    const int nblk2 = (rows + G - 1) / G;
+    const int wide = (d->M == 16 && (((uintptr_t)in->shs | (uintptr_t)in->blend_color_w | (uintptr_t)in->blend_color_b) & 15) == 0) ? 1 : 0;
+    const int staged = 0;      // measured at 32 poses x 98,562 rows: staging the rows (50 KB more LDS per block) 1.67 -> 2.27 ms
+    hipLaunchKernelGGL(gh_sh_colour_bwd2_kernel, dim3(nblk2), dim3(GH_BLOCK), staged ? GH_BLOCK * 49 * sizeof(float) : 0, s, *in, *gr,
+                       g.P, g.NV, d->sh_degree, d->M, d->flags, G, wide, staged, 1.0f / (float)nv, (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.sh_rgb),
+                       (const float4*)(ws + L.grad_sums), (float4*)(ws + L.dmean_sh), (float*)(ws + L.sh_scratch));
+    return (in->blend_color_w && !wpg2 && gr->dL_dblend_color_w) ? nblk2 : 0;
+  }
   const size_t threads = (size_t)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.N : g.P) * 16;
   const int nblk = (int)((threads + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_sh_colour_bwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, d->sh_degree, d->M, d->flags,
