@@ -267,6 +267,11 @@ def test_many_views_chain_rule_groups(dev):
     for nv in (70, 6):
         compare(make_scene("random1k", n_views=nv, P=300, use_rgb=True, blend=True), dev, check_stages=False)
     compare(make_scene("random1k", n_views=67, P=120, use_rgb=False, blend=True), dev, check_stages=False)
+    # SH mode with more views than a workgroup has lanes: the SH backward falls back to its 16-lanes-per-Gaussian form
+    # (gh_sh_colour_bwd_kernel); 3 and 100 views: view counts that do not divide the two-phase kernel's 256 lanes
+    compare(make_scene("random1k", n_views=260, P=40, use_rgb=False, blend=True), dev, check_stages=False)
+    for nv in (3, 100):
+        compare(make_scene("random1k", n_views=nv, P=90, use_rgb=False, blend=True), dev, check_stages=False)
 
 
 def test_config1_one_hand(dev):
