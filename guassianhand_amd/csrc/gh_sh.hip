@@ -333,10 +333,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd_kernel(
 //   2. one lane per (Gaussian, coefficient): the sums over the views of basis_k * dL/drgb in view order (registers), then the
 //      blend's chain rule and coalesced stores of dL/dshs, dL/dcolor_b, dL/dcolor_w, as before.
 __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
-    GhInputs in, GhGrads gr, int P, int NV, int sh_degree, int M, uint32_t flags, int G, int wide, int staged, float rdiv,
+    GhInputs in, GhGrads gr, int P, int NV, int sh_degree, int M, uint32_t flags, int G, int wide, float rdiv,
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ sh_rgb, const float4* __restrict__ gsum,
     float4* __restrict__ dmean_sh, float* __restrict__ scratch) {
-  extern __shared__ float s_rows[];                     // staged (pose batch, M == 16): [256][49] blended coefficients
   __shared__ float s_B[GH_BLOCK][17];                   // basis of pair p (0 where the pair contributes nothing), padded rows
   __shared__ float s_g[GH_BLOCK][3];                    // masked dL/drgb of pair p
   __shared__ float s_cw[GH_BLOCK / 16][48];
@@ -345,25 +344,6 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
   const int rows = per_view ? NV * P : P;
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * G;                      // first row of this block
-  if (staged) {                                         // G == 256 rows, one per lane: blend them with coalesced loads (see the forward)
-    const size_t e0 = (size_t)row0 * 48, e_end = (size_t)rows * 48;
-    const bool wpg_s = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
-    for (int idx = tid; idx < GH_BLOCK * 48; idx += GH_BLOCK) {
-      const size_t ge = e0 + (size_t)idx;
-      const int row = idx / 48, el = idx - row * 48;
-      float x = 0.0f;
-      if (ge < e_end) {
-        x = in.shs[ge];
-        if (in.blend_color_w) {
-          const float w = in.blend_color_w[wpg_s ? ge : (size_t)el];
-          x = x * w;
-          if (in.blend_color_b) { x = x * w; x = x + in.blend_color_b[ge]; }
-        }
-      }
-      s_rows[row * 49 + el] = x;
-    }
-    __syncthreads();
-  }
   // ---- phase 1 ----
   {
     const int il = rdiv > 0.0f ? (int)gh_div_small((uint32_t)tid, (uint32_t)nv, rdiv) : tid / nv, vv = tid - il * nv;
@@ -391,10 +371,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
         int nb = gh_sh_basis(sh_degree, ux, uy, uz, Bv);
         if (nb > M) nb = M;
         gh_sh_basis_grad(sh_degree, ux, uy, uz, dBx, dBy, dBz);
-        if (staged) {
-#pragma unroll
-          for (int q = 0; q < 48; ++q) e[q] = q < 3 * nb ? s_rows[tid * 49 + q] : 0.0f;
-        } else gh_blended_row(in, flags, M, i, nb, wide, e);
+        gh_blended_row(in, flags, M, i, nb, wide, e);
         float dd0 = 0.0f, dd1 = 0.0f, dd2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -485,9 +462,10 @@ int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in
     const int rows = per_view_rows ? g.N : g.P;
     const int nblk2 = (rows + G - 1) / G;
     const int wide = (d->M == 16 && (((uintptr_t)in->shs | (uintptr_t)in->blend_color_w | (uintptr_t)in->blend_color_b) & 15) == 0) ? 1 : 0;
-    const int staged = 0;      // measured at 32 poses x 98,562 rows: staging the rows (50 KB more LDS per block) 1.67 -> 2.27 ms
-    hipLaunchKernelGGL(gh_sh_colour_bwd2_kernel, dim3(nblk2), dim3(GH_BLOCK), staged ? GH_BLOCK * 49 * sizeof(float) : 0, s, *in, *gr,
-                       g.P, g.NV, d->sh_degree, d->M, d->flags, G, wide, staged, 1.0f / (float)nv, (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.sh_rgb),
+    // (staging the block's coefficient rows in LDS as the forward does: no gain with shared Gaussians, and 1.67 -> 2.27 ms for
+    // 32 poses x 98,562 rows, where the 50 KB more LDS per block halve the occupancy)
+    hipLaunchKernelGGL(gh_sh_colour_bwd2_kernel, dim3(nblk2), dim3(GH_BLOCK), 0, s, *in, *gr,
+                       g.P, g.NV, d->sh_degree, d->M, d->flags, G, wide, 1.0f / (float)nv, (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.sh_rgb),
                        (const float4*)(ws + L.grad_sums), (float4*)(ws + L.dmean_sh), (float*)(ws + L.sh_scratch));
     return (in->blend_color_w && !wpg2 && gr->dL_dblend_color_w) ? nblk2 : 0;
   }
