@@ -1,17 +1,12 @@
 // gh_sh.hip — spherical-harmonics colour stage (backward A.5-5/7) incl. the SH form of the
 // attribute blend (tgs/models/renderer_one_shot.py:330-334, with its double multiply when color_b is given).
 //
-// wave64 mapping: 16 lanes per (view, Gaussian) = one DPP row, lane = SH coefficient. The 48 coefficients of a
-// Gaussian (and its 48 blend biases) are 192 contiguous bytes, so a row reads them as one coalesced segment; the
-// fma chain over the coefficients runs IN ORDER over the row with row_newbcast (bit-identical to the sequential
-// sum of the oracle). The backward keeps its per-coefficient accumulators in registers across the view loop, so
-// dL/dshs and dL/dcolor_b are written once instead of read-modify-written per view.
+// Forward: one lane per (view, Gaussian), Gaussian-major, the fma chain over the coefficients IN ORDER in the lane
+// (bit-identical to the sequential sum of the oracle); 192-byte coefficient rows as twelve 16-byte loads, or blended into LDS
+// by the block for the pose batch. Backward: gh_sh_colour_bwd2_kernel (per (view, Gaussian), then per (Gaussian, coefficient));
+// the first-generation kernel — 16 lanes per Gaussian = one DPP row, lane = coefficient, per-coefficient accumulators in
+// registers across the view loop — serves calls with more than 256 views.
 #include "gh_internal.h"
-
-template <int K>
-__device__ __forceinline__ float gh_row_bcast(float v) {       // value of lane K of this lane's 16-lane row
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xF, 0xF, false));
-}
 
 __device__ __forceinline__ float gh_row_sum(float v) {          // sum over the 16 lanes of the row, in every lane
   v += gh_dpp<0xB1>(v);           // quad_perm [1,0,3,2]
@@ -29,13 +24,6 @@ __device__ __forceinline__ float gh_pick16(const float* a, int k) {   // a[k] wi
     asm("" : "+v"(r));          // keep the v_cndmask chain: without it the compiler spills the table to scratch and indexes it
   }
   return r;
-}
-
-template <int K>
-__device__ __forceinline__ void gh_sh_chain_step(float bk, float s0, float s1, float s2, int nb, float& a0, float& a1, float& a2) {
-  const float b = gh_row_bcast<K>(bk);
-  const float n0 = fmaf(b, gh_row_bcast<K>(s0), a0), n1 = fmaf(b, gh_row_bcast<K>(s1), a1), n2 = fmaf(b, gh_row_bcast<K>(s2), a2);
-  if (K < nb) { a0 = n0; a1 = n1; a2 = n2; }        // nb is wave-uniform (degree / M)
 }
 
 // Blended coefficients of row i, e[3 k + channel] for k < nb (others 0): gh_blended_sh element by element; `wide` (M == 16 and
@@ -77,22 +65,12 @@ __device__ __forceinline__ void gh_blended_row(const GhInputs& in, uint32_t flag
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in, int P, int NV, int N, int sh_degree, int M,
-                                                                     uint32_t flags, float4* __restrict__ sh_rgb, float rdiv,
-                                                                     int wide, int staged) {
-  // One lane per (view, Gaussian): direction, basis, then the fma chain over the coefficients IN ORDER (bit-identical to the
-  // oracle's sequential sum). Round 1 spread a (view, Gaussian) over 16 lanes (lane = coefficient, coalesced 192-byte rows, the
-  // chain through row broadcasts): every lane evaluated the whole basis, 500 instructions per FOUR rows. Here a lane reads
-  // its Gaussian's coefficients itself; with the Gaussian-major order below the views of a Gaussian sit in adjacent lanes,
-  // so a wave's load touches 64 / n_views rows, each fetched once (pose batch: 64 rows per load, still 10x fewer instructions).
-  extern __shared__ float s_rows[];                // staged: [256][49] blended coefficients of the block's 256 rows
-  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
-  if (staged) {
-    // Pose batch: every lane has a row of its own, so per-lane row loads would touch 64 different 192-byte rows per
-    // instruction. The block's 256 rows are contiguous: blend them with coalesced loads into LDS (row stride 49 words:
-    // conflict-free when lane l then reads row l).
-    const size_t e0 = (size_t)blockIdx.x * GH_BLOCK * 48;
-    const size_t e_end = (size_t)N * 48;
+// The 256 rows [row0, row0 + 256) of blended coefficients (48 per row, M == 16) into s_rows[256][49], by the whole block with
+// coalesced loads; wide: 16-byte pieces, 12 per thread, all loads in flight at once. Rows at or beyond n_rows are zero.
+__device__ __forceinline__ void gh_stage_rows(const GhInputs& in, uint32_t flags, size_t row0, size_t n_rows, int wide,
+                                              float* __restrict__ s_rows) {
+    const size_t e0 = row0 * 48;
+    const size_t e_end = n_rows * 48;
     const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
     if (wide) {                                    // 16-byte pieces: 12 per row, 12 per thread, all loads in flight at once
       const float4* sh4 = (const float4*)in.shs + e0 / 4;
@@ -142,6 +120,24 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in,
       }
       s_rows[row * 49 + el] = x;
     }
+}
+
+template <bool staged>                             // staged: pose batch (the 36 x 16 bytes in flight cost 144 registers: own kernel)
+__global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_fwd_kernel(GhInputs in, int P, int NV, int N, int sh_degree, int M,
+                                                                     uint32_t flags, float4* __restrict__ sh_rgb, float rdiv,
+                                                                     int wide) {
+  // One lane per (view, Gaussian): direction, basis, then the fma chain over the coefficients IN ORDER (bit-identical to the
+  // oracle's sequential sum). Round 1 spread a (view, Gaussian) over 16 lanes (lane = coefficient, coalesced 192-byte rows, the
+  // chain through row broadcasts): every lane evaluated the whole basis, 500 instructions per FOUR rows. Here a lane reads
+  // its Gaussian's coefficients itself; with the Gaussian-major order below the views of a Gaussian sit in adjacent lanes,
+  // so a wave's load touches 64 / n_views rows, each fetched once (pose batch: 64 rows per load, still 10x fewer instructions).
+  extern __shared__ float s_rows[];                // staged: [256][49] blended coefficients of the block's 256 rows
+  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (staged) {
+    // Pose batch: every lane has a row of its own, so per-lane row loads would touch 64 different 192-byte rows per
+    // instruction. The block's 256 rows are contiguous: blend them with coalesced loads into LDS (row stride 49 words:
+    // conflict-free when lane l then reads row l).
+    gh_stage_rows(in, flags, (size_t)blockIdx.x * GH_BLOCK, (size_t)N, wide, s_rows);
     __syncthreads();
   }
   if (t >= N) return;
@@ -332,10 +328,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd_kernel(
 //      in LDS;
 //   2. one lane per (Gaussian, coefficient): the sums over the views of basis_k * dL/drgb in view order (registers), then the
 //      blend's chain rule and coalesced stores of dL/dshs, dL/dcolor_b, dL/dcolor_w, as before.
+template <bool STAGED>                                  // STAGED (pose batch, M == 16): the block's 256 rows blended into LDS first
 __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
     GhInputs in, GhGrads gr, int P, int NV, int sh_degree, int M, uint32_t flags, int G, int wide, float rdiv,
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ sh_rgb, const float4* __restrict__ gsum,
     float4* __restrict__ dmean_sh, float* __restrict__ scratch) {
+  extern __shared__ float s_rows[];
   __shared__ float s_B[GH_BLOCK][17];                   // basis of pair p (0 where the pair contributes nothing), padded rows
   __shared__ float s_g[GH_BLOCK][3];                    // masked dL/drgb of pair p
   __shared__ float s_cw[GH_BLOCK / 16][48];
@@ -344,6 +342,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
   const int rows = per_view ? NV * P : P;
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * G;                      // first row of this block
+  if (STAGED) {                                         // G == 256: one row per lane (see the forward)
+    gh_stage_rows(in, flags, (size_t)row0, (size_t)rows, wide, s_rows);
+    __syncthreads();
+  }
   // ---- phase 1 ----
   {
     const int il = rdiv > 0.0f ? (int)gh_div_small((uint32_t)tid, (uint32_t)nv, rdiv) : tid / nv, vv = tid - il * nv;
@@ -367,18 +369,27 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
         const float dx = mx - cam[32], dy = my - cam[33], dz = mz - cam[34];
         const float len = sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
         const float ux = dx / len, uy = dy / len, uz = dz / len;
-        float dBx[16], dBy[16], dBz[16], e[48];
         int nb = gh_sh_basis(sh_degree, ux, uy, uz, Bv);
         if (nb > M) nb = M;
+        float sg[16];                                     // sum_ch sh'_k[ch] * dL/drgb[ch]: the 48 coefficients die here,
+        {                                                 // before the 48 basis-gradient values come alive
+          float e[48];
+          if (STAGED) {
+#pragma unroll
+            for (int q = 0; q < 48; ++q) e[q] = q < 3 * nb ? s_rows[tid * 49 + q] : 0.0f;
+          } else gh_blended_row(in, flags, M, i, nb, wide, e);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) sg[k] = k < nb ? e[3 * k] * g[0] + e[3 * k + 1] * g[1] + e[3 * k + 2] * g[2] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(sg[k]));
+        float dBx[16], dBy[16], dBz[16];
         gh_sh_basis_grad(sh_degree, ux, uy, uz, dBx, dBy, dBz);
-        gh_blended_row(in, flags, M, i, nb, wide, e);
         float dd0 = 0.0f, dd1 = 0.0f, dd2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-          if (k < nb) {
-            const float sg = e[3 * k] * g[0] + e[3 * k + 1] * g[1] + e[3 * k + 2] * g[2];   // sum_ch sh'_k[ch] * dL/drgb[ch]
-            dd0 += dBx[k] * sg; dd1 += dBy[k] * sg; dd2 += dBz[k] * sg;
-          } else Bv[k] = 0.0f;
+          if (k < nb) { dd0 += dBx[k] * sg[k]; dd1 += dBy[k] * sg[k]; dd2 += dBz[k] * sg[k]; }
+          else Bv[k] = 0.0f;
         }
         const float dot = ux * dd0 + uy * dd1 + uz * dd2;                                    // backward of d / |d|
         dmean_sh[n] = make_float4((dd0 - ux * dot) / len, (dd1 - uy * dot) / len, (dd2 - uz * dot) / len, 0.0f);
@@ -400,10 +411,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
     const int i = row0 + il;
     if (i >= rows || k >= M) continue;
     float raw[3], wv[3] = {1.0f, 1.0f, 1.0f};
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      raw[ch] = in.shs[((size_t)i * M + k) * 3 + ch];
-      if (has_w) wv[ch] = in.blend_color_w[(wpg ? (size_t)i * 48 : 0) + k * 3 + ch];
+    {                                                                      // (k, channel) triples are 12 contiguous bytes
+      const GhF3 r3 = *(const GhF3*)(in.shs + ((size_t)i * M + k) * 3);
+      raw[0] = r3.x; raw[1] = r3.y; raw[2] = r3.z;
+      if (has_w) {
+        const GhF3 w3 = *(const GhF3*)(in.blend_color_w + (wpg ? (size_t)i * 48 : 0) + k * 3);
+        wv[0] = w3.x; wv[1] = w3.y; wv[2] = w3.z;
+      }
     }
     float dsh[3] = {0.0f, 0.0f, 0.0f}, dcb[3] = {0.0f, 0.0f, 0.0f}, dcw[3] = {0.0f, 0.0f, 0.0f};
     for (int vv = 0; vv < nv; ++vv) {                                        // views in order, as the sequential sum
@@ -419,13 +433,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
         } else dsh[ch] += gk;
       }
     }
+    if (gr.dL_dshs) *(GhF3*)(gr.dL_dshs + ((size_t)i * M + k) * 3) = GhF3{dsh[0], dsh[1], dsh[2]};
+    if (has_b && gr.dL_dblend_color_b) *(GhF3*)(gr.dL_dblend_color_b + (size_t)i * 48 + k * 3) = GhF3{dcb[0], dcb[1], dcb[2]};
+    if (has_w && wpg && gr.dL_dblend_color_w) *(GhF3*)(gr.dL_dblend_color_w + (size_t)i * 48 + k * 3) = GhF3{dcw[0], dcw[1], dcw[2]};
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      if (gr.dL_dshs) gr.dL_dshs[((size_t)i * M + k) * 3 + ch] = dsh[ch];
-      if (has_b && gr.dL_dblend_color_b) gr.dL_dblend_color_b[(size_t)i * 48 + k * 3 + ch] = dcb[ch];
-      if (has_w && wpg && gr.dL_dblend_color_w) gr.dL_dblend_color_w[(size_t)i * 48 + k * 3 + ch] = dcw[ch];
-      cw[ch] += dcw[ch];
-    }
+    for (int ch = 0; ch < 3; ++ch) cw[ch] += dcw[ch];
   }
   if (has_w && !wpg && gr.dL_dblend_color_w) {         // global (48,) weights: fixed-order block partials
 #pragma unroll
@@ -443,12 +455,12 @@ void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* i
   if (g.N == 0 || !in->shs) return;
   const size_t threads = (size_t)g.N;
   const int staged = ((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) && d->M == 16) ? 1 : 0;       // rows of 48 coefficients, one per lane
-  hipLaunchKernelGGL(gh_sh_colour_fwd_kernel, dim3((unsigned)((threads + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK),
+  auto kern = staged ? gh_sh_colour_fwd_kernel<true> : gh_sh_colour_fwd_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((threads + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK),
                      staged ? GH_BLOCK * 49 * sizeof(float) : 0, s, *in, g.P,
                      g.NV, g.N, d->sh_degree, d->M, d->flags, (float4*)(ws + L.sh_rgb),
                      g.N < (1 << 24) && g.P > 0 ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f,
-                     (d->M == 16 && (((uintptr_t)in->shs | (uintptr_t)in->blend_color_w | (uintptr_t)in->blend_color_b) & 15) == 0) ? 1 : 0,
-                     staged);
+                     (d->M == 16 && (((uintptr_t)in->shs | (uintptr_t)in->blend_color_w | (uintptr_t)in->blend_color_b) & 15) == 0) ? 1 : 0);
 }
 
 // returns the number of scratch blocks written (0 when the global colour-weight reduction is not needed)
@@ -464,7 +476,9 @@ int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in
     const int wide = (d->M == 16 && (((uintptr_t)in->shs | (uintptr_t)in->blend_color_w | (uintptr_t)in->blend_color_b) & 15) == 0) ? 1 : 0;
     // (staging the block's coefficient rows in LDS as the forward does: no gain with shared Gaussians, and 1.67 -> 2.27 ms for
     // 32 poses x 98,562 rows, where the 50 KB more LDS per block halve the occupancy)
-    hipLaunchKernelGGL(gh_sh_colour_bwd2_kernel, dim3(nblk2), dim3(GH_BLOCK), 0, s, *in, *gr,
+    const bool staged = per_view_rows && d->M == 16;
+    auto kern2 = staged ? gh_sh_colour_bwd2_kernel<true> : gh_sh_colour_bwd2_kernel<false>;
+    hipLaunchKernelGGL(kern2, dim3(nblk2), dim3(GH_BLOCK), staged ? GH_BLOCK * 49 * sizeof(float) : 0, s, *in, *gr,
                        g.P, g.NV, d->sh_degree, d->M, d->flags, G, wide, 1.0f / (float)nv, (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.sh_rgb),
                        (const float4*)(ws + L.grad_sums), (float4*)(ws + L.dmean_sh), (float*)(ws + L.sh_scratch));
     return (in->blend_color_w && !wpg2 && gr->dL_dblend_color_w) ? nblk2 : 0;
