@@ -21,6 +21,14 @@ for r in rows[:34]:
     n = re.sub(r"\(.*", "", r["Name"])[:70]
     out.append(f'{n},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.0f},{r["Percentage"]},{r["MinNs"]},{r["MaxNs"]}')
 open(f"profiles/{tag}_kernel_stats_bench_8views.csv", "w").write("\n".join(out) + "\n")
+if os.path.exists(f"{O}/kernel_stats_hd.csv"):
+    rows_hd = list(csv.DictReader(open(f"{O}/kernel_stats_hd.csv")))
+    out_hd = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --config two_hands_hd --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline  (MI355X, 1024x1024, SH degree 3, 8 views; source {src})",
+              "name,calls,total_ns,avg_ns,pct,min_ns,max_ns"]
+    for r in rows_hd[:24]:
+        n = re.sub(r"\(.*", "", r["Name"])[:70]
+        out_hd.append(f'{n},{r["Calls"]},{r["TotalDurationNs"]},{float(r["AverageNs"]):.0f},{r["Percentage"]},{r["MinNs"]},{r["MaxNs"]}')
+    open(f"profiles/{tag}_kernel_stats_hd_sh3_8views.csv", "w").write("\n".join(out_hd) + "\n")
 vals, lines = {}, []
 for f in sorted(glob.glob(f"{O}/sum_*.csv")):
     for l in open(f):

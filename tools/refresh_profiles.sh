@@ -13,6 +13,9 @@ echo "== valu rate microbenchmark"
 echo "== kernel stats"
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 bench.py --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.log || exit 1
 cp $(find $O/stats -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv && rm -rf $O/stats
+echo "== kernel stats, 1024^2 SH3"
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats_hd -o st --output-format csv -- python3 bench.py --config two_hands_hd --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline > $O/stats_hd_bench.json 2> $O/stats_hd.log || exit 1
+cp $(find $O/stats_hd -name "*kernel_stats.csv" | head -1) $O/kernel_stats_hd.csv && rm -rf $O/stats_hd
 echo "== traffic"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $C -d $O/pmc_$C -o pmc --output-format csv -- python3 bench.py --steps 3 --warmup 2 --repeats 1 --no-cpu-baseline --no-stage-timing > $O/pmc_$C.log 2>&1 || exit 1
