@@ -125,3 +125,8 @@ def test_split_inside_captured_graph(dev):
     assert torch.equal(img, img_ref)
     for k in g:
         assert torch.equal(g[k], g_ref[k]), k
+    # the library's side stream is back to plain (eager) use after the capture
+    img_e, g_e = step()
+    torch.cuda.synchronize()
+    R.check_overflow()
+    assert torch.equal(img_e, img_ref) and all(torch.equal(g_e[k], g_ref[k]) for k in g_ref)
