@@ -86,6 +86,8 @@ def declare(lib: C.CDLL) -> None:
     lib.gh_uv_gather_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.gh_uv_gather_backward.restype = C.c_int
     lib.gh_uv_gather_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.gh_uv_scatter_sorted.restype = C.c_int
+    lib.gh_uv_scatter_sorted.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.gh_adam_reg_step.restype = C.c_int
     lib.gh_adam_reg_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
@@ -123,6 +125,6 @@ GH_BWD_RENDER, GH_BWD_PREPROCESS, GH_BWD_ALL = 1, 2, 3
 
 EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_forward", "gh_backward",
                     "gh_forward_stages", "gh_backward_stages", "gh_forward_shared", "gh_backward_shared", "gh_uv_sample_forward", "gh_uv_sample_backward",
-                    "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_adam_reg_step",
+                    "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_uv_scatter_sorted", "gh_adam_reg_step",
                     "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss", "gh_fit_loss",
                     "gh_select_workspace_bytes", "gh_select_rows")

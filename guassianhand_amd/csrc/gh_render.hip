@@ -11,11 +11,15 @@
 // The forward uses no LDS memory and no barriers, and a block retires as soon as its 16 pixels are saturated.
 // Culling never changes results: the exact per-pixel tests of App. A.3 still decide.
 //
-// Backward: same mapping back to front; the nine per-Gaussian partial gradients are summed over the 16 pixels of a
-// slot with DPP + the LDS crossbar, the four waves of a quadrant are combined through a double-buffered LDS stage
-// (one barrier per 64 entries) and stored as the quadrant's sub-record of the (tile, Gaussian) instance at the
-// instance's emit slot, plus a flag byte. No atomics: the per-Gaussian kernel adds each Gaussian's flagged
-// sub-records (contiguous slots) in fixed order, so the gradients are bitwise reproducible.
+// Backward (rewritten in round 2): the transposed mapping — lane = list entry. A wave owns one 8x8 quadrant of a (tile,
+// 256-entry depth segment) work item and loops over the pixels; the reverse recurrence is two prefix scans per pixel (DPP);
+// every lane accumulates the nine gradient moments of ITS entry in registers and the per-(entry, block) sums meet in
+// wave-private LDS rows. One wave per workgroup, no barriers; the wave stores the quadrant's 36-byte sub-record of every
+// blended entry at the instance's emit slot, plus a flag byte. No atomics: gh_record_sum_kernel adds each Gaussian's
+// flagged sub-records (contiguous slots) in fixed order, so the gradients are bitwise reproducible. (Round 3 built the
+// four quadrant waves of an item as ONE workgroup that writes one record per instance: the quadrants' loads differ by 2.1x
+// on average, the barrier made the kernel 58 us slower for 25 us saved in the record sum —
+// tools/experiments/r3_bwd_coupled_quadrants.patch, profiles/r3_bwd_coupled_ab.txt.)
 #include "gh_internal.h"
 
 // blockIdx -> (work item, quadrant) with the four quadrant workgroups of an item on ONE XCD: workgroups are dealt

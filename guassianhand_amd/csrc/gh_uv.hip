@@ -111,6 +111,26 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_uv_gather_bwd_kernel(const int32_
   if (s4.w >= 0) atomicAdd(&dtex[(size_t)s4.w * C + c], g * w4.w);
 }
 
+// Deterministic form of the two scatter-adds above: the (Gaussian, corner) pairs that touch a texel are listed per texel
+// once (CSR: row_ptr (U+1), pairs (nnz) = 4 * gaussian + corner, ascending within a texel), and the backward becomes a
+// GATHER — one lane per (texel, channel) adds its contributions in list order. No atomics: bitwise reproducible, like every
+// other kernel on the fit path. Lanes = channels, so the C floats of a contributing Gaussian's gradient row are read as
+// one contiguous segment.
+__global__ __launch_bounds__(GH_BLOCK) void gh_uv_scatter_sorted_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ pairs,
+                                                                         const float* __restrict__ w, const float* __restrict__ dout,
+                                                                         float* __restrict__ dtex, int U, int C) {
+  const size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (idx >= (size_t)U * C) return;
+  const int u = (int)(idx / C), c = (int)(idx - (size_t)u * C);
+  const int j0 = row_ptr[u], j1 = row_ptr[u + 1];
+  float acc = 0.0f;
+  for (int j = j0; j < j1; ++j) {
+    const int e = pairs[j];
+    acc += dout[(size_t)(e >> 2) * C + c] * w[e];
+  }
+  dtex[idx] += acc;
+}
+
 // One pass over a parameter array: regulariser value (sum|p|, sum p^2 of the PRE-update values, block partials),
 // regulariser gradient (l1*sign(p) + l2*2p) added to the accumulated image gradient, Adam update (torch.optim.Adam
 // semantics, no amsgrad / weight decay: infer_one_shot.py:345), and the gradient buffer is cleared for the next step.
@@ -178,6 +198,18 @@ extern "C" int gh_uv_gather_backward(const int32_t* slot, const float* w, const 
   const size_t n = (size_t)P * C;
   hipLaunchKernelGGL(gh_uv_gather_bwd_kernel, dim3((unsigned)((n + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0,
                      (hipStream_t)hip_stream, slot, w, dL_dout, dL_dtexels, P, C);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_uv_scatter_sorted(const int32_t* row_ptr, const int32_t* pairs, const float* w, const float* dL_dout,
+                                    float* dL_dtexels, int U, int C, void* hip_stream) {
+  if (U < 0 || C < 1) return GH_ERR_INVALID_ARG;
+  if (U == 0) return GH_OK;
+  if (!row_ptr || !pairs || !w || !dL_dout || !dL_dtexels) return GH_ERR_INVALID_ARG;
+  (void)hipGetLastError();
+  const size_t n = (size_t)U * C;
+  hipLaunchKernelGGL(gh_uv_scatter_sorted_kernel, dim3((unsigned)((n + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0,
+                     (hipStream_t)hip_stream, row_ptr, pairs, w, dL_dout, dL_dtexels, U, C);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 

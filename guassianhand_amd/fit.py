@@ -216,32 +216,56 @@ class OneShotFit(nn.Module):
                                     None if bbox_mask is None else sel(bbox_mask)) / n_total
             g = torch.autograd.grad(loss_img, [leaves[k] for k in names], allow_unused=True)
             grads = {k: (gi if gi is not None else torch.zeros_like(leaves[k])) for k, gi in zip(names, g)}
+        # Which collective runs must be the same decision on every rank: the in-place block path needs every rank to have
+        # rendered (its buffer is the one the backward kernels wrote), so it is taken only when every rank owns a camera
+        # (n_total >= world); with more ranks than cameras all ranks pack the same [loss | overflow | grads] buffer instead.
+        use_block = world > 1 and self._default_render and self.color_w.is_cuda and self.active and n_total >= world
+        # Device-side overflow guard of THIS rank's render (sync-free / graph replay): its loss kernel has emitted NaN and zero
+        # gradients. In a sharded fit the flag is summed with the gradients, so that every rank skips the same Adam step.
+        local_guard = None
+        if self._default_render and self.color_w.is_cuda and mine:
+            from . import rasterizer as R
+            local_guard = R.last_guard()
+        ovf = None
+        if world > 1 and self.color_w.is_cuda:
+            ovf = torch.zeros((), device=self.color_w.device) if local_guard is None else \
+                local_guard.view(torch.int32)[1].ne(0).float()
         blk = None
-        if world > 1 and self._default_render and self.color_w.is_cuda and self.active and mine:
+        if use_block:
             from . import rasterizer as R
             blk = R.last_grad_block()
+            if not all(grads[k].data_ptr() == blk[0].data_ptr() + 4 * a for k, _, a, _ in blk[2] if k in grads):
+                raise RuntimeError("sharded fit: the blend gradients are not views of the rasteriser's gradient block")
         if world == 1:
             loss_tot, red = loss_img.detach(), grads
-        elif blk is not None and all(grads[k].data_ptr() == blk[0].data_ptr() + 4 * a for k, _, a, _ in blk[2] if k in grads):
+        elif blk is not None:
             # The backward kernels wrote the blend gradients into ONE contiguous block; its leading floats are reserved for
-            # the loss: all-reduce that prefix in place on a side stream, right behind the backward (no packing pass).
+            # the loss (float 0) and the overflow flag (float 1): all-reduce that prefix in place on a side stream, right
+            # behind the backward (no packing pass).
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.color_w.device)
+            blk[0][1:2].copy_(ovf.reshape(1))
             work, buf = ghdist.allreduce_block(blk[0], blk[3], loss_img.detach(), stream=self._side)
             if work is not None:
                 work.wait()
             torch.cuda.current_stream().wait_stream(self._side)
-            loss_tot = buf[0]
-            red = {k: blk[0][a:a + n].view(shp) for k, shp, a, n in blk[2] if k in grads}
-        elif self.use_rgb and "color_b" in grads and grads["color_b"].shape[1] == 48:   # RGB mode touches color_b[:, 0:3] only (:328)
-            small = dict(grads)
-            small["color_b"] = grads["color_b"][:, :3].contiguous()
-            loss_tot, red = ghdist.allreduce_grads(small, loss_img.detach(), sorted(small))
-            full = torch.zeros_like(grads["color_b"])
-            full[:, :3] = red["color_b"]
-            red["color_b"] = full
+            loss_tot, ovf = buf[0], buf[1]
+            red = {k: blk[0][a:a + n].view(grads[k].shape) for k, shp, a, n in blk[2] if k in grads}
         else:
-            loss_tot, red = ghdist.allreduce_grads(grads, loss_img.detach(), sorted(grads))
+            small = dict(grads)
+            wide = self.use_rgb and "color_b" in grads and grads["color_b"].shape[1] == 48   # RGB mode touches color_b[:, 0:3] only (:328)
+            if wide:
+                small["color_b"] = grads["color_b"][:, :3].contiguous()
+            if ovf is not None:
+                small["~overflow"] = ovf.reshape(1)
+            loss_tot, red = ghdist.allreduce_grads(small, loss_img.detach(), sorted(small))
+            red = dict(red)
+            if ovf is not None:
+                ovf = red.pop("~overflow")[0]
+            if wide:
+                full = torch.zeros_like(grads["color_b"])
+                full[:, :3] = red["color_b"]
+                red["color_b"] = full
         if self.keep_boundary_grads:                                  # tests: the reduced gradient block at the rasteriser boundary
             self.boundary_grads = {k: v.detach().clone() for k, v in red.items()}
         if self.active:                                               # maps: scatter, then regulariser + Adam in one pass
@@ -250,12 +274,10 @@ class OneShotFit(nn.Module):
             self._adam["color_w"].grad.copy_(red["color_w"])
             lr = self.lr0 * 0.5 ** sum(1 for m in MILESTONES if m <= self.epoch)
             sums = {}
-            guard = None
-            if self._default_render and self.color_w.is_cuda and mine:
-                # device-side overflow guard: if this step's render overflowed its instance capacity (sync-free / graph
-                # replay), the loss kernel has already emitted NaN + zero gradients and Adam leaves the parameters alone
-                from . import rasterizer as R
-                guard = R.last_guard()
+            guard = local_guard
+            if ovf is not None:                                       # sharded: the SUM of the ranks' overflow flags, as GhCounters
+                guard = torch.zeros(4, dtype=torch.int32, device=self.color_w.device)
+                guard[1] = ovf.ne(0).to(torch.int32)
             for k, a in self._adam.items():
                 a.lr = lr
                 sums[k] = a.step(guard)
@@ -333,7 +355,8 @@ class CapturedFitStep:
         from . import rasterizer as R
         for counters, cap, key in self.counters:
             c4 = counters.tolist()
-            d = (c4[2] if key[-1] else c4[0]) & 0xFFFFFFFF
-            if d > cap:
-                R._capacity[key] = max(R._capacity.get(key, 0), int(d * 1.5) + 1024)
+            d = c4[0] & 0xFFFFFFFF
+            if (c4[1] & 0xFFFFFFFF) != 0:                          # the device-side flag decides (a split call's reserved[0] only sizes)
+                need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
+                R._capacity[key] = max(R._capacity.get(key, 0), int(need * 1.5) + 1024)
                 raise R.GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside the captured fit step")

@@ -48,9 +48,41 @@ class GhOverflowError(RuntimeError):
 # ---------------------------------------------------------------------------------------------------
 # capacity policy for the data-dependent instance count D
 _capacity: Dict[Tuple[int, int, int, int], int] = {}
-_pending = []  # (event, pinned counters, capacity, key) of sync-free calls not yet checked
+_pending = []      # _Pending records of sync-free calls not yet checked
 _free_slots = []   # recycled (pinned 4-int buffer, event) pairs: a sync-free call allocates neither
 _PENDING_MAX = 64
+
+
+class _Pending:
+    """The asynchronous counter read-back of one sync-free forward. `resolve()` waits for it (normally long done), recycles
+    the pinned buffer and remembers the verdict, so that both check_overflow() and the call's own backward can ask."""
+    __slots__ = ("ev", "host", "cap", "key", "done", "d", "over")
+
+    def __init__(self, ev, host, cap, key):
+        self.ev, self.host, self.cap, self.key, self.done, self.d, self.over = ev, host, cap, key, False, 0, False
+
+    def resolve(self) -> bool:
+        """True when the call overflowed its capacity (the learned capacity of its shape is raised then)."""
+        global _last_D
+        if not self.done:
+            self.ev.synchronize()
+            c = self.host.tolist()
+            self.d = c[0] & 0xFFFFFFFF
+            _last_D = self.d
+            # overflowed = the device-side flag, nothing else; a split call's reserved[0] (the max_instances that would give
+            # each half a large enough share) only sizes the NEXT capacity
+            self.over = (c[1] & 0xFFFFFFFF) != 0
+            need = (c[2] & 0xFFFFFFFF) if self.key[-1] else self.d
+            if self.over:
+                _capacity[self.key] = max(_capacity.get(self.key, 0), int(max(need, self.d) * 1.5) + 1024)
+            _free_slots.append((self.host, self.ev))
+            self.host = self.ev = None
+            self.done = True
+        return self.over
+
+    def message(self) -> str:
+        return (f"tile instances D={self.d} exceeded max_instances={self.cap}; the call returned a NaN image; "
+                "capacity raised, re-run the step")
 
 
 _last_D = 0
@@ -139,36 +171,32 @@ def _initial_capacity(P: int, NV: int) -> int:
     return max(1 << 16, 8 * P * NV)
 
 
-def check_overflow(block: bool = True) -> None:
-    """Verify every outstanding sync-free forward fitted its capacity (raises GhOverflowError)."""
+def check_overflow(block: bool = True, keep_recent: int = 0) -> None:
+    """Verify every outstanding sync-free forward fitted its capacity (raises GhOverflowError). block=False only looks at
+    read-backs that have arrived — except that all but the `keep_recent` latest calls are waited for regardless (they
+    finished long ago), which bounds how late an overflow can surface."""
     global _pending, _last_D
     for counters, cap, key in list(_graph_counters.values()):   # graph mode: workspaces are static, read them directly
         c4 = counters.tolist()
         d = c4[0] & 0xFFFFFFFF
         _last_D = d
-        if key[-1]:                                    # split call: the capacity that would have sufficed for both halves
-            d = c4[2] & 0xFFFFFFFF
-        if d > cap:
-            _capacity[key] = max(_capacity.get(key, 0), int(d * 1.5) + 1024)
+        if (c4[1] & 0xFFFFFFFF) != 0:                  # the device-side flag decides; reserved[0] of a split call sizes the next capacity
+            need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
+            _capacity[key] = max(_capacity.get(key, 0), int(need * 1.5) + 1024)
             raise GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside a captured graph")
     keep, bad = [], None
-    for ev, host, cap, key in _pending:
-        if not block and not ev.query():
-            keep.append((ev, host, cap, key))
+    n_old = len(_pending) - keep_recent if keep_recent > 0 else 0
+    for i, pc in enumerate(_pending):
+        if pc.done:
             continue
-        ev.synchronize()
-        d = int(host[0]) & 0xFFFFFFFF
-        _last_D = d
-        if key[-1]:
-            d = int(host[2]) & 0xFFFFFFFF
-        _free_slots.append((host, ev))
-        if d > cap:
-            _capacity[key] = max(_capacity.get(key, 0), int(d * 1.5) + 1024)
-            bad = (d, cap)
+        if not block and i >= n_old and not pc.ev.query():
+            keep.append(pc)
+            continue
+        if pc.resolve():
+            bad = pc
     _pending = keep
     if bad is not None:
-        raise GhOverflowError(f"tile instances D={bad[0]} exceeded max_instances={bad[1]}; the call returned a NaN image; "
-                              "capacity raised, re-run the step")
+        raise GhOverflowError(bad.message())
 
 
 # Workspace pool: a forward takes its workspace from here and the context gives it back when it dies (after its backward,
@@ -236,7 +264,7 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 class _Ctx:
     __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "rows", "stream", "alpha",
-                 "parent", "radii", "__weakref__")
+                 "parent", "radii", "pending", "__weakref__")
 
     def __del__(self):
         try:
@@ -249,7 +277,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                    sh_degree: int = 0, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
                    color_b=None, max_instances: Optional[int] = None, sync: Optional[bool] = True, return_alpha: bool = False,
                    per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None,
-                   split_streams: Optional[bool] = None):
+                   split_streams: Optional[bool] = None, expect_backward: bool = False):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
     with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha.
     per_view_gaussians (pose batch, the batch loop of GS3DRenderer.forward): every per-Gaussian tensor holds NV*P rows and
@@ -259,7 +287,10 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     the reference's mask pass after the RGB pass of a view. Colours must be colors_precomp.
     split_streams (GH_FLAG_SPLIT_STREAMS, n_views >= 2): the views run as two halves on two HIP streams inside the library
     (forked from / joined into the current stream, graph-capturable); bit-identical images, radii and gradients.
-    None = the module policy (set_split_streams)."""
+    None = the module policy (set_split_streams).
+    sync: True = read D back (and re-run with a larger capacity if needed); False = never block (check_overflow() is the
+    caller's job); None = auto: read D back for the first call of a shape and for calls whose backward will not come
+    (expect_backward False), otherwise sync-free with the check at the start of raster_backward."""
     global _last_D, _last_ws
     L = _lib.lib()
     dev = means3D.device
@@ -327,6 +358,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         ctx = _Ctx()
         ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
         ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
+        ctx.pending = g0.pending                 # the overflow flag is the geometry owner's
         return image, g0.radii, ctx           # same geometry, same radii; an overflow is the first call's (NaN image here too)
     while True:
         cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))
@@ -355,23 +387,27 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             raise RuntimeError(f"gh_forward failed: {_abi.status_name(rc)}")
         counters = ws[:16].view(torch.int32)
         _last_ws = ws
-        if sync is None:                                   # auto: read D back once per shape to size the capacity, then sync-free
-            sync = max_instances is None and key not in _capacity
+        pending, auto = None, sync is None
+        if sync is None:
+            # auto: read D back once per shape to size the capacity, then sync-free — but only for calls whose backward will
+            # come (it checks this call's counters before it produces a gradient, see raster_backward). A call outside
+            # autograd (inference) has no such second chance and reads D back like the reference wrapper does.
+            sync = (max_instances is None and key not in _capacity) or not expect_backward
             if not sync:
-                check_overflow(block=False)               # surfaces an overflow of an earlier sync-free call as soon as it is known
+                check_overflow(block=False, keep_recent=2)  # an overflow of an earlier sync-free call surfaces at most two calls late
         if sync:
             c4 = counters.tolist()                        # the one host read-back, as in the reference wrapper
             d = c4[0] & 0xFFFFFFFF
             _last_D = d
-            if split:                                      # the capacity that gives each half of the views a large enough share
-                d = c4[2] & 0xFFFFFFFF
-            if d > cap:
+            over = (c4[1] & 0xFFFFFFFF) != 0
+            need = max(d, c4[2] & 0xFFFFFFFF) if split else d   # split: the capacity that gives each half a large enough share
+            if over:
                 if max_instances is not None:
                     raise GhOverflowError(f"tile instances D={d} exceed max_instances={cap}")
-                _capacity[key] = int(d * 1.5) + 1024
+                _capacity[key] = int(need * 1.5) + 1024
                 continue                                       # (the too-small workspace is simply dropped)
             if max_instances is None and key not in _capacity:
-                _capacity[key] = max(int(d * 1.5) + 1024, 1 << 16)
+                _capacity[key] = max(int(need * 1.5) + 1024, 1 << 16)
         elif _graph_mode:
             # every captured workspace is registered (keyed by its address, so a workspace re-used by later captures is
             # listed once); check_overflow() reads each of them
@@ -384,12 +420,15 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             host, ev = _free_slots.pop() if _free_slots else (torch.empty(4, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
             host.copy_(counters, non_blocking=True)
             ev.record()
-            _pending.append((ev, host, cap, key))
+            pc = _Pending(ev, host, cap, key)
+            _pending.append(pc)
+            if auto:                                       # an explicit sync=False never blocks: check_overflow() is the caller's job
+                pending = pc
         break
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
     ctx.b_rgb, ctx.rows = b_rgb, rows
-    ctx.alpha, ctx.parent, ctx.radii, ctx.stream = alpha, None, radii, stream
+    ctx.alpha, ctx.parent, ctx.radii, ctx.stream, ctx.pending = alpha, None, radii, stream, pending
     return image, radii, ctx
 
 
@@ -398,6 +437,11 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
     """grad_scale: optional one-element device tensor multiplied into dL_dimage / dL_dalpha as the kernel reads them
     (GhGrads.upstream_scale): the dL/dloss of a scalar loss whose image gradient was produced unscaled."""
     L = _lib.lib()
+    if ctx.pending is not None and ctx.pending.resolve():
+        # auto-sync forward (the drop-in's default): its counters are checked HERE, before any gradient exists — an overflowed
+        # call returned a NaN image, and a NaN loss must not reach the caller's optimiser step. The forward finished long ago
+        # on any host-bound loop, so this wait is normally free.
+        raise GhOverflowError(ctx.pending.message())
     t = ctx.tensors
     dev = t["means3D"].device
     P, NV, M = ctx.P, ctx.NV, ctx.M
@@ -474,6 +518,11 @@ def last_grad_block():
     return _last_grad_block
 
 
+def workspace_counters(ctx: _Ctx):
+    """GhCounters of a forward as a host list [num_rendered, overflow, reserved0, reserved1] (synchronises; tests / tools)."""
+    return [c & 0xFFFFFFFF for c in ctx.ws[:16].view(torch.int32).tolist()]
+
+
 def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
     """Typed views of the internal stage arrays (for tests / profiling), via gh_workspace_layout."""
     L = _lib.lib()
@@ -519,7 +568,7 @@ def set_geometry_reuse(on: bool) -> None:
 def _geometry_key(means3D, opacities, scales, rotations, rs):
     objs = (means3D, opacities, scales, rotations, rs.viewmatrix, rs.projmatrix, rs.campos)
     vals = tuple(o._version for o in objs) + (int(rs.image_height), int(rs.image_width), float(rs.tanfovx), float(rs.tanfovy),
-                                               float(rs.scale_modifier))
+                                               float(rs.scale_modifier), _raw_stream(means3D.device))
     return objs, vals
 
 
@@ -531,16 +580,22 @@ class _RasterizeGaussians(torch.autograd.Function):
         cams = pack_camera(rs.viewmatrix, rs.projmatrix, rs.campos, rs.tanfovx, rs.tanfovy, rs.bg)
         parent = None
         if _reuse_geometry:
+            # Only the documented pair is shared: the call DIRECTLY after a full call, with the very same (unmodified, `is` +
+            # `_version`) geometry tensors and camera on the same stream, precomputed colours, while the first call's context is
+            # still alive (its backward has not run). The record holds weak references and is dropped after one reuse, so
+            # nothing of an earlier step can be picked up. (An in-place update through `.data` does not move `_version`:
+            # between an RGB call and its mask call nothing updates parameters.)
             objs, vals = _geometry_key(means3D, opacities, scales, rotations, rs)
-            g = _geom_last
-            if g is not None and sh is None and g[1] == vals and all(a is b for a, b in zip(g[0], objs)):
+            g, _geom_last = _geom_last, None
+            if g is not None and sh is None and g[1] == vals and all(a() is b for a, b in zip(g[0], objs)):
                 parent = g[2]()                    # alive until its backward has run
         image, radii, rctx = raster_forward(
             cams, means3D, opacities, scales, rotations, H=int(rs.image_height), W=int(rs.image_width),
             shs=sh, colors_precomp=colors_precomp, sh_degree=int(rs.sh_degree),
-            scale_modifier=float(rs.scale_modifier), sync=sync, geometry_of=parent)
+            scale_modifier=float(rs.scale_modifier), sync=sync, geometry_of=parent,
+            expect_backward=any(ctx.needs_input_grad))
         if _reuse_geometry and parent is None:
-            _geom_last = (objs, vals, weakref.ref(rctx))
+            _geom_last = (tuple(weakref.ref(o) for o in objs), vals, weakref.ref(rctx))
         ctx.rctx = rctx
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape,
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape, scales.shape,
@@ -566,9 +621,12 @@ class GaussianRasterizer(nn.Module):
 
     def __init__(self, raster_settings: GaussianRasterizationSettings, sync: Optional[bool] = None):
         """sync=None (default): the first call of an image / Gaussian-count shape reads the instance count D back once to size
-        the workspace capacity; every later call is sync-free. A sync-free call that overflows its capacity returns a NaN
-        image (device-side guard) and the next rasteriser call or rasterizer.check_overflow() raises GhOverflowError with the
-        capacity already raised. sync=True reads D back on every call like the reference wrapper does."""
+        the workspace capacity (1.5 D + 1024); later calls under autograd are sync-free in the forward, and their BACKWARD first
+        checks the forward's counters (an event that completed long before on a host-bound loop): an overflowed call — which
+        returned a NaN image, device-side guard — raises GhOverflowError there, before a gradient exists, with the capacity
+        already raised; the caller's optimiser never sees the NaN. Calls outside autograd (inference: no backward will come)
+        read D back like the reference wrapper and re-run transparently with a larger capacity.
+        sync=True reads D back on every call like the reference wrapper does; sync=False never blocks (check_overflow())."""
         super().__init__()
         self.raster_settings = raster_settings
         self.sync = sync

@@ -1,25 +1,24 @@
 """Host-side mirror of the reference's per-view render path (tgs/models/renderer_one_shot.py).
 
 Same names, argument meaning and outputs as the reference for the part of `GS3DRenderer` that sits on
-the hot path: `GaussianModel` (:114-119), the GSLayer activations (:191-214), `forward_single_view`
-(:259-382: settings, attribute blend, RGB pass + mask pass) and the per-view loop of
+the hot path: `GaussianModel` (:114-119), the GSLayer activations (:191-214) and the per-view loop of
 `forward_single_batch` (:494-510) with its Gaussian selection (:468-477, `select_gaussians`). The feature networks above it (attention, MLPs, UV lookups) are out
 of scope and stay in the reference.
 
-Two execution forms, identical results:
-  * `forward_single_view(...)`  — the reference's protocol: blend in torch, two `GaussianRasterizer` calls.
-  * `render_views(...)`         — MI355X form: all views in one launch sequence, blend fused into the kernels.
+`render_views(...)` is the MI355X form of the per-view loop: all views in one launch sequence, blend fused into the
+kernels. The reference's own protocol (blend in torch, two `GaussianRasterizer` calls per view) needs nothing from this
+module — the reference's unmodified `forward_single_view` runs on the import shim; the tests keep a restatement of it
+(`tests/helpers.py::forward_single_view`) to compare the two forms.
 """
 from __future__ import annotations
 
-import math
 from typing import Dict, NamedTuple, Optional
 
 import torch
 import torch.nn.functional as F
 
-from .camera import Camera, pack_cameras_from_w2c
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_views
+from .camera import pack_cameras_from_w2c
+from .rasterizer import rasterize_views
 
 
 class GaussianModel(NamedTuple):
@@ -117,57 +116,6 @@ def select_gaussians(if_gs_valid: torch.Tensor, query_points: torch.Tensor, gs_h
     indexings of the reference produce, with ONE host read-back (the two counts) instead of four (`gh_select_rows`).
     The caller continues like the reference: refine the copied positions, concatenate (:474-477)."""
     return _SelectRows.apply(if_gs_valid, query_points, gs_hidden_features, threshold_low, threshold_high)
-
-
-def forward_single_view(gs: GaussianModel, viewpoint_camera: Camera, background_color: torch.Tensor, ret_mask: bool = True,
-                        color_w=None, xyz_b=None, color_b=None, opacity_b=None, *, use_rgb: bool = True,
-                        sh_degree: int = 3, scaling_modifier: float = 1.0) -> Dict[str, torch.Tensor]:
-    """Line-for-line protocol of GS3DRenderer.forward_single_view (renderer_one_shot.py:259-382)."""
-    device = gs.xyz.device
-    screenspace_points = torch.zeros_like(gs.xyz, dtype=gs.xyz.dtype, requires_grad=True, device=device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
-    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
-    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
-    mk = lambda bg, deg: GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.height), image_width=int(viewpoint_camera.width), tanfovx=tanfovx,
-        tanfovy=tanfovy, bg=bg, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
-        projmatrix=viewpoint_camera.full_proj_transform.float(), sh_degree=deg, campos=viewpoint_camera.camera_center,
-        prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(raster_settings=mk(background_color, sh_degree))
-    means3D = gs.xyz
-    if xyz_b is not None:
-        means3D = means3D + xyz_b
-    opacity = gs.opacity
-    if opacity_b is not None:
-        opacity = opacity + opacity_b.view(-1, 1)
-    shs, colors_precomp = None, None
-    if use_rgb:
-        colors_precomp = gs.shs.squeeze(1)
-        if color_w is not None:
-            colors_precomp = colors_precomp * color_w.view(-1, 16, 3)[:, 0, :] + color_w.view(-1, 16, 3)[:, 1, :] - 1
-        if color_b is not None:
-            colors_precomp = colors_precomp + color_b.view(-1, 16, 3)[:, 0, :]
-    else:
-        shs = gs.shs
-        if color_w is not None:
-            shs = shs * color_w.view(-1, 16, 3)
-        if color_b is not None:
-            shs = shs * color_w.view(-1, 16, 3) + color_b.view(-1, 16, 3)
-    rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs,
-                                       colors_precomp=colors_precomp, opacities=opacity, scales=gs.scaling,
-                                       rotations=gs.rotation, cov3D_precomp=None)
-    ret = {"comp_rgb": rendered_image.permute(1, 2, 0), "comp_rgb_bg": background_color}
-    if ret_mask:
-        mask_bg = torch.zeros(3, dtype=torch.float32, device=device)
-        rasterizer = GaussianRasterizer(raster_settings=mk(mask_bg, 0))
-        rendered_mask, radii = rasterizer(means3D=means3D, means2D=screenspace_points,
-                                          colors_precomp=torch.ones_like(means3D), opacities=opacity,
-                                          scales=gs.scaling, rotations=gs.rotation, cov3D_precomp=None)
-        ret["comp_mask"] = rendered_mask.permute(1, 2, 0)
-    return ret
 
 
 def render_views(gs: GaussianModel, w2cs: torch.Tensor, intrinsics: torch.Tensor, height: int, width: int,

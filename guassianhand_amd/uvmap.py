@@ -46,17 +46,29 @@ class _UvSample(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        L = _lib.lib()
+        # Deterministic: the texels under the footprints are listed once per UV tensor (ActiveTexels, cached on identity +
+        # version) and the scatter runs as a fixed-order gather (gh_uv_scatter_sorted) — no float atomics on the fit path.
         (u,) = ctx.saved_tensors
         Hm, Wm, Cc = ctx.shape
+        at = _texels_of(u, Hm, Wm)
         g = grad_out.detach().float().contiguous()
-        dmap = torch.zeros(Hm, Wm, Cc, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
-            rc = L.gh_uv_sample_backward(C.c_void_p(u.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(dmap.data_ptr()),
-                                         u.shape[0], Cc, Hm, Wm, C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream))
-        if rc != 0:
-            raise RuntimeError(f"gh_uv_sample_backward failed: {_abi.status_name(rc)}")
-        return dmap, None
+        dtex = torch.zeros(at.U, Cc, dtype=torch.float32, device=g.device)
+        uv_gather_backward(g, at, dtex)
+        return at.dense(dtex), None
+
+
+_texel_cache = []      # [(weakref to the uv tensor, version, Hm, Wm, ActiveTexels)], most recent first
+
+
+def _texels_of(uv: torch.Tensor, Hm: int, Wm: int) -> "ActiveTexels":
+    import weakref
+    for i, (ref, ver, h, w, at) in enumerate(_texel_cache):
+        if ref() is uv and ver == uv._version and (h, w) == (Hm, Wm):
+            return at
+    at = ActiveTexels(uv, Hm, Wm)
+    _texel_cache.insert(0, (weakref.ref(uv), uv._version, Hm, Wm, at))
+    del _texel_cache[4:]
+    return at
 
 
 def uv_sample(map_hwc: torch.Tensor, uv: torch.Tensor) -> torch.Tensor:
@@ -95,6 +107,14 @@ class ActiveTexels:
         self.slot = torch.where(valid, slot, torch.full_like(slot, -1)).to(torch.int32).contiguous()
         self.w = torch.stack([wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1], 1).contiguous()
         self.Hm, self.Wm, self.P = Hm, Wm, uv.shape[0]
+        # the same incidence transposed (CSR by texel) for the deterministic backward (gh_uv_scatter_sorted): pairs =
+        # 4 * gaussian + corner of every valid corner, grouped by texel, ascending inside a texel
+        flat = self.slot.reshape(-1).long()
+        pairs = torch.nonzero(flat >= 0).reshape(-1)
+        order = torch.sort(flat[pairs], stable=True).indices
+        self.pairs = pairs[order].to(torch.int32).contiguous()
+        counts = torch.bincount(flat[pairs], minlength=int(self.index.numel()))
+        self.row_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32).contiguous()
 
     @property
     def U(self) -> int:
@@ -138,16 +158,17 @@ def uv_gather(texels: torch.Tensor, at: ActiveTexels) -> torch.Tensor:
 
 
 def uv_gather_backward(grad_out: torch.Tensor, at: ActiveTexels, grad_texels: torch.Tensor) -> None:
-    """Accumulates d(loss)/d(texels) (U,C) from d(loss)/d(per-Gaussian values) (P,C)."""
+    """Accumulates d(loss)/d(texels) (U,C) from d(loss)/d(per-Gaussian values) (P,C): a fixed-order gather over each
+    texel's (Gaussian, corner) list (gh_uv_scatter_sorted) — bitwise reproducible, no atomics."""
     g = grad_out.detach().float().contiguous()
-    _need_device(g, grad_texels, at.slot, at.w)
+    _need_device(g, grad_texels, at.row_ptr, at.pairs, at.w)
     assert g.shape == (at.P, grad_texels.shape[1]) and grad_texels.shape[0] == at.U
     L = _lib.lib()
     with torch.cuda.device(g.device):
-        rc = L.gh_uv_gather_backward(C.c_void_p(at.slot.data_ptr()), C.c_void_p(at.w.data_ptr()), C.c_void_p(g.data_ptr()),
-                                     C.c_void_p(grad_texels.data_ptr()), at.P, g.shape[1], _stream(g))
+        rc = L.gh_uv_scatter_sorted(C.c_void_p(at.row_ptr.data_ptr()), C.c_void_p(at.pairs.data_ptr()), C.c_void_p(at.w.data_ptr()),
+                                    C.c_void_p(g.data_ptr()), C.c_void_p(grad_texels.data_ptr()), at.U, g.shape[1], _stream(g))
     if rc != 0:
-        raise RuntimeError(f"gh_uv_gather_backward failed: {_abi.status_name(rc)}")
+        raise RuntimeError(f"gh_uv_scatter_sorted failed: {_abi.status_name(rc)}")
 
 
 class AdamReg:

@@ -12,8 +12,12 @@
  * Conventions
  *   - extern "C", plain pointers and sizes, no torch / STL types.
  *   - Every buffer (inputs, outputs, gradients, workspace) is allocated by the caller; the library
- *     owns no device memory and keeps no global state. All functions are re-entrant.
- *   - All device work is enqueued on the caller-supplied stream. The library never synchronises,
+ *     owns no device memory. All functions are re-entrant. The only process-wide state exists with
+ *     GH_FLAG_SPLIT_STREAMS: one side stream + fork / join events per device, created on first use and
+ *     guarded by a per-device mutex (split calls of one device are enqueued one after the other).
+ *     Without the flag, no call touches anything but its arguments.
+ *   - All device work is enqueued on the caller-supplied stream (and, with GH_FLAG_SPLIT_STREAMS, on the
+ *     library's side stream forked from and joined back into it). The library never synchronises,
  *     never allocates and never copies to the host: every entry point is HIP-graph capturable.
  *     Data-dependent sizes (the number of tile instances D) stay on the device; the caller bounds
  *     them with `max_instances` and reads `GhCounters` back whenever it chooses.
@@ -174,7 +178,7 @@ typedef struct GhLayout {
   size_t final_T;        /* float [n_views*H*W] */
   size_t n_contrib;      /* uint32[n_views*H*W] */
   size_t inst_grad;      /* float[max_instances][4][9] per-(instance, quadrant) gradient sub-records (backward scratch) */
-  size_t inst_flag;      /* uint8[max_instances][4]     1 where the quadrant wrote its sub-record (zeroed per backward) */
+  size_t inst_flag;      /* uint8[max_instances][4]     1 where the quadrant wrote its sub-record (zeroed per forward) */
   size_t sh_rgb;         /* float4[n_views*P] SH colour stage output (r, g, b, clamp-flag bits); unused with colors_precomp */
   size_t dmean_sh;       /* float4[n_views*P] d(loss)/d(mean) through the SH view direction (backward scratch) */
   size_t sh_scratch;     /* float[ceil(P/16)][64] block partials of the global colour-weight gradient (SH mode) */
@@ -250,7 +254,9 @@ int gh_backward_shared(const GhDims* dims, const GhInputs* in, const GhGrads* gr
  * F.grid_sample(..., align_corners=True, mode="bilinear") of query_triplane_texture (renderer_one_shot.py:420-446)
  * at the call sites :489-492. `map` is CHANNEL-LAST (Hm, Wm, C) fp32 (the reference parameter (C,Hm,Wm) permuted
  * once); `uv` is (P,2) in [-1,1] (x = u indexes Wm, y = v indexes Hm); texels outside the map read as zero.
- * gh_uv_sample_backward ACCUMULATES into dL_dmap (the caller zeroes it): float atomics, run-to-run order noise.
+ * gh_uv_sample_backward ACCUMULATES into dL_dmap (the caller zeroes it) with float atomics: run-to-run order noise. It is
+ * the one entry point of this header that is not bitwise reproducible; it needs no index built beforehand. The host side of
+ * this repository (uvmap.py) does not call it: it builds the texel lists once and uses gh_uv_scatter_sorted below.
  */
 int gh_uv_sample_forward(const float* map, const float* uv, float* out /* (P,C) */, int P, int C, int Hm, int Wm,
                          void* hip_stream);
@@ -262,12 +268,18 @@ int gh_uv_sample_backward(const float* uv, const float* dL_dout /* (P,C) */, flo
  * fixed during the fit, so only the texels under their bilinear footprints ever change (all others keep gradient 0
  * under the regularisers of :514-518 and stay 0 under Adam). `texels` holds those U texels compacted as (U, C);
  * slot (P,4) int32 = compact row of the nw, ne, sw, se corner (-1 = outside the map, reads as zero), w (P,4) = the
- * bilinear weights. gh_uv_gather_backward ACCUMULATES into dL_dtexels (float atomics).
+ * bilinear weights. gh_uv_gather_backward ACCUMULATES into dL_dtexels with float atomics (order noise, see above).
+ * gh_uv_scatter_sorted is the deterministic backward of both lookups: the caller lists, once per set of UVs, the
+ * (Gaussian, corner) pairs under every active texel — CSR, row_ptr (U+1) int32, pairs (nnz) int32 = 4 * gaussian + corner in
+ * ascending order inside a texel — and the kernel GATHERS: one lane per (texel, channel) adds dL_dout[gaussian][c] * w[pair]
+ * in list order and ACCUMULATES the sum into dL_dtexels (U,C). No atomics, bitwise reproducible.
  */
 int gh_uv_gather_forward(const float* texels, const int32_t* slot, const float* w, float* out /* (P,C) */, int P, int C,
                          void* hip_stream);
 int gh_uv_gather_backward(const int32_t* slot, const float* w, const float* dL_dout /* (P,C) */, float* dL_dtexels /* (U,C) */,
                           int P, int C, void* hip_stream);
+int gh_uv_scatter_sorted(const int32_t* row_ptr /* (U+1) */, const int32_t* pairs /* (nnz) */, const float* w /* (P,4) */,
+                         const float* dL_dout /* (P,C) */, float* dL_dtexels /* (U,C) */, int U, int C, void* hip_stream);
 
 /*
  * One fused pass over a parameter array of n floats: torch.optim.Adam's update (infer_one_shot.py:345; step >= 1 is

@@ -63,3 +63,58 @@ def tiny_fit_problem(P=160, n_views=4, hw=(32, 32), map_hw=(16, 32), seed=0, dev
     mv = lambda t: t.to(device)
     return dict(gs=GaussianModel(*[mv(t) for t in gs]), uv=mv(uv), w2c=mv(sc.w2c), K=mv(sc.K), H=H, W=W, bg=mv(torch.zeros(3)),
                 true={k: mv(v) for k, v in true.items()}, map_hw=map_hw)
+
+
+def forward_single_view(gs, viewpoint_camera, background_color: torch.Tensor, ret_mask: bool = True,
+                        color_w=None, xyz_b=None, color_b=None, opacity_b=None, *, use_rgb: bool = True,
+                        sh_degree: int = 3, scaling_modifier: float = 1.0):
+    """The call protocol of GS3DRenderer.forward_single_view (renderer_one_shot.py:259-382) restated for the tests and the
+    host-cost tools: blend in torch, then the RGB call and the mask call through the drop-in GaussianRasterizer — what the
+    reference's unmodified function does on the import shim."""
+    import math
+    from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    device = gs.xyz.device
+    screenspace_points = torch.zeros_like(gs.xyz, dtype=gs.xyz.dtype, requires_grad=True, device=device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+    mk = lambda bg, deg: GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.height), image_width=int(viewpoint_camera.width), tanfovx=tanfovx,
+        tanfovy=tanfovy, bg=bg, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform.float(), sh_degree=deg, campos=viewpoint_camera.camera_center,
+        prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=mk(background_color, sh_degree))
+    means3D = gs.xyz
+    if xyz_b is not None:
+        means3D = means3D + xyz_b
+    opacity = gs.opacity
+    if opacity_b is not None:
+        opacity = opacity + opacity_b.view(-1, 1)
+    shs, colors_precomp = None, None
+    if use_rgb:
+        colors_precomp = gs.shs.squeeze(1)
+        if color_w is not None:
+            colors_precomp = colors_precomp * color_w.view(-1, 16, 3)[:, 0, :] + color_w.view(-1, 16, 3)[:, 1, :] - 1
+        if color_b is not None:
+            colors_precomp = colors_precomp + color_b.view(-1, 16, 3)[:, 0, :]
+    else:
+        shs = gs.shs
+        if color_w is not None:
+            shs = shs * color_w.view(-1, 16, 3)
+        if color_b is not None:
+            shs = shs * color_w.view(-1, 16, 3) + color_b.view(-1, 16, 3)
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs,
+                                       colors_precomp=colors_precomp, opacities=opacity, scales=gs.scaling,
+                                       rotations=gs.rotation, cov3D_precomp=None)
+    ret = {"comp_rgb": rendered_image.permute(1, 2, 0), "comp_rgb_bg": background_color}
+    if ret_mask:
+        mask_bg = torch.zeros(3, dtype=torch.float32, device=device)
+        rasterizer = GaussianRasterizer(raster_settings=mk(mask_bg, 0))
+        rendered_mask, radii = rasterizer(means3D=means3D, means2D=screenspace_points,
+                                          colors_precomp=torch.ones_like(means3D), opacities=opacity,
+                                          scales=gs.scaling, rotations=gs.rotation, cov3D_precomp=None)
+        ret["comp_mask"] = rendered_mask.permute(1, 2, 0)
+    return ret

@@ -48,7 +48,7 @@ def test_bench_one_gpu_line():
     assert "workload" in d["config"] and "model" not in d["config"]
 
 
-def _run_bench(n_ranks, *extra):
+def _run_bench(n_ranks, *extra, backend="gloo"):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     tail = ["--steps", "2", "--warmup", "1", "--repeats", "1", "--no-stage-timing", "--no-cpu-baseline", *extra]
     if n_ranks == 1:
@@ -56,7 +56,7 @@ def _run_bench(n_ranks, *extra):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr",
                "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks),
-               "--dist-backend", "gloo", *tail]
+               "--dist-backend", backend, *tail]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=560)
     assert r.returncode == 0, r.stderr[-3000:]
     return _last_json(r.stdout)
@@ -84,5 +84,21 @@ def test_bench_two_ranks_equal_the_single_process_run():
 
     strong = _run_bench(2, "--views-per-step", "8", "--scaling", "strong", "--allreduce-grads")
     assert strong["scaling"] == "strong" and strong["config"]["views_per_step_per_gpu"] == 4 and strong["config"]["views_per_step_total"] == 8
+    assert strong["config"]["final_loss"] == pytest.approx(2 * L1, rel=1e-5)
+    assert strong["config"]["grad_l1"] == pytest.approx(2 * G1, rel=1e-4)
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_gpus_over_rccl():
+    """the driver's N > 1 launch line with the real backend ("nccl" = RCCL over xGMI), one rank per GPU —
+    runs wherever the box has two GPUs, so the first multi-GPU lease exercises RCCL in the test suite; skipped on one GPU."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL)")
+    one = _run_bench(1, "--views-per-step", "8")
+    L1, G1 = one["config"]["final_loss"], one["config"]["grad_l1"]
+    weak = _run_bench(2, "--views-per-step", "4", backend="nccl")
+    assert weak["n_gpus"] == 2 and weak["config"]["final_loss"] == pytest.approx(2 * L1, rel=1e-5)
+    strong = _run_bench(2, "--views-per-step", "8", "--scaling", "strong", "--allreduce-grads", backend="nccl")
     assert strong["config"]["final_loss"] == pytest.approx(2 * L1, rel=1e-5)
     assert strong["config"]["grad_l1"] == pytest.approx(2 * G1, rel=1e-4)

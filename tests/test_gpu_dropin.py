@@ -6,7 +6,7 @@ import math
 import pytest
 import torch
 
-from tests.helpers import max_rel, rel_l2
+from tests.helpers import forward_single_view, max_rel, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -99,7 +99,7 @@ def test_forward_single_view_equals_fused_batched_views(dev):
             cam.world_view_transform, cam.full_proj_transform = rec[:16].reshape(4, 4), rec[16:32].reshape(4, 4)
             cam.camera_center = rec[32:35]
             cam.FoVx, cam.FoVy = 2 * torch.atan(rec[35]), 2 * torch.atan(rec[36])
-            outs.append(R.forward_single_view(gs, cam, s.bg, color_w=a["color_w"], xyz_b=a["xyz_b"], color_b=a["color_b"],
+            outs.append(forward_single_view(gs, cam, s.bg, color_w=a["color_w"], xyz_b=a["xyz_b"], color_b=a["color_b"],
                                               opacity_b=a["opacity_b"], use_rgb=use_rgb, sh_degree=3))
         rgb_a = torch.stack([o["comp_rgb"] for o in outs])
         mask_a = torch.stack([o["comp_mask"] for o in outs])
@@ -292,7 +292,7 @@ def test_second_call_over_the_same_geometry_reuses_the_first_calls_lists_bit_for
         Rz.set_geometry_reuse(reuse)
         a = {n: getattr(s, n).clone().requires_grad_(True) for n in names}
         gs = R.GaussianModel(a["xyz"], a["opacity"], a["rotation"], a["scaling"], a["shs"])
-        outs = [R.forward_single_view(gs, cams[v], s.bg, color_w=a["color_w"], xyz_b=a["xyz_b"], color_b=a["color_b"],
+        outs = [forward_single_view(gs, cams[v], s.bg, color_w=a["color_w"], xyz_b=a["xyz_b"], color_b=a["color_b"],
                                       opacity_b=a["opacity_b"], use_rgb=use_rgb, sh_degree=3) for v in range(2)]
         rgb = torch.stack([o["comp_rgb"] for o in outs]); mask = torch.stack([o["comp_mask"] for o in outs])
         ((rgb - gt).abs().mean() + ((mask.mean(-1) - gt[..., 0]) ** 2).mean()).backward()
@@ -301,7 +301,6 @@ def test_second_call_over_the_same_geometry_reuses_the_first_calls_lists_bit_for
     try:
         rgb0, mask0, g0 = run(False)
         rgb1, mask1, g1 = run(True)
-        assert Rz._geom_last is not None
     finally:
         Rz.set_geometry_reuse(True)
     assert torch.equal(rgb0, rgb1) and torch.equal(mask0, mask1)
@@ -322,6 +321,83 @@ def test_second_call_over_the_same_geometry_reuses_the_first_calls_lists_bit_for
     img_a, _ = GaussianRasterizer(mk(s.bg))(colors_precomp=col, **kw)
     img_b, _ = GaussianRasterizer(mk(torch.zeros(3, device=dev)))(colors_precomp=torch.ones_like(col), **kw)
     assert img_a.grad_fn.rctx.parent is None and img_b.grad_fn.rctx.parent is img_a.grad_fn.rctx
+    assert Rz._geom_last is None                                          # the record is consumed by its one reuse ...
+    img_b2, _ = GaussianRasterizer(mk(s.bg))(colors_precomp=col, **kw)
+    assert img_b2.grad_fn.rctx.parent is None                             # ... so a third call over the same objects is a full call
     kw2 = dict(kw, opacities=s.opacity.clone())                           # another tensor object: geometry not provably the same
     img_c, _ = GaussianRasterizer(mk(s.bg))(colors_precomp=col, **kw2)
     assert img_c.grad_fn.rctx.parent is None
+    objs = Rz._geom_last[0]                                               # weak references only: the record keeps no tensor alive
+    del kw2
+    import gc
+    gc.collect()
+    assert any(o() is None for o in objs)
+
+
+def _dropin_leaves(sc, dev):
+    import math
+    from guassianhand_amd.camera import Camera
+    from guassianhand_amd.rasterizer import GaussianRasterizationSettings
+    s = sc.to(dev)
+    cam = Camera.from_w2c(s.w2c[0], s.K[0], sc.H, sc.W)
+    rs = GaussianRasterizationSettings(
+        image_height=sc.H, image_width=sc.W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=s.bg,
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform.float(), sh_degree=0,
+        campos=cam.camera_center, prefiltered=False, debug=False)
+    xyz = s.xyz.clone().requires_grad_(True)
+    col = s.shs.squeeze(1).clone().requires_grad_(True)
+    kw = dict(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=s.opacity, scales=s.scaling, rotations=s.rotation,
+              colors_precomp=col, cov3D_precomp=None)
+    return rs, kw, xyz, col
+
+
+def test_default_dropin_never_lets_an_overflowed_render_reach_the_optimiser(dev):
+    """with the default sync=None a call under autograd is sync-free after the first of its shape. If its
+    instance count then exceeds the learned capacity, the image is NaN (device-side guard) — and the call's BACKWARD raises
+    GhOverflowError before any gradient exists, so a reference-style loop never steps its optimiser on NaN. The re-run fits."""
+    from guassianhand_amd import rasterizer as Rz
+    from guassianhand_amd.rasterizer import GaussianRasterizer
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=1, P=3100)
+    rs, kw, xyz, col = _dropin_leaves(sc, dev)
+    Rz.check_overflow()
+    img0, _ = GaussianRasterizer(rs)(**kw)                                # first call of the shape: reads D, learns the capacity
+    img0.sum().backward()
+    g_ref = xyz.grad.clone()
+    xyz.grad = None; col.grad = None
+    key = Rz.capacity_key(sc.P, 1, sc.H, sc.W, False)
+    D = Rz.last_num_rendered()
+    assert D > 2048 and key in Rz._capacity
+    Rz._capacity[key] = D // 2                                            # as if the scene had grown since the capacity was learned
+    img1, _ = GaussianRasterizer(rs)(**kw)                                # sync-free: no error here
+    assert torch.isnan(img1).all()
+    with pytest.raises(Rz.GhOverflowError):
+        img1.sum().backward()
+    assert xyz.grad is None and col.grad is None                          # nothing reached the leaves
+    assert Rz._capacity[key] >= D                                         # capacity raised: the re-run step is whole
+    img2, _ = GaussianRasterizer(rs)(**kw)
+    img2.sum().backward()
+    assert torch.equal(img2, img0) and torch.equal(xyz.grad, g_ref)
+    Rz.check_overflow()
+
+
+def test_default_dropin_inference_call_reruns_transparently(dev):
+    """... and a call no backward will follow (no input requires grad / torch.no_grad: an inference render) reads D back
+    like the reference wrapper and is re-run with a larger capacity: it can never return a NaN image silently."""
+    from guassianhand_amd import rasterizer as Rz
+    from guassianhand_amd.rasterizer import GaussianRasterizer
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=1, P=3200)
+    rs, kw, xyz, col = _dropin_leaves(sc, dev)
+    img0, _ = GaussianRasterizer(rs)(**kw)
+    key = Rz.capacity_key(sc.P, 1, sc.H, sc.W, False)
+    D = Rz.last_num_rendered()
+    Rz._capacity[key] = D // 2
+    with torch.no_grad():
+        img1, _ = GaussianRasterizer(rs)(**kw)
+    assert torch.equal(img1, img0.detach()) and Rz._capacity[key] >= D
+    Rz._capacity[key] = D // 2
+    kw_ng = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    img2, _ = GaussianRasterizer(rs)(**kw_ng)
+    assert torch.equal(img2, img0.detach())
+    Rz.check_overflow()

@@ -1,0 +1,187 @@
+"""The sharded one-shot fit on the device (SURVEY §8 e / f-1): cameras dealt round-robin over ranks, parameters replicated,
+ONE all-reduce per step at the rasteriser boundary — driven here with several ranks on the one card over gloo (the
+collectives are real), and over RCCL ("nccl") when the box has at least two GPUs.
+
+Covers ADVICE r2: (high) ranks WITHOUT a camera (more ranks than cameras) must issue the same collective as the others;
+(medium) an instance-capacity overflow on ONE rank must turn the step into a no-op on EVERY rank.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N_STEPS = 3
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _problem(dev, n_views):
+    from tests.helpers import tiny_fit_problem
+    pb = tiny_fit_problem(P=600, n_views=n_views, hw=(64, 64), device=dev)
+    g = torch.Generator().manual_seed(11)
+    gt_rgb = torch.rand(n_views, 64, 64, 3, generator=g).to(dev)
+    gt_mask = (torch.rand(n_views, 64, 64, generator=g) > 0.5).float().to(dev)
+    return pb, (pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
+
+
+def _state(f):
+    return {k: a.param.detach().cpu().clone() for k, a in f._adam.items()}
+
+
+def _worker(rank, world, port, backend, n_views, overflow_rank, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    ndev = torch.cuda.device_count()
+    local = rank % ndev
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    kw = dict(device_id=dev) if backend == "nccl" else {}
+    dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    try:
+        _work(rank, world, backend, n_views, overflow_rank, q, dev)
+    except Exception:                                  # report at once: the other ranks are stuck in their next collective
+        import traceback
+        q.put((rank, traceback.format_exc()))
+        raise
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def _work(rank, world, backend, n_views, overflow_rank, q, dev):
+    import torch.distributed as dist
+    from guassianhand_amd import fit as F
+    from guassianhand_amd import rasterizer as R
+    pb, args = _problem(dev, n_views)
+    f = F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"])
+    f.keep_boundary_grads = True
+    losses = [float(f.step(*args, sync=True)) for _ in range(N_STEPS)]
+    out = dict(losses=losses, state=_state(f), steps=int(f._adam["color_w"].step_state.max()))
+    if overflow_rank is not None:
+        # one more step, sync-free, with THIS rank's capacity forced far too small on `overflow_rank` only
+        mine = [v for v in range(n_views) if v % world == rank]
+        key = R.capacity_key(600, len(mine), 64, 64, False)
+        R.check_overflow()
+        if rank == overflow_rank:
+            good = R._capacity[key]
+            R._capacity[key] = 64
+        before = _state(f)
+        l_bad = float(f.step(*args, sync=False))
+        after = _state(f)
+        out["bad_loss_is_nan"] = l_bad != l_bad
+        out["unchanged"] = all(torch.equal(before[k], after[k]) for k in before)
+        out["steps_after_bad"] = int(f._adam["color_w"].step_state.max())
+        raised = False
+        try:
+            R.check_overflow()
+        except R.GhOverflowError:
+            raised = True
+        out["raised"] = raised
+        if rank == overflow_rank:
+            R._capacity[key] = max(R._capacity[key], good)
+        out["loss_again"] = float(f.step(*args, sync=False))
+        R.check_overflow()
+        out["state_again"] = _state(f)
+    q.put((rank, out))
+    dist.barrier()
+
+
+def _run(world, backend, n_views, overflow_rank=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, n_views, overflow_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res, err = {}, None
+    try:
+        for _ in range(world):
+            r, out = q.get(timeout=300)
+            if isinstance(out, str):
+                err = (r, out)
+                break
+            res[r] = out
+    finally:
+        for p in procs:
+            p.join(timeout=5 if err else 60)
+            if p.is_alive():
+                p.kill()
+    assert err is None, f"rank {err[0]} failed:\n{err[1]}"
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return res
+
+
+def _single(n_views, extra_step=False):
+    from guassianhand_amd import fit as F
+    from guassianhand_amd import rasterizer as R
+    dev = torch.device("cuda:0")
+    pb, args = _problem(dev, n_views)
+    f = F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"])
+    losses = [float(f.step(*args, sync=True)) for _ in range(N_STEPS)]
+    st = _state(f)
+    again = None
+    if extra_step:
+        again = (float(f.step(*args, sync=True)), _state(f))
+    R.check_overflow()
+    return losses, st, again
+
+
+def _close(a, b):
+    # (the sum over the ranks' gradient blocks has another order than the single process's sum over its views)
+    return all(torch.allclose(a[k], b[k], rtol=2e-4, atol=1e-6) for k in a)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,n_views", [(2, 4), (3, 2)])
+def test_sharded_fit_equals_single_process_fit(world, n_views):
+    """(2, 4): every rank owns cameras — the gradient block the kernels wrote is all-reduced in place.
+    (3, 2): rank 2 owns NO camera (more ranks than cameras) — every rank must take the same (packed) collective."""
+    losses, st, _ = _single(n_views)
+    res = _run(world, "gloo", n_views)
+    for r in range(world):
+        assert res[r]["losses"] == pytest.approx(losses, rel=1e-5), r
+        assert _close(res[r]["state"], st), r
+        assert res[r]["steps"] == N_STEPS
+    for r in range(1, world):                         # replicas stay bit-identical: every rank applied the same reduced block
+        assert all(torch.equal(res[r]["state"][k], res[0]["state"][k]) for k in st)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,n_views,bad", [(2, 4, 1), (3, 2, 0)])
+def test_overflow_on_one_rank_skips_the_step_on_every_rank(world, n_views, bad):
+    """the overflow flag travels with the reduced block, so a sync-free step in which ONE rank's render
+    overflowed its capacity leaves parameters, moments and the bias-correction step count untouched on ALL ranks (loss NaN
+    everywhere); after the capacity is raised the ranks take the step a fit that never overflowed takes."""
+    losses, st, again = _single(n_views, extra_step=True)
+    res = _run(world, "gloo", n_views, overflow_rank=bad)
+    for r in range(world):
+        o = res[r]
+        assert o["bad_loss_is_nan"] and o["unchanged"] and o["steps_after_bad"] == N_STEPS, (r, o)
+        assert o["raised"] == (r == bad)              # only the rank that overflowed has something to report on the host
+        assert o["loss_again"] == pytest.approx(again[0], rel=1e-5)
+        assert _close(o["state_again"], again[1]), r
+    for r in range(1, world):
+        assert all(torch.equal(res[r]["state_again"][k], res[0]["state_again"][k]) for k in st)
+
+
+@pytest.mark.timeout(900)
+def test_sharded_fit_over_rccl():
+    """the same sharded fit over RCCL (backend "nccl"), one rank per GPU — runs wherever the box has two
+    GPUs (the first multi-GPU lease exercises RCCL inside the test suite); skipped on a one-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL)")
+    losses, st, _ = _single(4)
+    res = _run(2, "nccl", 4)
+    for r in range(2):
+        assert res[r]["losses"] == pytest.approx(losses, rel=1e-5)
+        assert _close(res[r]["state"], st)
+    assert all(torch.equal(res[1]["state"][k], res[0]["state"][k]) for k in st)

@@ -91,6 +91,32 @@ def test_split_overflow_reports_needed_capacity(dev):
     assert torch.equal(img3, img)
 
 
+def test_split_call_that_fits_is_not_reported_as_overflowed(dev):
+    """ADVICE r2 (low): `reserved[0]` of a split call is the capacity that WOULD give each half a comfortable share (padded);
+    it may exceed max_instances although neither half overflowed. Only GhCounters.overflow decides."""
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.scenes import make_scene
+    s = make_scene("two_hands", n_views=4, P=20000).to(dev)
+    cols = s.shs.reshape(s.shs.shape[0], 3)
+    cams = s.cams()
+    d_half = []
+    for v0 in (0, 2):
+        R.raster_forward(cams[v0:v0 + 2], s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, colors_precomp=cols, sync=True)
+        d_half.append(R.last_num_rendered())
+    cap = 2 * max(d_half) + 128                       # each half's share (cap / 2, rounded down to 64) holds its instances
+    ref, _, _ = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, colors_precomp=cols, sync=True)
+    img, _, ctx = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, colors_precomp=cols, sync=True,
+                                   split_streams=True, max_instances=cap)
+    c = R.workspace_counters(ctx)
+    assert c[1] == 0 and c[2] > cap                   # fits, yet the comfortable capacity is larger than the one given
+    assert torch.equal(img, ref)
+    R.check_overflow()
+    img2, _, _ = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, colors_precomp=cols, sync=False,
+                                  split_streams=True, max_instances=cap)
+    R.check_overflow()                                # no error, no NaN
+    assert torch.equal(img2, ref)
+
+
 def test_split_inside_captured_graph(dev):
     from guassianhand_amd import rasterizer as R
     from guassianhand_amd.scenes import make_scene

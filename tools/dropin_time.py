@@ -4,7 +4,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from guassianhand_amd import rasterizer as R
 from guassianhand_amd.camera import Camera, pack_camera
-from guassianhand_amd.renderer import GaussianModel, forward_single_view
+from guassianhand_amd.renderer import GaussianModel
+from tests.helpers import forward_single_view
 from guassianhand_amd.scenes import make_scene
 dev = torch.device("cuda:0")
 sc = make_scene("two_hands", n_views=1).to(dev)

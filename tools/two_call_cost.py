@@ -5,7 +5,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from guassianhand_amd.camera import Camera
-from guassianhand_amd.renderer import GaussianModel, forward_single_view, render_views
+from guassianhand_amd.renderer import GaussianModel, render_views
+from tests.helpers import forward_single_view
 from guassianhand_amd.scenes import make_scene
 from guassianhand_amd import rasterizer as R
 dev = torch.device("cuda:0")
