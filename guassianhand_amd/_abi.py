@@ -9,6 +9,7 @@ GH_FLAG_BLEND_W_PER_GAUSSIAN = 1
 GH_FLAG_BLEND_COLOR_B_RGB = 2
 GH_FLAG_PER_VIEW_GAUSSIANS = 4
 GH_FLAG_SPLIT_STREAMS = 8
+GH_FLAG_STATIC_LISTS = 16
 
 GH_OK = 0
 GH_ERR_INVALID_ARG = -1
@@ -109,6 +110,10 @@ def declare(lib: C.CDLL) -> None:
     lib.gh_backward_shared.restype = C.c_int
     lib.gh_backward_shared.argtypes = [C.POINTER(GhDims), C.POINTER(GhInputs), C.POINTER(GhGrads), C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p]
+    lib.gh_forward_refresh.restype = C.c_int
+    lib.gh_forward_refresh.argtypes = lib.gh_forward_shared.argtypes
+    lib.gh_backward_refresh.restype = C.c_int
+    lib.gh_backward_refresh.argtypes = lib.gh_backward_shared.argtypes
     lib.gh_forward_stages.restype = C.c_int
     lib.gh_forward_stages.argtypes = lib.gh_forward.argtypes + [C.c_uint32]
     lib.gh_backward_stages.restype = C.c_int
@@ -124,7 +129,7 @@ GH_FWD_PREPROCESS, GH_FWD_BINNING, GH_FWD_RENDER, GH_FWD_ALL = 1, 2, 4, 7
 GH_BWD_RENDER, GH_BWD_PREPROCESS, GH_BWD_ALL = 1, 2, 3
 
 EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_forward", "gh_backward",
-                    "gh_forward_stages", "gh_backward_stages", "gh_forward_shared", "gh_backward_shared", "gh_uv_sample_forward", "gh_uv_sample_backward",
+                    "gh_forward_stages", "gh_backward_stages", "gh_forward_shared", "gh_backward_shared", "gh_forward_refresh", "gh_backward_refresh", "gh_uv_sample_forward", "gh_uv_sample_backward",
                     "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_uv_scatter_sorted", "gh_adam_reg_step",
                     "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss", "gh_fit_loss",
                     "gh_select_workspace_bytes", "gh_select_rows")

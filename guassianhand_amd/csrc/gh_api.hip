@@ -372,3 +372,53 @@ extern "C" int gh_backward_shared(const GhDims* d, const GhInputs* in, const GhG
   gh_launch_preprocess_bwd(d, g, in, gr, (const char*)geometry_ws, (char*)workspace, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
+
+// ---- a later step over static geometry ------------------------------------------------------------------------------
+static int check_refresh(const GhDims* d, const GhInputs* in) {
+  int rc = check_dims(d);
+  if (rc != GH_OK) return rc;
+  rc = check_inputs(d, in);
+  if (rc != GH_OK) return rc;
+  if (d->flags & GH_FLAG_SPLIT_STREAMS) return GH_ERR_UNSUPPORTED;
+  if (!(d->flags & GH_FLAG_STATIC_LISTS)) return GH_ERR_INVALID_ARG;    // the lists must have been built for re-use
+  return GH_OK;
+}
+
+extern "C" int gh_forward_refresh(const GhDims* d, const GhInputs* in, const GhOutputs* out, const void* geometry_ws,
+                                  void* workspace, size_t ws_bytes, void* hip_stream) {
+  int rc = check_refresh(d, in);
+  if (rc != GH_OK) return rc;
+  if (!out || !out->image || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
+  GhLayout L;
+  gh_workspace_layout(d, &L);
+  if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
+  hipStream_t s = (hipStream_t)hip_stream;
+  GhGrid g = gh_make_grid(d);
+  (void)hipGetLastError();
+  if (g.N == 0) {                                        // nothing to draw: the background, through the plain path's state
+    gh_launch_preprocess_fwd(d, g, in, nullptr, (char*)workspace, L, s);
+    gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s);
+    return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+  }
+  gh_launch_sh_colour_fwd(d, g, in, (char*)workspace, L, s);           // SH mode only
+  gh_launch_refresh(d, g, in, (const char*)geometry_ws, (char*)workspace, L, s);
+  gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_backward_refresh(const GhDims* d, const GhInputs* in, const GhGrads* gr, const void* geometry_ws,
+                                   void* workspace, size_t ws_bytes, void* hip_stream) {
+  int rc = check_refresh(d, in);
+  if (rc != GH_OK) return rc;
+  if (!gr || !gr->dL_dimage || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
+  if ((((uintptr_t)gr->dL_dblend_color_b | (uintptr_t)gr->dL_dblend_color_w) & 15) != 0) return GH_ERR_INVALID_ARG;
+  GhLayout L;
+  gh_workspace_layout(d, &L);
+  if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
+  hipStream_t s = (hipStream_t)hip_stream;
+  GhGrid g = gh_make_grid(d);
+  (void)hipGetLastError();
+  gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, (const char*)geometry_ws, (char*)workspace, L, s);
+  gh_launch_preprocess_bwd(d, g, in, gr, (const char*)geometry_ws, (char*)workspace, L, s);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}

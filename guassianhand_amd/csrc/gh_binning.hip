@@ -421,7 +421,7 @@ __device__ __forceinline__ uint32_t gh_kth_set_bit(uint32_t lo, uint32_t hi, uin
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ slot_begin, float4* __restrict__ geom,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP) {
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP, uint32_t flags) {
   constexpr int NW = GH_BLOCK / GH_WAVE;
   __shared__ uint32_t s_w[NW], s_p[NW];
   __shared__ uint32_t s_end[NW][GH_WAVE];               // per wave: inclusive prefix of the lanes' instance counts
@@ -488,7 +488,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   }
   if (i >= N || cnt == 0 || small) return;
   uint32_t off = wave_base + x - cnt;
-  const float4 g0 = grec[0], g1 = make_float4(grec[1].x, grec[1].y, 0.0f, 0.0f);   // (C, opacity): the projection kernel's operands
+  // (C, opacity): the projection kernel's operands — the opacity it culled with (GH_FLAG_STATIC_LISTS: at least 1)
+  const float4 g0 = grec[0], g1 = make_float4(grec[1].x, (flags & GH_FLAG_STATIC_LISTS) ? fmaxf(grec[1].y, 1.0f) : grec[1].y, 0.0f, 0.0f);
   for (int ty = miny; ty < maxy; ++ty)
     for (int tx = minx; tx < maxx; ++tx) {
       if (!gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1))) continue;
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               uint2* __restrict__ ranges, float4* __restrict__ r0,
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
                                                               uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin,
-                                                              float rtiles, float rgx) {
+                                                              float rtiles, float rgx, uint32_t flags) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
   // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
@@ -550,9 +551,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   } else {                                              // rect larger than the mask: recount (rare, huge footprints)
     before = 0;
     uint32_t k = 0;
+    const float4 bc = make_float4(b.x, (flags & GH_FLAG_STATIC_LISTS) ? fmaxf(b.y, 1.0f) : b.y, 0.0f, 0.0f);   // as culled
     for (uint32_t yy = miny; yy < maxy && k < bit; ++yy)
       for (uint32_t xx = minx; xx < maxx && k < bit; ++xx, ++k)
-        before += gh_block_hit(a, b, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
+        before += gh_block_hit(a, bc, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
   }
   sorted_slot[i] = slot0 + before;
   const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
@@ -627,7 +629,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
                      (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (float4*)(ws + L.geom), k_in, v_in, ctr,
-                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f);
+                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags);
   if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }    // the emit kernel has written D (it stores nothing past cap)
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
@@ -637,6 +639,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (uint2*)(ws + L.ranges), (float4*)(ws + L.inst_r0),
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
                      (const uint32_t*)(ws + L.slot_begin),
-                     (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx);   // gh_div_small's range
+                     (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,   // gh_div_small's range
+                     d->flags);
   gh_launch_tile_order(g, ws, L, s);
 }

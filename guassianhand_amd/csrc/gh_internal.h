@@ -48,6 +48,8 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
 void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
+// gh_forward_refresh: per-instance records (opacity, colour, block mask) of the CURRENT opacities / colours over the lists of wg
+void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
 // LSD radix sort of (keys, vals) on bits [0, nbits): ceil(nbits/8) stable passes, element count read from device memory
 // (*n_ptr <= cap); pointers are swapped so that on return k_in / v_in hold the result. table: gh_radix_table_words(cap).
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
@@ -62,7 +64,8 @@ void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32
                       int n_bits = 0);
 size_t gh_radix_table_words(size_t per_segment, int segs);
 void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, char* ws, const GhLayout& L, hipStream_t s);
-int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws,
+// wg: workspace whose tiles_touched (visibility of a (view, Gaussian)) counts — the geometry owner's
+int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, const char* wg, char* ws,
                             const GhLayout& L, hipStream_t s);
 // parts: GH_PBWD_RECORD_SUM (fixed-order sums of the render backward's sub-records, per (view, Gaussian)) and / or
 // GH_PBWD_CHAIN (SH colour backward, chain rule, blend-parameter reductions)

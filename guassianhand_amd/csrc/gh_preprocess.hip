@@ -36,6 +36,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     const int n = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : v * P + i;
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     int radius = 0;
+    float cull_bound = __uint_as_float(0x7F800000u);    // +inf: no tile can be missing for a Gaussian without a rect
     GhGeo e;
     gh_geo_forward(in, cam, i, mod, H, W, e);
     bool ok = (e.tz > 0.2f) && (e.det != 0.0f);
@@ -60,10 +61,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         radius = rad;                                   // API output: the reference's 3-sigma radius (App. A.1-6)
         op = in.opacities[i];
         if (in.blend_opacity_b) op = op + in.blend_opacity_b[i];
+        // GH_FLAG_STATIC_LISTS: the lists outlive this call's opacities (gh_forward_refresh): cull as if opacity >= 1
+        const float op_cull = (flags & GH_FLAG_STATIC_LISTS) ? fmaxf(op, 1.0f) : op;
+        cull_bound = op_cull;
         // Exact tile culling: of the tiles in the 3-sigma rect only those are instanced in which the alpha >= 1/255
         // ellipse reaches a pixel centre (gh_block_hit, conservative within its margin). A dropped tile holds no pixel
         // that would blend this Gaussian, so images and gradients are unchanged; gh_emit_kernel repeats this test.
-        const float4 g0 = make_float4(px, py, e.c * dinv, -e.b * dinv), g1 = make_float4(e.a * dinv, op, 0.0f, 0.0f);
+        const float4 g0 = make_float4(px, py, e.c * dinv, -e.b * dinv), g1 = make_float4(e.a * dinv, op_cull, 0.0f, 0.0f);
         int bit = 0;                                    // row-major position in the rect; rects of <= 64 tiles keep the
         for (int ty = miny; ty < maxy; ++ty)            // hit mask so that the emit kernel does not repeat the tests
           for (int tx = minx; tx < maxx; ++tx, ++bit) {
@@ -93,8 +97,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
       }
     }
     // .x = instance count: the emit kernel, which walks the Gaussians in depth order, finds it in the line it reads anyway
-    // (written for every Gaussian: a culled one keeps a stale line from an earlier call apart from this count of 0)
-    geom[(size_t)n * 4 + 3] = make_float4(__uint_as_float(tiles), 0.0f, 0.0f, 0.0f);
+    // (written for every Gaussian: a culled one keeps a stale line from an earlier call apart from this float4);
+    // .y = the opacity its tiles were culled with (gh_refresh_kernel's guard)
+    geom[(size_t)n * 4 + 3] = make_float4(__uint_as_float(tiles), cull_bound, 0.0f, 0.0f);
     tiles_touched[n] = tiles;
     rect[n] = rect_bits;                               // 3-sigma tile rect of every projected Gaussian (0 = none)
     depth_key[n] = dkey;
@@ -232,7 +237,9 @@ __device__ __forceinline__ float gh_group_sum(float v, int lg) {
 // (P threads cannot fill 256 CUs); the per-view results are combined over the group in fixed order (gh_group_sum), no
 // atomics, bitwise reproducible. Pose batch (GH_FLAG_PER_VIEW_GAUSSIANS): NV*P rows, row i is seen by view i / P only
 // and G = 1.
-template <bool RGB_MODE>
+// GEOM = false (no gradient w.r.t. means / scales / rotations / means2D / xyz_b is asked for — the one-shot fit trains colour
+// and opacity biases only): the chain rule through the projection is skipped and the kernel only sums over the views.
+template <bool RGB_MODE, bool GEOM>
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags, int lg,
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ dmean_sh, const float4* __restrict__ gsum,
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
   constexpr bool rgb_mode = RGB_MODE;
   const bool wpg = (flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   const bool red_w = rgb_mode && in.blend_color_w && !wpg && gr.dL_dblend_color_w;   // global (48,) weights: block reduce
-  const bool red_x = in.blend_xyz_b && gr.dL_dblend_xyz_b;
+  const bool red_x = GEOM && in.blend_xyz_b && gr.dL_dblend_xyz_b;
   if (threadIdx.x < 64) {
 #pragma unroll
     for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) s_part[w][threadIdx.x] = 0.0f;
@@ -271,7 +278,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     float dm[3] = {0, 0, 0};
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     const float* V = cam; const float* PM = cam + 16;
-    if (vis) {
+    if (!GEOM) {
+      if (vis) {
+        if (rgb_mode) { araw[0] += s9[6]; araw[1] += s9[7]; araw[2] += s9[8]; }
+        ao += s9[5];
+      }
+    } else if (vis) {
       GhGeo e;
       gh_geo_forward(in, cam, i, mod, H, W, e);
       // The render backward sums the raw pixel moments of h = G * dL/dalpha per instance:
@@ -364,19 +376,21 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
       am[0] += dm[0]; am[1] += dm[1]; am[2] += dm[2];
       ao += g_o;
     }
-    if (live && vok && gr.dL_dmeans2D) {
+    if (GEOM && live && vok && gr.dL_dmeans2D) {
       gr.dL_dmeans2D[3 * n] = vis ? g_px * 0.5f * (float)W : 0.0f;
       gr.dL_dmeans2D[3 * n + 1] = vis ? g_py * 0.5f * (float)H : 0.0f;
       gr.dL_dmeans2D[3 * n + 2] = 0.0f;
     }
-    if (red_x) { gh_block_acc(s_part, 48, dm[0]); gh_block_acc(s_part, 49, dm[1]); gh_block_acc(s_part, 50, dm[2]); }
+    if (GEOM && red_x) { gh_block_acc(s_part, 48, dm[0]); gh_block_acc(s_part, 49, dm[1]); gh_block_acc(s_part, 50, dm[2]); }
   }
 
   // per-view results -> per-Gaussian sums, in every lane of the group
+  if (GEOM) {
 #pragma unroll
-  for (int c3 = 0; c3 < 3; ++c3) { am[c3] = gh_group_sum(am[c3], lg); as[c3] = gh_group_sum(as[c3], lg); }
+    for (int c3 = 0; c3 < 3; ++c3) { am[c3] = gh_group_sum(am[c3], lg); as[c3] = gh_group_sum(as[c3], lg); }
 #pragma unroll
-  for (int c4 = 0; c4 < 4; ++c4) aq[c4] = gh_group_sum(aq[c4], lg);
+    for (int c4 = 0; c4 < 4; ++c4) aq[c4] = gh_group_sum(aq[c4], lg);
+  }
   ao = gh_group_sum(ao, lg);
   if (rgb_mode) {
 #pragma unroll
@@ -384,11 +398,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
   }
   const bool writer = live && vv == 0;                  // one lane per row writes / contributes the per-Gaussian terms
   if (writer) {
-    if (gr.dL_dmeans3D) { gr.dL_dmeans3D[3 * i] = am[0]; gr.dL_dmeans3D[3 * i + 1] = am[1]; gr.dL_dmeans3D[3 * i + 2] = am[2]; }
+    if (GEOM && gr.dL_dmeans3D) { gr.dL_dmeans3D[3 * i] = am[0]; gr.dL_dmeans3D[3 * i + 1] = am[1]; gr.dL_dmeans3D[3 * i + 2] = am[2]; }
     if (gr.dL_dopacities) gr.dL_dopacities[i] = ao;
     if (gr.dL_dblend_opacity_b && in.blend_opacity_b) gr.dL_dblend_opacity_b[i] = ao;
-    if (gr.dL_dscales) { gr.dL_dscales[3 * i] = as[0]; gr.dL_dscales[3 * i + 1] = as[1]; gr.dL_dscales[3 * i + 2] = as[2]; }
-    if (gr.dL_drotations) { gr.dL_drotations[4 * i] = aq[0]; gr.dL_drotations[4 * i + 1] = aq[1]; gr.dL_drotations[4 * i + 2] = aq[2]; gr.dL_drotations[4 * i + 3] = aq[3]; }
+    if (GEOM && gr.dL_dscales) { gr.dL_dscales[3 * i] = as[0]; gr.dL_dscales[3 * i + 1] = as[1]; gr.dL_dscales[3 * i + 2] = as[2]; }
+    if (GEOM && gr.dL_drotations) { gr.dL_drotations[4 * i] = aq[0]; gr.dL_drotations[4 * i + 1] = aq[1]; gr.dL_drotations[4 * i + 2] = aq[2]; gr.dL_drotations[4 * i + 3] = aq[3]; }
   }
   if (rgb_mode) {
     // c' = ((c*w0 + w1) - 1) + b0  (renderer_one_shot.py:324,328): araw = sum over views of dL/dc'
@@ -459,21 +473,23 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   int lg = 0;                                            // lanes per row: the smallest power of two >= n_views, at most 64
   if (!per_view) while ((1 << lg) < g.NV && lg < 6) ++lg;
   int nblk = (int)((((size_t)rows << lg) + GH_BLOCK - 1) / GH_BLOCK);   // <= 2 N / 256 + 1: bwd_scratch holds 64 floats per block
-  auto kern = in->colors_precomp ? gh_preprocess_bwd_kernel<true> : gh_preprocess_bwd_kernel<false>;
+  const bool geom = gr->dL_dmeans3D || gr->dL_dmeans2D || gr->dL_dscales || gr->dL_drotations || (in->blend_xyz_b && gr->dL_dblend_xyz_b);
+  auto kern = in->colors_precomp ? (geom ? gh_preprocess_bwd_kernel<true, true> : gh_preprocess_bwd_kernel<true, false>)
+                                 : (geom ? gh_preprocess_bwd_kernel<false, true> : gh_preprocess_bwd_kernel<false, false>);
   const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
   if (parts & GH_PBWD_RECORD_SUM)
     hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
                        (const uint32_t*)(wg + L.slot_begin), (const uint32_t*)(wg + L.tiles_touched),
                        (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
   if (!(parts & GH_PBWD_CHAIN)) return;
-  const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, ws, L, s);     // SH mode only; no-op with colors_precomp
+  const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, wg, ws, L, s);     // SH mode only; no-op with colors_precomp
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, lg,
                      (const uint32_t*)(wg + L.tiles_touched), (const float4*)(ws + L.dmean_sh),
                      (const float4*)(ws + L.grad_sums), (float*)(ws + L.bwd_scratch));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;
-  float* dx = in->blend_xyz_b ? gr->dL_dblend_xyz_b : nullptr;
+  float* dx = (geom && in->blend_xyz_b) ? gr->dL_dblend_xyz_b : nullptr;
   if (nblk_sh > 0) {                     // SH mode: the colour-weight partials come from the SH kernel's own scratch
     hipLaunchKernelGGL(gh_blend_reduce_kernel, dim3(48), dim3(GH_BLOCK), 0, s, (const float*)(ws + L.sh_scratch), nblk_sh, dw, (float*)nullptr);
     dw = nullptr;

@@ -464,8 +464,8 @@ void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* i
 }
 
 // returns the number of scratch blocks written (0 when the global colour-weight reduction is not needed)
-int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, char* ws, const GhLayout& L,
-                            hipStream_t s) {
+int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, const char* wg, char* ws,
+                            const GhLayout& L, hipStream_t s) {
   if (g.P == 0 || !in->shs) return 0;
   const bool per_view_rows = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   const bool wpg2 = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
@@ -479,14 +479,14 @@ int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in
     const bool staged = per_view_rows && d->M == 16;
     auto kern2 = staged ? gh_sh_colour_bwd2_kernel<true> : gh_sh_colour_bwd2_kernel<false>;
     hipLaunchKernelGGL(kern2, dim3(nblk2), dim3(GH_BLOCK), staged ? GH_BLOCK * 49 * sizeof(float) : 0, s, *in, *gr,
-                       g.P, g.NV, d->sh_degree, d->M, d->flags, G, wide, 1.0f / (float)nv, (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.sh_rgb),
+                       g.P, g.NV, d->sh_degree, d->M, d->flags, G, wide, 1.0f / (float)nv, (const uint32_t*)(wg + L.tiles_touched), (const float4*)(ws + L.sh_rgb),
                        (const float4*)(ws + L.grad_sums), (float4*)(ws + L.dmean_sh), (float*)(ws + L.sh_scratch));
     return (in->blend_color_w && !wpg2 && gr->dL_dblend_color_w) ? nblk2 : 0;
   }
   const size_t threads = (size_t)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.N : g.P) * 16;
   const int nblk = (int)((threads + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_sh_colour_bwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, d->sh_degree, d->M, d->flags,
-                     (const uint32_t*)(ws + L.tiles_touched), (const float4*)(ws + L.sh_rgb), (const float4*)(ws + L.grad_sums),
+                     (const uint32_t*)(wg + L.tiles_touched), (const float4*)(ws + L.sh_rgb), (const float4*)(ws + L.grad_sums),
                      (float4*)(ws + L.dmean_sh), (float*)(ws + L.sh_scratch));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   return (in->blend_color_w && !wpg && gr->dL_dblend_color_w) ? nblk : 0;

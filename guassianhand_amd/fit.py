@@ -62,7 +62,7 @@ def fit_loss(comp_rgb, comp_mask, gt_rgb, gt_mask, bbox_mask=None, lambda_l1: fl
 class OneShotFit(nn.Module):
     def __init__(self, gs: GaussianModel, uv: torch.Tensor, *, use_rgb: bool = True, sh_degree: int = 3,
                  map_hw: Sequence[int] = (1024, 2048), lr: float = 0.01, render_fn: Optional[Callable] = None,
-                 active_texels: Optional[bool] = None):
+                 active_texels: Optional[bool] = None, static_geometry: Optional[bool] = None):
         super().__init__()
         self.gs = GaussianModel(*[t.detach() for t in gs])          # frozen network outputs
         self.register_buffer("uv", uv.detach().float())
@@ -75,7 +75,17 @@ class OneShotFit(nn.Module):
         self.lr0, self.epoch = lr, 0
         self.active = uv.is_cuda if active_texels is None else bool(active_texels)
         self._default_render = render_fn is None
-        self._cams, self._cams_src = None, None
+        self._cams, self._cams_src, self._mine_src = None, None, None
+        # Static geometry (default with the default renderer on a device): `gs` is frozen here (detached network outputs), xyz_b
+        # is not trained (:161) and a fit renders the same cameras every step, so projection, both sorts and the record gather
+        # are done ONCE; every later step only refreshes opacities / colours in the per-instance records (gh_forward_refresh).
+        # Any other camera tensor, image size or a changed `_version` of a geometry tensor rebuilds automatically; after an
+        # in-place change through `.data` call invalidate_geometry(). (The reference's map_bias / identity codes move the
+        # Gaussians themselves, infer_one_shot.py:340-343: a fit that trains them passes static_geometry=False.)
+        self._geom_cache = None
+        if (static_geometry if static_geometry is not None else (render_fn is None and gs.xyz.is_cuda)):
+            from .rasterizer import GeometryCache
+            self._geom_cache = GeometryCache()
         self.keep_boundary_grads, self.boundary_grads, self.last_reg = False, None, None
         self._side = None
         if render_fn is None:
@@ -163,10 +173,17 @@ class OneShotFit(nn.Module):
             return 100.0 * self.color_b_tex.abs().sum() / (48 * Hm * Wm) + self.opacity_b_tex.pow(2.0).sum() / (Hm * Wm)
         return 100.0 * self.color_b_map.abs().mean() + self.opacity_b_map.pow(2.0).mean()   # infer_one_shot.py:514-518
 
+    def invalidate_geometry(self) -> None:
+        """Forget the static tile lists (after modifying a geometry tensor in place through `.data`)."""
+        if self._geom_cache is not None:
+            self._geom_cache.clear()
+
     def render(self, w2cs, Ks, H, W, bg, blend: Dict[str, torch.Tensor], sync: bool = True):
         kw = {}
         if self._default_render:                                      # the camera records of a fit never change: pack them once
             kw["cams"] = self._packed_cameras(w2cs, Ks, H, W, bg)
+            if self._geom_cache is not None:
+                kw["geometry_cache"] = self._geom_cache
         return self.render_fn(self.gs, w2cs, Ks, H, W, bg, color_w=blend["color_w"], xyz_b=blend["xyz_b"],
                               color_b=blend["color_b"], opacity_b=blend["opacity_b"], use_rgb=self.use_rgb,
                               sh_degree=self.sh_degree, sync=sync, **kw)
@@ -200,9 +217,17 @@ class OneShotFit(nn.Module):
                                                    self.gs.shs, gt_rgb, gt_mask, None if bbox_mask is None else bbox_mask.float(),
                                                    scale=1.0 / n_total, H=H, W=W, use_rgb=self.use_rgb, sh_degree=self.sh_degree,
                                                    xyz_b=leaves["xyz_b"], opacity_b=leaves["opacity_b"], color_w=leaves["color_w"],
-                                                   color_b=leaves["color_b"], sync=sync)
+                                                   color_b=leaves["color_b"], sync=sync, geometry_cache=self._geom_cache)
             else:
-                out = self.render(w2cs if allv else w2cs[mine], Ks if allv else Ks[mine], H, W, bg, leaves, sync=sync)
+                if allv:
+                    w_sel, k_sel = w2cs, Ks
+                else:                                 # this rank's cameras: sliced once, so that the packed records and the
+                    mk = (w2cs, Ks, w2cs._version, Ks._version, tuple(mine))       # static tile lists are found again next step
+                    ms = self._mine_src
+                    if ms is None or ms[0][0] is not w2cs or ms[0][1] is not Ks or ms[0][2:] != mk[2:]:
+                        self._mine_src = ms = (mk, w2cs[mine].contiguous(), Ks[mine].contiguous())
+                    w_sel, k_sel = ms[1], ms[2]
+                out = self.render(w_sel, k_sel, H, W, bg, leaves, sync=sync)
             if out is None:
                 pass
             elif "image_chw" in out and out["image_chw"].is_cuda:    # fused loss + gradients on the rasteriser's layouts

@@ -109,15 +109,15 @@ class _RenderedLoss(torch.autograd.Function):
     its pixels, so the autograd product `dL/dimage * dL/dloss` costs no pass over the images."""
 
     @staticmethod
-    def forward(ctx, spec, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, per_view, xyz, opacity,
+    def forward(ctx, spec, cache, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, per_view, xyz, opacity,
                 scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b):
         from . import rasterizer as R
         kind = spec[0]
         kw = dict(colors_precomp=shs.reshape(shs.shape[0], 3)) if use_rgb else dict(shs=shs)
-        image, radii, rctx = R.raster_forward(cams, xyz, opacity, scaling, rotation, H=H, W=W, sh_degree=sh_degree,
-                                              scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b, color_w=color_w,
-                                              color_b=color_b, sync=sync, max_instances=max_instances,
-                                              return_alpha=(kind == "fit"), per_view_gaussians=per_view, **kw)
+        image, radii, rctx = R.cached_raster_forward(cache, cams, xyz, opacity, scaling, rotation, H=H, W=W, sh_degree=sh_degree,
+                                                     scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b,
+                                                     color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances,
+                                                     return_alpha=(kind == "fit"), per_view_gaussians=per_view, **kw)
         guard = rctx.ws[:16]                          # device-side overflow guard: an overflowed render yields loss NaN, zero gradients
         if kind == "l1":
             loss, dimg = _l1_kernel(image, spec[1], guard)
@@ -136,19 +136,21 @@ class _RenderedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _gi, _ga, _gr):
         from . import rasterizer as R
-        g = R.raster_backward(ctx.rctx, ctx.dimg, want_means2D=False, dL_dalpha=ctx.dal, grad_scale=g_loss)
+        g = R.raster_backward(ctx.rctx, ctx.dimg, want_means2D=False, dL_dalpha=ctx.dal, grad_scale=g_loss,
+                              want=R._wanted(ctx.needs_input_grad[11:20], ctx.use_rgb))
         ctx.rctx = None
         s = ctx.shapes
-        col = g["colors_precomp"] if ctx.use_rgb else g["shs"]
+        col = g.get("colors_precomp" if ctx.use_rgb else "shs")
         opt = lambda k, i: g[k].reshape(s[i]) if (s[i] is not None and k in g) else None
-        return (None,) * 10 + (g["means3D"].reshape(s[0]), g["opacities"].reshape(s[1]), g["scales"].reshape(s[2]),
-                              g["rotations"].reshape(s[3]), col.reshape(s[4]), opt("xyz_b", 5), opt("opacity_b", 6),
+        return (None,) * 11 + (opt("means3D", 0), opt("opacities", 1), opt("scales", 2), opt("rotations", 3),
+                              None if col is None else col.reshape(s[4]), opt("xyz_b", 5), opt("opacity_b", 6),
                               opt("color_w", 7), opt("color_b", 8))
 
 
 def _rendered_loss(spec, cams, xyz, opacity, scaling, rotation, shs, *, H, W, use_rgb, sh_degree=3, scale_modifier=1.0, xyz_b=None,
-                   opacity_b=None, color_w=None, color_b=None, sync=True, max_instances=None, per_view_gaussians=False):
-    return _RenderedLoss.apply(spec, cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier), bool(use_rgb),
+                   opacity_b=None, color_w=None, color_b=None, sync=True, max_instances=None, per_view_gaussians=False,
+                   geometry_cache=None):
+    return _RenderedLoss.apply(spec, geometry_cache, cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier), bool(use_rgb),
                                bool(sync), max_instances, bool(per_view_gaussians), xyz, opacity, scaling, rotation, shs, xyz_b,
                                opacity_b, color_w, color_b)
 

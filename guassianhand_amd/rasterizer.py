@@ -45,6 +45,49 @@ class GhOverflowError(RuntimeError):
     """The tile-instance capacity (max_instances) was too small for a sync-free call."""
 
 
+class GhStaleGeometryError(GhOverflowError):
+    """A static-geometry call (gh_forward_refresh) found an opacity above the bound its tile lists were built for: the lists
+    may miss a tile. The call returned a NaN image (device-side guard, same mechanism as an instance overflow); every
+    GeometryCache has been cleared, so re-running the step rebuilds the lists."""
+
+
+class GeometryCache:
+    """Static geometry for calls that render the SAME Gaussians (means3D, scales, rotations, xyz_b) from the SAME cameras again
+    and again while only opacities and colours move — the one-shot fit (infer_one_shot.py:489-524). The first call through a
+    cache is a full forward with GH_FLAG_STATIC_LISTS; its context is kept here, and later calls whose geometry inputs are
+    the very same tensor objects, unmodified (`is` + `_version`), go through gh_forward_refresh: no projection, no sorts.
+    Anything else — another tensor, a bumped version, another image size — is a miss: a full call that replaces the entry.
+    `clear()` forces the next call to rebuild (call it after changing a geometry tensor in place through `.data`, which
+    `_version` cannot see). Opt-in: a caller passes its cache to rasterize_views / rendered_*_loss."""
+    _all = weakref.WeakSet()
+
+    def __init__(self):
+        self.ctx, self.key, self.refs = None, None, None
+        self.hits, self.builds = 0, 0
+        GeometryCache._all.add(self)
+
+    def clear(self) -> None:
+        self.ctx, self.key, self.refs = None, None, None
+
+    @staticmethod
+    def clear_all() -> None:
+        for c in list(GeometryCache._all):
+            c.clear()
+
+    def lookup(self, objs, vals):
+        """The cached context if `objs` are the cached tensors, unmodified, and `vals` the cached scalars."""
+        if self.ctx is None or self.key != vals or len(self.refs) != len(objs):
+            return None
+        for r, o in zip(self.refs, objs):
+            if (r is None) != (o is None) or (r is not None and r() is not o):
+                return None
+        return self.ctx
+
+    def store(self, objs, vals, ctx) -> None:
+        self.refs = tuple(None if o is None else weakref.ref(o) for o in objs)
+        self.key, self.ctx = vals, ctx
+
+
 # ---------------------------------------------------------------------------------------------------
 # capacity policy for the data-dependent instance count D
 _capacity: Dict[Tuple[int, int, int, int], int] = {}
@@ -56,10 +99,10 @@ _PENDING_MAX = 64
 class _Pending:
     """The asynchronous counter read-back of one sync-free forward. `resolve()` waits for it (normally long done), recycles
     the pinned buffer and remembers the verdict, so that both check_overflow() and the call's own backward can ask."""
-    __slots__ = ("ev", "host", "cap", "key", "done", "d", "over")
+    __slots__ = ("ev", "host", "cap", "key", "done", "d", "over", "stale")
 
     def __init__(self, ev, host, cap, key):
-        self.ev, self.host, self.cap, self.key, self.done, self.d, self.over = ev, host, cap, key, False, 0, False
+        self.ev, self.host, self.cap, self.key, self.done, self.d, self.over, self.stale = ev, host, cap, key, False, 0, False, False
 
     def resolve(self) -> bool:
         """True when the call overflowed its capacity (the learned capacity of its shape is raised then)."""
@@ -72,8 +115,11 @@ class _Pending:
             # overflowed = the device-side flag, nothing else; a split call's reserved[0] (the max_instances that would give
             # each half a large enough share) only sizes the NEXT capacity
             self.over = (c[1] & 0xFFFFFFFF) != 0
+            self.stale = (c[1] & 2) != 0
             need = (c[2] & 0xFFFFFFFF) if self.key[-1] else self.d
-            if self.over:
+            if self.stale:
+                GeometryCache.clear_all()
+            if self.over and (c[1] & 1):
                 _capacity[self.key] = max(_capacity.get(self.key, 0), int(max(need, self.d) * 1.5) + 1024)
             _free_slots.append((self.host, self.ev))
             self.host = self.ev = None
@@ -81,8 +127,17 @@ class _Pending:
         return self.over
 
     def message(self) -> str:
+        if self.stale:
+            return _STALE_MSG
         return (f"tile instances D={self.d} exceeded max_instances={self.cap}; the call returned a NaN image; "
                 "capacity raised, re-run the step")
+
+    def error(self) -> GhOverflowError:
+        return (GhStaleGeometryError if self.stale else GhOverflowError)(self.message())
+
+
+_STALE_MSG = ("an opacity rose above the bound the static tile lists were built for; the call returned a NaN image; "
+              "the geometry caches are cleared, re-run the step (it rebuilds the lists)")
 
 
 _last_D = 0
@@ -180,6 +235,9 @@ def check_overflow(block: bool = True, keep_recent: int = 0) -> None:
         c4 = counters.tolist()
         d = c4[0] & 0xFFFFFFFF
         _last_D = d
+        if c4[1] & 2:                                  # a static-geometry replay met an opacity above its lists' bound
+            GeometryCache.clear_all()
+            raise GhStaleGeometryError(_STALE_MSG + " [inside a captured graph: capture again]")
         if (c4[1] & 0xFFFFFFFF) != 0:                  # the device-side flag decides; reserved[0] of a split call sizes the next capacity
             need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
             _capacity[key] = max(_capacity.get(key, 0), int(need * 1.5) + 1024)
@@ -196,7 +254,7 @@ def check_overflow(block: bool = True, keep_recent: int = 0) -> None:
             bad = pc
     _pending = keep
     if bad is not None:
-        raise GhOverflowError(bad.message())
+        raise bad.error()
 
 
 # Workspace pool: a forward takes its workspace from here and the context gives it back when it dies (after its backward,
@@ -264,7 +322,7 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 class _Ctx:
     __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "rows", "stream", "alpha",
-                 "parent", "radii", "pending", "__weakref__")
+                 "parent", "radii", "pending", "refresh", "__weakref__")
 
     def __del__(self):
         try:
@@ -277,7 +335,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                    sh_degree: int = 0, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
                    color_b=None, max_instances: Optional[int] = None, sync: Optional[bool] = True, return_alpha: bool = False,
                    per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None,
-                   split_streams: Optional[bool] = None, expect_backward: bool = False):
+                   split_streams: Optional[bool] = None, expect_backward: bool = False, static_lists: bool = False,
+                   refresh_of: Optional["_Ctx"] = None):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
     with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha.
     per_view_gaussians (pose batch, the batch loop of GS3DRenderer.forward): every per-Gaussian tensor holds NV*P rows and
@@ -288,6 +347,12 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     split_streams (GH_FLAG_SPLIT_STREAMS, n_views >= 2): the views run as two halves on two HIP streams inside the library
     (forked from / joined into the current stream, graph-capturable); bit-identical images, radii and gradients.
     None = the module policy (set_split_streams).
+    static_lists (GH_FLAG_STATIC_LISTS): build tile lists that stay valid for other opacities / colours (culling treats
+    every opacity as max(1, opacity)); same image and gradients, larger D. refresh_of: context of such a forward with the SAME
+    means3D / scales / rotations / xyz_b / cameras: this call (gh_forward_refresh) skips projection and sorts, refreshes the
+    per-instance records with ITS opacities and colours (shs or colors_precomp) and walks the lists; forward bit-identical
+    to a full call. An opacity above the lists' bound poisons the call (NaN image, GhStaleGeometryError). GeometryCache is
+    the policy object on top of the two.
     sync: True = read D back (and re-run with a larger capacity if needed); False = never block (check_overflow() is the
     caller's job); None = auto: read D back for the first call of a shape and for calls whose backward will not come
     (expect_backward False), otherwise sync-free with the check at the start of raster_backward."""
@@ -313,9 +378,12 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     P = rows // NV if per_view_gaussians else rows
     if split_streams is None:
         split_streams = _split_policy is True or (_split_policy == "auto" and NV >= _SPLIT_AUTO_MIN_VIEWS)
-    split = bool(split_streams) and NV >= 2 and P > 0 and geometry_of is None and not _stage_timing
+    split = bool(split_streams) and NV >= 2 and P > 0 and geometry_of is None and refresh_of is None and not static_lists \
+        and not _stage_timing
     if split:
         flags |= _abi.GH_FLAG_SPLIT_STREAMS
+    if static_lists or refresh_of is not None:
+        flags |= _abi.GH_FLAG_STATIC_LISTS
     wpg = False
     if t["color_w"] is not None:
         if t["color_w"].numel() == 48:
@@ -359,7 +427,59 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
         ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
         ctx.pending = g0.pending                 # the overflow flag is the geometry owner's
+        ctx.refresh = False
         return image, g0.radii, ctx           # same geometry, same radii; an overflow is the first call's (NaN image here too)
+    if refresh_of is not None:
+        g0 = refresh_of
+        if not (g0.dims.flags & _abi.GH_FLAG_STATIC_LISTS) or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (P, NV, H, W, rows) or \
+                (g0.dims.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) != (flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) or g0.parent is not None:
+            raise ValueError("refresh_of: needs the context of a static_lists forward with this call's shapes")
+        cap = int(g0.dims.max_instances)
+        dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
+        nbytes = L.gh_workspace_bytes(C.byref(dims))
+        stream = _raw_stream(dev)
+        ws = _ws_acquire(dev, nbytes, stream)
+        image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
+        alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
+        inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
+                            _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
+                            _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
+        out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha))
+        with _OnDevice(dev):
+            rc = L.gh_forward_refresh(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(g0.ws.data_ptr()),
+                                      C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(f"gh_forward_refresh failed: {_abi.status_name(rc)}")
+        counters = ws[:16].view(torch.int32)
+        _last_ws = ws
+        pending = None
+        gkey = (P, NV, H, W, False)
+        if sync is None:
+            sync = not expect_backward
+        if sync:
+            c4 = counters.tolist()
+            _last_D = c4[0] & 0xFFFFFFFF
+            if c4[1] & 2:
+                GeometryCache.clear_all()
+                raise GhStaleGeometryError(_STALE_MSG)
+            if c4[1] & 1:
+                raise GhOverflowError("the static tile lists were built by a call that overflowed its capacity")
+        elif _graph_mode:
+            _graph_counters[ws.data_ptr()] = (counters, cap, gkey)
+        else:
+            if len(_pending) >= _PENDING_MAX:
+                check_overflow(block=True)
+            host, ev = _free_slots.pop() if _free_slots else (torch.empty(4, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+            host.copy_(counters, non_blocking=True)
+            ev.record()
+            pc = _Pending(ev, host, cap, gkey)
+            _pending.append(pc)
+            pending = pc
+        ctx = _Ctx()
+        ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
+        ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
+        ctx.pending, ctx.refresh = pending, True
+        return image, g0.radii, ctx
     while True:
         cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))
         dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
@@ -428,20 +548,53 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
     ctx.b_rgb, ctx.rows = b_rgb, rows
-    ctx.alpha, ctx.parent, ctx.radii, ctx.stream, ctx.pending = alpha, None, radii, stream, pending
+    ctx.alpha, ctx.parent, ctx.radii, ctx.stream, ctx.pending, ctx.refresh = alpha, None, radii, stream, pending, False
+    return image, radii, ctx
+
+
+def cached_raster_forward(cache: Optional[GeometryCache], cams, means3D, opacities, scales, rotations, **kw):
+    """raster_forward through a GeometryCache (None: a plain call). A hit re-uses the cached static tile lists
+    (gh_forward_refresh); a miss is a full forward with static_lists=True whose context becomes the cache entry. With
+    sync=True a refresh that finds an opacity above the lists' bound is re-run as a full call, transparently."""
+    if cache is None:
+        return raster_forward(cams, means3D, opacities, scales, rotations, **kw)
+    if kw.get("geometry_of") is not None or kw.get("split_streams"):
+        raise ValueError("a GeometryCache call takes neither geometry_of nor split_streams")
+    xyz_b = kw.get("xyz_b")
+    objs = (cams, means3D, scales, rotations, xyz_b)
+    vals = tuple(None if o is None else (o._version, tuple(o.shape), o.device) for o in objs) + \
+        (int(kw["H"]), int(kw["W"]), float(kw.get("scale_modifier", 1.0)), bool(kw.get("per_view_gaussians", False)))
+    g0 = cache.lookup(objs, vals)
+    if g0 is not None:
+        try:
+            out = raster_forward(cams, means3D, opacities, scales, rotations, refresh_of=g0,
+                                 **{k: v for k, v in kw.items() if k != "max_instances"})
+            cache.hits += 1
+            return out
+        except GhStaleGeometryError:               # (sync=True only) the caches are cleared: rebuild below
+            pass
+    image, radii, ctx = raster_forward(cams, means3D, opacities, scales, rotations, static_lists=True, split_streams=False, **kw)
+    cache.store(objs, vals, ctx)
+    cache.builds += 1
     return image, radii, ctx
 
 
 def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: bool = True,
-                    dL_dalpha: Optional[torch.Tensor] = None, grad_scale: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                    dL_dalpha: Optional[torch.Tensor] = None, grad_scale: Optional[torch.Tensor] = None,
+                    want=None) -> Dict[str, torch.Tensor]:
     """grad_scale: optional one-element device tensor multiplied into dL_dimage / dL_dalpha as the kernel reads them
-    (GhGrads.upstream_scale): the dL/dloss of a scalar loss whose image gradient was produced unscaled."""
+    (GhGrads.upstream_scale): the dL/dloss of a scalar loss whose image gradient was produced unscaled.
+    want: the gradients to produce, a subset of {means3D, opacities, scales, rotations, shs, colors_precomp, xyz_b, opacity_b,
+    color_w, color_b} (None = all): the others get a NULL pointer in GhGrads — with no geometry gradient asked for the
+    per-Gaussian chain rule is skipped altogether (the one-shot fit trains colour / opacity biases only)."""
     L = _lib.lib()
     if ctx.pending is not None and ctx.pending.resolve():
         # auto-sync forward (the drop-in's default): its counters are checked HERE, before any gradient exists — an overflowed
         # call returned a NaN image, and a NaN loss must not reach the caller's optimiser step. The forward finished long ago
         # on any host-bound loop, so this wait is normally free.
-        raise GhOverflowError(ctx.pending.message())
+        global _geom_last
+        _geom_last = None                          # the re-run of the step must not be taken for this call's mask pass
+        raise ctx.pending.error()
     t = ctx.tensors
     dev = t["means3D"].device
     P, NV, M = ctx.P, ctx.NV, ctx.M
@@ -465,7 +618,7 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
               ("means2D", (NV, P, 3) if want_means2D else None)]
     off, spans = 4, []                             # floats 0..3: reserved for the caller (e.g. the loss of the sharded fit)
     for k, shp in shapes:
-        if shp is None:
+        if shp is None or (want is not None and k != "means2D" and k not in want):
             continue
         n = 1
         for d_ in shp:
@@ -476,7 +629,7 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
     o = {k: None for k, _ in shapes}
     for k, shp, a, n in spans:
         o[k] = block[a:a + n].view(shp)
-    reducible = spans[-1][2] if want_means2D else off          # means2D is per view: not part of the all-reduced prefix
+    reducible = spans[-1][2] if (want_means2D and spans and spans[-1][0] == "means2D") else off   # means2D is per view: not part of the all-reduced prefix
     blend_end = 4
     for k, shp, a, n in spans:
         if k in ("color_w", "opacity_b", "color_b", "xyz_b"):
@@ -493,8 +646,9 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
         bargs = (C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(),
                  C.c_void_p(stream))
         if ctx.parent is not None:
-            rc = L.gh_backward_shared(C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.parent.ws.data_ptr()),
-                                      C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), C.c_void_p(stream))
+            fn = L.gh_backward_refresh if ctx.refresh else L.gh_backward_shared
+            rc = fn(C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.parent.ws.data_ptr()),
+                    C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), C.c_void_p(stream))
         elif _stage_timing:
             rc = _run_stages(L.gh_backward_stages, bargs, (("render_bwd", _abi.GH_BWD_RENDER),
                                                             ("preprocess_bwd", _abi.GH_BWD_PREPROCESS)))
@@ -647,15 +801,27 @@ class GaussianRasterizer(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------
+_GRAD_NAMES = ("means3D", "opacities", "scales", "rotations", "colour", "xyz_b", "opacity_b", "color_w", "color_b")
+
+
+def _wanted(needs, use_rgb: bool):
+    """Names of the gradients autograd asks for, from the needs_input_grad flags of the nine tensor arguments."""
+    w = {n for n, need in zip(_GRAD_NAMES, needs) if need}
+    if "colour" in w:
+        w.discard("colour")
+        w.add("colors_precomp" if use_rgb else "shs")
+    return w
+
+
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, want_alpha, per_view, xyz, opacity,
+    def forward(ctx, cache, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, want_alpha, per_view, xyz, opacity,
                 scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b):
         kw = dict(colors_precomp=shs.reshape(shs.shape[0], 3)) if use_rgb else dict(shs=shs)
-        image, radii, rctx = raster_forward(cams, xyz, opacity, scaling, rotation, H=H, W=W, sh_degree=sh_degree,
-                                            scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b,
-                                            color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances,
-                                            return_alpha=want_alpha, per_view_gaussians=per_view, **kw)
+        image, radii, rctx = cached_raster_forward(cache, cams, xyz, opacity, scaling, rotation, H=H, W=W, sh_degree=sh_degree,
+                                                   scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b,
+                                                   color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances,
+                                                   return_alpha=want_alpha, per_view_gaussians=per_view, **kw)
         ctx.rctx = rctx
         ctx.use_rgb = use_rgb
         ctx.shapes = [None if t is None else t.shape for t in (xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b)]
@@ -670,20 +836,21 @@ class _RasterizeViews(torch.autograd.Function):
     def backward(ctx, grad_image, grad_alpha, _gr):
         if ctx.rctx.alpha is None:
             grad_alpha = None
-        g = raster_backward(ctx.rctx, grad_image, want_means2D=False, dL_dalpha=grad_alpha)
+        g = raster_backward(ctx.rctx, grad_image, want_means2D=False, dL_dalpha=grad_alpha,
+                            want=_wanted(ctx.needs_input_grad[11:20], ctx.use_rgb))
         ctx.rctx = None
         s = ctx.shapes
-        col = g["colors_precomp"] if ctx.use_rgb else g["shs"]
+        col = g.get("colors_precomp" if ctx.use_rgb else "shs")
         opt = lambda k, i: g[k].reshape(s[i]) if (s[i] is not None and k in g) else None
-        return (None,) * 10 + (g["means3D"].reshape(s[0]), g["opacities"].reshape(s[1]), g["scales"].reshape(s[2]),
-                              g["rotations"].reshape(s[3]), col.reshape(s[4]), opt("xyz_b", 5), opt("opacity_b", 6),
+        return (None,) * 11 + (opt("means3D", 0), opt("opacities", 1), opt("scales", 2), opt("rotations", 3),
+                              None if col is None else col.reshape(s[4]), opt("xyz_b", 5), opt("opacity_b", 6),
                               opt("color_w", 7), opt("color_b", 8))
 
 
 def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *, H: int, W: int, use_rgb: bool,
                     sh_degree: int = 3, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
                     color_b=None, sync: bool = True, max_instances: Optional[int] = None, return_alpha: bool = False,
-                    per_view_gaussians: bool = False):
+                    per_view_gaussians: bool = False, geometry_cache: Optional[GeometryCache] = None):
     """View-batched render with the attribute blend of renderer_one_shot.py:298-334 fused into the kernels.
     per_view_gaussians=True renders a POSE BATCH: the Gaussian tensors hold Nv*P rows and camera v sees rows
     [v*P, (v+1)*P) only — the batch loop of GS3DRenderer.forward (renderer_one_shot.py:615-633) in one launch sequence.
@@ -691,9 +858,10 @@ def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *,
     cams: (Nv, GH_CAM_FLOATS) from camera.pack_cameras_from_w2c; returns (images (Nv,3,H,W), radii (Nv,P)) or, with
     return_alpha, (images, alpha (Nv,H,W), radii): alpha is the reference's mask render (colour 1, bg 0,
     renderer_one_shot.py:353-380) produced by the same pass as a 4th channel (bit-identical to a separate pass).
-    Differentiable w.r.t. xyz, opacity, scaling, rotation, shs and the blend parameters (through image and alpha).
+    Differentiable w.r.t. xyz, opacity, scaling, rotation, shs and the blend parameters (through image and alpha); only
+    the gradients autograd needs are computed. geometry_cache: see GeometryCache (static Gaussians and cameras).
     """
-    image, alpha, radii = _RasterizeViews.apply(cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier),
+    image, alpha, radii = _RasterizeViews.apply(geometry_cache, cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier),
                                  bool(use_rgb), bool(sync), max_instances, bool(return_alpha), bool(per_view_gaussians), xyz, opacity,
                                  scaling,
                                  rotation, shs, xyz_b, opacity_b, color_w, color_b)

@@ -121,17 +121,20 @@ def select_gaussians(if_gs_valid: torch.Tensor, query_points: torch.Tensor, gs_h
 def render_views(gs: GaussianModel, w2cs: torch.Tensor, intrinsics: torch.Tensor, height: int, width: int,
                  background_color: torch.Tensor, ret_mask: bool = True, color_w=None, xyz_b=None, color_b=None,
                  opacity_b=None, *, use_rgb: bool = True, sh_degree: int = 3, scaling_modifier: float = 1.0,
-                 sync: bool = True, cams: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                 sync: bool = True, cams: Optional[torch.Tensor] = None, geometry_cache=None) -> Dict[str, torch.Tensor]:
     """The view loop of forward_single_batch (renderer_one_shot.py:494-510) as ONE batched launch sequence:
     all cameras at once, the attribute blend fused into the projection kernel, and the RGB pass and the mask
     pass of every view (:338-346, :372-379) fused into one 4-channel walk (same preprocess, same sort).
     Returns stacked (Nv,H,W,3) maps like the reference's `torch.stack(v, dim=0)`; comp_mask repeats the
-    accumulated alpha over 3 channels exactly as the reference's colour=1 render does."""
+    accumulated alpha over 3 channels exactly as the reference's colour=1 render does.
+    geometry_cache (rasterizer.GeometryCache, needs `cams`): the Gaussians' geometry and the cameras do not change from
+    call to call — projection and sorts are done once, later calls only refresh opacities / colours."""
     if cams is None:                                    # callers that render the same cameras every step pass the packed records
         cams = pack_cameras_from_w2c(w2cs, intrinsics, height, width, background_color)
     img, alpha, _ = rasterize_views(cams, gs.xyz, gs.opacity, gs.scaling, gs.rotation, gs.shs, H=height, W=width,
                                     use_rgb=use_rgb, sh_degree=sh_degree, scale_modifier=scaling_modifier, xyz_b=xyz_b,
-                                    opacity_b=opacity_b, color_w=color_w, color_b=color_b, sync=sync, return_alpha=True)
+                                    opacity_b=opacity_b, color_w=color_w, color_b=color_b, sync=sync, return_alpha=True,
+                                    geometry_cache=geometry_cache)
     out = {"comp_rgb": img.permute(0, 2, 3, 1), "comp_rgb_bg": background_color}
     if ret_mask:
         out["comp_mask"] = alpha.unsqueeze(-1).expand(-1, -1, -1, 3)

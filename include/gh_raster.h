@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define GH_VERSION_MAJOR 0
-#define GH_VERSION_MINOR 3
+#define GH_VERSION_MINOR 4
 
 #define GH_TILE 16           /* tile edge in pixels (binning granularity; fixes which Gaussians a pixel sees) */
 #define GH_CAM_FLOATS 40     /* floats per camera record, see GhCamera */
@@ -63,6 +63,11 @@ typedef enum GhStatus {
                                          [v*P, (v+1)*P) only (its own pose); color_w (48,), xyz_b stay shared */
 #define GH_FLAG_BLEND_COLOR_B_RGB 2u    /* colors_precomp mode only: blend_color_b and dL_dblend_color_b are (P,3), the
                                            three columns of the (P,48) view that renderer_one_shot.py:328 reads */
+#define GH_FLAG_STATIC_LISTS 16u       /* this forward's tile lists will be re-used by gh_forward_refresh with OTHER opacities and
+                                           colours (same means / scales / rotations / cameras): tile culling treats every
+                                           opacity as max(1, opacity), so the lists hold every tile the Gaussian can reach while
+                                           its opacity stays <= that bound. Images and gradients are those of the plain call
+                                           (a tile that holds no contributing pixel changes nothing): only D is larger. */
 #define GH_FLAG_SPLIT_STREAMS 8u        /* n_views >= 2: the views are rendered as two independent halves (views [0, n/2) and
                                            [n/2, n)), the second on a HIP stream of the library's own, forked from and joined
                                            back into the caller's stream inside every call (graph-capturable): the drain of one
@@ -248,6 +253,26 @@ int gh_forward_shared(const GhDims* dims, const GhInputs* in, const GhOutputs* o
                       void* workspace, size_t ws_bytes, void* hip_stream);
 int gh_backward_shared(const GhDims* dims, const GhInputs* in, const GhGrads* grads, const void* geometry_ws,
                        void* workspace, size_t ws_bytes, void* hip_stream);
+
+/*
+ * A later step over STATIC geometry. The one-shot fit (infer_one_shot.py:489-524) renders the same Gaussians from the same
+ * cameras every step; only the blend parameters it trains move — colours (color_w, color_b) and opacities (opacity_b),
+ * renderer_one_shot.py:306-334. `geometry_ws` is the workspace of a completed gh_forward with GH_FLAG_STATIC_LISTS and the
+ * same dims and means3D / scales / rotations / xyz_b / cameras; this call skips projection, both sorts, emit and the record
+ * gather and only (a) [shs given] re-evaluates the SH colours, (b) refreshes the per-instance render records — opacity,
+ * colour and the 4x4-block mask of the CURRENT opacity — in one streaming pass, (c) walks the lists. Forward images are those
+ * of a full gh_forward bit for bit; gradients agree to rounding (another partition of the lists into depth segments).
+ * Guard: a Gaussian whose opacity (+ opacity_b) has risen above the bound its tiles were culled with (max(1, opacity at
+ * build time)) might reach a tile that is not listed: the call then sets GhCounters.overflow |= 2 and the image is NaN,
+ * exactly like an instance overflow — rebuild the lists with a full gh_forward.
+ * gh_backward_refresh: gradients w.r.t. whatever `grads` asks for; with every geometry gradient pointer (dL_dmeans3D,
+ * dL_dmeans2D, dL_dscales, dL_drotations, dL_dblend_xyz_b) NULL the per-Gaussian chain rule reduces to sums over the views
+ * (the fit trains colour / opacity biases only).
+ */
+int gh_forward_refresh(const GhDims* dims, const GhInputs* in, const GhOutputs* out, const void* geometry_ws,
+                       void* workspace, size_t ws_bytes, void* hip_stream);
+int gh_backward_refresh(const GhDims* dims, const GhInputs* in, const GhGrads* grads, const void* geometry_ws,
+                        void* workspace, size_t ws_bytes, void* hip_stream);
 
 /*
  * Per-Gaussian bilinear lookup of a learnable UV map and its backward. Replaces

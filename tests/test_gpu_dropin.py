@@ -328,7 +328,7 @@ def test_second_call_over_the_same_geometry_reuses_the_first_calls_lists_bit_for
     img_c, _ = GaussianRasterizer(mk(s.bg))(colors_precomp=col, **kw2)
     assert img_c.grad_fn.rctx.parent is None
     objs = Rz._geom_last[0]                                               # weak references only: the record keeps no tensor alive
-    del kw2
+    del kw2, img_c                                                        # (the call's own context held the tensor until now)
     import gc
     gc.collect()
     assert any(o() is None for o in objs)

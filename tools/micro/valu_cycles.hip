@@ -5,8 +5,10 @@
 // MI355X_MICROARCH.md 'Per-instruction cycle constants'), and W = 1 / 2 / 4 / 8 waves are made resident per SIMD
 // (workgroups of 4 W waves, one or two per CU), so the number reported is
 //     cycles per wave64 instruction per SIMD = (cycles one wave needed) / (W x instructions per wave)
-// for a stream of 8 independent dependency chains per lane. Clock-independent. The guide's figure for plain FP32 is
-// 2 cycles per SIMD (SIMD-32) and 4 for one wave alone.
+// for a stream of 8 independent dependency chains per lane. The guide's figure for plain FP32 is 2 cycles per SIMD
+// (SIMD-32) and 4 for one wave alone. Whether an s_memtime tick IS a shader cycle under load is checked too: the W = 8
+// launch is also timed with HIP events, which gives the tick rate (ticks per wall ns = GHz of the counter) and the absolute
+// issue rate in wave-instructions per ns per SIMD — the number a kernel's (instructions / time / SIMDs) is compared with.
 //
 // build: hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_cycles tools/micro/valu_cycles.hip
 #include <hip/hip_runtime.h>
@@ -64,27 +66,38 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float a, floa
 }
 
 template <int KIND> void run(const char* name, unsigned long long* d, int packed = 1) {
-  const int iters = (KIND == 14 || KIND == 23) ? 1000 : 4000;
+  const int iters = (KIND == 14 || KIND == 23) ? 4000 : 40000;      // W = 8: tens of ms per launch, so that the clocks settle
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   printf("%-28s", name);
   for (int W : {1, 2, 4, 8}) {
     const int waves_per_block = W >= 4 ? 16 : 4 * W;          // W waves on each of the CU's 4 SIMDs (two blocks per CU for W = 8)
     const int blocks = 256 * (W == 8 ? 2 : 1);
     const int nw = blocks * waves_per_block;
     (void)hipMemset(d, 0, nw * 8);
-    for (int rep = 0; rep < 2; ++rep)
+    float ms = 0.0f;
+    for (int rep = 0; rep < 2; ++rep) {
+      (void)hipEventRecord(e0);
       hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64 * waves_per_block), 0, 0, d, 1.0f, 0.999f, iters);
-    (void)hipDeviceSynchronize();
+      (void)hipEventRecord(e1);
+      (void)hipDeviceSynchronize();
+      (void)hipEventElapsedTime(&ms, e0, e1);
+    }
     std::vector<unsigned long long> h(nw);
     (void)hipMemcpy(h.data(), d, nw * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     const double med = (double)h[nw / 2];
     const double per = med / ((double)W * NCHAIN * iters) * (KIND == 15 || KIND == 16 ? 2.0 : 1.0);   // packed: 4 instructions per 8 chains
     printf("  W=%d %6.2f", W, per);
+    if (W == 8) {
+      const double n_inst = (double)NCHAIN * iters / (KIND == 15 || KIND == 16 ? 2.0 : 1.0);      // per wave
+      printf("  | W=8: %.3f wave-instr/ns/SIMD, counter %.2f ticks/ns (kernel %.1f ms)", 8.0 * n_inst / (ms * 1e6), med / (ms * 1e6), ms);
+    }
   }
-  printf("   cycles / wave-instruction / SIMD\n");
+  printf("\n");
 }
 
 int main() {
+  printf("columns: s_memtime ticks per wave-instruction per SIMD with W waves resident per SIMD\n");
   unsigned long long* d; (void)hipMalloc(&d, 8 * 8192 * 8);
   run<0>("v_fma_f32", d); run<1>("v_mul_f32", d); run<2>("v_add_f32", d); run<21>("v_sub_f32", d); run<4>("v_min_f32", d); run<22>("v_max_f32", d);
   run<3>("v_cndmask_b32 (sgpr mask)", d); run<7>("v_and_b32", d); run<24>("v_bfe_u32", d); run<8>("v_cmp_gt_f32", d);
