@@ -488,8 +488,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   }
   if (i >= N || cnt == 0 || small) return;
   uint32_t off = wave_base + x - cnt;
-  // (C, opacity): the projection kernel's operands — the opacity it culled with (GH_FLAG_STATIC_LISTS: at least 1)
-  const float4 g0 = grec[0], g1 = make_float4(grec[1].x, (flags & GH_FLAG_STATIC_LISTS) ? fmaxf(grec[1].y, 1.0f) : grec[1].y, 0.0f, 0.0f);
+  // (C, opacity): the projection kernel's operands — the opacity it culled with (GH_FLAG_STATIC_LISTS: gh_static_cull_opacity)
+  const float4 g0 = grec[0], g1 = make_float4(grec[1].x, (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(grec[1].y) : grec[1].y, 0.0f, 0.0f);
   for (int ty = miny; ty < maxy; ++ty)
     for (int tx = minx; tx < maxx; ++tx) {
       if (!gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1))) continue;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   } else {                                              // rect larger than the mask: recount (rare, huge footprints)
     before = 0;
     uint32_t k = 0;
-    const float4 bc = make_float4(b.x, (flags & GH_FLAG_STATIC_LISTS) ? fmaxf(b.y, 1.0f) : b.y, 0.0f, 0.0f);   // as culled
+    const float4 bc = make_float4(b.x, (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(b.y) : b.y, 0.0f, 0.0f);   // as culled
     for (uint32_t yy = miny; yy < maxy && k < bit; ++yy)
       for (uint32_t xx = minx; xx < maxx && k < bit; ++xx, ++k)
         before += gh_block_hit(a, bc, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;

@@ -310,6 +310,12 @@ __device__ __forceinline__ uint32_t gh_div_small(uint32_t t, uint32_t d, float r
   return q;
 }
 
+// GH_FLAG_STATIC_LISTS: the opacity a Gaussian's tiles are culled with when the lists must outlive the call's opacities
+// (gh_forward_refresh) — at least 2, and twice the current value. The alpha >= 1/255 ellipse grows with sqrt(ln(255 o)):
+// doubling an opacity of 1 widens it by 6 %, so the bound is cheap (a few per cent more instances) and a fit's opacity
+// bias has to double an opacity — or push it past 2 — before the guard asks for new lists.
+__device__ __forceinline__ float gh_static_cull_opacity(float op) { return fmaxf(2.0f, 2.0f * op); }
+
 // wave64 ballot of a predicate, straight from the compare (HIP's __ballot(int) goes through a 0/1 integer first)
 __device__ __forceinline__ uint64_t gh_ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         radius = rad;                                   // API output: the reference's 3-sigma radius (App. A.1-6)
         op = in.opacities[i];
         if (in.blend_opacity_b) op = op + in.blend_opacity_b[i];
-        // GH_FLAG_STATIC_LISTS: the lists outlive this call's opacities (gh_forward_refresh): cull as if opacity >= 1
-        const float op_cull = (flags & GH_FLAG_STATIC_LISTS) ? fmaxf(op, 1.0f) : op;
+        // GH_FLAG_STATIC_LISTS: the lists outlive this call's opacities (gh_forward_refresh): cull with a bound above them
+        const float op_cull = (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(op) : op;
         cull_bound = op_cull;
         // Exact tile culling: of the tiles in the 3-sigma rect only those are instanced in which the alpha >= 1/255
         // ellipse reaches a pixel centre (gh_block_hit, conservative within its margin). A dropped tile holds no pixel

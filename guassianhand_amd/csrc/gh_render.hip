@@ -739,7 +739,7 @@ void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, co
 
 // ------------------------------------------------------------------------------------------------
 // A later step over static geometry (gh_forward_refresh): the lists of `wg` were built with GH_FLAG_STATIC_LISTS (tiles culled
-// as if every opacity were >= 1); this call's opacities and colours differ from the build call's. One streaming pass over
+// with gh_static_cull_opacity: max(2, twice the opacity of the build call)); this call's opacities and colours differ from the build call's. One streaming pass over
 // the sorted instances rebuilds the part of the render records that moved — opacity, colour and the 4x4-block mask OF THE
 // CURRENT OPACITY (so the render kernels skip, with one bit test, the instances the exact culling of a full call would not
 // have listed) — from the static part (centre, conic: inst_r0 / inst_r1.x of the geometry owner; tile id: its sorted keys).

@@ -348,7 +348,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     (forked from / joined into the current stream, graph-capturable); bit-identical images, radii and gradients.
     None = the module policy (set_split_streams).
     static_lists (GH_FLAG_STATIC_LISTS): build tile lists that stay valid for other opacities / colours (culling treats
-    every opacity as max(1, opacity)); same image and gradients, larger D. refresh_of: context of such a forward with the SAME
+    every opacity o as max(2, 2 o)); same image and gradients, larger D. refresh_of: context of such a forward with the SAME
     means3D / scales / rotations / xyz_b / cameras: this call (gh_forward_refresh) skips projection and sorts, refreshes the
     per-instance records with ITS opacities and colours (shs or colors_precomp) and walks the lists; forward bit-identical
     to a full call. An opacity above the lists' bound poisons the call (NaN image, GhStaleGeometryError). GeometryCache is

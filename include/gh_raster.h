@@ -65,7 +65,7 @@ typedef enum GhStatus {
                                            three columns of the (P,48) view that renderer_one_shot.py:328 reads */
 #define GH_FLAG_STATIC_LISTS 16u       /* this forward's tile lists will be re-used by gh_forward_refresh with OTHER opacities and
                                            colours (same means / scales / rotations / cameras): tile culling treats every
-                                           opacity as max(1, opacity), so the lists hold every tile the Gaussian can reach while
+                                           opacity o as max(2, 2 o), so the lists hold every tile the Gaussian can reach while
                                            its opacity stays <= that bound. Images and gradients are those of the plain call
                                            (a tile that holds no contributing pixel changes nothing): only D is larger. */
 #define GH_FLAG_SPLIT_STREAMS 8u        /* n_views >= 2: the views are rendered as two independent halves (views [0, n/2) and
@@ -262,8 +262,8 @@ int gh_backward_shared(const GhDims* dims, const GhInputs* in, const GhGrads* gr
  * gather and only (a) [shs given] re-evaluates the SH colours, (b) refreshes the per-instance render records — opacity,
  * colour and the 4x4-block mask of the CURRENT opacity — in one streaming pass, (c) walks the lists. Forward images are those
  * of a full gh_forward bit for bit; gradients agree to rounding (another partition of the lists into depth segments).
- * Guard: a Gaussian whose opacity (+ opacity_b) has risen above the bound its tiles were culled with (max(1, opacity at
- * build time)) might reach a tile that is not listed: the call then sets GhCounters.overflow |= 2 and the image is NaN,
+ * Guard: a Gaussian whose opacity (+ opacity_b) has risen above the bound its tiles were culled with (max(2, twice the
+ * opacity at build time)) might reach a tile that is not listed: the call then sets GhCounters.overflow |= 2 and the image is NaN,
  * exactly like an instance overflow — rebuild the lists with a full gh_forward.
  * gh_backward_refresh: gradients w.r.t. whatever `grads` asks for; with every geometry gradient pointer (dL_dmeans3D,
  * dL_dmeans2D, dL_dscales, dL_drotations, dL_dblend_xyz_b) NULL the per-Gaussian chain rule reduces to sums over the views
