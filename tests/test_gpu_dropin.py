@@ -389,15 +389,19 @@ def test_default_dropin_inference_call_reruns_transparently(dev):
     from guassianhand_amd.scenes import make_scene
     sc = make_scene("random1k", n_views=1, P=3200)
     rs, kw, xyz, col = _dropin_leaves(sc, dev)
-    img0, _ = GaussianRasterizer(rs)(**kw)
-    key = Rz.capacity_key(sc.P, 1, sc.H, sc.W, False)
-    D = Rz.last_num_rendered()
-    Rz._capacity[key] = D // 2
-    with torch.no_grad():
-        img1, _ = GaussianRasterizer(rs)(**kw)
-    assert torch.equal(img1, img0.detach()) and Rz._capacity[key] >= D
-    Rz._capacity[key] = D // 2
-    kw_ng = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in kw.items()}
-    img2, _ = GaussianRasterizer(rs)(**kw_ng)
-    assert torch.equal(img2, img0.detach())
-    Rz.check_overflow()
+    Rz.set_geometry_reuse(False)                   # (every call below is to be a full call, not the mask pass of the one before)
+    try:
+        img0, _ = GaussianRasterizer(rs)(**kw)
+        key = Rz.capacity_key(sc.P, 1, sc.H, sc.W, False)
+        D = Rz.last_num_rendered()
+        Rz._capacity[key] = D // 2
+        with torch.no_grad():
+            img1, _ = GaussianRasterizer(rs)(**kw)
+        assert torch.equal(img1, img0.detach()) and Rz._capacity[key] >= D
+        Rz._capacity[key] = D // 2
+        kw_ng = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in kw.items()}
+        img2, _ = GaussianRasterizer(rs)(**kw_ng)
+        assert torch.equal(img2, img0.detach())
+        Rz.check_overflow()
+    finally:
+        Rz.set_geometry_reuse(True)
