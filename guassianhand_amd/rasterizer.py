@@ -728,7 +728,7 @@ def _geometry_key(means3D, opacities, scales, rotations, rs):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, raster_settings, sync):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, raster_settings, sync, expect_backward):
         global _geom_last
         rs = raster_settings
         cams = pack_camera(rs.viewmatrix, rs.projmatrix, rs.campos, rs.tanfovx, rs.tanfovy, rs.bg)
@@ -747,7 +747,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             cams, means3D, opacities, scales, rotations, H=int(rs.image_height), W=int(rs.image_width),
             shs=sh, colors_precomp=colors_precomp, sh_degree=int(rs.sh_degree),
             scale_modifier=float(rs.scale_modifier), sync=sync, geometry_of=parent,
-            expect_backward=any(ctx.needs_input_grad))
+            expect_backward=expect_backward)
         if _reuse_geometry and parent is None:
             _geom_last = (tuple(weakref.ref(o) for o in objs), vals, weakref.ref(rctx))
         ctx.rctx = rctx
@@ -766,7 +766,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (g["means3D"].reshape(s[0]), g["means2D"][0].reshape(s[1]),
                 g["shs"].reshape(s[2]) if s[2] is not None else None,
                 g["colors_precomp"].reshape(s[3]) if s[3] is not None else None,
-                g["opacities"].reshape(s[4]), g["scales"].reshape(s[5]), g["rotations"].reshape(s[6]), None, None)
+                g["opacities"].reshape(s[4]), g["scales"].reshape(s[5]), g["rotations"].reshape(s[6]), None, None, None)
 
 
 class GaussianRasterizer(nn.Module):
@@ -795,9 +795,13 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is not None:
             raise NotImplementedError("cov3D_precomp is never passed by the reference "
                                       "(renderer_one_shot.py:313, :346) and is not supported")
+        # will a backward come? (decided here: inside an autograd Function's forward the grad mode is always off, and
+        # needs_input_grad ignores torch.no_grad())
+        expect_backward = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (means3D, means2D, shs, colors_precomp, opacities, scales, rotations))
         with torch.autocast(device_type=means3D.device.type, enabled=False):
             return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                             self.raster_settings, self.sync)
+                                             self.raster_settings, self.sync, expect_backward)
 
 
 # ---------------------------------------------------------------------------------------------------
