@@ -117,7 +117,7 @@ class _Pending:
             self.over = (c[1] & 0xFFFFFFFF) != 0
             self.stale = (c[1] & 2) != 0
             need = (c[2] & 0xFFFFFFFF) if self.key[-1] else self.d
-            if self.stale:
+            if self.over:                          # stale lists, or lists truncated by an instance overflow: never re-use them
                 GeometryCache.clear_all()
             if self.over and (c[1] & 1):
                 _capacity[self.key] = max(_capacity.get(self.key, 0), int(max(need, self.d) * 1.5) + 1024)
@@ -241,6 +241,7 @@ def check_overflow(block: bool = True, keep_recent: int = 0) -> None:
         if (c4[1] & 0xFFFFFFFF) != 0:                  # the device-side flag decides; reserved[0] of a split call sizes the next capacity
             need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
             _capacity[key] = max(_capacity.get(key, 0), int(need * 1.5) + 1024)
+            GeometryCache.clear_all()
             raise GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside a captured graph")
     keep, bad = [], None
     n_old = len(_pending) - keep_recent if keep_recent > 0 else 0
@@ -452,7 +453,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             raise RuntimeError(f"gh_forward_refresh failed: {_abi.status_name(rc)}")
         counters = ws[:16].view(torch.int32)
         _last_ws = ws
-        pending = None
+        pending, auto = None, sync is None
         gkey = (P, NV, H, W, False)
         if sync is None:
             sync = not expect_backward
@@ -463,7 +464,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                 GeometryCache.clear_all()
                 raise GhStaleGeometryError(_STALE_MSG)
             if c4[1] & 1:
-                raise GhOverflowError("the static tile lists were built by a call that overflowed its capacity")
+                GeometryCache.clear_all()
+                raise GhOverflowError("the static tile lists were built by a call that overflowed its capacity; caches cleared")
         elif _graph_mode:
             _graph_counters[ws.data_ptr()] = (counters, cap, gkey)
         else:
@@ -474,7 +476,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             ev.record()
             pc = _Pending(ev, host, cap, gkey)
             _pending.append(pc)
-            pending = pc
+            if auto:
+                pending = pc
         ctx = _Ctx()
         ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
         ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
