@@ -74,6 +74,7 @@ def _work(rank, world, backend, n_views, overflow_rank, q, dev):
         if rank == overflow_rank:
             good = R._capacity[key]
             R._capacity[key] = 64
+            f.invalidate_geometry()                # (the static tile lists would need no capacity: make this step build anew)
         before = _state(f)
         l_bad = float(f.step(*args, sync=False))
         after = _state(f)
