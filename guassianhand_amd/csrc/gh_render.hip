@@ -746,7 +746,15 @@ void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, co
 // Also this call's per-tile walk state, backward flags and counters, and the GUARD: thread t < N compares the current
 // opacity of (view, Gaussian) t with the bound its tiles were culled with (geometry line [3].y); above it a tile may be
 // missing from the lists, so the call is poisoned like an instance overflow (GhCounters.overflow |= 2 -> NaN image).
-// The counters were zeroed by a memset node in front of this kernel.
+// The counters are initialised by a one-wave kernel in front of this one (not by a memset: inside a replayed HIP graph a
+// 16-byte memset node was seen to land AFTER the kernels that follow it on ROCm 7.2 — back-to-back replays of a fit step
+// lost the forward's work-list counter and produced NaN gradients).
+__global__ void gh_refresh_init_kernel(const GhCounters* __restrict__ gctr, GhCounters* __restrict__ ctr) {
+  if (threadIdx.x == 0) {
+    ctr->num_rendered = gctr->num_rendered; ctr->overflow = gctr->overflow; ctr->reserved[0] = gctr->reserved[0]; ctr->reserved[1] = 0u;
+  }
+}
+
 __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_kernel(GhInputs in, uint32_t flags, int P, int N, int T, uint32_t cap, int gx, int tiles,
                                                                float rtiles, float rgx, const GhCounters* __restrict__ gctr,
                                                                const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
@@ -757,10 +765,6 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_kernel(GhInputs in, uint3
                                                                GhCounters* __restrict__ ctr) {
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   const uint32_t D = gctr->num_rendered;
-  if (i == 0) {
-    ctr->num_rendered = D; ctr->reserved[0] = gctr->reserved[0];
-    if (gctr->overflow) atomicOr(&ctr->overflow, gctr->overflow);
-  }
   if (i < (uint32_t)T) { tile_walk[i] = 0u; tile_walk[T + i] = 0u; }
   const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   if (i < (uint32_t)N) {                                      // guard, one thread per (view, Gaussian)
@@ -797,7 +801,7 @@ void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, con
   size_t n = (size_t)g.cap > (size_t)T ? (size_t)g.cap : (size_t)T;
   if ((size_t)g.N > n) n = (size_t)g.N;
   const int nblk = (int)((n + GH_BLOCK - 1) / GH_BLOCK);
-  (void)hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s);
+  hipLaunchKernelGGL(gh_refresh_init_kernel, dim3(1), dim3(GH_WAVE), 0, s, (const GhCounters*)(wg + L.counters), (GhCounters*)(ws + L.counters));
   hipLaunchKernelGGL(gh_refresh_kernel, dim3(nblk > 0 ? nblk : 1), dim3(GH_BLOCK), 0, s, *in, d->flags, g.P, g.N, T, (uint32_t)g.cap, g.gx, g.tiles,
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,
                      (const GhCounters*)(wg + L.counters), (const uint32_t*)(wg + L.keys_a), (const uint32_t*)(wg + L.vals_a),

@@ -31,10 +31,13 @@ for static in (False, True):
     D = R.last_num_rendered()
     eager = t(lambda: f.step(*args, sync=False))
     R.check_overflow()
+    l_eager = float(f.step(*args, sync=False))
     cap = f.captured(*args)
+    l_cap0 = float(cap.replay())
     graph = t(lambda: cap.replay())
     cap.check()
     loss = float(cap.replay())
+    print(f"   losses: after the eager loop {l_eager:.6f}, first replay {l_cap0:.6f}, last replay {loss:.6f}")
     print(f"fit step, {nv} views, P={sc.P}, static_geometry={static}: eager {eager:.3f} ms, captured graph {graph:.3f} ms; "
           f"instances D={D}; loss after the timed steps {loss:.6f}" +
           (f"; cache builds/hits {f._geom_cache.builds}/{f._geom_cache.hits}" if static else ""))
