@@ -103,6 +103,9 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->sh_scratch = take(sh_mode ? ((N * 16 + GH_BLOCK - 1) / GH_BLOCK + 1) * 64 * 4 : 0);   // sized for the pose-batch row count
   L->grad_sums = take(N * 48);
   L->bwd_scratch = take((2 * nblk_pre + 2) * 64 * 4);     // per-block partials of the chain-rule kernel (<= 2N lanes)
+  L->cull_bound = take(N * 4);
+  L->inst_c = take(cap * 4);
+  L->attr = take(N * 16);
   L->half_counters = take(512);
   L->key_bits = take((gh_proj_blocks(g) + 4) * 8);        // (OR, AND) of the visible depth keys per projection block (+1 word; two
                                                           // halves: + 1 block of rounding + 1 word each)
@@ -164,6 +167,7 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     o.inst_grad += cap0 * 4 * GH_REC_G * 4; o.inst_flag += cap0 * 4;
     if (sh_mode) { o.sh_rgb += n0 * 16; o.dmean_sh += n0 * 16; }
     o.grad_sums += n0 * 48;
+    o.cull_bound += n0 * 4; o.inst_c += cap0 * 4; o.attr += n0 * 16;
     o.key_bits += h ? (proj_a + 1) * 8 : 0;
     if (h == 0) {
       blk_a = ((size_t)H.g.N + GH_BLOCK - 1) / GH_BLOCK; items_a = (size_t)H.g.n_items; tab_a = gh_sort_table_words(H.g);

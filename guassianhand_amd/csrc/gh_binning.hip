@@ -511,7 +511,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               uint2* __restrict__ ranges, float4* __restrict__ r0,
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
                                                               uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin,
-                                                              float rtiles, float rgx, uint32_t flags) {
+                                                              float rtiles, float rgx, uint32_t flags, float* __restrict__ inst_c) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
   // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
@@ -559,6 +559,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   sorted_slot[i] = slot0 + before;
   const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
   r0[i] = a; r1[i] = b; r2[i] = make_float2(cb, __uint_as_float(m));
+  if (flags & GH_FLAG_STATIC_LISTS) inst_c[i] = b.x;   // the conic's C again, compact: what gh_forward_refresh reads of r1
 }
 
 // Longest-processing-time-first launch order for the render kernels: a counting sort of the tiles by list length (256
@@ -640,6 +641,6 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
                      (const uint32_t*)(ws + L.slot_begin),
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,   // gh_div_small's range
-                     d->flags);
+                     d->flags, (float*)(ws + L.inst_c));
   gh_launch_tile_order(g, ws, L, s);
 }

@@ -12,7 +12,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk,
-    uint2* __restrict__ key_bits, float rdiv) {
+    uint2* __restrict__ key_bits, float rdiv, float* __restrict__ cull_bound_out) {
   __shared__ uint2 s_bits[GH_BLOCK / GH_WAVE];
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
@@ -97,9 +97,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
       }
     }
     // .x = instance count: the emit kernel, which walks the Gaussians in depth order, finds it in the line it reads anyway
-    // (written for every Gaussian: a culled one keeps a stale line from an earlier call apart from this float4);
-    // .y = the opacity its tiles were culled with (gh_refresh_kernel's guard)
-    geom[(size_t)n * 4 + 3] = make_float4(__uint_as_float(tiles), cull_bound, 0.0f, 0.0f);
+    // (written for every Gaussian: a culled one keeps a stale line from an earlier call apart from this float4)
+    geom[(size_t)n * 4 + 3] = make_float4(__uint_as_float(tiles), 0.0f, 0.0f, 0.0f);
+    cull_bound_out[n] = cull_bound;                    // the opacity its tiles were culled with (guard of gh_forward_refresh)
     tiles_touched[n] = tiles;
     rect[n] = rect_bits;                               // 3-sigma tile rect of every projected Gaussian (0 = none)
     depth_key[n] = dkey;
@@ -132,7 +132,8 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                      (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii,
                      T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk), (uint2*)(ws + L.key_bits),
-                     g.N < (1 << 24) ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f);
+                     g.N < (1 << 24) ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f,
+                     (float*)(ws + L.cull_bound));
 }
 
 // ------------------------------------------------------------------------------------------------

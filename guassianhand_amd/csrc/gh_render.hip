@@ -739,73 +739,78 @@ void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, co
 
 // ------------------------------------------------------------------------------------------------
 // A later step over static geometry (gh_forward_refresh): the lists of `wg` were built with GH_FLAG_STATIC_LISTS (tiles culled
-// with gh_static_cull_opacity: max(2, twice the opacity of the build call)); this call's opacities and colours differ from the build call's. One streaming pass over
-// the sorted instances rebuilds the part of the render records that moved — opacity, colour and the 4x4-block mask OF THE
-// CURRENT OPACITY (so the render kernels skip, with one bit test, the instances the exact culling of a full call would not
-// have listed) — from the static part (centre, conic: inst_r0 / inst_r1.x of the geometry owner; tile id: its sorted keys).
-// Also this call's per-tile walk state, backward flags and counters, and the GUARD: thread t < N compares the current
-// opacity of (view, Gaussian) t with the bound its tiles were culled with (geometry line [3].y); above it a tile may be
-// missing from the lists, so the call is poisoned like an instance overflow (GhCounters.overflow |= 2 -> NaN image).
-// The counters are initialised by a one-wave kernel in front of this one (not by a memset: inside a replayed HIP graph a
-// 16-byte memset node was seen to land AFTER the kernels that follow it on ROCm 7.2 — back-to-back replays of a fit step
-// lost the forward's work-list counter and produced NaN gradients).
+// with gh_static_cull_opacity: max(2, twice the opacity of the build call)); this call's opacities and colours differ from the
+// build call's. Two streaming kernels rebuild the part of the render records that moved:
+//   gh_refresh_attr_kernel      one thread per (view, Gaussian): (opacity, r, g, b) of THIS step as one 16-byte record, and the
+//                               GUARD — above the opacity its tiles were culled with (cull_bound) a tile may be missing from the
+//                               lists, so the call is poisoned like an instance overflow (GhCounters.overflow |= 2 -> NaN image);
+//                               also this call's per-tile walk state. (The counters are written by a one-wave kernel in front —
+//                               NOT a memset: inside a replayed HIP graph a 16-byte memset node was seen to land after the
+//                               kernels that follow it on ROCm 7.2, and a store by thread 0 of this kernel could land after
+//                               another block's atomicOr);
+//   gh_refresh_instance_kernel  one thread per sorted instance: its Gaussian's record (one 16-byte gather), the static centre /
+//                               conic (inst_r0, inst_c of the geometry owner) and tile id (its sorted keys) -> opacity, colour and
+//                               the 4x4-block mask OF THE CURRENT OPACITY, so that the render kernels skip, with one bit test,
+//                               the instances the exact culling of a full call would not have listed.
 __global__ void gh_refresh_init_kernel(const GhCounters* __restrict__ gctr, GhCounters* __restrict__ ctr) {
   if (threadIdx.x == 0) {
     ctr->num_rendered = gctr->num_rendered; ctr->overflow = gctr->overflow; ctr->reserved[0] = gctr->reserved[0]; ctr->reserved[1] = 0u;
   }
 }
 
-__global__ __launch_bounds__(GH_BLOCK) void gh_refresh_kernel(GhInputs in, uint32_t flags, int P, int N, int T, uint32_t cap, int gx, int tiles,
-                                                               float rtiles, float rgx, const GhCounters* __restrict__ gctr,
-                                                               const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                               const float4* __restrict__ geom, const float4* __restrict__ g_r0,
-                                                               const float4* __restrict__ g_r1, const float4* __restrict__ sh_rgb,
-                                                               float4* __restrict__ r1, float2* __restrict__ r2,
-                                                               uint32_t* __restrict__ inst_flag, uint32_t* __restrict__ tile_walk,
-                                                               GhCounters* __restrict__ ctr) {
-  const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
-  const uint32_t D = gctr->num_rendered;
-  if (i < (uint32_t)T) { tile_walk[i] = 0u; tile_walk[T + i] = 0u; }
-  const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
-  if (i < (uint32_t)N) {                                      // guard, one thread per (view, Gaussian)
-    const int row = per_view ? (int)i : (int)(i % (uint32_t)P);
-    float op = in.opacities[row];
-    if (in.blend_opacity_b) op = op + in.blend_opacity_b[row];
-    if (op > geom[(size_t)i * 4 + 3].y) atomicOr(&ctr->overflow, 2u);
-  }
-  const uint32_t n = D < cap ? D : cap;
-  if (i >= n) return;
-  inst_flag[i] = 0;
-  const uint32_t gid = vals[i];
-  const int row = per_view ? (int)gid : (int)(gid % (uint32_t)P);
+__global__ __launch_bounds__(GH_BLOCK) void gh_refresh_attr_kernel(GhInputs in, uint32_t flags, int P, int NV, int N, int T,
+                                                                    const GhCounters* __restrict__ gctr, const float* __restrict__ cull_bound,
+                                                                    const float4* __restrict__ sh_rgb, float4* __restrict__ attr,
+                                                                    uint32_t* __restrict__ tile_walk, GhCounters* __restrict__ ctr) {
+  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (t < T) { tile_walk[t] = 0u; tile_walk[T + t] = 0u; }
+  if (t >= N) return;
+  const int row = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : t % P;       // n = view * P + row (view-major, as the lists' payload)
   float op = in.opacities[row];
   if (in.blend_opacity_b) op = op + in.blend_opacity_b[row];
   float rgb[3];
   if (in.colors_precomp) gh_blended_rgb(in, flags, row, rgb);
-  else { const float4 c4 = sh_rgb[gid]; rgb[0] = c4.x; rgb[1] = c4.y; rgb[2] = c4.z; }
+  else { const float4 c4 = sh_rgb[t]; rgb[0] = c4.x; rgb[1] = c4.y; rgb[2] = c4.z; }
+  attr[t] = make_float4(op, rgb[0], rgb[1], rgb[2]);
+  if (op > cull_bound[t]) atomicOr(&ctr->overflow, 2u);
+}
+
+__global__ __launch_bounds__(GH_BLOCK) void gh_refresh_instance_kernel(uint32_t cap, int gx, int tiles, float rtiles, float rgx,
+                                                                        const GhCounters* __restrict__ gctr,
+                                                                        const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                        const float4* __restrict__ g_r0, const float* __restrict__ g_c,
+                                                                        const float4* __restrict__ attr, float4* __restrict__ r1,
+                                                                        float2* __restrict__ r2, uint32_t* __restrict__ inst_flag) {
+  const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const uint32_t D = gctr->num_rendered;
+  const uint32_t n = D < cap ? D : cap;
+  if (i >= n) return;
+  inst_flag[i] = 0;
+  const float4 at = attr[vals[i]];                      // (opacity, r, g, b) of the instance's (view, Gaussian)
   const float4 a = g_r0[i];
-  const float cC = g_r1[i].x;
+  const float cC = g_c[i];
   const uint32_t t = keys[i];
   uint32_t tl, ty;
   if (rtiles > 0.0f) { tl = t - gh_div_small(t, (uint32_t)tiles, rtiles) * (uint32_t)tiles; ty = gh_div_small(tl, (uint32_t)gx, rgx); }
   else { tl = t % (uint32_t)tiles; ty = tl / (uint32_t)gx; }
   const uint32_t tx = tl - ty * (uint32_t)gx;
-  const float4 b = make_float4(cC, op, rgb[0], rgb[1]);
+  const float4 b = make_float4(cC, at.x, at.y, at.z);
   const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
   r1[i] = b;
-  r2[i] = make_float2(rgb[2], __uint_as_float(m));
+  r2[i] = make_float2(at.w, __uint_as_float(m));
 }
 
 void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s) {
   const int T = g.NV * g.tiles;
-  size_t n = (size_t)g.cap > (size_t)T ? (size_t)g.cap : (size_t)T;
-  if ((size_t)g.N > n) n = (size_t)g.N;
-  const int nblk = (int)((n + GH_BLOCK - 1) / GH_BLOCK);
+  const int na = g.N > T ? g.N : T;
   hipLaunchKernelGGL(gh_refresh_init_kernel, dim3(1), dim3(GH_WAVE), 0, s, (const GhCounters*)(wg + L.counters), (GhCounters*)(ws + L.counters));
-  hipLaunchKernelGGL(gh_refresh_kernel, dim3(nblk > 0 ? nblk : 1), dim3(GH_BLOCK), 0, s, *in, d->flags, g.P, g.N, T, (uint32_t)g.cap, g.gx, g.tiles,
+  hipLaunchKernelGGL(gh_refresh_attr_kernel, dim3((na + GH_BLOCK - 1) / GH_BLOCK), dim3(GH_BLOCK), 0, s, *in, d->flags, g.P, g.NV, g.N, T,
+                     (const GhCounters*)(wg + L.counters), (const float*)(wg + L.cull_bound), (const float4*)(ws + L.sh_rgb),
+                     (float4*)(ws + L.attr), (uint32_t*)(ws + L.tile_walk), (GhCounters*)(ws + L.counters));
+  const int nblk = (int)(((size_t)g.cap + GH_BLOCK - 1) / GH_BLOCK);
+  hipLaunchKernelGGL(gh_refresh_instance_kernel, dim3(nblk > 0 ? nblk : 1), dim3(GH_BLOCK), 0, s, (uint32_t)g.cap, g.gx, g.tiles,
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,
                      (const GhCounters*)(wg + L.counters), (const uint32_t*)(wg + L.keys_a), (const uint32_t*)(wg + L.vals_a),
-                     (const float4*)(wg + L.geom), (const float4*)(wg + L.inst_r0), (const float4*)(wg + L.inst_r1),
-                     (const float4*)(ws + L.sh_rgb), (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2),
-                     (uint32_t*)(ws + L.inst_flag), (uint32_t*)(ws + L.tile_walk), (GhCounters*)(ws + L.counters));
+                     (const float4*)(wg + L.inst_r0), (const float*)(wg + L.inst_c), (const float4*)(ws + L.attr),
+                     (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag));
 }

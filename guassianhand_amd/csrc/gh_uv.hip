@@ -147,9 +147,15 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(float* __restrict
   const bool skip = guard && guard->overflow != 0u;
   int t = host_step;
   if (step_state) t = __hip_atomic_load(&step_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-  // bias corrections in double, as torch.optim.Adam's Python arithmetic (once per thread, not per element)
-  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
-  const float lr_over_bc1 = (float)((double)lr / bc1), inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  // bias corrections in double, as torch.optim.Adam's Python arithmetic — by ONE thread per block (two double pow() per
+  // thread made this kernel 28 us for a million parameters: the fit step's three launches cost 85 us)
+  __shared__ float s_bc[2];
+  if (threadIdx.x == 0) {
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    s_bc[0] = (float)((double)lr / bc1); s_bc[1] = (float)(1.0 / sqrt(bc2));
+  }
+  __syncthreads();
+  const float lr_over_bc1 = s_bc[0], inv_sqrt_bc2 = s_bc[1];
   float sa = 0.0f, sb = 0.0f;
   for (size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; idx < n; idx += (size_t)gridDim.x * GH_BLOCK) {
     const float pv = p[idx];

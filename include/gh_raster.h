@@ -189,6 +189,11 @@ typedef struct GhLayout {
   size_t sh_scratch;     /* float[ceil(P/16)][64] block partials of the global colour-weight gradient (SH mode) */
   size_t grad_sums;      /* float4[n_views*P][3] per-(view,Gaussian) sums of the sub-records: dpx dpy dA dB | dC do dr dg | db */
   size_t bwd_scratch;    /* blend-parameter reduction scratch */
+  size_t cull_bound;     /* float [n_views*P]  opacity every (view, Gaussian)'s tiles were culled with (+inf: no rect); the guard of
+                            gh_forward_refresh compares the current opacity with it */
+  size_t inst_c;         /* float [max_instances] conic C of every sorted instance (the static part of inst_r1), read by
+                            gh_forward_refresh */
+  size_t attr;           /* float4[n_views*P]  (opacity, r, g, b) of the CURRENT step per (view, Gaussian): gh_forward_refresh */
   size_t half_counters;  /* GhCounters[2], 256 bytes apart: the counters of the two halves of a GH_FLAG_SPLIT_STREAMS call (every
                             per-view / per-tile / per-pixel array keeps its place; a half's per-instance arrays start at its
                             share of max_instances) */
