@@ -93,6 +93,9 @@ def declare(lib: C.CDLL) -> None:
     lib.gh_adam_reg_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p]
+    lib.gh_reg_total.restype = C.c_int
+    lib.gh_reg_total.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]
     lib.gh_l1_loss.restype = C.c_int
     lib.gh_l1_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.gh_fit_loss.restype = C.c_int
@@ -130,6 +133,6 @@ GH_BWD_RENDER, GH_BWD_PREPROCESS, GH_BWD_ALL = 1, 2, 3
 
 EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_forward", "gh_backward",
                     "gh_forward_stages", "gh_backward_stages", "gh_forward_shared", "gh_backward_shared", "gh_forward_refresh", "gh_backward_refresh", "gh_uv_sample_forward", "gh_uv_sample_backward",
-                    "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_uv_scatter_sorted", "gh_adam_reg_step",
+                    "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_uv_scatter_sorted", "gh_adam_reg_step", "gh_reg_total",
                     "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss", "gh_fit_loss",
                     "gh_select_workspace_bytes", "gh_select_rows")

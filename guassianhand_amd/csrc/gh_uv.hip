@@ -176,12 +176,46 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(float* __restrict
     partials[2 * blockIdx.x + 1] = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3];
   }
   if (threadIdx.x == 0 && step_state) {
-    const int ticket = __hip_atomic_fetch_add(&step_state[1], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // Relaxed agent-scope atomics only (an agent-scope release / acquire writes back / invalidates the whole L2: with 1,024
+    // blocks that was most of this kernel's 25 us). Nothing but the two words themselves is handed over: every block has
+    // consumed its own read of step_state[0] (its value feeds the update above) before it takes a ticket, and the new count
+    // is read by the NEXT launch.
+    const int ticket = __hip_atomic_fetch_add(&step_state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ticket == (int)gridDim.x - 1) {                  // the last block out: nobody is left to read the old count
       __hip_atomic_store(&step_state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&step_state[0], skip ? t - 1 : t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&step_state[0], skip ? t - 1 : t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// Loss assembly of the fit step (infer_one_shot.py:514-519): out[0] = base[0] + ka * sum_i pa[i * 2 + ca] + kb * sum_i pb[i * 2 + cb],
+// out[1] = the regulariser part alone — the two sums over gh_adam_reg_step's block partials in fixed order, one block. Replaces
+// two torch reductions and five scalar elementwise kernels per step.
+__global__ __launch_bounds__(GH_BLOCK) void gh_reg_total_kernel(const float* __restrict__ pa, int na, int ca, float ka,
+                                                                 const float* __restrict__ pb, int nb, int cb, float kb,
+                                                                 const float* __restrict__ base, float* __restrict__ out) {
+  __shared__ float s_a[GH_BLOCK / GH_WAVE], s_b[GH_BLOCK / GH_WAVE];
+  float a = 0.0f, b = 0.0f;
+  for (int i = threadIdx.x; i < na; i += GH_BLOCK) a += pa[2 * i + ca];
+  for (int i = threadIdx.x; i < nb; i += GH_BLOCK) b += pb[2 * i + cb];
+  a = gh_wave_sum_to63(a); b = gh_wave_sum_to63(b);
+  if ((threadIdx.x & 63) == 63) { s_a[threadIdx.x >> 6] = a; s_b[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float reg = ka * (((s_a[0] + s_a[1]) + s_a[2]) + s_a[3]) + kb * (((s_b[0] + s_b[1]) + s_b[2]) + s_b[3]);
+    out[1] = reg;
+    out[0] = (base ? base[0] : 0.0f) + reg;
+  }
+}
+
+extern "C" int gh_reg_total(const float* partials_a, int n_a, int col_a, float k_a, const float* partials_b, int n_b, int col_b,
+                            float k_b, const float* base, float* out2, void* hip_stream) {
+  if (n_a < 0 || n_b < 0 || (col_a | col_b) < 0 || col_a > 1 || col_b > 1 || !out2) return GH_ERR_INVALID_ARG;
+  if ((n_a > 0 && !partials_a) || (n_b > 0 && !partials_b)) return GH_ERR_INVALID_ARG;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gh_reg_total_kernel, dim3(1), dim3(GH_BLOCK), 0, (hipStream_t)hip_stream, partials_a, n_a, col_a, k_a,
+                     partials_b, n_b, col_b, k_b, base, out2);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 
 extern "C" int gh_uv_gather_forward(const float* texels, const int32_t* slot, const float* w, float* out, int P, int C, void* hip_stream) {

@@ -34,7 +34,7 @@ import torch.nn.functional as F
 
 from . import dist as ghdist
 from .renderer import GaussianModel
-from .uvmap import ActiveTexels, AdamReg, to_reference_layout, uv_gather, uv_gather_backward, uv_sample
+from .uvmap import ActiveTexels, AdamReg, reg_total, to_reference_layout, uv_gather, uv_gather_backward, uv_sample
 
 MILESTONES = (2, 5, 10, 20, 35, 50, 75)
 
@@ -75,7 +75,7 @@ class OneShotFit(nn.Module):
         self.lr0, self.epoch = lr, 0
         self.active = uv.is_cuda if active_texels is None else bool(active_texels)
         self._default_render = render_fn is None
-        self._cams, self._cams_src, self._mine_src = None, None, None
+        self._cams, self._cams_src, self._mine_src, self._one = None, None, None, None
         # Static geometry (default with the default renderer on a device): `gs` is frozen here (detached network outputs), xyz_b
         # is not trained (:161) and a fit renders the same cameras every step, so projection, both sorts and the record gather
         # are done ONCE; every later step only refreshes opacities / colours in the per-instance records (gh_forward_refresh).
@@ -239,7 +239,9 @@ class OneShotFit(nn.Module):
             else:
                 loss_img = fit_loss(out["comp_rgb"], out["comp_mask"], sel(gt_rgb), sel(gt_mask),
                                     None if bbox_mask is None else sel(bbox_mask)) / n_total
-            g = torch.autograd.grad(loss_img, [leaves[k] for k in names], allow_unused=True)
+            if self._one is None or self._one.device != loss_img.device:
+                self._one = torch.ones((), dtype=torch.float32, device=loss_img.device)
+            g = torch.autograd.grad(loss_img, [leaves[k] for k in names], grad_outputs=self._one, allow_unused=True)
             grads = {k: (gi if gi is not None else torch.zeros_like(leaves[k])) for k, gi in zip(names, g)}
         # Which collective runs must be the same decision on every rank: the in-place block path needs every rank to have
         # rendered (its buffer is the one the backward kernels wrote), so it is taken only when every rank owns a camera
@@ -296,20 +298,23 @@ class OneShotFit(nn.Module):
         if self.active:                                               # maps: scatter, then regulariser + Adam in one pass
             uv_gather_backward(red["color_b"], self.texels, self._adam["color_b"].grad)
             uv_gather_backward(red["opacity_b"], self.texels, self._adam["opacity_b"].grad)
-            self._adam["color_w"].grad.copy_(red["color_w"])
             lr = self.lr0 * 0.5 ** sum(1 for m in MILESTONES if m <= self.epoch)
-            sums = {}
             guard = local_guard
             if ovf is not None:                                       # sharded: the SUM of the ranks' overflow flags, as GhCounters
                 guard = torch.zeros(4, dtype=torch.int32, device=self.color_w.device)
                 guard[1] = ovf.ne(0).to(torch.int32)
+            gw = red["color_w"]                                       # (the kernels' own buffer when it can be used as it stands)
+            gw = gw if (gw.is_contiguous() and gw.dtype is torch.float32 and gw.numel() == 48) else None
+            if gw is None:
+                self._adam["color_w"].grad.copy_(red["color_w"])
             for k, a in self._adam.items():
                 a.lr = lr
-                sums[k] = a.step(guard)
+                a.step(guard, grad=gw if k == "color_w" else None, sums=False)
             Hm, Wm = self.map_hw
-            reg = 100.0 * sums["color_b"][0] / (48 * Hm * Wm) + sums["opacity_b"][1] / (Hm * Wm)
-            self.last_reg = reg
-            return loss_tot + reg
+            # loss = image loss + 100 * mean|color_b| + mean(opacity_b^2) of the values this step started from (:514-519)
+            tot = reg_total(self._adam["color_b"], 0, 100.0 / (48 * Hm * Wm), self._adam["opacity_b"], 1, 1.0 / (Hm * Wm), loss_tot)
+            self.last_reg = tot[1]
+            return tot[0]
         reg = self.regulariser()                                      # identical on every rank: never reduced
         self.last_reg = reg.detach()
         torch.autograd.backward([blend[k] for k in names] + [reg], [red[k] for k in names] + [torch.ones_like(reg)])

@@ -190,18 +190,45 @@ class AdamReg:
         self.partials = torch.zeros(self.n_partials, 2, dtype=torch.float32, device=param.device)
         self.step_state = torch.zeros(2, dtype=torch.int32, device=param.device)   # steps actually applied (device side)
 
-    def step(self, guard: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def step(self, guard: Optional[torch.Tensor] = None, grad: Optional[torch.Tensor] = None, sums: bool = True):
         """guard: device GhCounters of the render whose gradients are in `.grad` (rasterizer.last_guard()): when its
-        overflow flag is set the kernel leaves param / moments untouched and does not count the step."""
+        overflow flag is set the kernel leaves param / moments untouched and does not count the step.
+        grad: use this buffer (same shape, fp32, contiguous; it is cleared like `.grad`) instead of `.grad` — a gradient the
+        kernels already wrote somewhere needs no copy. sums=False: do not reduce the block partials (see `sums()`)."""
         self.t += 1
         L = _lib.lib()
         p = self.param
+        g = self.grad if grad is None else grad
+        if grad is not None:
+            _need_device(g)
+            assert g.numel() == p.numel()
         with torch.cuda.device(p.device):
-            rc = L.gh_adam_reg_step(C.c_void_p(p.data_ptr()), C.c_void_p(self.grad.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
+            rc = L.gh_adam_reg_step(C.c_void_p(p.data_ptr()), C.c_void_p(g.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
                                     C.c_void_p(self.exp_avg_sq.data_ptr()), p.numel(), self.t, self.lr, self.betas[0], self.betas[1],
                                     self.eps, self.reg_l1, self.reg_l2, C.c_void_p(self.partials.data_ptr()), self.n_partials,
                                     None if guard is None else C.c_void_p(guard.data_ptr()),
                                     C.c_void_p(self.step_state.data_ptr()), _stream(p))
         if rc != 0:
             raise RuntimeError(f"gh_adam_reg_step failed: {_abi.status_name(rc)}")
+        return self.partials.sum(0) if sums else None
+
+    def sums(self) -> torch.Tensor:
+        """(sum|p|, sum p^2) of the values the last step() started from."""
         return self.partials.sum(0)
+
+
+def reg_total(a: AdamReg, col_a: int, k_a: float, b: AdamReg, col_b: int, k_b: float, base: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(base + reg, reg) with reg = k_a * sums(a)[col_a] + k_b * sums(b)[col_b] of the last steps' block partials, as one
+    2-element device tensor from one small kernel (gh_reg_total)."""
+    L = _lib.lib()
+    out = torch.empty(2, dtype=torch.float32, device=a.param.device)
+    if base is not None:
+        base = base.detach().reshape(1)
+        _need_device(base)
+    with torch.cuda.device(out.device):
+        rc = L.gh_reg_total(C.c_void_p(a.partials.data_ptr()), a.n_partials, int(col_a), float(k_a), C.c_void_p(b.partials.data_ptr()),
+                            b.n_partials, int(col_b), float(k_b), None if base is None else C.c_void_p(base.data_ptr()),
+                            C.c_void_p(out.data_ptr()), _stream(out))
+    if rc != 0:
+        raise RuntimeError(f"gh_reg_total failed: {_abi.status_name(rc)}")
+    return out

@@ -332,6 +332,15 @@ int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_s
                      const GhCounters* guard, int32_t* step_state, void* hip_stream);
 
 /*
+ * Loss assembly of the fit step (infer_one_shot.py:514-519: loss = image loss + 100 * mean|color_b| + mean(opacity_b^2)):
+ * out2[1] = k_a * sum_i partials_a[i][col_a] + k_b * sum_i partials_b[i][col_b] — fixed-order sums over the (n, 2) block
+ * partials gh_adam_reg_step left (col 0 = sum|param|, col 1 = sum param^2) — and out2[0] = base[0] + out2[1] (base may be
+ * NULL). One block; bitwise reproducible.
+ */
+int gh_reg_total(const float* partials_a, int n_a, int col_a, float k_a, const float* partials_b, int n_b, int col_b, float k_b,
+                 const float* base, float* out2, void* hip_stream);
+
+/*
  * Image-loss consumer (the L1 term of utils.py:282-294 as bench.py / the fit loop use it):
  * loss_out[0] = mean|image - target| over n floats and dL_dimage = sign(image - target) / n (sign(0) = 0, as
  * torch.abs' backward) in one pass. image / target / dL_dimage must be 16-byte aligned; partials holds n_partials
