@@ -64,13 +64,31 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def pmc_profile(name: str, kernel: str, args, V: int):
-    """Per-kernel entry of a committed rocprofv3 counter summary (profiles/<name>.json), or (None, why). The counters come from
-    separate profiling runs (`tools/refresh_profiles.sh`), NOT from this run: the entry is returned with its source tag and
-    only when it was collected on this workload AND on this build (source_hash)."""
+PROFILE_TAG = "r3"        # profiles/<tag>_pmc_*.json: the committed counter passes this build's bench lines quote
+
+
+def workload_key(args, V: int):
+    """Which committed counter summary (tools/refresh_profiles.sh) belongs to this run's workload, or None."""
+    if args.scaling != "weak":
+        return None
+    if args.config == "two_hands" and V == 8 and not args.pose_batch:
+        return "default"
+    if args.config == "two_hands_hd" and V == 8 and not args.pose_batch:
+        return "hd_sh3"
+    if args.config == "two_hands_hd" and V == 32 and args.pose_batch:
+        return "hd_sh3_pose32"
+    return None
+
+
+def pmc_profile(kind: str, kernel: str, args, V: int):
+    """Per-kernel entry of a committed rocprofv3 counter summary (profiles/<tag>_pmc_<kind>[_<workload>].json), or (None, why).
+    The counters come from separate profiling runs (`tools/refresh_profiles.sh`), NOT from this run: the entry is returned
+    with its source tag and only when it was collected on this workload AND on this build (source_hash)."""
+    w = workload_key(args, V)
+    if w is None:
+        return None, "no offline counter pass exists for this workload (default, two_hands_hd x 8 views, two_hands_hd pose batch 32)"
+    name = f"{PROFILE_TAG}_pmc_{kind}" + ("" if w == "default" else "_" + w)
     path = os.path.join(ROOT, "profiles", name + ".json")
-    if args.config != "two_hands" or V != 8 or args.pose_batch or args.scaling != "weak":
-        return None, "offline counters exist for the default workload only"
     if not os.path.exists(path):
         return None, f"profiles/{name}.json missing"
     try:
@@ -83,14 +101,36 @@ def pmc_profile(name: str, kernel: str, args, V: int):
     return ent, f"profiles/{name}.json (offline rocprofv3 --pmc passes, source {doc['source_hash']})"
 
 
-def cpu_baseline(scene, seconds: float):
-    """The C oracle (oracle/gh_oracle.c, OpenMP over tiles) on the host cores: a reported baseline only."""
-    from oracle import oracle_c
+def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
+    """The CPU restatement on the host cores: a reported baseline only. Default: the C oracle (oracle/gh_oracle.c, OpenMP over
+    tiles). torch_reference (BASELINE configs[0], `--config random1k`): the literal "PyTorch CPU autograd reference" — the dense
+    pixel x Gaussian oracle (oracle/oracle_torch.py), forward + autograd backward, torch threads = all cores."""
     s = scene
     cams = s.cams()[:1]
-    kw = dict(colors_precomp=s.shs.squeeze(1)) if s.use_rgb else dict(shs=s.shs, sh_degree=s.sh_degree)
     g = torch.Generator().manual_seed(11)
     dimg = torch.randn(1, 3, s.H, s.W, generator=g) / (3 * s.H * s.W)
+    if torch_reference:
+        from oracle import oracle_torch as OT
+        torch.set_num_threads(os.cpu_count() or 1)
+        c = cams[0]
+        n, t0 = 0, time.perf_counter()
+        while True:
+            leaves = [t.clone().requires_grad_(True) for t in (s.xyz, s.opacity, s.scaling, s.rotation, s.shs)]
+            bl = {k: getattr(s, k).clone().requires_grad_(True) for k in ("color_w", "xyz_b", "color_b", "opacity_b") if getattr(s, k) is not None}
+            means, opac, cols, sh = OT.blend_attributes(leaves[0], leaves[1], leaves[4], use_rgb=s.use_rgb, **bl)
+            kw = dict(colors_precomp=cols) if s.use_rgb else dict(shs=sh, sh_degree=s.sh_degree)
+            img, _ = OT.rasterize_dense(means, opac, leaves[2], leaves[3], viewmatrix=c[:16].reshape(4, 4), projmatrix=c[16:32].reshape(4, 4),
+                                        campos=c[32:35], tanfovx=float(c[35]), tanfovy=float(c[36]), bg=c[37:40], H=s.H, W=s.W, **kw)
+            (img * dimg[0]).sum().backward()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds and n >= 2:
+                break
+        return {"value": n / dt, "unit": "renders/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n} fwd+bwd renders of view 0 of the same workload ({dt:.1f} s), oracle/oracle_torch.py: dense PyTorch CPU "
+                          "autograd (BASELINE configs[0]'s reference)"}
+    from oracle import oracle_c
+    kw = dict(colors_precomp=s.shs.squeeze(1)) if s.use_rgb else dict(shs=s.shs, sh_degree=s.sh_degree)
     n, t0 = 0, time.perf_counter()
     while True:
         r = oracle_c.OracleRender(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, xyz_b=s.xyz_b,
@@ -103,6 +143,59 @@ def cpu_baseline(scene, seconds: float):
             break
     return {"value": n / dt, "unit": "renders/s", "cores": oracle_c.num_threads(), "kind": "port",
             "sample": f"{n} fwd+bwd renders of view 0 of the same workload ({dt:.1f} s), oracle/gh_oracle.c OpenMP"}
+
+
+def two_call_cost(s, cams_w2c_K, n_iter: int = 12):
+    """per-view cost of the REFERENCE's protocol through the drop-in — blend in torch, then the RGB call and the
+    mask call of renderer_one_shot.py:338-346 / :372-379 through GaussianRasterizer (autograd, L1 + mask loss), forward +
+    backward — as a maintainer who changes nothing gets it. Milliseconds per view; host-bound."""
+    import math
+    from guassianhand_amd.camera import Camera
+    from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    w2c, K = cams_w2c_K
+    cam = Camera.from_w2c(w2c, K, s.H, s.W)
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    mk = lambda bg, deg: GaussianRasterizationSettings(
+        image_height=s.H, image_width=s.W, tanfovx=tfx, tanfovy=tfy, bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+        projmatrix=cam.full_proj_transform.float(), sh_degree=deg, campos=cam.camera_center, prefiltered=False, debug=False)
+    leaves = {k: getattr(s, k).clone().requires_grad_(True) for k in ("xyz", "opacity", "scaling", "rotation", "shs", "color_w", "color_b", "opacity_b")
+              if getattr(s, k) is not None}
+    zero = torch.zeros(3, device=s.xyz.device)
+    gt = torch.rand(3, s.H, s.W, device=s.xyz.device)
+
+    def one():
+        for p in leaves.values():
+            p.grad = None
+        means, op = leaves["xyz"], leaves["opacity"]
+        if "opacity_b" in leaves:
+            op = op + leaves["opacity_b"].view(-1, 1)
+        sp = torch.zeros_like(means, requires_grad=True) + 0
+        if s.use_rgb:
+            col, shs = leaves["shs"].squeeze(1), None
+            if "color_w" in leaves:
+                w = leaves["color_w"].view(-1, 16, 3)
+                col = col * w[:, 0, :] + w[:, 1, :] - 1
+            if "color_b" in leaves:
+                col = col + leaves["color_b"].view(-1, 16, 3)[:, 0, :]
+        else:
+            col, shs = None, leaves["shs"]
+            if "color_w" in leaves:
+                shs = shs * leaves["color_w"].view(-1, 16, 3)
+            if "color_b" in leaves:
+                shs = shs * leaves["color_w"].view(-1, 16, 3) + leaves["color_b"].view(-1, 16, 3)
+        kw = dict(means3D=means, means2D=sp, opacities=op, scales=leaves["scaling"], rotations=leaves["rotation"], cov3D_precomp=None)
+        img, _ = GaussianRasterizer(mk(s.bg, s.sh_degree))(shs=shs, colors_precomp=col, **kw)
+        msk, _ = GaussianRasterizer(mk(zero, 0))(colors_precomp=torch.ones_like(means), **kw)
+        ((img - gt).abs().mean() + ((msk.mean(0) - gt[0]) ** 2).mean()).backward()
+
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_iter):
+        one()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n_iter * 1e3
 
 
 def main():
@@ -298,6 +391,22 @@ def main():
     dt, t_enq, loss = timed_window()                 # THE timed region: exactly --steps steps between two barriers
     extra = [timed_window()[0] for _ in range(max(0, args.repeats - 1))]      # repeat statistics (not `value`)
     R.check_overflow()
+    # per-step spread (>= 20 timed iterations, median and p10 / p90): every step bracketed by its own HIP events
+    step_ms = []
+    if world == 1:
+        evs = []
+        for _ in range(max(20, args.steps)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if graph is not None:
+                graph.replay()
+            else:
+                step(sync=False)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        step_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        R.check_overflow()
     if graph is not None:
         R.set_graph_mode(False)
 
@@ -342,15 +451,15 @@ def main():
             dom = max(single, key=single.get)
             ach = ab[dom] / (stage_ms[dom] * 1e-3) / 1e9
             kname = "gh_" + dom + "_kernel"
-            tr, tr_src = pmc_profile("r2_pmc_traffic", kname, args, V)
-            sq, sq_src = pmc_profile("r2_pmc_sq", kname, args, V)
+            tr, tr_src = pmc_profile("traffic", kname, args, V)
+            sq, sq_src = pmc_profile("sq", kname, args, V)
             roofline = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr["traffic_bytes"] if tr else None,
                         "traffic_source": tr_src,
                         "alg_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom],
                         "timing": f"HIP events around the stage entry points, {args.steps} eager steps run right after the timed steps",
                         # what actually bounds the kernel (it is not bandwidth): vector-ALU issue and the LDS pipe, from the
-                        # committed SQ counter passes — arithmetic in profiles/r2_pmc_sq.json
+                        # committed SQ counter passes — arithmetic in profiles/r3_pmc_sq*.json
                         "secondary": sq["secondary"] if sq else None, "secondary_source": sq_src}
         out = {
             "metric": "fwd+bwd renders/sec @512x334, ~100k Gaussians", "value": value, "unit": "renders/s",
@@ -372,6 +481,9 @@ def main():
                                    "ms_per_step_median": sorted([dt] + extra)[len([dt] + extra) // 2] / args.steps * 1e3,
                                    "ms_per_step_max": max([dt] + extra) / args.steps * 1e3,
                                    "note": "`value` / `ms_per_step` are window 1 (the contract's timed region); the others follow it"},
+                       "step_ms": None if not step_ms else {
+                           "n": len(step_ms), "median": step_ms[len(step_ms) // 2], "p10": step_ms[len(step_ms) // 10],
+                           "p90": step_ms[(len(step_ms) * 9) // 10], "how": "HIP events around every single step, after the timed windows"},
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
                        "split_streams": bool(V >= 2 and (R._split_policy is True or (R._split_policy == "auto" and V >= 4))),
                        "hip_graph": graph is not None, "timed_steps": "HIP graph replay of one captured step" if graph is not None
@@ -379,7 +491,11 @@ def main():
             "roofline": roofline, "stages": stages,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene_one, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(scene_one, args.cpu_seconds, torch_reference=(args.config == "random1k"))
+            if not args.pose_batch:
+                # the reference's own 2-call protocol through the drop-in, per view, beside the fused per-view cost
+                out["config"]["two_call_ms_per_view"] = two_call_cost(s, (s.w2c[mine[0]], s.K[mine[0]]))
+                out["config"]["fused_ms_per_view"] = dt / args.steps * 1e3 / V
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

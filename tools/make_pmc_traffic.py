@@ -3,6 +3,7 @@ usage: make_pmc_traffic.py <fetch counter_collection.csv> <write counter_collect
 import collections, csv, json, re, sys
 
 fetch_csv, write_csv, out_json, out_csv = sys.argv[1:5]
+workload = sys.argv[5] if len(sys.argv) > 5 else "default: bench.py"
 
 
 def per_kernel(path, counter):
@@ -17,8 +18,8 @@ def per_kernel(path, counter):
 
 
 fe, wr = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
-note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 2 "
-        "--no-cpu-baseline --no-stage-timing`; KB per dispatch; traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
+note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py <workload args> --steps 3 "
+        "--warmup 2 --no-cpu-baseline --no-stage-timing`; KB per dispatch; traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per "
         "MI355X_MICROARCH.md (gfx950 FETCH_SIZE counts wide streaming reads at half)")
 kern = {}
 for k in sorted(set(fe) | set(wr), key=lambda k: -(2 * fe.get(k, 0) + wr.get(k, 0))):
@@ -26,7 +27,7 @@ for k in sorted(set(fe) | set(wr), key=lambda k: -(2 * fe.get(k, 0) + wr.get(k, 
         continue
     kern[k] = {"fetch_size_kb": fe.get(k, 0.0), "write_size_kb": wr.get(k, 0.0),
                "traffic_bytes": (2 * fe.get(k, 0.0) + wr.get(k, 0.0)) * 1024}
-json.dump({"note": note, "workload": "two_hands P=98562 512x334 RGB blend, 8 views per launch", "kernels": kern},
+json.dump({"note": note, "workload": workload, "kernels": kern},
           open(out_json, "w"), indent=1)
 with open(out_csv, "w") as f:
     f.write("# " + note + "\nkernel,fetch_size_kb,write_size_kb,traffic_bytes\n")
