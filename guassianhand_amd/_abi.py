@@ -49,6 +49,12 @@ class GhGrads(C.Structure):
         "dL_dblend_color_b", "upstream_scale")]
 
 
+class GhAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_size_t),
+                ("reg_l1", C.c_float), ("reg_l2", C.c_float), ("partials", C.c_void_p), ("n_partials", C.c_int),
+                ("step_state", C.c_void_p)]
+
+
 LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "depth", "rect", "clamped",
                  "tiles_touched", "slot_begin", "depth_keys_a", "depth_keys_b", "depth_vals_a", "depth_vals_b",
                  "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "sorted_slot", "inst_r0", "inst_r1", "inst_r2",
@@ -93,6 +99,15 @@ def declare(lib: C.CDLL) -> None:
     lib.gh_adam_reg_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_float,
                                      C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p]
+    lib.gh_adam_reg_step_group.restype = C.c_int
+    lib.gh_adam_reg_step_group.argtypes = [C.POINTER(GhAdamTensor), C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                           C.c_void_p, C.c_void_p]
+    lib.gh_uv_gather_forward2.restype = C.c_int
+    lib.gh_uv_gather_forward2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_void_p]
+    lib.gh_uv_scatter_sorted2.restype = C.c_int
+    lib.gh_uv_scatter_sorted2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_int, C.c_void_p]
     lib.gh_reg_total.restype = C.c_int
     lib.gh_reg_total.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
@@ -133,6 +148,6 @@ GH_BWD_RENDER, GH_BWD_PREPROCESS, GH_BWD_ALL = 1, 2, 3
 
 EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_forward", "gh_backward",
                     "gh_forward_stages", "gh_backward_stages", "gh_forward_shared", "gh_backward_shared", "gh_forward_refresh", "gh_backward_refresh", "gh_uv_sample_forward", "gh_uv_sample_backward",
-                    "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_uv_scatter_sorted", "gh_adam_reg_step", "gh_reg_total",
+                    "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_uv_scatter_sorted", "gh_adam_reg_step", "gh_reg_total", "gh_adam_reg_step_group", "gh_uv_gather_forward2", "gh_uv_scatter_sorted2",
                     "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss", "gh_fit_loss",
                     "gh_select_workspace_bytes", "gh_select_rows")

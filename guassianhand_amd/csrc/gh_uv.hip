@@ -131,25 +131,70 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_uv_scatter_sorted_kernel(const in
   dtex[idx] += acc;
 }
 
+// The fit looks TWO maps up at the same UVs every step (colour bias, opacity bias: renderer_one_shot.py:489-492): one launch
+// for both, lane = channel of the concatenated (Ca + Cb) row — the same per-lane arithmetic as the single-map kernels, so the
+// values are bit-identical to two separate launches.
+__global__ __launch_bounds__(GH_BLOCK) void gh_uv_gather_fwd2_kernel(const float* __restrict__ tex_a, int Ca, const float* __restrict__ tex_b,
+                                                                      int Cb, const int32_t* __restrict__ slot, const float* __restrict__ w,
+                                                                      float* __restrict__ out_a, float* __restrict__ out_b, int P) {
+  const int Ct = Ca + Cb;
+  const size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (idx >= (size_t)P * Ct) return;
+  const int i = (int)(idx / Ct), ct = (int)(idx - (size_t)i * Ct);
+  const bool second = ct >= Ca;
+  const float* tex = second ? tex_b : tex_a;
+  const int C = second ? Cb : Ca, c = second ? ct - Ca : ct;
+  const int4 s4 = ((const int4*)slot)[i];
+  const float4 w4 = ((const float4*)w)[i];
+  float acc = 0.0f;
+  if (s4.x >= 0) acc += tex[(size_t)s4.x * C + c] * w4.x;
+  if (s4.y >= 0) acc += tex[(size_t)s4.y * C + c] * w4.y;
+  if (s4.z >= 0) acc += tex[(size_t)s4.z * C + c] * w4.z;
+  if (s4.w >= 0) acc += tex[(size_t)s4.w * C + c] * w4.w;
+  (second ? out_b : out_a)[(size_t)i * C + c] = acc;
+}
+
+__global__ __launch_bounds__(GH_BLOCK) void gh_uv_scatter_sorted2_kernel(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ pairs,
+                                                                          const float* __restrict__ w, const float* __restrict__ dout_a, int Ca,
+                                                                          float* __restrict__ dtex_a, const float* __restrict__ dout_b, int Cb,
+                                                                          float* __restrict__ dtex_b, int U) {
+  const int Ct = Ca + Cb;
+  const size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x;
+  if (idx >= (size_t)U * Ct) return;
+  const int u = (int)(idx / Ct), ct = (int)(idx - (size_t)u * Ct);
+  const bool second = ct >= Ca;
+  const float* dout = second ? dout_b : dout_a;
+  const int C = second ? Cb : Ca, c = second ? ct - Ca : ct;
+  const int j0 = row_ptr[u], j1 = row_ptr[u + 1];
+  float acc = 0.0f;
+  for (int j = j0; j < j1; ++j) {
+    const int e = pairs[j];
+    acc += dout[(size_t)(e >> 2) * C + c] * w[e];
+  }
+  (second ? dtex_b : dtex_a)[(size_t)u * C + c] += acc;
+}
+
 // One pass over a parameter array: regulariser value (sum|p|, sum p^2 of the PRE-update values, block partials),
 // regulariser gradient (l1*sign(p) + l2*2p) added to the accumulated image gradient, Adam update (torch.optim.Adam
 // semantics, no amsgrad / weight decay: infer_one_shot.py:345), and the gradient buffer is cleared for the next step.
-__global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                                float* __restrict__ v, size_t n, int host_step, float lr,
-                                                                float beta1, float beta2, float eps, float l1, float l2,
-                                                                float* __restrict__ partials /* [gridDim][2] */,
-                                                                const GhCounters* __restrict__ guard, int32_t* __restrict__ step_state) {
+struct GhAdamOne {
+  float* p; float* g; float* m; float* v; size_t n; float l1, l2; float* partials; int32_t* step_state; int nblk;
+};
+
+// The body of one block (index `b` of `nblk`) of the update of ONE tensor. Main loop over float4s (the four arrays stream at
+// 16 bytes per lane; the scalar form ran at 1.7 TB/s), tail elements by block 0; also when an array is not 16-byte aligned.
+__device__ __forceinline__ void gh_adam_block(const GhAdamOne& T, int b, int host_step, float lr, float beta1, float beta2, float eps,
+                                              const GhCounters* __restrict__ guard) {
   __shared__ float s_a[GH_BLOCK / GH_WAVE], s_b[GH_BLOCK / GH_WAVE];
+  __shared__ float s_bc[2];
   // Device-side guard: a step whose render overflowed its instance capacity must not touch the parameters. The step count
   // of the bias correction then lives on the device too: step_state[0] = steps applied so far, read by every block when it
   // starts; the block that FINISHES last (a ticket in step_state[1]) writes the new count — every other block has read the old
   // one by then. No host value changes from launch to launch, so a captured step replays correctly.
   const bool skip = guard && guard->overflow != 0u;
   int t = host_step;
-  if (step_state) t = __hip_atomic_load(&step_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-  // bias corrections in double, as torch.optim.Adam's Python arithmetic — by ONE thread per block (two double pow() per
-  // thread made this kernel 28 us for a million parameters: the fit step's three launches cost 85 us)
-  __shared__ float s_bc[2];
+  if (T.step_state) t = __hip_atomic_load(&T.step_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  // bias corrections in double, as torch.optim.Adam's Python arithmetic — by ONE thread per block
   if (threadIdx.x == 0) {
     const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
     s_bc[0] = (float)((double)lr / bc1); s_bc[1] = (float)(1.0 / sqrt(bc2));
@@ -157,35 +202,68 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(float* __restrict
   __syncthreads();
   const float lr_over_bc1 = s_bc[0], inv_sqrt_bc2 = s_bc[1];
   float sa = 0.0f, sb = 0.0f;
-  for (size_t idx = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; idx < n; idx += (size_t)gridDim.x * GH_BLOCK) {
-    const float pv = p[idx];
+  auto one = [&](float pv, float gin, float& mv, float& vv) -> float {       // returns the new parameter value
     sa += fabsf(pv); sb += pv * pv;
-    if (skip) { g[idx] = 0.0f; continue; }
     const float sgn = pv > 0.0f ? 1.0f : (pv < 0.0f ? -1.0f : 0.0f);
-    const float gv = g[idx] + l1 * sgn + l2 * 2.0f * pv;
-    const float mv = beta1 * m[idx] + (1.0f - beta1) * gv;
-    const float vv = beta2 * v[idx] + (1.0f - beta2) * gv * gv;
-    m[idx] = mv; v[idx] = vv; g[idx] = 0.0f;
-    p[idx] = pv - lr_over_bc1 * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+    const float gv = gin + T.l1 * sgn + T.l2 * 2.0f * pv;
+    mv = beta1 * mv + (1.0f - beta1) * gv;
+    vv = beta2 * vv + (1.0f - beta2) * gv * gv;
+    return pv - lr_over_bc1 * (mv / (sqrtf(vv) * inv_sqrt_bc2 + eps));
+  };
+  const bool wide = ((((uintptr_t)T.p | (uintptr_t)T.g | (uintptr_t)T.m | (uintptr_t)T.v) & 15) == 0);
+  const size_t n4 = wide ? T.n / 4 : 0;
+  float4* p4 = (float4*)T.p; float4* g4 = (float4*)T.g; float4* m4 = (float4*)T.m; float4* v4 = (float4*)T.v;
+  for (size_t i = (size_t)b * GH_BLOCK + threadIdx.x; i < n4; i += (size_t)T.nblk * GH_BLOCK) {
+    float4 pv = p4[i];
+    if (skip) { sa += (fabsf(pv.x) + fabsf(pv.y)) + (fabsf(pv.z) + fabsf(pv.w)); sb += (pv.x * pv.x + pv.y * pv.y) + (pv.z * pv.z + pv.w * pv.w);
+                g4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); continue; }
+    const float4 gv = g4[i];
+    float4 mv = m4[i], vv = v4[i];
+    pv.x = one(pv.x, gv.x, mv.x, vv.x); pv.y = one(pv.y, gv.y, mv.y, vv.y);
+    pv.z = one(pv.z, gv.z, mv.z, vv.z); pv.w = one(pv.w, gv.w, mv.w, vv.w);
+    p4[i] = pv; m4[i] = mv; v4[i] = vv; g4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  // tail (n % 4 elements), or everything when the arrays are not 16-byte aligned: scalar, spread over the blocks
+  for (size_t idx = n4 * 4 + (size_t)b * GH_BLOCK + threadIdx.x; idx < T.n; idx += (size_t)T.nblk * GH_BLOCK) {
+    const float pv = T.p[idx];
+    if (skip) { sa += fabsf(pv); sb += pv * pv; T.g[idx] = 0.0f; continue; }
+    float mv = T.m[idx], vv = T.v[idx];
+    T.p[idx] = one(pv, T.g[idx], mv, vv);
+    T.m[idx] = mv; T.v[idx] = vv; T.g[idx] = 0.0f;
   }
   sa = gh_wave_sum_to63(sa); sb = gh_wave_sum_to63(sb);
   if ((threadIdx.x & 63) == 63) { s_a[threadIdx.x >> 6] = sa; s_b[threadIdx.x >> 6] = sb; }
   __syncthreads();
-  if (threadIdx.x == 0 && partials) {
-    partials[2 * blockIdx.x] = ((s_a[0] + s_a[1]) + s_a[2]) + s_a[3];
-    partials[2 * blockIdx.x + 1] = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3];
+  if (threadIdx.x == 0 && T.partials) {
+    T.partials[2 * b] = ((s_a[0] + s_a[1]) + s_a[2]) + s_a[3];
+    T.partials[2 * b + 1] = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3];
   }
-  if (threadIdx.x == 0 && step_state) {
+  if (threadIdx.x == 0 && T.step_state) {
     // Relaxed agent-scope atomics only (an agent-scope release / acquire writes back / invalidates the whole L2: with 1,024
     // blocks that was most of this kernel's 25 us). Nothing but the two words themselves is handed over: every block has
     // consumed its own read of step_state[0] (its value feeds the update above) before it takes a ticket, and the new count
     // is read by the NEXT launch.
-    const int ticket = __hip_atomic_fetch_add(&step_state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket == (int)gridDim.x - 1) {                  // the last block out: nobody is left to read the old count
-      __hip_atomic_store(&step_state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&step_state[0], skip ? t - 1 : t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int ticket = __hip_atomic_fetch_add(&T.step_state[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == T.nblk - 1) {                          // the last block out: nobody is left to read the old count
+      __hip_atomic_store(&T.step_state[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&T.step_state[0], skip ? t - 1 : t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+__global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_kernel(GhAdamOne T, int host_step, float lr, float beta1, float beta2, float eps,
+                                                                const GhCounters* __restrict__ guard) {
+  gh_adam_block(T, (int)blockIdx.x, host_step, lr, beta1, beta2, eps, guard);
+}
+
+// Up to four tensors in one launch (blockIdx.y = tensor; blocks beyond a tensor's own count exit): the fit steps color_w,
+// color_b and opacity_b together.
+struct GhAdamFour { GhAdamOne t[4]; };
+__global__ __launch_bounds__(GH_BLOCK) void gh_adam_reg_group_kernel(GhAdamFour G, int host_step, float lr, float beta1, float beta2, float eps,
+                                                                      const GhCounters* __restrict__ guard) {
+  const GhAdamOne& T = G.t[blockIdx.y];
+  if ((int)blockIdx.x >= T.nblk) return;
+  gh_adam_block(T, (int)blockIdx.x, host_step, lr, beta1, beta2, eps, guard);
 }
 
 // Loss assembly of the fit step (infer_one_shot.py:514-519): out[0] = base[0] + ka * sum_i pa[i * 2 + ca] + kb * sum_i pb[i * 2 + cb],
@@ -260,7 +338,51 @@ extern "C" int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float
   if (n == 0) return GH_OK;
   if (!param || !grad || !exp_avg || !exp_avg_sq || !partials) return GH_ERR_INVALID_ARG;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(gh_adam_reg_kernel, dim3((unsigned)n_partials), dim3(GH_BLOCK), 0, (hipStream_t)hip_stream, param, grad,
-                     exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, reg_l1, reg_l2, partials, guard, step_state);
+  const GhAdamOne T{param, grad, exp_avg, exp_avg_sq, n, reg_l1, reg_l2, partials, step_state, n_partials};
+  hipLaunchKernelGGL(gh_adam_reg_kernel, dim3((unsigned)n_partials), dim3(GH_BLOCK), 0, (hipStream_t)hip_stream, T, step, lr, beta1, beta2,
+                     eps, guard);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_adam_reg_step_group(const GhAdamTensor* tensors, int n_tensors, int step, float lr, float beta1, float beta2, float eps,
+                                      const GhCounters* guard, void* hip_stream) {
+  if (step < 1 || n_tensors < 1 || n_tensors > 4 || !tensors) return GH_ERR_INVALID_ARG;
+  GhAdamFour G;
+  int max_blk = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (k >= n_tensors) { G.t[k] = GhAdamOne{nullptr, nullptr, nullptr, nullptr, 0, 0.0f, 0.0f, nullptr, nullptr, 0}; continue; }
+    const GhAdamTensor& a = tensors[k];
+    if (a.n_partials < 1 || (a.n > 0 && (!a.param || !a.grad || !a.exp_avg || !a.exp_avg_sq || !a.partials))) return GH_ERR_INVALID_ARG;
+    G.t[k] = GhAdamOne{a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.n, a.reg_l1, a.reg_l2, a.partials, a.step_state, a.n == 0 ? 0 : a.n_partials};
+    if (G.t[k].nblk > max_blk) max_blk = G.t[k].nblk;
+  }
+  if (max_blk == 0) return GH_OK;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gh_adam_reg_group_kernel, dim3((unsigned)max_blk, (unsigned)n_tensors), dim3(GH_BLOCK), 0, (hipStream_t)hip_stream, G, step,
+                     lr, beta1, beta2, eps, guard);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_uv_gather_forward2(const float* texels_a, int Ca, const float* texels_b, int Cb, const int32_t* slot, const float* w,
+                                     float* out_a, float* out_b, int P, void* hip_stream) {
+  if (P < 0 || Ca < 1 || Cb < 1) return GH_ERR_INVALID_ARG;
+  if (P == 0) return GH_OK;
+  if (!texels_a || !texels_b || !slot || !w || !out_a || !out_b) return GH_ERR_INVALID_ARG;
+  (void)hipGetLastError();
+  const size_t n = (size_t)P * (Ca + Cb);
+  hipLaunchKernelGGL(gh_uv_gather_fwd2_kernel, dim3((unsigned)((n + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0, (hipStream_t)hip_stream,
+                     texels_a, Ca, texels_b, Cb, slot, w, out_a, out_b, P);
+  return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
+}
+
+extern "C" int gh_uv_scatter_sorted2(const int32_t* row_ptr, const int32_t* pairs, const float* w, const float* dL_dout_a, int Ca,
+                                     float* dL_dtexels_a, const float* dL_dout_b, int Cb, float* dL_dtexels_b, int U, void* hip_stream) {
+  if (U < 0 || Ca < 1 || Cb < 1) return GH_ERR_INVALID_ARG;
+  if (U == 0) return GH_OK;
+  if (!row_ptr || !pairs || !w || !dL_dout_a || !dL_dtexels_a || !dL_dout_b || !dL_dtexels_b) return GH_ERR_INVALID_ARG;
+  (void)hipGetLastError();
+  const size_t n = (size_t)U * (Ca + Cb);
+  hipLaunchKernelGGL(gh_uv_scatter_sorted2_kernel, dim3((unsigned)((n + GH_BLOCK - 1) / GH_BLOCK)), dim3(GH_BLOCK), 0, (hipStream_t)hip_stream,
+                     row_ptr, pairs, w, dL_dout_a, Ca, dL_dtexels_a, dL_dout_b, Cb, dL_dtexels_b, U);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -34,7 +34,8 @@ import torch.nn.functional as F
 
 from . import dist as ghdist
 from .renderer import GaussianModel
-from .uvmap import ActiveTexels, AdamReg, reg_total, to_reference_layout, uv_gather, uv_gather_backward, uv_sample
+from .uvmap import (ActiveTexels, AdamReg, adam_group_step, reg_total, to_reference_layout, uv_gather, uv_gather2,
+                    uv_gather_backward, uv_gather_backward2, uv_sample)
 
 MILESTONES = (2, 5, 10, 20, 35, 50, 75)
 
@@ -162,8 +163,8 @@ class OneShotFit(nn.Module):
         """Per-Gaussian blend values: the device UV lookup of renderer_one_shot.py:489-492 (gh_uv_sample_* /
         gh_uv_gather_*)."""
         if self.active:
-            return dict(color_w=self.color_w, color_b=uv_gather(self.color_b_tex, self.texels),
-                        opacity_b=uv_gather(self.opacity_b_tex, self.texels), xyz_b=self.xyz_b)
+            cb, ob = uv_gather2(self.color_b_tex, self.opacity_b_tex, self.texels)       # both maps in one launch
+            return dict(color_w=self.color_w, color_b=cb, opacity_b=ob, xyz_b=self.xyz_b)
         return dict(color_w=self.color_w, color_b=uv_sample(self.color_b_map, self.uv),
                     opacity_b=uv_sample(self.opacity_b_map, self.uv), xyz_b=self.xyz_b)
 
@@ -296,8 +297,7 @@ class OneShotFit(nn.Module):
         if self.keep_boundary_grads:                                  # tests: the reduced gradient block at the rasteriser boundary
             self.boundary_grads = {k: v.detach().clone() for k, v in red.items()}
         if self.active:                                               # maps: scatter, then regulariser + Adam in one pass
-            uv_gather_backward(red["color_b"], self.texels, self._adam["color_b"].grad)
-            uv_gather_backward(red["opacity_b"], self.texels, self._adam["opacity_b"].grad)
+            uv_gather_backward2(red["color_b"], red["opacity_b"], self.texels, self._adam["color_b"].grad, self._adam["opacity_b"].grad)
             lr = self.lr0 * 0.5 ** sum(1 for m in MILESTONES if m <= self.epoch)
             guard = local_guard
             if ovf is not None:                                       # sharded: the SUM of the ranks' overflow flags, as GhCounters
@@ -307,9 +307,9 @@ class OneShotFit(nn.Module):
             gw = gw if (gw.is_contiguous() and gw.dtype is torch.float32 and gw.numel() == 48) else None
             if gw is None:
                 self._adam["color_w"].grad.copy_(red["color_w"])
-            for k, a in self._adam.items():
+            for a in self._adam.values():
                 a.lr = lr
-                a.step(guard, grad=gw if k == "color_w" else None, sums=False)
+            adam_group_step(list(self._adam.values()), guard, [gw if k == "color_w" else None for k in self._adam])   # one launch
             Hm, Wm = self.map_hw
             # loss = image loss + 100 * mean|color_b| + mean(opacity_b^2) of the values this step started from (:514-519)
             tot = reg_total(self._adam["color_b"], 0, 100.0 / (48 * Hm * Wm), self._adam["opacity_b"], 1, 1.0 / (Hm * Wm), loss_tot)

@@ -171,6 +171,39 @@ def uv_gather_backward(grad_out: torch.Tensor, at: ActiveTexels, grad_texels: to
         raise RuntimeError(f"gh_uv_scatter_sorted failed: {_abi.status_name(rc)}")
 
 
+def uv_gather2(texels_a: torch.Tensor, texels_b: torch.Tensor, at: ActiveTexels):
+    """uv_gather of two maps that share the texel index, in one launch (gh_uv_gather_forward2): ((P,Ca), (P,Cb))."""
+    _need_device(texels_a, texels_b, at.slot, at.w)
+    L = _lib.lib()
+    Ca, Cb = texels_a.shape[1], texels_b.shape[1]
+    oa = torch.empty(at.P, Ca, dtype=torch.float32, device=texels_a.device)
+    ob = torch.empty(at.P, Cb, dtype=torch.float32, device=texels_a.device)
+    with torch.cuda.device(texels_a.device):
+        rc = L.gh_uv_gather_forward2(C.c_void_p(texels_a.data_ptr()), Ca, C.c_void_p(texels_b.data_ptr()), Cb, C.c_void_p(at.slot.data_ptr()),
+                                     C.c_void_p(at.w.data_ptr()), C.c_void_p(oa.data_ptr()), C.c_void_p(ob.data_ptr()), at.P, _stream(texels_a))
+    if rc != 0:
+        raise RuntimeError(f"gh_uv_gather_forward2 failed: {_abi.status_name(rc)}")
+    return oa, ob
+
+
+def uv_gather_backward2(grad_a: torch.Tensor, grad_b: torch.Tensor, at: ActiveTexels, grad_texels_a: torch.Tensor,
+                        grad_texels_b: torch.Tensor) -> None:
+    """uv_gather_backward of both maps in one launch (gh_uv_scatter_sorted2), bit-identical to two calls."""
+    ga, gb = grad_a.detach().float().contiguous(), grad_b.detach().float().contiguous()
+    if gb.dim() == 1:
+        gb = gb.reshape(-1, 1)
+    _need_device(ga, gb, grad_texels_a, grad_texels_b, at.row_ptr, at.pairs, at.w)
+    assert ga.shape == (at.P, grad_texels_a.shape[1]) and gb.shape == (at.P, grad_texels_b.shape[1])
+    assert grad_texels_a.shape[0] == at.U and grad_texels_b.shape[0] == at.U
+    L = _lib.lib()
+    with torch.cuda.device(ga.device):
+        rc = L.gh_uv_scatter_sorted2(C.c_void_p(at.row_ptr.data_ptr()), C.c_void_p(at.pairs.data_ptr()), C.c_void_p(at.w.data_ptr()),
+                                     C.c_void_p(ga.data_ptr()), ga.shape[1], C.c_void_p(grad_texels_a.data_ptr()),
+                                     C.c_void_p(gb.data_ptr()), gb.shape[1], C.c_void_p(grad_texels_b.data_ptr()), at.U, _stream(ga))
+    if rc != 0:
+        raise RuntimeError(f"gh_uv_scatter_sorted2 failed: {_abi.status_name(rc)}")
+
+
 class AdamReg:
     """State of gh_adam_reg_step for one parameter tensor: torch.optim.Adam's update with the gradient of
     reg_l1*sum|p| + reg_l2*sum(p^2) folded in; `step()` returns (sum|p|, sum p^2) of the pre-update values as a
@@ -215,6 +248,27 @@ class AdamReg:
     def sums(self) -> torch.Tensor:
         """(sum|p|, sum p^2) of the values the last step() started from."""
         return self.partials.sum(0)
+
+
+def adam_group_step(adams, guard: Optional[torch.Tensor] = None, grads=None) -> None:
+    """One launch for the step of up to four AdamReg states that share lr / betas / eps (gh_adam_reg_step_group): the same
+    updates, moments, step counts and block partials as stepping them one by one. grads[i] (optional) replaces adams[i].grad."""
+    L = _lib.lib()
+    a0 = adams[0]
+    arr = (_abi.GhAdamTensor * len(adams))()
+    for i, a in enumerate(adams):
+        a.t += 1
+        assert (a.lr, a.betas, a.eps) == (a0.lr, a0.betas, a0.eps) and a.t == a0.t
+        g = a.grad if (grads is None or grads[i] is None) else grads[i]
+        _need_device(g)
+        assert g.numel() == a.param.numel()
+        arr[i] = _abi.GhAdamTensor(a.param.data_ptr(), g.data_ptr(), a.exp_avg.data_ptr(), a.exp_avg_sq.data_ptr(), a.param.numel(),
+                                   a.reg_l1, a.reg_l2, a.partials.data_ptr(), a.n_partials, a.step_state.data_ptr())
+    with torch.cuda.device(a0.param.device):
+        rc = L.gh_adam_reg_step_group(arr, len(adams), a0.t, a0.lr, a0.betas[0], a0.betas[1], a0.eps,
+                                      None if guard is None else C.c_void_p(guard.data_ptr()), _stream(a0.param))
+    if rc != 0:
+        raise RuntimeError(f"gh_adam_reg_step_group failed: {_abi.status_name(rc)}")
 
 
 def reg_total(a: AdamReg, col_a: int, k_a: float, b: AdamReg, col_b: int, k_b: float, base: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -331,6 +331,27 @@ int gh_adam_reg_step(float* param, float* grad, float* exp_avg, float* exp_avg_s
                      float beta2, float eps, float reg_l1, float reg_l2, float* partials, int n_partials,
                      const GhCounters* guard, int32_t* step_state, void* hip_stream);
 
+/* The same update for up to four tensors in ONE launch (the fit steps color_w, color_b and opacity_b together,
+ * infer_one_shot.py:345): `tensors` is a HOST array of n_tensors descriptors; results are those of n_tensors
+ * gh_adam_reg_step calls with the same step / lr / betas / eps / guard, bit for bit. */
+typedef struct GhAdamTensor {
+  float* param; float* grad; float* exp_avg; float* exp_avg_sq;
+  size_t n;
+  float reg_l1, reg_l2;
+  float* partials; int n_partials;    /* (n_partials, 2) block sums of |param| and param^2 of the pre-update values */
+  int32_t* step_state;                /* [2] device-side step count of the bias correction, or NULL (use `step`) */
+} GhAdamTensor;
+int gh_adam_reg_step_group(const GhAdamTensor* tensors, int n_tensors, int step, float lr, float beta1, float beta2, float eps,
+                           const GhCounters* guard, void* hip_stream);
+
+/* Two maps looked up at the same UVs in one launch (the fit's colour-bias and opacity-bias maps, renderer_one_shot.py:489-492)
+ * and the deterministic backward of both: bit-identical to two gh_uv_gather_forward / gh_uv_scatter_sorted calls. */
+int gh_uv_gather_forward2(const float* texels_a, int Ca, const float* texels_b, int Cb, const int32_t* slot, const float* w,
+                          float* out_a /* (P,Ca) */, float* out_b /* (P,Cb) */, int P, void* hip_stream);
+int gh_uv_scatter_sorted2(const int32_t* row_ptr, const int32_t* pairs, const float* w, const float* dL_dout_a /* (P,Ca) */, int Ca,
+                          float* dL_dtexels_a /* (U,Ca) */, const float* dL_dout_b /* (P,Cb) */, int Cb, float* dL_dtexels_b /* (U,Cb) */,
+                          int U, void* hip_stream);
+
 /*
  * Loss assembly of the fit step (infer_one_shot.py:514-519: loss = image loss + 100 * mean|color_b| + mean(opacity_b^2)):
  * out2[1] = k_a * sum_i partials_a[i][col_a] + k_b * sum_i partials_b[i][col_b] — fixed-order sums over the (n, 2) block

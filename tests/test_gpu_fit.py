@@ -161,6 +161,50 @@ def test_fused_adam_regulariser_step_matches_torch_adam(dev):
         assert float(mine.param[:50].abs().max()) == 0.0
 
 
+def test_grouped_adam_and_two_map_kernels_equal_the_single_calls(dev):
+    """The fit's fused launches — gh_adam_reg_step_group (three tensors in one launch), gh_uv_gather_forward2 /
+    gh_uv_scatter_sorted2 (colour-bias and opacity-bias maps in one launch) and gh_reg_total (loss assembly) — produce exactly
+    what the single-tensor / single-map entry points produce, incl. an unaligned tail, the device-side step count and a
+    guarded (skipped) step."""
+    from guassianhand_amd.uvmap import (ActiveTexels, AdamReg, adam_group_step, reg_total, uv_gather, uv_gather2, uv_gather_backward,
+                                        uv_gather_backward2)
+    g = torch.Generator().manual_seed(8)
+    sizes = (48, 100_003, 359_653 * 3)
+    mk = lambda: [AdamReg((0.1 * torch.randn(n, generator=torch.Generator().manual_seed(n))).to(dev), 0.01, reg_l1=1e-4 * (i == 1),
+                          reg_l2=1e-3 * (i == 2)) for i, n in enumerate(sizes)]
+    one, grp = mk(), mk()
+    guard_ok = torch.zeros(4, dtype=torch.int32, device=dev)
+    guard_bad = torch.tensor([0, 1, 0, 0], dtype=torch.int32, device=dev)
+    for it in range(5):
+        guard = guard_bad if it == 2 else guard_ok
+        ext = (0.01 * torch.randn(sizes[0], generator=g)).to(dev)            # tensor 0 steps from a caller-supplied gradient buffer
+        for a, b in zip(one, grp):
+            gr = (0.01 * torch.randn(a.param.numel(), generator=g)).to(dev)
+            a.grad += gr; b.grad += gr
+        for i, a in enumerate(one):
+            a.step(guard, grad=ext.clone() if i == 0 else None, sums=False)
+        adam_group_step(grp, guard, [ext.clone(), None, None])
+        for a, b in zip(one, grp):
+            for x, y in ((a.param, b.param), (a.exp_avg, b.exp_avg), (a.exp_avg_sq, b.exp_avg_sq), (a.partials, b.partials), (a.grad, b.grad)):
+                assert torch.equal(x, y), it
+            assert a.step_state.tolist() == b.step_state.tolist() == [it + 1 - (it >= 2), 0]
+    tot = reg_total(grp[1], 0, 2.5, grp[2], 1, 0.5, base=torch.tensor(3.0, device=dev))
+    want = 2.5 * grp[1].partials[:, 0].double().sum() + 0.5 * grp[2].partials[:, 1].double().sum()
+    assert float(tot[1]) == pytest.approx(float(want), rel=1e-6) and float(tot[0]) == pytest.approx(3.0 + float(want), rel=1e-6)
+    # two maps at the same UVs
+    P, Hm, Wm = 5000, 37, 53
+    uv = (torch.rand(P, 2, generator=g) * 2.2 - 1.1).to(dev)
+    at = ActiveTexels(uv, Hm, Wm)
+    ta, tb = torch.randn(at.U, 3, generator=g).to(dev), torch.randn(at.U, 1, generator=g).to(dev)
+    oa, ob = uv_gather2(ta, tb, at)
+    assert torch.equal(oa, uv_gather(ta, at)) and torch.equal(ob, uv_gather(tb, at))
+    da, db = torch.randn(P, 3, generator=g).to(dev), torch.randn(P, generator=g).to(dev)
+    ga, gb, ga2, gb2 = torch.zeros_like(ta), torch.zeros_like(tb), torch.zeros_like(ta), torch.zeros_like(tb)
+    uv_gather_backward(da, at, ga); uv_gather_backward(db.reshape(-1, 1), at, gb)
+    uv_gather_backward2(da, db, at, ga2, gb2)
+    assert torch.equal(ga, ga2) and torch.equal(gb, gb2)
+
+
 def test_active_texel_fit_equals_dense_fit(dev):
     """The active-texel fit (compact texels, fused regulariser + Adam) follows the dense torch.optim.Adam fit of the
     reference (infer_one_shot.py:345-349, :489-524) step by step, across an lr milestone, and leaves every inactive

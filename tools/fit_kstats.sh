@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/fit_kstats
 rm -rf $O && mkdir -p $O
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 tools/fit_loop.py $1 22 > $O/log.txt 2>&1 || exit 1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format csv -- python3 tools/fit_loop.py $1 22 ${2:-8} > $O/log.txt 2>&1 || exit 1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob("gpurun_out/fit_kstats/stats/**/*kernel_stats.csv", recursive=True)[0]

@@ -8,7 +8,8 @@ from guassianhand_amd.scenes import make_scene
 static = sys.argv[1] == "1"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
-sc = make_scene("two_hands", n_views=8, blend=False).to(dev)
+nv = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+sc = make_scene("two_hands", n_views=nv, blend=False).to(dev)
 g = torch.Generator().manual_seed(4)
 uv = (torch.rand(sc.P, 2, generator=g) * 2 - 1).to(dev)
 gs = GaussianModel(sc.xyz, sc.opacity, sc.rotation, sc.scaling, sc.shs)
