@@ -177,6 +177,15 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_uv_scatter_sorted2_kernel(const i
 // One pass over a parameter array: regulariser value (sum|p|, sum p^2 of the PRE-update values, block partials),
 // regulariser gradient (l1*sign(p) + l2*2p) added to the accumulated image gradient, Adam update (torch.optim.Adam
 // semantics, no amsgrad / weight decay: infer_one_shot.py:345), and the gradient buffer is cleared for the next step.
+// beta^t for an integer step count by repeated squaring in double (a dozen multiplies; the library pow() in double is ~10 us of
+// dependent instructions and every block waited for it: 13 us per launch whatever the tensor's size). Agrees with pow() to
+// double rounding, i.e. the float factors derived from it are the same.
+__device__ __forceinline__ double gh_powi(double b, int t) {
+  double r = 1.0;
+  for (unsigned e = (unsigned)t; e; e >>= 1) { if (e & 1u) r *= b; b *= b; }
+  return r;
+}
+
 struct GhAdamOne {
   float* p; float* g; float* m; float* v; size_t n; float l1, l2; float* partials; int32_t* step_state; int nblk;
 };
@@ -196,7 +205,7 @@ __device__ __forceinline__ void gh_adam_block(const GhAdamOne& T, int b, int hos
   if (T.step_state) t = __hip_atomic_load(&T.step_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   // bias corrections in double, as torch.optim.Adam's Python arithmetic — by ONE thread per block
   if (threadIdx.x == 0) {
-    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    const double bc1 = 1.0 - gh_powi((double)beta1, t), bc2 = 1.0 - gh_powi((double)beta2, t);
     s_bc[0] = (float)((double)lr / bc1); s_bc[1] = (float)(1.0 / sqrt(bc2));
   }
   __syncthreads();

@@ -10,6 +10,6 @@ f = glob.glob("gpurun_out/fit_kstats/stats/**/*kernel_stats.csv", recursive=True
 rows = list(csv.DictReader(open(f)))
 tot = 0.0
 for r in rows[:30]:
-    print(f"{r['Name'][:64]:64s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:8.2f} total_us {float(r['TotalDurationNs'])/1e3:9.1f}")
+    print(f"{r['Name'][:56]:56s} calls {r['Calls']:>5s} avg_us {float(r['AverageNs'])/1e3:8.2f} min_us {float(r['MinNs'])/1e3:8.2f} max_us {float(r['MaxNs'])/1e3:8.2f}")
 PY
 rm -rf $O/stats
