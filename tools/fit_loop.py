@@ -16,7 +16,7 @@ gs = GaussianModel(sc.xyz, sc.opacity, sc.rotation, sc.scaling, sc.shs)
 f = F.OneShotFit(gs, uv, static_geometry=static)
 with torch.no_grad():
     out = f.render(sc.w2c, sc.K, sc.H, sc.W, sc.bg, f.blend_values())
-gt_rgb, gt_mask = (out["comp_rgb"] * 0.9).clone(), out["comp_mask"].mean(-1).clone()
+gt_rgb, gt_mask = (out["comp_rgb"] * 0.9).contiguous(), out["comp_mask"].mean(-1).contiguous()
 args = (sc.w2c, sc.K, sc.H, sc.W, sc.bg, gt_rgb, gt_mask)
 for i in range(n):
     f.step(*args, sync=(i == 0))
