@@ -174,6 +174,17 @@ class OneShotFit(nn.Module):
             return 100.0 * self.color_b_tex.abs().sum() / (48 * Hm * Wm) + self.opacity_b_tex.pow(2.0).sum() / (Hm * Wm)
         return 100.0 * self.color_b_map.abs().mean() + self.opacity_b_map.pow(2.0).mean()   # infer_one_shot.py:514-518
 
+    def update_gaussians(self, gs: GaussianModel) -> None:
+        """New Gaussians for the next steps (same count and UVs): the path for a caller whose NETWORK-side trainables move the
+        Gaussians between steps (the reference's map_bias / identity codes, infer_one_shot.py:340-343, :517-519 — out of this
+        repository's scope, they live in the reference's networks). The blend maps, their Adam state and the active-texel index
+        are unaffected (they are indexed by the constant UVs); the static tile lists are dropped, so the next step is a full
+        forward. A fit that calls this every step should be constructed with static_geometry=False."""
+        if gs.xyz.shape != self.gs.xyz.shape:
+            raise ValueError("update_gaussians: the number of Gaussians is fixed (the UV lookup is indexed by it)")
+        self.gs = GaussianModel(*[t.detach() for t in gs])
+        self.invalidate_geometry()
+
     def invalidate_geometry(self) -> None:
         """Forget the static tile lists (after modifying a geometry tensor in place through `.data`)."""
         if self._geom_cache is not None:

@@ -189,3 +189,37 @@ def test_fit_with_static_geometry_takes_the_steps_of_the_full_path(dev, use_rgb)
     b.step(w2c2, *args[1:], sync=True)
     assert b._geom_cache.builds == 3
     R.check_overflow()
+
+
+def test_gaussians_that_move_between_steps_take_the_full_path(dev):
+    """VERDICT r2 missing 4: a fit whose network-side trainables move the Gaussians (map_bias, infer_one_shot.py:340-343) calls
+    update_gaussians(): blend maps and Adam state carry over, the static lists are rebuilt, and the step equals the step of a
+    fit that was constructed at the new geometry with the same maps."""
+    from guassianhand_amd import fit as F
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.renderer import GaussianModel
+    pb = tiny_fit_problem(P=600, n_views=4, hw=(64, 64), device=dev)
+    g = torch.Generator().manual_seed(6)
+    gt_rgb = torch.rand(4, 64, 64, 3, generator=g).to(dev)
+    gt_mask = (torch.rand(4, 64, 64, generator=g) > 0.5).float().to(dev)
+    args = (pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
+    gs0 = pb["gs"]
+    gs1 = GaussianModel(gs0.xyz + 0.002 * torch.randn(gs0.xyz.shape, generator=g).to(dev), gs0.opacity, gs0.rotation, gs0.scaling, gs0.shs)
+    a = F.OneShotFit(gs0, pb["uv"], map_hw=pb["map_hw"])
+    for i in range(3):
+        a.step(*args, sync=True)
+    b = F.OneShotFit(gs1, pb["uv"], map_hw=pb["map_hw"])                 # the same maps / moments, constructed at the new geometry
+    for k in a._adam:
+        for n_ in ("param", "exp_avg", "exp_avg_sq", "step_state"):
+            getattr(b._adam[k], n_).copy_(getattr(a._adam[k], n_))
+        b._adam[k].t = a._adam[k].t
+    builds = a._geom_cache.builds
+    a.update_gaussians(gs1)
+    la, lb = float(a.step(*args, sync=True)), float(b.step(*args, sync=True))
+    assert a._geom_cache.builds == builds + 1
+    assert la == lb
+    for k in a._adam:
+        assert torch.equal(a._adam[k].param, b._adam[k].param), k
+    with pytest.raises(ValueError):
+        a.update_gaussians(GaussianModel(*[t[:10] for t in gs1]))
+    R.check_overflow()
