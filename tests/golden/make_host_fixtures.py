@@ -213,6 +213,31 @@ def main():
     out["offset_pts"] = pts.numpy()
     out["offset_out"] = ((torch.sigmoid(v) - 0.5) * (1.2 / 32) + pts).numpy()   # renderer_one_shot.py:208-211
 
+    # ---- 4b. GSLayer.forward itself (renderer_one_shot.py:191-214), called unbound on a stand-in `self` that carries what the
+    # method reads: cfg.feature_channels / use_rgb / restrict_offset / xyz_offset / clip_scaling and the linear heads.
+    from types import SimpleNamespace
+    N, Cin = 13, 16
+    x_feat = torch.randn(N, Cin, generator=g)
+    pts2 = torch.randn(N, 3, generator=g)
+    out["gslayer_x"], out["gslayer_pts"] = x_feat.numpy(), pts2.numpy()
+    for tag, use_rgb, restrict, clip in (("a", True, True, None), ("b", False, False, 0.02)):
+        chans = {"xyz": 3, "scaling": 3, "rotation": 4, "opacity": 1, "shs": 3 if use_rgb else 48}
+        layers = torch.nn.ModuleList()
+        for k, oc in chans.items():
+            lin = torch.nn.Linear(Cin, oc)
+            with torch.no_grad():
+                lin.weight.copy_(0.3 * torch.randn(oc, Cin, generator=g)); lin.bias.copy_(0.3 * torch.randn(oc, generator=g))
+                if k == "scaling":
+                    lin.bias.add_(-5.0)                     # around the reference's init_scaling (:165)
+            layers.append(lin)
+            out[f"gslayer_{tag}_{k}_raw"] = lin(x_feat).detach().numpy()      # the head outputs the activations act on
+        self_ns = SimpleNamespace(cfg=SimpleNamespace(feature_channels=chans, use_rgb=use_rgb, restrict_offset=restrict, xyz_offset=True,
+                                                      clip_scaling=clip), out_layers=layers)
+        gm = ref.GSLayer.forward(self_ns, x_feat, pts2)
+        for k in ("xyz", "opacity", "rotation", "scaling", "shs"):
+            out[f"gslayer_{tag}_{k}"] = getattr(gm, k).detach().numpy()
+        out[f"gslayer_{tag}_cfg"] = np.array([int(use_rgb), int(restrict), -1.0 if clip is None else clip])
+
     np.savez_compressed(OUT, **out)
     print(f"wrote {OUT}: {len(out)} arrays, {os.path.getsize(OUT)} bytes")
 

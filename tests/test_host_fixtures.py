@@ -115,3 +115,20 @@ def test_gs_activations(fx):
     assert np.allclose(gs.xyz.numpy(), fx["offset_out"], atol=1e-7)
     assert torch.allclose(gs.rotation.norm(dim=1), torch.ones(11), atol=1e-6)
     assert gs.shs.shape == (11, 1, 3) and torch.all(gs.opacity == 0.5)
+
+
+def test_gs_activations_reproduce_the_reference_gslayer_forward(fx):
+    """a2: `renderer.gs_activations` against outputs CAPTURED from the reference's own GSLayer.forward
+    (renderer_one_shot.py:191-214, run unbound on the head outputs in the fixture): RGB mode with the restricted offset
+    (1.2 / 32), and SH mode with the free offset and clip_scaling."""
+    pts = torch.tensor(fx["gslayer_pts"])
+    for tag in ("a", "b"):
+        use_rgb, restrict, clip = fx[f"gslayer_{tag}_cfg"]
+        raw = {k: torch.tensor(fx[f"gslayer_{tag}_{k}_raw"]) for k in ("xyz", "scaling", "rotation", "opacity", "shs")}
+        gm = R.gs_activations(raw, pts, use_rgb=bool(use_rgb), xyz_offset=True, restrict_offset=bool(restrict),
+                              clip_scaling=None if clip < 0 else float(clip))
+        for k in ("xyz", "opacity", "rotation", "scaling", "shs"):
+            want = fx[f"gslayer_{tag}_{k}"]
+            got = getattr(gm, k).numpy()
+            assert got.shape == want.shape, (tag, k)
+            assert np.array_equal(got, want), (tag, k, float(np.abs(got - want).max()))
