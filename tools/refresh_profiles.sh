@@ -41,6 +41,11 @@ timeout 300 python3 tools/dropin_time.py 2> /dev/null | grep -v amdgpu.ids > $O/
 # the bench lines last: they quote the counter summaries of THIS build (profiles/<tag>_pmc_*.json, written here on the box by the
 # assemble step; run tools/assemble_profiles.py again at home to pick up the bench lines themselves)
 python3 tools/assemble_profiles.py $TAG > /dev/null || exit 1
+for V in 2 4 16; do
+  echo "== bench $V views" && timeout 300 python3 bench.py --views-per-step $V --no-cpu-baseline --no-stage-timing > $O/bench_${V}view.json 2> $O/bench_${V}view.err || exit 1
+done
+echo "== bench split streams" && timeout 300 python3 bench.py --split-streams on --no-cpu-baseline --no-stage-timing > $O/bench_split.json 2> $O/bench_split.err || exit 1
+for V in 1 2 4; do timeout 200 python3 tools/fit_static_time.py $V 2> /dev/null | grep "fit step" >> $O/fit_step_views.txt; done
 echo "== bench 1 view" && timeout 300 python3 bench.py --views-per-step 1 --no-cpu-baseline > $O/bench_1view.json 2> $O/bench_1view.err || exit 1
 echo "== bench hd sh3" && timeout 300 python3 bench.py --config two_hands_hd --no-cpu-baseline > $O/bench_hd_sh3.json 2> $O/bench_hd.err || exit 1
 echo "== bench hd sh3 pose batch 32" && timeout 400 python3 bench.py --config two_hands_hd --pose-batch --views-per-step 32 --steps 5 --warmup 2 --repeats 3 --no-cpu-baseline > $O/bench_hd_sh3_pose32.json 2> $O/bench_hd_pb.err || exit 1
