@@ -78,13 +78,15 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
 #if defined(__HIPCC__)
 // ---- arithmetic contract: fp32, no implicit contraction, FMAs only where written ----
 
-// exp(x), x <= 0, from IEEE primitives only so CPU oracle and GPU agree bit for bit:
-// 2^(x*log2e): n = rne(t), Taylor-6 of 2^f on [-.5,.5], v_ldexp_f32.
-// Below t = -126 the oracle returns 0; here t is clamped (one v_max, no compare / selects) and the result is 2^-126:
-// the only consumer is alpha = min(0.99, o * exp), and o * 1.2e-38 < 1/255 is skipped exactly like o * 0 (any finite
-// opacity below 3e35), so no output differs.
+// exp(x) from IEEE primitives only so CPU oracle and GPU agree bit for bit wherever the value is USED (x <= 0, result not
+// negligible): 2^(x*log2e): n = rne(t), Taylor-6 of 2^f on [-.5,.5], v_ldexp_f32.
+// No clamps (round 3: v_min / v_max cost 4.4 cycles each, as much as an fma — profiles/r3_valu_cycles_pmc.txt). Below t = -126
+// the oracle returns 0; here v_cvt_i32_f32 saturates and v_ldexp_f32 underflows to a denormal or 0 — the only consumer is
+// alpha = min(0.99, o * exp), and o * (<= 2^-126) < 1/255 is skipped exactly like o * 0 (any finite opacity below 3e35). For
+// x > 0 (a conic that is not positive definite) the value may overflow to +inf: every caller rejects the entry on `power > 0`
+// by a select, never by arithmetic on this value.
 __device__ __forceinline__ float gh_exp(float x) {
-  float t = fmaxf(x * 1.44269504088896341f, -126.0f);
+  float t = x * 1.44269504088896341f;
   float n = __builtin_rintf(t);
   float f = t - n;
   float p = 1.5403530393381608e-04f;

@@ -68,17 +68,19 @@ struct GhPixelFwd {
   int done;               // 0 / 1 (kept as int so it can travel through DPP)
 };
 
+// (quad_perm gives every lane a source lane, so no `old` value is needed: mov_dpp, not update_dpp(0, ..) — the latter costs a
+// v_mov 0 in front of every use)
 template <int S>
 __device__ __forceinline__ float gh_quad_bcast(float v) {     // value of the quad's lane S, in all 4 lanes
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), S * 0x55, 0xF, 0xF, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), S * 0x55, 0xF, 0xF, false));
 }
 template <int CTRL>
 __device__ __forceinline__ int gh_quad_perm_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, false);
 }
 template <int S>
 __device__ __forceinline__ int gh_quad_bcast_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, S * 0x55, 0xF, 0xF, false);
+  return __builtin_amdgcn_mov_dpp(v, S * 0x55, 0xF, 0xF, false);
 }
 
 // acc = (((acc + m[slot 0]) + m[slot 1]) + m[slot 2]) + m[slot 3] over the lane's quad: four DPP-fused adds. Written as
@@ -184,7 +186,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float r = col.x, g = col.y, bl = col.z, op = col.w;
     const float dx = gpx - pxf, dy = gpy - pyf;
     const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
-    const float alpha = fminf(0.99f, op * gh_exp(fminf(power, 0.0f)));
+    const float alpha = fminf(0.99f, op * gh_exp(power));          // (power > 0: rejected below, whatever this evaluates to)
     const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
     // The recurrence collapses to DPP-fused prefix products / sums over the quad, in exact list order.
     const bool valid = (p.done == 0) && ok;
@@ -200,9 +202,13 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     // (computed from products that never happen) are masked by the first one.
     bool blend = valid;
     float Tn = P4;
-    const uint64_t sb = gh_ballot(valid && Pn < 0.0001f);
-    if (sb) {                                                      // wave-uniform, rare
-      const uint32_t qb = (uint32_t)(sb >> (lane & 60)) & 0xFu;   // stop flags of this pixel's four slots
+    const bool stopc = valid && Pn < 0.0001f;
+    if (gh_ballot(stopc)) {                                        // wave-uniform, rare
+      // stop flags of this pixel's four slots, gathered over the quad HERE: taking them from the ballot's value made the
+      // compiler rebuild the mask with two vector instructions in every trip of the common path
+      const int sf = stopc ? 1 : 0;
+      const uint32_t qb = (uint32_t)(gh_quad_bcast_i<0>(sf) | (gh_quad_bcast_i<1>(sf) << 1) | (gh_quad_bcast_i<2>(sf) << 2) |
+                                     (gh_quad_bcast_i<3>(sf) << 3));
       blend = valid && ((qb & ((2u << slot) - 1u)) == 0u);         // no stop at or before this slot
       Tn = (qb & 1u) ? p.T : ((qb & 2u) ? P1 : ((qb & 4u) ? P2 : ((qb & 8u) ? P3 : P4)));   // T right before the stop
       if (qb) p.done = 1;
@@ -378,11 +384,19 @@ __device__ __forceinline__ float gh_scan_mul(float v) {
   else asm(GH_SCAN_ROW("v_mul_f32_dpp") : "+v"(v));
   return v;
 }
+// The additive scan leaves its INPUT alive (the caller needs it again): the first step writes a new register — a lane without
+// a source lane reads 0 (bound_ctrl), 0 + x = x — instead of working in place on a copy (one v_mov per pixel iteration).
+#define GH_SCAN_ROW_ADD_OUT \
+  GH_NOP "v_add_f32_dpp %0, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t" \
+  GH_NOP "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t" \
+  GH_NOP "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t" \
+  GH_NOP "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
 template <int L>
-__device__ __forceinline__ float gh_scan_add(float v) {
-  if (L == 64) asm(GH_SCAN_ROW("v_add_f32_dpp") GH_SCAN_B15("v_add_f32_dpp") GH_SCAN_B31("v_add_f32_dpp") : "+v"(v));
-  else if (L == 32) asm(GH_SCAN_ROW("v_add_f32_dpp") GH_SCAN_B15("v_add_f32_dpp") : "+v"(v));
-  else asm(GH_SCAN_ROW("v_add_f32_dpp") : "+v"(v));
+__device__ __forceinline__ float gh_scan_add(float x) {
+  float v;
+  if (L == 64) asm(GH_SCAN_ROW_ADD_OUT GH_SCAN_B15("v_add_f32_dpp") GH_SCAN_B31("v_add_f32_dpp") : "=&v"(v) : "v"(x));
+  else if (L == 32) asm(GH_SCAN_ROW_ADD_OUT GH_SCAN_B15("v_add_f32_dpp") : "=&v"(v) : "v"(x));
+  else asm(GH_SCAN_ROW_ADD_OUT : "=&v"(v) : "v"(x));
   return v;
 }
 
@@ -427,12 +441,13 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     // alpha exactly as the forward evaluated it (same expression, same gh_exp): the same entries count as blended
     const float dx = e.a.x - p1.z, dy = e.a.y - p1.w;
     const float power = -0.5f * (e.a.z * dx * dx + e.b.x * dy * dy) - e.a.w * dx * dy;
-    const float G = gh_exp(fminf(power, 0.0f));
+    const float G = gh_exp(power);                              // (power > 0: `contrib` is false, G is never used)
     const float alpha = fminf(0.99f, e.b.y * G);
     const bool contrib = valid && (e.pos < __float_as_int(p1.y)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
     any |= contrib;
     const float ae = contrib ? alpha : 0.0f;                    // entries the pixel did not blend: factor 1, weight 0
     const float m1 = 1.0f - ae;
+    const float rm1 = __builtin_amdgcn_rcpf(m1);                // taken BEFORE the scan, which then runs in place on m1's register
     // Q_l = product of (1 - alpha) over this entry and everything behind it in the batch:
     // T in front of the entry = (T behind the batch) / Q_l
     const float Q = gh_scan_mul<L>(m1);
@@ -448,7 +463,7 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     p0 = s_pix[2 * pidx]; p1 = s_pix[2 * pidx + 1];
     const float S = gh_scan_add<L>(we) + sB;          // d . (colour blended at or behind this entry) + background / mask term
     // dL/dalpha_k = T_k (d . c_k) - (d . colour strictly behind + background / mask term) / (1 - alpha_k)
-    const float dLda = Tk * ec - __builtin_amdgcn_rcpf(m1) * (S - we);
+    const float dLda = Tk * ec - rm1 * (S - we);
     const float h = contrib ? G * dLda : 0.0f;        // raw moments of h = G dL/dalpha; opacity / conic factors are applied
     const float hx = h * dx, hy = h * dy;             // once per (view, Gaussian) by gh_preprocess_bwd_kernel
     acc[0] += hx; acc[1] += hy;
