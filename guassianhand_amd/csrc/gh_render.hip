@@ -182,7 +182,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const bool have = slot < nh;
     const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
     const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src);
-    const float4 col = s_col[src >> 2];
+    const float4 col = *(const float4*)((const char*)s_col + 4 * src);   // s_col[src >> 2]: src is 4 * lane, one shift-add
     const float r = col.x, g = col.y, bl = col.z, op = col.w;
     const float dx = gpx - pxf, dy = gpy - pyf;
     const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
@@ -223,7 +223,9 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     p.T = Tn;
     // n_contrib: every lane remembers the last entry of ITS slot that was blended; the pixel's value is the maximum
     // over its four lanes, taken once after the walk.
-    p.last = blend ? (uint32_t)(base + 1) + (uint32_t)(src >> 2) : p.last;   // per LANE (positions ascend); quad max at the end
+    // per LANE (positions ascend), kept in units of a quarter entry — 4 * (position + 1) = 4 * (base + 1) + src — so that the
+    // byte the lane extracted serves as it stands; converted once after the walk (quad max at the end)
+    p.last = blend ? (uint32_t)(4 * (base + 1)) + (uint32_t)src : p.last;
   }
   return finished;
 }
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       }
     }
   }
+  p.last >>= 2;                                      // quarter-entry units -> list position + 1 (gh_fwd_consume)
   {                                                  // n_contrib of the pixel = max over the four slot lanes of its quad
     const uint32_t a = (uint32_t)gh_quad_perm_i<0xB1>((int)p.last);      // quad_perm [1,0,3,2]
     p.last = a > p.last ? a : p.last;
@@ -377,11 +380,16 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   GH_NOP OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf"
 #define GH_SCAN_B15(OP) "\n\t" GH_NOP OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
 #define GH_SCAN_B31(OP) "\n\t" GH_NOP OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+// The multiplicative scan works in place (a lane without a source lane must keep its value, and 0 is not the identity here);
+// its caller needs 1 / input afterwards: the reciprocal is taken as the block's first instruction, so that the input register
+// itself can be scanned (the compiler otherwise sinks the v_rcp below the scan and scans a copy).
 template <int L>
-__device__ __forceinline__ float gh_scan_mul(float v) {
-  if (L == 64) asm(GH_SCAN_ROW("v_mul_f32_dpp") GH_SCAN_B15("v_mul_f32_dpp") GH_SCAN_B31("v_mul_f32_dpp") : "+v"(v));
-  else if (L == 32) asm(GH_SCAN_ROW("v_mul_f32_dpp") GH_SCAN_B15("v_mul_f32_dpp") : "+v"(v));
-  else asm(GH_SCAN_ROW("v_mul_f32_dpp") : "+v"(v));
+__device__ __forceinline__ float gh_scan_mul_rcp(float v, float& rcp_in) {
+  float r;
+  if (L == 64) asm("v_rcp_f32 %1, %0\n\t" GH_SCAN_ROW("v_mul_f32_dpp") GH_SCAN_B15("v_mul_f32_dpp") GH_SCAN_B31("v_mul_f32_dpp") : "+v"(v), "=&v"(r));
+  else if (L == 32) asm("v_rcp_f32 %1, %0\n\t" GH_SCAN_ROW("v_mul_f32_dpp") GH_SCAN_B15("v_mul_f32_dpp") : "+v"(v), "=&v"(r));
+  else asm("v_rcp_f32 %1, %0\n\t" GH_SCAN_ROW("v_mul_f32_dpp") : "+v"(v), "=&v"(r));
+  rcp_in = r;
   return v;
 }
 // The additive scan leaves its INPUT alive (the caller needs it again): the first step writes a new register — a lane without
@@ -447,10 +455,10 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     any |= contrib;
     const float ae = contrib ? alpha : 0.0f;                    // entries the pixel did not blend: factor 1, weight 0
     const float m1 = 1.0f - ae;
-    const float rm1 = __builtin_amdgcn_rcpf(m1);                // taken BEFORE the scan, which then runs in place on m1's register
     // Q_l = product of (1 - alpha) over this entry and everything behind it in the batch:
-    // T in front of the entry = (T behind the batch) / Q_l
-    const float Q = gh_scan_mul<L>(m1);
+    // T in front of the entry = (T behind the batch) / Q_l;   rm1 = 1 / (1 - alpha_l)
+    float rm1;
+    const float Q = gh_scan_mul_rcp<L>(m1, rm1);
     const float Tk = p0.x * __builtin_amdgcn_rcpf(Q);
     const float ec = fmaf(p1.x, e.cb, fmaf(p0.w, e.b.w, p0.z * e.b.z));      // d . c of this entry
     const float w = ae * Tk;                                               // the forward's blend weight alpha * T
