@@ -177,7 +177,9 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     int j0, j1, j2, j3;
     gh_pop4_low(mask, j0, j1, j2, j3);
     // the four entry lanes travel as bytes of one scalar: a lane extracts its slot's with a single v_bfe
-    const uint32_t packed4 = ((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2;
+    // (& 0xFCFC..: with fewer than four hits the trailing picks are -1 and spill set bits into the later bytes; every byte must
+    // stay a valid 4 * lane, because the colour record is read at byte address 4 * src — a scalar instruction, not a vector one)
+    const uint32_t packed4 = (((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2) & 0xFCFCFCFCu;
     const int src = (int)((packed4 >> slot8) & 0xFFu);              // 4 * entry lane = ds_bpermute address
     const bool have = slot < nh;
     const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
