@@ -171,16 +171,9 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
   const bool hit = (base + lane < total) && ((t.blocks >> blk) & 1u);
   uint64_t mask = gh_ballot(hit);
   bool finished = false;                                             // set (and the mask cleared) inside the rare stop branch, so
-  // Per-lane conditions that change rarely or not at all live as wave-uniform LANE MASKS in scalar registers and enter the
-  // per-trip predicate through s_and (inverse ballot) instead of a vector compare per trip (a v_cmp costs 4.6 cycles, as much
-  // as an fma): `alive` = pixels not yet saturated (changes in the rare stop branch only), `have` = slots that hold an entry
-  // this trip (all of them unless the batch runs out: 0x1111.. * (2^nh - 1)).
-  uint64_t alive = gh_ballot(p.done == 0);
   while (mask) {                                                     // the common path's loop control is one scalar compare
     // next four set bits, ascending (wave-uniform scalar work)
     const int nh = __builtin_popcountll(mask);                      // entries left in this batch (>= 1)
-    const uint32_t hm32 = 0x11111111u * (nh >= 4 ? 15u : ((1u << nh) - 1u));
-    const uint64_t have_mask = ((uint64_t)hm32 << 32) | hm32;
     int j0, j1, j2, j3;
     gh_pop4_low(mask, j0, j1, j2, j3);
     // the four entry lanes travel as bytes of one scalar: a lane extracts its slot's with a single v_bfe
@@ -188,6 +181,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     // stay a valid 4 * lane, because the colour record is read at byte address 4 * src — a scalar instruction, not a vector one)
     const uint32_t packed4 = (((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2) & 0xFCFCFCFCu;
     const int src = (int)((packed4 >> slot8) & 0xFFu);              // 4 * entry lane = ds_bpermute address
+    const bool have = slot < nh;
     const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
     const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src);
     const float4 col = *(const float4*)((const char*)s_col + 4 * src);   // s_col[src >> 2]: src is 4 * lane, one shift-add
@@ -195,9 +189,9 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float dx = gpx - pxf, dy = gpy - pyf;
     const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
     const float alpha = fminf(0.99f, op * gh_exp(power));          // (power > 0: rejected below, whatever this evaluates to)
-    const bool ok = (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
+    const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
     // The recurrence collapses to DPP-fused prefix products / sums over the quad, in exact list order.
-    const bool valid = ok && __builtin_amdgcn_inverse_ballot_w64(have_mask & alive);
+    const bool valid = (p.done == 0) && ok;
     const float f = valid ? 1.0f - alpha : 1.0f;                   // x*1 == x: skipped entries leave T bit-identical
     float P1, P2, P3;                                              // T before slot 1, 2, 3: three DPP-fused multiplies
     gh_quad_prefix3(p.T, f, P1, P2, P3);
@@ -220,8 +214,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
       blend = valid && ((qb & ((2u << slot) - 1u)) == 0u);         // no stop at or before this slot
       Tn = (qb & 1u) ? p.T : ((qb & 2u) ? P1 : ((qb & 4u) ? P2 : ((qb & 8u) ? P3 : P4)));   // T right before the stop
       if (qb) p.done = 1;
-      alive = gh_ballot(p.done == 0);
-      if (alive == 0) { finished = true; mask = 0; }                // every pixel of the block is saturated: last trip
+      if (__all(p.done != 0)) { finished = true; mask = 0; }        // every pixel of the block is saturated: last trip
     }
     const float w = blend ? alpha * Pm : 0.0f;                     // C + c*0 == C exactly
     const float m0 = r * w, m1 = g * w, m2 = bl * w;
