@@ -181,7 +181,8 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     // stay a valid 4 * lane, because the colour record is read at byte address 4 * src — a scalar instruction, not a vector one)
     const uint32_t packed4 = (((uint32_t)j0 | ((uint32_t)j1 << 8) | ((uint32_t)j2 << 16) | ((uint32_t)j3 << 24)) << 2) & 0xFCFCFCFCu;
     const int src = (int)((packed4 >> slot8) & 0xFFu);              // 4 * entry lane = ds_bpermute address
-    const bool have = slot < nh;
+    const bool have = slot < nh;             // (round 3: `have` and `p.done == 0` as scalar lane masks through an inverse ballot
+                                             // instead of two v_cmp per trip: +6 us — the 64-bit scalar arithmetic lengthens every trip)
     const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
     const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src);
     const float4 col = *(const float4*)((const char*)s_col + 4 * src);   // s_col[src >> 2]: src is 4 * lane, one shift-add
