@@ -193,7 +193,10 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
     // The recurrence collapses to DPP-fused prefix products / sums over the quad, in exact list order.
     const bool valid = (p.done == 0) && ok;
-    const float f = valid ? 1.0f - alpha : 1.0f;                   // x*1 == x: skipped entries leave T bit-identical
+    // alpha of the entries that count, 0 for the others: ONE select serves the transmittance factor (1 - 0 == 1 exactly:
+    // skipped entries leave T bit-identical) and the blend weight (0 * T == +0, C + c * 0 == C exactly)
+    const float ae = valid ? alpha : 0.0f;
+    const float f = 1.0f - ae;
     float P1, P2, P3;                                              // T before slot 1, 2, 3: three DPP-fused multiplies
     gh_quad_prefix3(p.T, f, P1, P2, P3);
     const float Pm = gh_slot_select(p.T, P1, P2, P3);             // T seen by this lane's entry
@@ -205,6 +208,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     // (computed from products that never happen) are masked by the first one.
     bool blend = valid;
     float Tn = P4;
+    float w = ae * Pm;                                             // blend weight alpha * T of the entries that count
     const bool stopc = valid && Pn < 0.0001f;
     if (gh_ballot(stopc)) {                                        // wave-uniform, rare
       // stop flags of this pixel's four slots, gathered over the quad HERE: taking them from the ballot's value made the
@@ -213,11 +217,11 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
       const uint32_t qb = (uint32_t)(gh_quad_bcast_i<0>(sf) | (gh_quad_bcast_i<1>(sf) << 1) | (gh_quad_bcast_i<2>(sf) << 2) |
                                      (gh_quad_bcast_i<3>(sf) << 3));
       blend = valid && ((qb & ((2u << slot) - 1u)) == 0u);         // no stop at or before this slot
+      w = blend ? w : 0.0f;
       Tn = (qb & 1u) ? p.T : ((qb & 2u) ? P1 : ((qb & 4u) ? P2 : ((qb & 8u) ? P3 : P4)));   // T right before the stop
       if (qb) p.done = 1;
       if (__all(p.done != 0)) { finished = true; mask = 0; }        // every pixel of the block is saturated: last trip
     }
-    const float w = blend ? alpha * Pm : 0.0f;                     // C + c*0 == C exactly
     const float m0 = r * w, m1 = g * w, m2 = bl * w;
     gh_quad_accumulate(p.C0, m0);              // C = (((C + m[slot 0]) + m[slot 1]) + m[slot 2]) + m[slot 3], in list order
     gh_quad_accumulate(p.C1, m1);
