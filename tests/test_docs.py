@@ -13,6 +13,8 @@ def test_design_numbers_are_the_profiles():
     s = open(os.path.join(ROOT, "DESIGN.md")).read()
     a, z = s.index(T.BEGIN), s.index(T.END) + len(T.END)
     assert s[a:z] == T.block(), "run `python tools/design_table.py --write` after refreshing profiles/"
+    a, z = s.index(T.BEGIN7), s.index(T.END7) + len(T.END7)
+    assert s[a:z] == T.numbers(), "run `python tools/design_table.py --write` after refreshing profiles/"
 
 
 def test_profiles_share_one_source_hash():
