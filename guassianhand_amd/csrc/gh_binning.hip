@@ -149,6 +149,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __res
 // SELF (segments of at most 128 blocks, e.g. the per-view depth sort): there is no scan kernel; the histogram table is
 // block-major and every block adds up the rows of the blocks before it (its prefix) and of all blocks (the digit totals)
 // with coalesced reads — one launch less per pass where the row scan was nothing but launch latency.
+#ifndef GH_SELF_LOADS
+#define GH_SELF_LOADS 13u
+#endif
 template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
@@ -191,28 +194,63 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   }
 
   // digit base = exclusive scan over digits of tot[] + this block's row prefix
-  {
+  if (SELF) {
+    // The segment's histogram rows [block][digit] are summed by the whole workgroup: every wave-load takes 256 consecutive
+    // words (16 bytes per lane) of the table, so a lane always meets the same four digits, a few loads cover all the rows
+    // (one per thread and row took ~100 dependent-latency-bound 4-byte loads), and the partial sums meet in LDS.
+    static_assert(!SELF || DPT == 1, "SELF: one digit per thread");
+    const uint32_t nact = (n + (uint32_t)(GH_BLOCK * ITEMS) - 1u) / (uint32_t)(GH_BLOCK * ITEMS);   // blocks that wrote a row
+    const uint32_t* seg_tab = table + (size_t)seg * nblk * ndig;
+    uint32_t* s_tall = s_key;                              // (the key / value staging area is not in use yet)
+    uint32_t* s_tpre = s_key + MAXD;
+    s_tall[tid] = 0u; s_tpre[tid] = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s_cnt[w][tid] = 0;
+    __syncthreads();
+    if (ndig >= 4u) {
+      const uint32_t nq = nact * ndig / 4u;                // 16-byte words in the rows
+      const uint32_t lg = 31u - (uint32_t)__clz((int)ndig);
+      uint32_t t_all[4] = {0u, 0u, 0u, 0u}, t_pre[4] = {0u, 0u, 0u, 0u};
+      for (uint32_t q0 = (uint32_t)wid * GH_WAVE + lane; q0 < nq; q0 += GH_SELF_LOADS * GH_BLOCK) {
+        uint4 c[GH_SELF_LOADS];
+#pragma unroll
+        for (uint32_t j = 0; j < GH_SELF_LOADS; ++j) {
+          const uint32_t q = q0 + j * GH_BLOCK;
+          c[j] = q < nq ? ((const uint4*)seg_tab)[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < GH_SELF_LOADS; ++j) {
+          const bool pre = (((q0 + j * GH_BLOCK) * 4u) >> lg) < blockIdx.x;      // the row this word belongs to
+          t_all[0] += c[j].x; t_all[1] += c[j].y; t_all[2] += c[j].z; t_all[3] += c[j].w;
+          t_pre[0] += pre ? c[j].x : 0u; t_pre[1] += pre ? c[j].y : 0u; t_pre[2] += pre ? c[j].z : 0u; t_pre[3] += pre ? c[j].w : 0u;
+        }
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t d = ((uint32_t)lane * 4u + j) & dmask;
+        atomicAdd(&s_tall[d], t_all[j]);
+        atomicAdd(&s_tpre[d], t_pre[j]);
+      }
+    } else {
+      const uint32_t d = (uint32_t)tid;
+      if (d < ndig) {
+        uint32_t ta = 0, tp = 0;
+        for (uint32_t b = 0; b < nact; ++b) { const uint32_t c = seg_tab[(size_t)b * ndig + d]; ta += c; tp += b < blockIdx.x ? c : 0u; }
+        s_tall[d] = ta; s_tpre[d] = tp;
+      }
+    }
+    __syncthreads();
+    const uint32_t v = (uint32_t)tid < ndig ? s_tall[tid] : 0u, pre = (uint32_t)tid < ndig ? s_tpre[tid] : 0u;
+    uint32_t total;
+    const uint32_t run = gh_block_excl_scan(v, s_w, &total);
+    s_base[tid] = run + pre;
+  } else {
     uint32_t v[DPT], pre[DPT], sum = 0;
 #pragma unroll
     for (int k = 0; k < DPT; ++k) {
       const uint32_t d = (uint32_t)(tid * DPT + k);
-      if (SELF) {
-        const uint32_t nact = (n + (uint32_t)(GH_BLOCK * ITEMS) - 1u) / (uint32_t)(GH_BLOCK * ITEMS);   // blocks that wrote a row
-        const uint32_t* col = table + (size_t)seg * nblk * ndig + d;
-        uint32_t t_all = 0, t_pre = 0;
-        if (d < ndig) {
-#pragma unroll 8
-          for (uint32_t b = 0; b < nact; ++b) {
-            const uint32_t c = col[(size_t)b * ndig];
-            t_all += c;
-            t_pre += b < blockIdx.x ? c : 0u;
-          }
-        }
-        v[k] = t_all; pre[k] = t_pre;
-      } else {
-        v[k] = d < ndig ? tot[(size_t)seg * ndig + d] : 0u;
-        pre[k] = d < ndig ? table[((size_t)seg * ndig + d) * nblk + blockIdx.x] : 0u;
-      }
+      v[k] = d < ndig ? tot[(size_t)seg * ndig + d] : 0u;
+      pre[k] = d < ndig ? table[((size_t)seg * ndig + d) * nblk + blockIdx.x] : 0u;
       sum += v[k];
 #pragma unroll
       for (int w = 0; w < NW; ++w) s_cnt[w][d] = 0;
@@ -353,27 +391,37 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
 }
 
 // keys per thread: measured on the 8-view workload (98 k keys per segment / 3 M instances): 2 / 4 / 8 for the small class
-// gave 0.296 / 0.287 / 0.294 ms of binning, 4 / 8 / 16 for the middle class 0.298 / 0.287 / 0.294
-int gh_radix_items(size_t per_segment) { return per_segment <= ((size_t)1 << 21) ? 4 : (per_segment <= ((size_t)1 << 25) ? 8 : 16); }
+// gave 0.296 / 0.287 / 0.294 ms of binning, 4 / 8 / 16 for the middle class 0.298 / 0.287 / 0.294. Fixed-length segment sorts
+// (the per-view depth sort; every block sums the histogram rows of its segment, so fewer, larger blocks read less): 8 from
+// half a million keys in all (8 views x 98 k: scatter pass 11.5 -> 10.3 us; 2 views: 7.4 -> 8.2 us, so 4 below that).
+static int gh_radix_items(size_t per_segment, int segs, bool seg_sort) {
+  if (seg_sort && per_segment <= ((size_t)1 << 21)) return per_segment * (size_t)segs >= ((size_t)1 << 19) ? 8 : 4;
+  return per_segment <= ((size_t)1 << 21) ? 4 : (per_segment <= ((size_t)1 << 25) ? 8 : 16);
+}
 
 // Table words for sorting `segs` segments of `per_segment` elements (capacity).
 size_t gh_radix_table_words(size_t per_segment, int segs) {
-  const size_t tile = (size_t)GH_BLOCK * gh_radix_items(per_segment);
+  // the smallest tile this segment length may be sorted with (keys per thread depend on the number of segments, and a call
+  // split into two halves shares one table): linear in `segs`
+  const size_t tile = (size_t)GH_BLOCK * (per_segment <= ((size_t)1 << 21) ? 4 : gh_radix_items(per_segment, segs, true));
   return (size_t)segs * 1024 * ((per_segment + tile - 1) / tile) + (size_t)segs * 1024;      // up to 1024 digits per pass
 }
 
-size_t gh_radix_table_words(size_t cap) { return gh_radix_table_words(cap, 1); }
+size_t gh_radix_table_words(size_t cap) {
+  const size_t tile = (size_t)GH_BLOCK * gh_radix_items(cap, 1, false);
+  return (size_t)1024 * ((cap + tile - 1) / tile) + 1024;
+}
 
 // Passes gh_radix_sort runs for `nbits` key bits on one segment of capacity `cap` (callers pick the start buffer by its parity).
 int gh_radix_passes(size_t cap, int nbits) {
-  if (gh_radix_items(cap) == 4 && nbits > 8 && nbits <= 10) return 1;
+  if (gh_radix_items(cap, 1, false) == 4 && nbits > 8 && nbits <= 10) return 1;
   return (nbits + 7) / 8;
 }
 
 void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                       int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s, const uint2* key_bits, int n_bits) {
   const size_t per_seg = seg_len ? seg_len : cap;
-  const int items = gh_radix_items(per_seg);
+  const int items = gh_radix_items(per_seg, segs, seg_len != 0u);
   if (items == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
   else if (items == 8) gh_radix_sort_t<8>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
   else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
