@@ -325,7 +325,8 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
       if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(&H.d, H.g, &H.in, gr, ws, ws, H.L, sh, GH_PBWD_RECORD_SUM);
     }
     if (!gh_join(S, s)) return GH_ERR_LAUNCH;
-    if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s, GH_PBWD_CHAIN);
+    if (stages & GH_BWD_PREPROCESS)
+      gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s, GH_PBWD_CHAIN, hv[1].v0, (size_t)hv[0].d.max_instances);
     return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
   }
   if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, ws, L, s);

@@ -68,12 +68,14 @@ void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* i
 int gh_launch_sh_colour_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, const char* wg, char* ws,
                             const GhLayout& L, hipStream_t s);
 // parts: GH_PBWD_RECORD_SUM (fixed-order sums of the render backward's sub-records, per (view, Gaussian)) and / or
-// GH_PBWD_CHAIN (SH colour backward, chain rule, blend-parameter reductions)
+// GH_PBWD_CHAIN (SH colour backward, chain rule, blend-parameter reductions). With precomputed colours the chain-rule kernel
+// sums the sub-records itself and GH_PBWD_RECORD_SUM launches nothing. v_split >= 0: the chain call of a split backward — the
+// sub-records of views >= v_split sit cap_a instances further on (the second half's share of the per-instance arrays).
 #define GH_PBWD_RECORD_SUM 1
 #define GH_PBWD_CHAIN 2
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr,
                               const char* wg, char* ws, const GhLayout& L, hipStream_t s,
-                              int parts = GH_PBWD_RECORD_SUM | GH_PBWD_CHAIN);
+                              int parts = GH_PBWD_RECORD_SUM | GH_PBWD_CHAIN, int v_split = -1, size_t cap_a = 0);
 
 #if defined(__HIPCC__)
 // ---- arithmetic contract: fp32, no implicit contraction, FMAs only where written ----

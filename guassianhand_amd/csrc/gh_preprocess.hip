@@ -146,6 +146,7 @@ __device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, floa
 
 // One thread per Gaussian; loops the views so gradients w.r.t. view-independent attributes are summed
 // in registers/own memory in a fixed order (no atomics, bitwise reproducible).
+// (SH colours only — with precomputed colours the chain-rule kernel sums the records itself, gh_sum_records.)
 // Fixed-order sum of every Gaussian's per-(instance, quadrant) gradient sub-records; its instances are the
 // consecutive emit slots [slot_begin, slot_begin + tiles). Few registers, so the reads run at full occupancy; the
 // chain-rule kernel then reads the 9 sums coalesced. Gaussians are taken in INDEX order: slot_begin / tiles_touched /
@@ -233,6 +234,42 @@ __device__ __forceinline__ float gh_group_sum(float v, int lg) {
 }
 
 // RGB_MODE is a template parameter so the colours-precomputed path does not pay the registers of the SH path.
+// The record sum inside the chain-rule kernel (colours precomputed: nothing else reads the sums): the lane of a (view,
+// Gaussian) adds up the sub-records of its instances itself — emit slots [o0, o1), four quadrant flags per slot, quadrants in
+// order — with one float64 accumulator per moment. No 48-byte sum record is written and read back and one launch less;
+// a lane has four times the reads of gh_record_sum_kernel's quad lanes, measured 55 -> 66 us for the sums alone at the
+// chain rule's occupancy, against the 37 us kernel that now runs inside those waits.
+__device__ __forceinline__ void gh_sum_records(uint32_t o0, uint32_t o1, const float* __restrict__ inst_grad,
+                                               const uint32_t* __restrict__ inst_flag, float* s9) {
+  // float64 accumulators (9 adds per sub-record where the compensated float32 sum of gh_record_sum_kernel takes 36): a
+  // footprint of hundreds of tiles adds thousands of signed sub-records that largely cancel
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // one emit slot per trip (two slots' records in flight: 143 VGPRs, three waves per SIMD, no faster)
+  uint32_t fl = o0 < o1 ? inst_flag[o0] : 0u;
+  for (uint32_t sl = o0; sl < o1; ++sl) {
+    const uint32_t f = fl;
+    if (sl + 1 < o1) fl = inst_flag[sl + 1];             // the next slot's flags travel while this slot's records are summed
+    GhF3 r[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if ((f >> (8 * q)) & 1u) {
+        const GhF3* p = (const GhF3*)(inst_grad + ((size_t)sl * 4 + q) * GH_REC_G);
+        r[q][0] = p[0]; r[q][1] = p[1]; r[q][2] = p[2];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if ((f >> (8 * q)) & 1u) {
+        acc[0] += (double)r[q][0].x; acc[1] += (double)r[q][0].y; acc[2] += (double)r[q][0].z;
+        acc[3] += (double)r[q][1].x; acc[4] += (double)r[q][1].y; acc[5] += (double)r[q][1].z;
+        acc[6] += (double)r[q][2].x; acc[7] += (double)r[q][2].y; acc[8] += (double)r[q][2].z;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s9[k] = (float)acc[k];
+}
+
 // Chain rule per (view, Gaussian): a group of G = 2^lg adjacent lanes shares one row of the attribute arrays and
 // splits its views (lane vv takes views vv, vv + G, ...), so 8 views run 8-wide instead of as a loop of 8 in one thread
 // (P threads cannot fill 256 CUs); the per-view results are combined over the group in fixed order (gh_group_sum), no
@@ -240,11 +277,14 @@ __device__ __forceinline__ float gh_group_sum(float v, int lg) {
 // and G = 1.
 // GEOM = false (no gradient w.r.t. means / scales / rotations / means2D / xyz_b is asked for — the one-shot fit trains colour
 // and opacity biases only): the chain rule through the projection is skipped and the kernel only sums over the views.
-template <bool RGB_MODE, bool GEOM>
+// FUSED (RGB_MODE only): the sums come straight from the render backward's sub-records (gh_sum_records). A split call's second
+// half keeps its per-instance arrays cap_a entries further on (views >= v_split; unsplit: v_split = NV).
+template <bool RGB_MODE, bool GEOM, bool FUSED>
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags, int lg,
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ dmean_sh, const float4* __restrict__ gsum,
-    float* __restrict__ scratch) {
+    float* __restrict__ scratch, const uint32_t* __restrict__ slot_begin, const float* __restrict__ inst_grad,
+    const uint32_t* __restrict__ inst_flag, int v_split, uint32_t cap_a, uint32_t cap_b) {
   __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
   const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   const int G = 1 << lg;
@@ -268,9 +308,19 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     const bool vok = per_view || v_raw < NV;
     const int v = vok ? v_raw : 0;
     const size_t n = per_view ? (size_t)(live ? i : 0) : (size_t)v * P + (live ? i : 0);
-    const bool vis = live && vok && tiles_touched[n] != 0;
+    const uint32_t tt = live && vok ? tiles_touched[n] : 0u;
+    const bool vis = tt != 0u;
     float s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (vis) {
+    if (FUSED) {
+      if (vis) {
+        const bool hb = v >= v_split;
+        const uint32_t capv = hb ? cap_b : cap_a, off = hb ? cap_a : 0u;
+        uint32_t o0 = slot_begin[n], o1 = o0 + tt;
+        if (o1 > capv) o1 = capv;
+        if (o0 > o1) o0 = o1;
+        gh_sum_records(off + o0, off + o1, inst_grad, inst_flag, s9);
+      }
+    } else if (vis) {
       const float4* r = gsum + n * 3;
       const float4 r0 = r[0], r1 = r[1]; const float r2 = r[2].x;
       s9[0] = r0.x; s9[1] = r0.y; s9[2] = r0.z; s9[3] = r0.w; s9[4] = r1.x; s9[5] = r1.y; s9[6] = r1.z; s9[7] = r1.w; s9[8] = r2;
@@ -467,7 +517,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_blend_reduce_kernel(const float* 
 }
 
 void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const GhGrads* gr, const char* wg, char* ws,
-                              const GhLayout& L, hipStream_t s, int parts) {
+                              const GhLayout& L, hipStream_t s, int parts, int v_split, size_t cap_a) {
   if (g.P == 0) return;
   const bool per_view = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   const int rows = per_view ? g.N : g.P;
@@ -475,19 +525,25 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   if (!per_view) while ((1 << lg) < g.NV && lg < 6) ++lg;
   int nblk = (int)((((size_t)rows << lg) + GH_BLOCK - 1) / GH_BLOCK);   // <= 2 N / 256 + 1: bwd_scratch holds 64 floats per block
   const bool geom = gr->dL_dmeans3D || gr->dL_dmeans2D || gr->dL_dscales || gr->dL_drotations || (in->blend_xyz_b && gr->dL_dblend_xyz_b);
-  auto kern = in->colors_precomp ? (geom ? gh_preprocess_bwd_kernel<true, true> : gh_preprocess_bwd_kernel<true, false>)
-                                 : (geom ? gh_preprocess_bwd_kernel<false, true> : gh_preprocess_bwd_kernel<false, false>);
+  // colours precomputed: only the chain-rule kernel reads the record sums, and it takes them itself (FUSED); SH colours:
+  // gh_sh_colour_bwd2_kernel reads the colour moments first, so the sums are a kernel of their own
+  const bool fused = in->colors_precomp != nullptr;
+  auto kern = fused ? (geom ? gh_preprocess_bwd_kernel<true, true, true> : gh_preprocess_bwd_kernel<true, false, true>)
+                    : (geom ? gh_preprocess_bwd_kernel<false, true, false> : gh_preprocess_bwd_kernel<false, false, false>);
   const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
-  if (parts & GH_PBWD_RECORD_SUM)
+  if ((parts & GH_PBWD_RECORD_SUM) && !fused)
     hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
                        (const uint32_t*)(wg + L.slot_begin), (const uint32_t*)(wg + L.tiles_touched),
                        (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
   if (!(parts & GH_PBWD_CHAIN)) return;
   const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, wg, ws, L, s);     // SH mode only; no-op with colors_precomp
+  const bool halves = v_split >= 0;                      // a split call: the second half's instance arrays start cap_a entries in
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, lg,
                      (const uint32_t*)(wg + L.tiles_touched), (const float4*)(ws + L.dmean_sh),
-                     (const float4*)(ws + L.grad_sums), (float*)(ws + L.bwd_scratch));
+                     (const float4*)(ws + L.grad_sums), (float*)(ws + L.bwd_scratch),
+                     (const uint32_t*)(wg + L.slot_begin), (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag),
+                     halves ? v_split : g.NV, (uint32_t)(halves ? cap_a : (size_t)g.cap), (uint32_t)(halves ? (size_t)g.cap - cap_a : 0));
   const bool wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) != 0;
   float* dw = (in->blend_color_w && !wpg) ? gr->dL_dblend_color_w : nullptr;
   float* dx = (geom && in->blend_xyz_b) ? gr->dL_dblend_xyz_b : nullptr;

@@ -241,12 +241,14 @@ def test_culling_is_conservative_for_thin_faint_and_border_gaussians(dev):
     sc.xyz[k, 2] = 0.0
     sc.xyz[5000:5200, 0] += 0.5                                                   # far outside the frustum
     # The subject here is the FORWARD (bit-exact, asserted inside compare). Every gradient keeps the 1e-3 bar except
-    # dL/dscales: the chain rule dSigma2D -> dSigma3D -> dscale of a 1000:1 needle subtracts terms ~(s_max / s_min)^2 = 1e6
-    # times larger than the result for the 3e-5 m axes, in fp32 on BOTH sides (the oracle's per-Gaussian stage is fp32 as
-    # well; only its pixel sums are double). The two sides' nine per-Gaussian sums agree to ~1e-7 relative (fp32 eps), which
-    # that cancellation amplifies to 1.8e-3 of the entry scale (measured, round 2; 5e-3 before the compensated record
-    # sums). A bar of 1e-3 here would need the per-Gaussian chain rule in double on the GPU.
-    compare(sc, dev, grad_l2=1e-4, grad_rtol={"scales": 3e-3})
+    # dL/dscales and dL/drotations: the chain rule dSigma2D -> dSigma3D -> (dscale, dR) of a 1000:1 needle subtracts terms
+    # ~(s_max / s_min)^2 = 1e6 times larger than the result, in fp32 on BOTH sides (the oracle's per-Gaussian stage is fp32 as
+    # well; only its pixel sums are double). Measured against the float64 dense autograd oracle on this scene at a third of
+    # its size (tools/needle_accuracy.py, profiles/r3_needle_accuracy.txt): scales / rotations max-rel 2.0e-3 / 4.1e-3 for
+    # the HIP path (float64 record sums), 2.5e-3 / 4.7e-3 for the C oracle — neither float32 implementation is within 1e-3
+    # of the truth here, and the HIP path is the closer one; the two differ from each other by ≈1e-3 (1.1e-3 on scales in that
+    # run, 1.2e-3 on rotations at this test's size).
+    compare(sc, dev, grad_l2=1e-4, grad_rtol={"scales": 3e-3, "rotations": 3e-3})
 
 
 def test_frustum_clamp_edge_gradients(dev):
