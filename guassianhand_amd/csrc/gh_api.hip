@@ -321,7 +321,7 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
       const size_t pix0 = (size_t)H.v0 * g.H * g.W;
       if (stages & GH_BWD_RENDER)
         gh_launch_render_bwd(&H.d, H.g, &H.in, gr->dL_dimage + pix0 * 3, gr->dL_dalpha ? gr->dL_dalpha + pix0 : nullptr,
-                             gr->upstream_scale, ws, ws, H.L, sh);
+                             gr->upstream_scale, ws, ws, H.L, sh, gh_records_need_geometry(in, gr));
       if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(&H.d, H.g, &H.in, gr, ws, ws, H.L, sh, GH_PBWD_RECORD_SUM);
     }
     if (!gh_join(S, s)) return GH_ERR_LAUNCH;
@@ -329,7 +329,7 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
       gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s, GH_PBWD_CHAIN, hv[1].v0, (size_t)hv[0].d.max_instances);
     return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
   }
-  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, ws, L, s);
+  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, ws, L, s, gh_records_need_geometry(in, gr));
   if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
@@ -373,7 +373,8 @@ extern "C" int gh_backward_shared(const GhDims* d, const GhInputs* in, const GhG
   hipStream_t s = (hipStream_t)hip_stream;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
-  gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, (const char*)geometry_ws, (char*)workspace, L, s);
+  gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, (const char*)geometry_ws, (char*)workspace, L, s,
+                       gh_records_need_geometry(in, gr));
   gh_launch_preprocess_bwd(d, g, in, gr, (const char*)geometry_ws, (char*)workspace, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
@@ -423,7 +424,8 @@ extern "C" int gh_backward_refresh(const GhDims* d, const GhInputs* in, const Gh
   hipStream_t s = (hipStream_t)hip_stream;
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
-  gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, (const char*)geometry_ws, (char*)workspace, L, s);
+  gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, (const char*)geometry_ws, (char*)workspace, L, s,
+                       gh_records_need_geometry(in, gr));
   gh_launch_preprocess_bwd(d, g, in, gr, (const char*)geometry_ws, (char*)workspace, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -45,8 +45,19 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
 // they differ for a second call over the same geometry (gh_forward_shared).
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha,
                           const char* wg, char* ws, const GhLayout& L, hipStream_t s);
+// geom: gh_records_need_geometry(in, gr) — false: the sub-records carry the colour / opacity moments only
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
-                          const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
+                          const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s,
+                          bool geom);
+// Is a gradient that flows through the projection wanted (means, scales, rotations, means2D, xyz_b)?
+static inline bool gh_wants_geometry(const GhInputs* in, const GhGrads* gr) {
+  return gr->dL_dmeans3D || gr->dL_dmeans2D || gr->dL_dscales || gr->dL_drotations || (in->blend_xyz_b && gr->dL_dblend_xyz_b);
+}
+// Do the render backward's sub-records need their five position / conic moments? Not when no geometry gradient is wanted and
+// the colours are precomputed (with SH colours gh_record_sum_kernel reads whole records).
+static inline bool gh_records_need_geometry(const GhInputs* in, const GhGrads* gr) {
+  return gh_wants_geometry(in, gr) || !in->colors_precomp;
+}
 void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
 // gh_forward_refresh: per-instance records (opacity, colour, block mask) of the CURRENT opacities / colours over the lists of wg
 void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s);

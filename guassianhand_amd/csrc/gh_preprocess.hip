@@ -277,6 +277,40 @@ __device__ __forceinline__ void gh_sum_records(uint32_t o0, uint32_t o1, const f
 // and G = 1.
 // GEOM = false (no gradient w.r.t. means / scales / rotations / means2D / xyz_b is asked for — the one-shot fit trains colour
 // and opacity biases only): the chain rule through the projection is skipped and the kernel only sums over the views.
+// The same for a call that wants no geometry gradient (the one-shot fit: colour and opacity only): of the nine moments only
+// sum h (opacity) and the three colour moments are read — the last 16 bytes of a 36-byte sub-record, one load instead of three —
+// two emit slots per trip.
+struct GhF4u { float x, y, z, w; };                      // 16-byte access at 4-byte alignment (global_load_dwordx4)
+__device__ __forceinline__ void gh_sum_records_colour(uint32_t o0, uint32_t o1, const float* __restrict__ inst_grad,
+                                                      const uint32_t* __restrict__ inst_flag, float* s9) {
+  double acc[4] = {0, 0, 0, 0};
+  uint32_t fl0 = o0 < o1 ? inst_flag[o0] : 0u, fl1 = o0 + 1 < o1 ? inst_flag[o0 + 1] : 0u;
+  for (uint32_t sl = o0; sl < o1; sl += 2) {
+    const uint32_t f0 = fl0, f1 = fl1;
+    fl0 = sl + 2 < o1 ? inst_flag[sl + 2] : 0u;
+    fl1 = sl + 3 < o1 ? inst_flag[sl + 3] : 0u;
+    GhF4u r[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t f = i ? f1 : f0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((f >> (8 * q)) & 1u) r[i][q] = *(const GhF4u*)(inst_grad + ((size_t)(sl + i) * 4 + q) * GH_REC_G + 5);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t f = i ? f1 : f0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if ((f >> (8 * q)) & 1u) {
+          acc[0] += (double)r[i][q].x; acc[1] += (double)r[i][q].y; acc[2] += (double)r[i][q].z; acc[3] += (double)r[i][q].w;
+        }
+      }
+    }
+  }
+  s9[5] = (float)acc[0]; s9[6] = (float)acc[1]; s9[7] = (float)acc[2]; s9[8] = (float)acc[3];
+}
+
 // FUSED (RGB_MODE only): the sums come straight from the render backward's sub-records (gh_sum_records). A split call's second
 // half keeps its per-instance arrays cap_a entries further on (views >= v_split; unsplit: v_split = NV).
 template <bool RGB_MODE, bool GEOM, bool FUSED>
@@ -318,7 +352,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
         uint32_t o0 = slot_begin[n], o1 = o0 + tt;
         if (o1 > capv) o1 = capv;
         if (o0 > o1) o0 = o1;
-        gh_sum_records(off + o0, off + o1, inst_grad, inst_flag, s9);
+        if (GEOM) gh_sum_records(off + o0, off + o1, inst_grad, inst_flag, s9);
+        else gh_sum_records_colour(off + o0, off + o1, inst_grad, inst_flag, s9);
       }
     } else if (vis) {
       const float4* r = gsum + n * 3;
@@ -524,12 +559,17 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   int lg = 0;                                            // lanes per row: the smallest power of two >= n_views, at most 64
   if (!per_view) while ((1 << lg) < g.NV && lg < 6) ++lg;
   int nblk = (int)((((size_t)rows << lg) + GH_BLOCK - 1) / GH_BLOCK);   // <= 2 N / 256 + 1: bwd_scratch holds 64 floats per block
-  const bool geom = gr->dL_dmeans3D || gr->dL_dmeans2D || gr->dL_dscales || gr->dL_drotations || (in->blend_xyz_b && gr->dL_dblend_xyz_b);
+  const bool geom = gh_wants_geometry(in, gr);
   // colours precomputed: only the chain-rule kernel reads the record sums, and it takes them itself (FUSED); SH colours:
   // gh_sh_colour_bwd2_kernel reads the colour moments first, so the sums are a kernel of their own
-  const bool fused = in->colors_precomp != nullptr;
-  auto kern = fused ? (geom ? gh_preprocess_bwd_kernel<true, true, true> : gh_preprocess_bwd_kernel<true, false, true>)
-                    : (geom ? gh_preprocess_bwd_kernel<false, true, false> : gh_preprocess_bwd_kernel<false, false, false>);
+  // — up to half a megapixel per view: a lane of the fused form reads all the instances of its (view, Gaussian) one after the
+  // other, and their number grows with the image (3.8 on average at 512x334: 93.6 -> 80.9 us fused; 8.6 at 1024x1024: 156 ->
+  // 164 us). The image size decides, so every call of a shape (and both halves of a split call) takes the same path.
+  const bool rgb = in->colors_precomp != nullptr;
+  const bool fused = rgb && (size_t)g.H * (size_t)g.W <= ((size_t)1 << 19);
+  auto kern = rgb ? (fused ? (geom ? gh_preprocess_bwd_kernel<true, true, true> : gh_preprocess_bwd_kernel<true, false, true>)
+                           : (geom ? gh_preprocess_bwd_kernel<true, true, false> : gh_preprocess_bwd_kernel<true, false, false>))
+                  : (geom ? gh_preprocess_bwd_kernel<false, true, false> : gh_preprocess_bwd_kernel<false, false, false>);
   const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
   if ((parts & GH_PBWD_RECORD_SUM) && !fused)
     hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,

@@ -424,7 +424,8 @@ struct GhBwdEntry {            // one list entry in the lane's registers
 // One batch: cnt <= L entries (lane % L = index from the back), 64 / L pixels per iteration. am: the block's pixels that
 // blend into the batch (bit i = pixel i of the block, wave-uniform); pix_base: LDS record index of the block's pixel 0.
 // Adds the lane's nine sums into acc[9]; returns whether some pixel blended the lane's entry.
-template <int L>
+// GEOM = false (no gradient w.r.t. the geometry is wanted — the one-shot fit): the five position / conic moments are left out.
+template <int L, bool GEOM>
 __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, uint32_t am_in, int pix_base, int lane,
                                              float4* s_pix, float (&acc)[9]) {
   constexpr int NPX = GH_WAVE / L;
@@ -481,8 +482,10 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     const float dLda = Tk * ec - rm1 * (S - we);
     const float h = contrib ? G * dLda : 0.0f;        // raw moments of h = G dL/dalpha; opacity / conic factors are applied
     const float hx = h * dx, hy = h * dy;             // once per (view, Gaussian) by gh_preprocess_bwd_kernel
-    acc[0] += hx; acc[1] += hy;
-    acc[2] = fmaf(hx, dx, acc[2]); acc[3] = fmaf(hx, dy, acc[3]); acc[4] = fmaf(hy, dy, acc[4]);
+    if (GEOM) {
+      acc[0] += hx; acc[1] += hy;
+      acc[2] = fmaf(hx, dx, acc[2]); acc[3] = fmaf(hx, dy, acc[3]); acc[4] = fmaf(hy, dy, acc[4]);
+    }
     acc[5] += h;
     // state in front of the batch: the group's last lane holds the totals (lanes past the count: factor 1, weight 0)
     if (seg_last) *(float2*)&s_pix[2 * pcur] = make_float2(Tk, S);
@@ -493,7 +496,8 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
 // NW = waves per workgroup. 1: a wave walks the quadrant's four blocks one after the other. 4 (small launches: one or two
 // views leave most of the 256 CUs idle and the longest quadrant IS the kernel): the quadrant's four blocks run in four
 // waves of one workgroup, each with its own accumulator rows, and are combined in fixed wave order behind one barrier.
-template <bool ALPHA, int NW>
+// GEOM = false: sub-records carry sum h and the three colour moments only (their last 16 bytes; the rest is not written).
+template <bool ALPHA, int NW, bool GEOM>
 __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ items, const GhCounters* __restrict__ ctr,
     const uint32_t* __restrict__ sorted_slot,
@@ -650,9 +654,9 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
         float acc[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         bool any = false;
         if (am) {
-          if (L == 64) any = gh_bwd_batch<64>(e, valid, am, 16 * b, lane, s_pix, acc);
-          else if (L == 32) any = gh_bwd_batch<32>(e, valid, am, 16 * b, lane, s_pix, acc);
-          else any = gh_bwd_batch<16>(e, valid, am, 16 * b, lane, s_pix, acc);
+          if (L == 64) any = gh_bwd_batch<64, GEOM>(e, valid, am, 16 * b, lane, s_pix, acc);
+          else if (L == 32) any = gh_bwd_batch<32, GEOM>(e, valid, am, 16 * b, lane, s_pix, acc);
+          else any = gh_bwd_batch<16, GEOM>(e, valid, am, 16 * b, lane, s_pix, acc);
         }
         // The lane groups of a 32- / 16-lane batch hold partial sums of the SAME entries (different pixels): fold them into
         // group 0 (fixed order). Then plain read-modify-write of the entry's accumulator row: the wave owns the rows and the
@@ -660,18 +664,18 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
         int anyi = any ? 1 : 0;
         if (L < 64) {
 #pragma unroll
-          for (int q = 0; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 32);
+          for (int q = GEOM ? 0 : 5; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 32);
           anyi |= __shfl_xor(anyi, 32);
           if (L < 32) {
 #pragma unroll
-            for (int q = 0; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 16);
+            for (int q = GEOM ? 0 : 5; q < GH_REC; ++q) acc[q] += __shfl_xor(acc[q], 16);
             anyi |= __shfl_xor(anyi, 16);
           }
         }
         if (lane < L && anyi) {                                       // lane's entry was blended by some pixel of the block
           float* d = s_acc + ci * GH_REC;
 #pragma unroll
-          for (int q = 0; q < GH_REC; ++q) d[q] += acc[q];
+          for (int q = GEOM ? 0 : 5; q < GH_REC; ++q) d[q] += acc[q];
           ((volatile uint8_t*)s_f)[ci] = 1;
         }
         __builtin_amdgcn_wave_barrier();
@@ -692,14 +696,16 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
           any = true;
           const float* a9 = s_acc_all[w] + crow[k] * GH_REC;
 #pragma unroll
-          for (int q = 0; q < GH_REC; ++q) s9[q] += a9[q];
+          for (int q = GEOM ? 0 : 5; q < GH_REC; ++q) s9[q] += a9[q];
         }
       }
       if (any) {
         const uint32_t sl = slots[seg_lo + k * GH_WAVE + lane];
         GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC_G);
-        rec[0] = GhF3{s9[0], s9[1], s9[2]};
-        rec[1] = GhF3{s9[3], s9[4], s9[5]};
+        if (GEOM) {
+          rec[0] = GhF3{s9[0], s9[1], s9[2]};
+          rec[1] = GhF3{s9[3], s9[4], s9[5]};
+        } else ((float*)rec)[5] = s9[5];
         rec[2] = GhF3{s9[6], s9[7], s9[8]};
         inst_flag[(size_t)sl * 4 + quad] = 1;
       }
@@ -710,7 +716,8 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
 }
 
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
-                          const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s) {
+                          const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s,
+                          bool geom) {
   if (g.cap == 0) return;
   // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (they depend on the forward's
   // n_contrib only). The work list (tile, depth segment) was written by the forward's last wave of every tile.
@@ -725,8 +732,14 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                        (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, upstream_scale, (float*)(ws + L.inst_grad),
                        (uint8_t*)(ws + L.inst_flag));
   };
-  if (small) { if (dL_dalpha) launch(gh_render_bwd_kernel<true, 4>); else launch(gh_render_bwd_kernel<false, 4>); }
-  else { if (dL_dalpha) launch(gh_render_bwd_kernel<true, 1>); else launch(gh_render_bwd_kernel<false, 1>); }
+  // geom = false (precomputed colours and no geometry gradient wanted): colour / opacity moments only, see the kernel
+  if (small) {
+    if (geom) { if (dL_dalpha) launch(gh_render_bwd_kernel<true, 4, true>); else launch(gh_render_bwd_kernel<false, 4, true>); }
+    else { if (dL_dalpha) launch(gh_render_bwd_kernel<true, 4, false>); else launch(gh_render_bwd_kernel<false, 4, false>); }
+  } else {
+    if (geom) { if (dL_dalpha) launch(gh_render_bwd_kernel<true, 1, true>); else launch(gh_render_bwd_kernel<false, 1, true>); }
+    else { if (dL_dalpha) launch(gh_render_bwd_kernel<true, 1, false>); else launch(gh_render_bwd_kernel<false, 1, false>); }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -187,7 +187,9 @@ typedef struct GhLayout {
   size_t sh_rgb;         /* float4[n_views*P] SH colour stage output (r, g, b, clamp-flag bits); unused with colors_precomp */
   size_t dmean_sh;       /* float4[n_views*P] d(loss)/d(mean) through the SH view direction (backward scratch) */
   size_t sh_scratch;     /* float[ceil(P/16)][64] block partials of the global colour-weight gradient (SH mode) */
-  size_t grad_sums;      /* float4[n_views*P][3] per-(view,Gaussian) sums of the sub-records: dpx dpy dA dB | dC do dr dg | db */
+  size_t grad_sums;      /* float4[n_views*P][3] per-(view,Gaussian) sums of the sub-records: dpx dpy dA dB | dC do dr dg | db
+                            (a kernel of its own writes them for SH colours and above half a megapixel per view; otherwise the
+                            chain-rule kernel keeps them in registers) */
   size_t bwd_scratch;    /* blend-parameter reduction scratch */
   size_t cull_bound;     /* float [n_views*P]  opacity every (view, Gaussian)'s tiles were culled with (+inf: no rect); the guard of
                             gh_forward_refresh compares the current opacity with it */
