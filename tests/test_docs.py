@@ -25,3 +25,12 @@ def test_profiles_share_one_source_hash():
     b = json.load(open(os.path.join(ROOT, "profiles", "r3_bench_default.json")))
     # the committed bench line quotes counters of its own build (null + the reason otherwise)
     assert b["roofline"]["traffic"] is not None and tr["source_hash"] in b["roofline"]["traffic_source"]
+
+
+def test_profiles_were_measured_on_the_committed_sources():
+    """A source change after the last `tools/refresh_profiles.sh` leaves bench.py without counters to quote (it reports
+    `traffic: null` and why): the committed profiles must carry the hash of the committed HIP sources + C header."""
+    sys.path.insert(0, ROOT)
+    import bench
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")))
+    assert tr["source_hash"] == bench.source_hash(), "sources changed since profiles/ were refreshed: bash tools/refresh_profiles.sh r3"
