@@ -534,19 +534,41 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
       vals[slot] = g.w;                                  // the emit slot is recomputed from (n, tile) after the sort
     }
   }
-  if (i >= N || cnt == 0 || small) return;
-  uint32_t off = wave_base + x - cnt;
-  // (C, opacity): the projection kernel's operands — the opacity it culled with (GH_FLAG_STATIC_LISTS: gh_static_cull_opacity)
-  const float4 g0 = grec[0], g1 = make_float4(grec[1].x, (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(grec[1].y) : grec[1].y, 0.0f, 0.0f);
-  for (int ty = miny; ty < maxy; ++ty)
-    for (int tx = minx; tx < maxx; ++tx) {
-      if (!gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1))) continue;
-      if (off < cap) {
-        keys[off] = vbase + (uint32_t)(ty * gx + tx);
-        vals[off] = n;
+  // Rects larger than the hit mask: the culling test again, by the WAVE for one such Gaussian at a time (64 tiles per trip,
+  // the hits of a trip take consecutive slots in tile order), not by the Gaussian's own lane with the other 63 waiting.
+  const bool bigl = i < N && cnt != 0 && !small;
+  for (uint64_t m = gh_ballot(bigl); m != 0ull; m &= m - 1ull) {
+    const int src = (int)__builtin_ctzll(m);
+    auto bf = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+    const float4 g0v = grec[0], g1v = grec[1];          // (every lane reads its own line; the source lane's values are broadcast)
+    const float4 s0 = make_float4(bf(g0v.x), bf(g0v.y), bf(g0v.z), bf(g0v.w));
+    const float sop = bf(g1v.y);
+    // (C, opacity): the projection kernel's operands — the opacity it culled with (GH_FLAG_STATIC_LISTS: gh_static_cull_opacity)
+    const float4 s1 = make_float4(bf(g1v.x), (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(sop) : sop, 0.0f, 0.0f);
+    const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)r, src);
+    const uint32_t sminx = sr & 255u, sminy = (sr >> 8) & 255u, sw = ((sr >> 16) & 255u) - sminx, sn = sw * ((sr >> 24) - sminy);
+    const uint32_t sn_id = (uint32_t)__builtin_amdgcn_readlane((int)n, src), svb = (uint32_t)__builtin_amdgcn_readlane((int)vbase, src);
+    uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)(wave_base + x - cnt), src);
+    for (uint32_t base = 0; base < sn; base += GH_WAVE) {
+      const uint32_t k = base + (uint32_t)lane;
+      bool h = false;
+      uint32_t tx = 0, ty = 0;
+      if (k < sn) {
+        const uint32_t dy = k / sw;
+        ty = sminy + dy; tx = sminx + (k - dy * sw);
+        h = gh_block_hit(s0, s1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
       }
-      ++off;
+      const uint64_t hm = gh_ballot(h);
+      if (h) {
+        const uint32_t slot = off + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+        if (slot < cap) {
+          keys[slot] = svb + ty * (uint32_t)gx + tx;
+          vals[slot] = sn_id;
+        }
+      }
+      off += (uint32_t)__popcll(hm);
     }
+  }
 }
 
 // Per sorted instance: tile ranges, the render record gathered from the Gaussian's 64-byte geometry line, and the
@@ -592,17 +614,48 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   const uint32_t r = __float_as_uint(c.y);
   const uint32_t minx = r & 255u, miny = (r >> 8) & 255u, maxx = (r >> 16) & 255u, maxy = r >> 24;
   const uint32_t bit = (ty - miny) * (maxx - minx) + (tx - minx);
-  uint32_t before;
-  if ((maxx - minx) * (maxy - miny) <= 64u) {
+  uint32_t before = 0;
+  const bool small = (maxx - minx) * (maxy - miny) <= 64u;
+  if (small) {
     const unsigned long long hm = ((unsigned long long)__float_as_uint(c.w) << 32) | __float_as_uint(c.z);
     before = (uint32_t)__popcll(hm & ((1ull << bit) - 1ull));
-  } else {                                              // rect larger than the mask: recount (rare, huge footprints)
-    before = 0;
-    uint32_t k = 0;
-    const float4 bc = make_float4(b.x, (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(b.y) : b.y, 0.0f, 0.0f);   // as culled
-    for (uint32_t yy = miny; yy < maxy && k < bit; ++yy)
-      for (uint32_t xx = minx; xx < maxx && k < bit; ++xx, ++k)
-        before += gh_block_hit(a, bc, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
+  }
+  // Rects larger than the hit mask (huge footprints): the tiles in front of this one are counted again with the culling test,
+  // by the WAVE for one such instance at a time — 64 tiles per trip — where the instance's own lane took one tile per trip with
+  // the other 63 lanes waiting (at 1024x1024 0.04 % of the instances cost 8 % of the kernel that way).
+  const uint64_t bigm = gh_ballot(!small);
+  if (bigm != 0ull) {
+    if (gh_ballot(true) == ~0ull) {
+      const int lane = threadIdx.x & 63;
+      uint64_t m = bigm;
+      while (m != 0ull) {
+        const int src = (int)__builtin_ctzll(m);
+        m &= m - 1ull;
+        auto bf = [&](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); };
+        const float4 sa = make_float4(bf(a.x), bf(a.y), bf(a.z), bf(a.w));
+        const float sop = bf(b.y);
+        const float4 sbc = make_float4(bf(b.x), (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(sop) : sop, 0.0f, 0.0f);   // as culled
+        const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)r, src), sbit = (uint32_t)__builtin_amdgcn_readlane((int)bit, src);
+        const uint32_t sminx = sr & 255u, sminy = (sr >> 8) & 255u, sw = ((sr >> 16) & 255u) - sminx;
+        uint32_t cnt = 0;
+        for (uint32_t base = 0; base < sbit; base += GH_WAVE) {
+          const uint32_t k = base + (uint32_t)lane;
+          bool h = false;
+          if (k < sbit) {
+            const uint32_t dy = k / sw, dx = k - dy * sw;
+            h = gh_block_hit(sa, sbc, (float)((sminx + dx) * GH_TILE), (float)((sminy + dy) * GH_TILE), (float)(GH_TILE - 1));
+          }
+          cnt += (uint32_t)__popcll(gh_ballot(h));
+        }
+        if (lane == src) before = cnt;
+      }
+    } else if (!small) {                                // (the last, partial wave: lane by lane)
+      uint32_t k = 0;
+      const float4 bc = make_float4(b.x, (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(b.y) : b.y, 0.0f, 0.0f);   // as culled
+      for (uint32_t yy = miny; yy < maxy && k < bit; ++yy)
+        for (uint32_t xx = minx; xx < maxx && k < bit; ++xx, ++k)
+          before += gh_block_hit(a, bc, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
+    }
   }
   sorted_slot[i] = slot0 + before;
   const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));

@@ -21,25 +21,31 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     ctr->num_rendered = 0; ctr->overflow = 0; ctr->reserved[0] = (uint32_t)N; ctr->reserved[1] = 0;
   }
   if (t < T) { ranges[t] = make_uint2(0u, 0u); tile_walk[t] = 0u; tile_walk[T + t] = 0u; }   // per-tile state of the later stages
+  // Per-lane state that crosses the wave-cooperative tile count below
+  uint32_t dkey = 0xFFFFFFFFu;                          // culled Gaussians sort behind everything and emit nothing
+  unsigned rect_bits = 0;
+  int n = 0, i = 0, radius = 0;
+  float cull_bound = __uint_as_float(0x7F800000u);      // +inf: no tile can be missing for a Gaussian without a rect
+  float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = g0;   // (px, py, A, B), (C, culling opacity): operands of the tile test
+  float op = 0.0f, tz = 0.0f;
+  int minx = 0, miny = 0, maxx = 0, maxy = 0;
+  unsigned long long hitmask = 0ull;
+  bool big = false;                                     // rect of more than 64 tiles: counted by the wave
   if (t < N) {
-    uint32_t dkey = 0xFFFFFFFFu;                        // culled Gaussians sort behind everything and emit nothing
-    unsigned rect_bits = 0;
     // Thread -> (Gaussian row i, view v). Shared Gaussians: GAUSSIAN-major, the NV views of a row in adjacent lanes, so the
     // row's attributes (and its 192-byte blend rows) reach the wave once per Gaussian instead of once per (view, Gaussian)
     // — the views' loads of one row coalesce into one request. Every per-(view, Gaussian) output is a whole 64-byte line or
     // a 4-byte element of a view-major array (n = v * P + i): consecutive rows of a view stay adjacent in memory.
     // Pose batch (own rows per view): n = t, row = n.
-    int v, i;
+    int v;
     // (rdiv = 1 / divisor where gh_div_small's range allows it: a run-time integer division costs ~40 instructions)
     if (flags & GH_FLAG_PER_VIEW_GAUSSIANS) { v = rdiv > 0.0f ? (int)gh_div_small((uint32_t)t, (uint32_t)P, rdiv) : t / P; i = t; }
     else { i = rdiv > 0.0f ? (int)gh_div_small((uint32_t)t, (uint32_t)NV, rdiv) : t / NV; v = t - i * NV; }
-    const int n = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : v * P + i;
+    n = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : v * P + i;
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
-    int radius = 0;
-    float cull_bound = __uint_as_float(0x7F800000u);    // +inf: no tile can be missing for a Gaussian without a rect
     GhGeo e;
     gh_geo_forward(in, cam, i, mod, H, W, e);
-    bool ok = (e.tz > 0.2f) && (e.det != 0.0f);
+    const bool ok = (e.tz > 0.2f) && (e.det != 0.0f);
     if (ok) {
       float dinv = 1.0f / e.det;
       float mid = 0.5f * (e.a + e.c);
@@ -49,52 +55,74 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
       float ndcx = e.hx * e.winv, ndcy = e.hy * e.winv;
       float px = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
       float py = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
-      int minx = (int)((px - (float)rad) / (float)GH_TILE); minx = minx < 0 ? 0 : (minx > gx ? gx : minx);
-      int miny = (int)((py - (float)rad) / (float)GH_TILE); miny = miny < 0 ? 0 : (miny > gy ? gy : miny);
-      int maxx = (int)((px + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
-      int maxy = (int)((py + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
+      minx = (int)((px - (float)rad) / (float)GH_TILE); minx = minx < 0 ? 0 : (minx > gx ? gx : minx);
+      miny = (int)((py - (float)rad) / (float)GH_TILE); miny = miny < 0 ? 0 : (miny > gy ? gy : miny);
+      maxx = (int)((px + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
+      maxy = (int)((py + (float)rad + (float)(GH_TILE - 1)) / (float)GH_TILE); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
       int cnt = (maxx - minx) * (maxy - miny);
-      if (cnt > 0) rect_bits = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);
-      float op = 0.0f;
-      unsigned long long hitmask = 0ull;
       if (cnt > 0) {
+        rect_bits = (unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24);
         radius = rad;                                   // API output: the reference's 3-sigma radius (App. A.1-6)
         op = in.opacities[i];
         if (in.blend_opacity_b) op = op + in.blend_opacity_b[i];
         // GH_FLAG_STATIC_LISTS: the lists outlive this call's opacities (gh_forward_refresh): cull with a bound above them
         const float op_cull = (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(op) : op;
         cull_bound = op_cull;
+        tz = e.tz;
         // Exact tile culling: of the tiles in the 3-sigma rect only those are instanced in which the alpha >= 1/255
         // ellipse reaches a pixel centre (gh_block_hit, conservative within its margin). A dropped tile holds no pixel
         // that would blend this Gaussian, so images and gradients are unchanged; gh_emit_kernel repeats this test.
-        const float4 g0 = make_float4(px, py, e.c * dinv, -e.b * dinv), g1 = make_float4(e.a * dinv, op_cull, 0.0f, 0.0f);
-        int bit = 0;                                    // row-major position in the rect; rects of <= 64 tiles keep the
-        for (int ty = miny; ty < maxy; ++ty)            // hit mask so that the emit kernel does not repeat the tests
-          for (int tx = minx; tx < maxx; ++tx, ++bit) {
-            const bool h = gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
-            tiles += h ? 1u : 0u;
-            if (h && bit < 64) hitmask |= 1ull << bit;
-          }
+        g0 = make_float4(px, py, e.c * dinv, -e.b * dinv); g1 = make_float4(e.a * dinv, op_cull, 0.0f, 0.0f);
+        if (cnt <= 64) {
+          int bit = 0;                                  // row-major position in the rect; rects of <= 64 tiles keep the
+          for (int ty = miny; ty < maxy; ++ty)          // hit mask so that the emit kernel does not repeat the tests
+            for (int tx = minx; tx < maxx; ++tx, ++bit) {
+              const bool h = gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
+              tiles += h ? 1u : 0u;
+              if (h) hitmask |= 1ull << bit;
+            }
+        } else big = true;
       }
-      if (tiles > 0) {
-        float rgb[3];
-        unsigned cl = 0;
-        if (in.colors_precomp) {
-          gh_blended_rgb(in, flags, i, rgb);
-        } else {                                       // SH colours: evaluated by gh_sh_colour_fwd_kernel (gh_sh.hip)
-          const float4 c4 = sh_rgb[n];
-          rgb[0] = c4.x; rgb[1] = c4.y; rgb[2] = c4.z; cl = __float_as_uint(c4.w);
-        }
-        float4* grec = geom + (size_t)n * 4;           // one 64-byte line per Gaussian
-        grec[0] = make_float4(px, py, e.c * dinv, -e.b * dinv);
-        grec[1] = make_float4(e.a * dinv, op, rgb[0], rgb[1]);
-        // .y = packed tile rect, .zw = tile hit mask: the post-sort gather reads one line
-        grec[2] = make_float4(rgb[2], __uint_as_float((unsigned)minx | ((unsigned)miny << 8) | ((unsigned)maxx << 16) | ((unsigned)maxy << 24)),
-                              __uint_as_float((unsigned)hitmask), __uint_as_float((unsigned)(hitmask >> 32)));
-        depth[n] = e.tz;
-        dkey = __float_as_uint(e.tz);                   // tz > 0.2: positive floats order like their bit patterns
-        clamped[n] = (uint8_t)cl;
+    }
+  }
+  // Rects of more than 64 tiles (huge footprints; no hit mask is kept for them): counted by the WAVE, one such Gaussian at a
+  // time, 64 tiles per trip — its own lane would take one tile per trip with the other 63 waiting.
+  for (uint64_t m = gh_ballot(big); m != 0ull; m &= m - 1ull) {
+    const int src = (int)__builtin_ctzll(m), lane = threadIdx.x & 63;
+    auto bf = [&](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src)); };
+    const float4 s0 = make_float4(bf(g0.x), bf(g0.y), bf(g0.z), bf(g0.w)), s1 = make_float4(bf(g1.x), bf(g1.y), 0.0f, 0.0f);
+    const int sminx = __builtin_amdgcn_readlane(minx, src), sminy = __builtin_amdgcn_readlane(miny, src);
+    const int sw = __builtin_amdgcn_readlane(maxx, src) - sminx, sn = sw * (__builtin_amdgcn_readlane(maxy, src) - sminy);
+    unsigned cnt = 0;
+    for (int base = 0; base < sn; base += GH_WAVE) {
+      const int k = base + lane;
+      bool h = false;
+      if (k < sn) {
+        const int dy = k / sw, dx = k - dy * sw;
+        h = gh_block_hit(s0, s1, (float)((sminx + dx) * GH_TILE), (float)((sminy + dy) * GH_TILE), (float)(GH_TILE - 1));
       }
+      cnt += (unsigned)__popcll(gh_ballot(h));
+    }
+    if (lane == src) tiles = cnt;
+  }
+  if (t < N) {
+    if (tiles > 0) {
+      float rgb[3];
+      unsigned cl = 0;
+      if (in.colors_precomp) {
+        gh_blended_rgb(in, flags, i, rgb);
+      } else {                                       // SH colours: evaluated by gh_sh_colour_fwd_kernel (gh_sh.hip)
+        const float4 c4 = sh_rgb[n];
+        rgb[0] = c4.x; rgb[1] = c4.y; rgb[2] = c4.z; cl = __float_as_uint(c4.w);
+      }
+      float4* grec = geom + (size_t)n * 4;           // one 64-byte line per Gaussian
+      grec[0] = g0;
+      grec[1] = make_float4(g1.x, op, rgb[0], rgb[1]);
+      // .y = packed tile rect, .zw = tile hit mask: the post-sort gather reads one line
+      grec[2] = make_float4(rgb[2], __uint_as_float(rect_bits), __uint_as_float((unsigned)hitmask), __uint_as_float((unsigned)(hitmask >> 32)));
+      depth[n] = tz;
+      dkey = __float_as_uint(tz);                     // tz > 0.2: positive floats order like their bit patterns
+      clamped[n] = (uint8_t)cl;
     }
     // .x = instance count: the emit kernel, which walks the Gaussians in depth order, finds it in the line it reads anyway
     // (written for every Gaussian: a culled one keeps a stale line from an earlier call apart from this float4)

@@ -274,7 +274,8 @@ int gh_backward_shared(const GhDims* dims, const GhInputs* in, const GhGrads* gr
  * exactly like an instance overflow — rebuild the lists with a full gh_forward.
  * gh_backward_refresh: gradients w.r.t. whatever `grads` asks for; with every geometry gradient pointer (dL_dmeans3D,
  * dL_dmeans2D, dL_dscales, dL_drotations, dL_dblend_xyz_b) NULL the per-Gaussian chain rule reduces to sums over the views
- * (the fit trains colour / opacity biases only).
+ * (the fit trains colour / opacity biases only), and — with precomputed colours, in gh_backward as well — the list walk leaves
+ * the position / conic moments out of its sub-records.
  */
 int gh_forward_refresh(const GhDims* dims, const GhInputs* in, const GhOutputs* out, const void* geometry_ws,
                        void* workspace, size_t ws_bytes, void* hip_stream);
