@@ -334,8 +334,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ sh_rgb, const float4* __restrict__ gsum,
     float4* __restrict__ dmean_sh, float* __restrict__ scratch) {
   extern __shared__ float s_rows[];
-  __shared__ float s_B[GH_BLOCK][17];                   // basis of pair p (0 where the pair contributes nothing), padded rows
-  __shared__ float s_g[GH_BLOCK][3];                    // masked dL/drgb of pair p
+  // basis of pair p (0 where the pair contributes nothing; padded rows) and masked dL/drgb of pair p. STAGED: they take the place
+  // of the staged rows once phase 1 has read those (the 50 KB of rows + 20 KB of these allowed two workgroups per CU, 50 KB three)
+  __shared__ float s_B_own[STAGED ? 1 : GH_BLOCK][17];
+  __shared__ float s_g_own[STAGED ? 1 : GH_BLOCK][3];
+  float (*s_B)[17] = STAGED ? (float (*)[17])s_rows : s_B_own;
+  float (*s_g)[3] = STAGED ? (float (*)[3])(s_rows + GH_BLOCK * 17) : s_g_own;
   __shared__ float s_cw[GH_BLOCK / 16][48];
   const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   const int nv = per_view ? 1 : NV;                     // views per row of the attribute arrays
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
         dmean_sh[n] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
     }
+    if (STAGED) __syncthreads();                          // every lane has taken its coefficients out of s_rows
 #pragma unroll
     for (int k = 0; k < 16; ++k) s_B[tid][k] = vis ? Bv[k] : 0.0f;
     s_g[tid][0] = g[0]; s_g[tid][1] = g[1]; s_g[tid][2] = g[2];
