@@ -592,7 +592,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   if ((blockIdx.x >> 3) >= chunk) return;
   const uint32_t i = ((blockIdx.x & 7u) * chunk + (blockIdx.x >> 3)) * GH_BLOCK + threadIdx.x;
   if (i >= n) return;
-  inst_flag[i] = 0;                                    // quadrant flags of the backward's sub-records (emit slots 0 .. D-1)
+  gh_stream(&inst_flag[i], 0u);                        // quadrant flags of the backward's sub-records (emit slots 0 .. D-1)
   const uint32_t t = keys[i];
   if (i == 0) ranges[t].x = 0;
   else {
@@ -657,10 +657,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
           before += gh_block_hit(a, bc, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
     }
   }
-  sorted_slot[i] = slot0 + before;
+  gh_stream(&sorted_slot[i], slot0 + before);           // (streamed: see gh_stream)
   const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
-  r0[i] = a; r1[i] = b; r2[i] = make_float2(cb, __uint_as_float(m));
-  if (flags & GH_FLAG_STATIC_LISTS) inst_c[i] = b.x;   // the conic's C again, compact: what gh_forward_refresh reads of r1
+  gh_stream(&r0[i], a); gh_stream(&r1[i], b); gh_stream(&r2[i], make_float2(cb, __uint_as_float(m)));
+  if (flags & GH_FLAG_STATIC_LISTS) gh_stream(&inst_c[i], b.x);   // the conic's C again, compact: what gh_forward_refresh reads of r1
 }
 
 // Longest-processing-time-first launch order for the render kernels: a counting sort of the tiles by list length (256
