@@ -225,7 +225,7 @@ def main():
                          "step are split over the ranks (BASELINE configs[3]: 8 novel views sharded over 8 GPUs = 1 view per GPU)")
     ap.add_argument("--split-streams", default="off", choices=["off", "on", "auto"],
                     help="GH_FLAG_SPLIT_STREAMS: render the step's views as two halves on two HIP streams inside the library "
-                         "(bit-identical results); auto = from 4 views per rank up")
+                         "(bit-identical results); auto = from 4 views of more than half a megapixel per rank up")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of --steps steps each; `value` / `ms_per_step` are the FIRST window's (the contract's exactly-K "
                          "steps), the others are reported as repeat statistics")

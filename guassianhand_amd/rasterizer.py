@@ -205,12 +205,13 @@ def set_graph_mode(on: bool) -> None:
 
 
 _split_policy = False       # False | True | "auto"
-_SPLIT_AUTO_MIN_VIEWS = 4
+_SPLIT_AUTO_MIN_PIXELS = 1 << 19   # "auto": where the split measured a gain (1024x1024 x 8 views: +4.9 %; 512x334: 8 views -1 %, 16 views +0.8 %)
 
 
 def set_split_streams(mode) -> None:
     """Module policy for calls that do not say (split_streams=None): False = one stream, True = split whenever n_views >= 2,
-    "auto" = split from 4 views up (GH_FLAG_SPLIT_STREAMS; results are bit-identical either way)."""
+    "auto" = split where it measured a gain: four or more views of more than half a megapixel each (GH_FLAG_SPLIT_STREAMS;
+    results are bit-identical either way)."""
     global _split_policy
     if mode not in (False, True, "auto"):
         raise ValueError("set_split_streams: False, True or 'auto'")
@@ -378,7 +379,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         flags |= _abi.GH_FLAG_PER_VIEW_GAUSSIANS
     P = rows // NV if per_view_gaussians else rows
     if split_streams is None:
-        split_streams = _split_policy is True or (_split_policy == "auto" and NV >= _SPLIT_AUTO_MIN_VIEWS)
+        split_streams = _split_policy is True or (_split_policy == "auto" and NV >= 4 and H * W > _SPLIT_AUTO_MIN_PIXELS)
     split = bool(split_streams) and NV >= 2 and P > 0 and geometry_of is None and refresh_of is None and not static_lists \
         and not _stage_timing
     if split:

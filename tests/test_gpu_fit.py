@@ -301,7 +301,7 @@ def test_device_side_overflow_guard_keeps_a_sync_free_fit_from_stepping_on_garba
     args = (pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
     ref = mk()
     l_ref = float(ref.step(*args, sync=True))
-    key = R.capacity_key(600, 4, 64, 64, split=R._split_policy is True or R._split_policy == "auto")
+    key = R.capacity_key(600, 4, 64, 64, split=R._split_policy is True)             # ("auto" does not split 64x64 views)
     good_cap = R._capacity[key]
     f = mk()
     before = {k: a.param.clone() for k, a in f._adam.items()}
