@@ -80,6 +80,7 @@ def numbers() -> str:
          f"| two hands 1024², SH degree 3 (configs[4] shape), 8 views/step; dominant kernel `{hd['roofline']['kernel']}` {hd['roofline']['frac']:.3f} of 8 TB/s, counter traffic {hd['roofline']['traffic'] / 1e6:.0f} MB | {hd['value']:,.0f} | {hd['ms_per_step']:.2f} | 4,880 / 1.64 |",
          f"| same with `--split-streams on` (bit-identical) | {B('hd_sh3_split')['value']:,.0f} | {B('hd_sh3_split')['ms_per_step']:.2f} | — |",
          f"| same, **32 different poses per step** (configs[4]'s batch: `--pose-batch --views-per-step 32`); dominant kernel `{pb['roofline']['kernel']}` {pb['roofline']['frac']:.3f} of 8 TB/s, counter traffic {pb['roofline']['traffic'] / 1e9:.2f} GB | {pb['value']:,.0f} | {pb['ms_per_step']:.2f} | 4,390 / 7.29 |",
+         f"| same with `--split-streams on` (bit-identical) | {B('hd_sh3_pose32_split')['value']:,.0f} | {B('hd_sh3_pose32_split')['ms_per_step']:.2f} | — |",
          f"| 1k random Gaussians, 128², 1 view (configs[0]) | {rk['value']:,.0f} | {rk['ms_per_step']:.3f} | — |",
          f"| reference protocol through the drop-in (2 rasteriser calls per view), per view fwd+bwd (`tools/two_call_cost.py`; the bench line's own harness: {d['config']['two_call_ms_per_view']:.2f}) | — | {two} (host-bound) | 0.57–0.82 by box |",
          f"| full-size one-shot fit step, 8 views (fused α, 1024×2048 maps, active texels, static geometry, captured graph; `profiles/{TAG}_fit_step_profile.txt`) | — | **{fit[(8, True)]:.2f}** (full path {fit[(8, False)]:.2f}) | 0.86 |",

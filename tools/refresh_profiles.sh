@@ -50,6 +50,7 @@ echo "== bench 1 view" && timeout 300 python3 bench.py --views-per-step 1 --no-c
 echo "== bench hd sh3" && timeout 300 python3 bench.py --config two_hands_hd --no-cpu-baseline > $O/bench_hd_sh3.json 2> $O/bench_hd.err || exit 1
 echo "== bench hd sh3, split streams" && timeout 300 python3 bench.py --config two_hands_hd --split-streams on --no-cpu-baseline --no-stage-timing > $O/bench_hd_sh3_split.json 2> $O/bench_hd_split.err || exit 1
 echo "== bench hd sh3 pose batch 32" && timeout 400 python3 bench.py --config two_hands_hd --pose-batch --views-per-step 32 --steps 5 --warmup 2 --repeats 3 --no-cpu-baseline > $O/bench_hd_sh3_pose32.json 2> $O/bench_hd_pb.err || exit 1
+echo "== bench hd sh3 pose batch 32, split streams" && timeout 400 python3 bench.py --config two_hands_hd --pose-batch --views-per-step 32 --steps 5 --warmup 2 --repeats 3 --split-streams on --no-cpu-baseline --no-stage-timing > $O/bench_hd_sh3_pose32_split.json 2> $O/bench_hd_pb_split.err || exit 1
 echo "== bench random1k (configs[0]: PyTorch CPU autograd baseline)" && timeout 300 python3 bench.py --config random1k --views-per-step 1 > $O/bench_random1k.json 2> $O/bench_random1k.err || exit 1
 echo "== bench default" && timeout 300 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || exit 1
 echo done
