@@ -126,23 +126,40 @@ def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
             dt = time.perf_counter() - t0
             if dt >= seconds and n >= 2:
                 break
+        from oracle import oracle_c
         return {"value": n / dt, "unit": "renders/s", "cores": torch.get_num_threads(), "kind": "port",
+                "threads": torch.get_num_threads(), "host_cpus": os.cpu_count(), "cpu_model": oracle_c.cpu_model(),
+                "serial_fraction": None,
                 "sample": f"{n} fwd+bwd renders of view 0 of the same workload ({dt:.1f} s), oracle/oracle_torch.py: dense PyTorch CPU "
                           "autograd (BASELINE configs[0]'s reference)"}
     from oracle import oracle_c
     kw = dict(colors_precomp=s.shs.squeeze(1)) if s.use_rgb else dict(shs=s.shs, sh_degree=s.sh_degree)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        r = oracle_c.OracleRender(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, xyz_b=s.xyz_b,
-                                  opacity_b=s.opacity_b, color_w=s.color_w, color_b=s.color_b, **kw)
-        r.backward(dimg)
-        r.close()
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds and n >= 3:
-            break
+    # baseline mode: every stage under OpenMP (the checker's default keeps emit / sort / chain rule on one thread); what still
+    # runs on one thread is measured inside the library and reported as serial_fraction
+    oracle_c.set_parallel(True)
+    try:
+        oracle_c.timing(reset=True)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            r = oracle_c.OracleRender(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, xyz_b=s.xyz_b,
+                                      opacity_b=s.opacity_b, color_w=s.color_w, color_b=s.color_b, **kw)
+            r.backward(dimg)
+            r.close()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds and n >= 3:
+                break
+        t_lib, t_ser = oracle_c.timing()
+    finally:
+        oracle_c.set_parallel(False)
     return {"value": n / dt, "unit": "renders/s", "cores": oracle_c.num_threads(), "kind": "port",
-            "sample": f"{n} fwd+bwd renders of view 0 of the same workload ({dt:.1f} s), oracle/gh_oracle.c OpenMP"}
+            "threads": oracle_c.num_threads(), "host_cpus": os.cpu_count(), "cpu_model": oracle_c.cpu_model(),
+            "serial_fraction": t_ser / t_lib if t_lib > 0 else None,
+            "library_fraction_of_wall": t_lib / dt if dt > 0 else None,
+            "sample": f"{n} fwd+bwd renders of view 0 of the same workload ({dt:.1f} s), oracle/gh_oracle.c in its baseline mode: "
+                      "projection, instance emit + per-tile sort, both render walks and the chain rule under OpenMP; "
+                      "serial_fraction = library time on one thread (tile-count scan, tile prefix) / library time; the rest of "
+                      "the wall time is the ctypes wrapper allocating the outputs"}
 
 
 def two_call_cost(s, cams_w2c_K, n_iter: int = 12):
@@ -198,6 +215,22 @@ def two_call_cost(s, cams_w2c_K, n_iter: int = 12):
     return (time.perf_counter() - t0) / n_iter * 1e3
 
 
+def self_launch(n: int) -> int:
+    """Run this very command line as n ranks under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:                       # a free rendezvous port
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    env["GH_BENCH_LAUNCHER"] = "bench.py self-launch (torch.distributed.run, child processes)"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +264,13 @@ def main():
                          "steps), the others are reported as repeat statistics")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the driver's own torchrun line, as CHILD
+        # processes, before this process has made a single GPU call — never an exec of a process that touched the GPU), pass
+        # rank 0's JSON line through and exit with the launcher's code. Replaces the reference's PL-DDP launch
+        # (infer_one_shot.py:631, :638).
+        sys.exit(self_launch(args.gpus))
+
     from guassianhand_amd import dist as ghdist
     from guassianhand_amd import rasterizer as R
     from guassianhand_amd.loss import rendered_l1_loss
@@ -240,8 +280,23 @@ def main():
     if args.dist_backend == "gloo":                     # functional check of the N>1 path on a box with fewer GPUs than ranks
         os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
     rank, local, world = ghdist.init_from_env(args.dist_backend)
-    assert world == args.gpus or world == 1, f"WORLD_SIZE {world} != --gpus {args.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device (there is no CPU fallback)"
+    if world != args.gpus:                              # fail loudly: a line that says n_gpus N must come from N ranks
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}; launch it as `python bench.py --gpus {args.gpus}` (self-"
+              f"launching) or under torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a ROCm device (there is no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    rccl_ranks = None
+    if world > 1:
+        # one real collective before anything is measured: the line reports the number of ranks that ANSWERED it
+        # (sum of ones over the process group), not the number that was asked for
+        ones = torch.ones(1, device=torch.device("cuda", local))
+        tdist.all_reduce(ones, op=tdist.ReduceOp.SUM)
+        rccl_ranks = int(round(float(ones.item())))
+        if rccl_ranks != args.gpus:
+            print(f"bench.py: the all-reduce reached {rccl_ranks} ranks, --gpus says {args.gpus}", file=sys.stderr)
+            sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -431,6 +486,20 @@ def main():
     # checksum of the step's result (after the last timed step): the N-rank control tests compare it with a 1-rank run
     grad_l1 = float(sum(params[k].grad.detach().abs().sum() for k in names if params[k].grad is not None))
 
+    strong_info = None
+    if args.scaling == "strong":
+        # predicted step = the committed single-GPU step of the SAME per-rank view count (profiles/<tag>_bench_<V>view.json);
+        # the difference to `ms_per_step` is what the collective and the launch skew cost
+        pred = None
+        f = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_bench_{V}view.json" if V != 8 else f"{PROFILE_TAG}_bench_default.json")
+        if args.config == "two_hands" and not args.pose_batch and os.path.exists(f):
+            try:
+                pred = json.load(open(f))["ms_per_step"]
+            except (KeyError, ValueError):
+                pred = None
+        strong_info = {"views_total": V_total, "views_per_rank": V, "predicted_ms_per_step": pred,
+                       "predicted_from": os.path.relpath(f, ROOT) if pred is not None else None,
+                       "measured_ms_per_step": dt / args.steps * 1e3}
     if rank == 0:
         # instance count of the published algorithm (every tile of the 3-sigma rects) beside the exactly culled one
         with torch.no_grad():
@@ -476,6 +545,10 @@ def main():
                                                               else "all-reduce(loss)"),
                        "loss": "mean|img-gt|", "final_loss": float(loss.detach()), "grad_l1": grad_l1,
                        "views_per_step_total": V * world,
+                       "ranks": {"world_size": world, "answered_all_reduce": rccl_ranks,
+                                 "backend": None if world == 1 else tdist.get_backend(),
+                                 "launched_by": os.environ.get("GH_BENCH_LAUNCHER", "external launcher" if world > 1 else "single process")},
+                       "strong_scaling": strong_info,
                        "repeats": {"windows": 1 + len(extra), "steps_per_window": args.steps,
                                    "ms_per_step_min": min([dt] + extra) / args.steps * 1e3,
                                    "ms_per_step_median": sorted([dt] + extra)[len([dt] + extra) // 2] / args.steps * 1e3,
@@ -485,7 +558,8 @@ def main():
                            "n": len(step_ms), "median": step_ms[len(step_ms) // 2], "p10": step_ms[len(step_ms) // 10],
                            "p90": step_ms[(len(step_ms) * 9) // 10], "how": "HIP events around every single step, after the timed windows"},
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
-                       "split_streams": bool(V >= 2 and (R._split_policy is True or (R._split_policy == "auto" and V >= 4))),
+                       "split_streams": bool(V >= 2 and (R._split_policy is True or (
+                           R._split_policy == "auto" and V >= 4 and H * W > R._SPLIT_AUTO_MIN_PIXELS))),
                        "hip_graph": graph is not None, "timed_steps": "HIP graph replay of one captured step" if graph is not None
                        else "eager kernel-by-kernel enqueue" + (f" [{graph_note}]" if graph_note else "")},
             "roofline": roofline, "stages": stages,

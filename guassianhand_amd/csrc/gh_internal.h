@@ -110,6 +110,9 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
 // alpha = min(0.99, o * exp), and o * (<= 2^-126) < 1/255 is skipped exactly like o * 0 (any finite opacity below 3e35). For
 // x > 0 (a conic that is not positive definite) the value may overflow to +inf: every caller rejects the entry on `power > 0`
 // by a select, never by arithmetic on this value.
+// PRECONDITION: x is finite or NaN-free. x = -inf gives t - rint(t) = NaN and a NaN result, which the callers' fminf(0.99f, ·)
+// would turn into alpha = 0.99 where the oracle's clamped exp gives 0: reachable only through a non-finite conic or pixel
+// offset, which the +0.3 dilation (det >= 0.09 for finite inputs) and the finite-input contract of the projection rule out.
 __device__ __forceinline__ float gh_exp(float x) {
   float t = x * 1.44269504088896341f;
   float n = __builtin_rintf(t);

@@ -384,10 +384,27 @@ class CapturedFitStep:
         finally:
             R.set_graph_mode(False)
         self.lr = self._lr()
+        # The captured refresh reads the static tile lists out of the geometry owner's workspace by ADDRESS. Hold the owner
+        # here: were it only the cache's (cleared by any overflow in the process, invalidate_geometry(), update_gaussians()),
+        # its workspace would go back to the pool and the next forward of that size would overwrite the lists under the graph.
+        gc = self.fit._geom_cache
+        self._geom = None if gc is None else gc.ctx
+
+    def _stale(self) -> bool:
+        gc = self.fit._geom_cache
+        return gc is not None and gc.ctx is not self._geom
 
     def replay(self) -> torch.Tensor:
         if self._lr() != self.lr:
             self._capture()
+        elif self._stale():
+            # the cache was cleared or rebuilt since the capture: the graph would render the OLD lists (kept alive above, so
+            # not a fault — but not what the fit holds now). This step runs as a regular one (it rebuilds the lists), then capture again.
+            from . import rasterizer as R
+            loss = self.fit.step(*self.args, sync=True).detach().clone()   # THIS replay's step, run eagerly
+            R.check_overflow()
+            self._capture()
+            return loss
         self.graph.replay()
         return self.loss
 
@@ -397,7 +414,11 @@ class CapturedFitStep:
         for counters, cap, key in self.counters:
             c4 = counters.tolist()
             d = c4[0] & 0xFFFFFFFF
+            if c4[1] & 2:                                          # stale static lists (an opacity above their bound): not a capacity matter
+                R.GeometryCache.clear_all()
+                raise R.GhStaleGeometryError(R._STALE_MSG + " [inside the captured fit step: the next replay() rebuilds and re-captures]")
             if (c4[1] & 0xFFFFFFFF) != 0:                          # the device-side flag decides (a split call's reserved[0] only sizes)
                 need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
                 R._capacity[key] = max(R._capacity.get(key, 0), int(need * 1.5) + 1024)
+                R.GeometryCache.clear_all()                        # lists truncated by the overflow must not be refreshed again
                 raise R.GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside the captured fit step")

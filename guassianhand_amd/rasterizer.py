@@ -439,6 +439,12 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         cap = int(g0.dims.max_instances)
         dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
         nbytes = L.gh_workspace_bytes(C.byref(dims))
+        # the library applies THIS call's layout to the owner's workspace: everything a refresh reads of it lies in front of the
+        # arrays sized by the colour mode (gh_workspace_layout), and the owner's workspace must at least span that prefix
+        lay = _abi.GhLayout()
+        L.gh_workspace_layout(C.byref(dims), C.byref(lay))
+        if g0.ws.numel() < lay.attr:
+            raise ValueError("refresh_of: the geometry owner's workspace is smaller than this call's static part")
         stream = _raw_stream(dev)
         ws = _ws_acquire(dev, nbytes, stream)
         image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
@@ -470,6 +476,9 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         elif _graph_mode:
             _graph_counters[ws.data_ptr()] = (counters, cap, gkey)
         else:
+            # a refresh whose opacity guard fired (or whose lists an overflow truncated) poisons every later step too: look at
+            # the read-backs that have arrived, so that a stale loop surfaces within two calls instead of _PENDING_MAX
+            check_overflow(block=False, keep_recent=2)
             if len(_pending) >= _PENDING_MAX:
                 check_overflow(block=True)
             host, ev = _free_slots.pop() if _free_slots else (torch.empty(4, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
@@ -566,8 +575,12 @@ def cached_raster_forward(cache: Optional[GeometryCache], cams, means3D, opaciti
         raise ValueError("a GeometryCache call takes neither geometry_of nor split_streams")
     xyz_b = kw.get("xyz_b")
     objs = (cams, means3D, scales, rotations, xyz_b)
+    shs = kw.get("shs")
     vals = tuple(None if o is None else (o._version, tuple(o.shape), o.device) for o in objs) + \
-        (int(kw["H"]), int(kw["W"]), float(kw.get("scale_modifier", 1.0)), bool(kw.get("per_view_gaussians", False)))
+        (int(kw["H"]), int(kw["W"]), float(kw.get("scale_modifier", 1.0)), bool(kw.get("per_view_gaussians", False)),
+         # the colour mode: the workspace layout behind the static part depends on M (one cache used with
+         # use_rgb=True and use_rgb=False is two entries, i.e. a miss)
+         0 if shs is None else int(shs.shape[1]), int(kw.get("sh_degree", 0)))
     g0 = cache.lookup(objs, vals)
     if g0 is not None:
         try:

@@ -99,6 +99,28 @@ static int inst_cmp(const void* a, const void* b) {
   return 0;
 }
 
+/* ---- baseline mode (bench.py's cpu_baseline leg only) -------------------------------------------------------------
+ * gho_set_parallel(1): the stages that the checker runs on one thread (instance emit + sort, the A.5 chain rule, the final
+ * write-out) run under OpenMP too — per-tile buckets + per-tile stable sort instead of one global qsort (same (key, slot)
+ * total order, so the lists are identical), the chain rule over Gaussians in parallel with the views of a Gaussian summed in
+ * the checker's order (per-Gaussian results bit-identical; the global (48,) color_w sum is reduced from per-thread double
+ * partials). Default 0: the serial checker path every parity test uses.
+ * gho_timing(): wall seconds inside gho_forward / gho_backward since the last reset, and the part of it spent in sections
+ * that ran on one thread whatever the mode (what bounds the all-core number: bench.py reports serial / total). */
+static int g_parallel = 0;
+static double g_t_total = 0.0, g_t_serial = 0.0;
+#ifdef _OPENMP
+extern double omp_get_wtime(void);
+static inline double gho_now(void) { return omp_get_wtime(); }
+#else
+#include <time.h>
+static inline double gho_now(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#endif
+void gho_set_parallel(int on) { g_parallel = on ? 1 : 0; }
+int gho_get_parallel(void) { return g_parallel; }
+void gho_timing_reset(void) { g_t_total = 0.0; g_t_serial = 0.0; }
+void gho_timing(double* total, double* serial) { if (total) *total = g_t_total; if (serial) *serial = g_t_serial; }
+
 /* Persistent oracle context (host memory) so backward can reuse forward state. */
 typedef struct GhoCtx {
   GhDims dims;
@@ -255,6 +277,8 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
   /* layout variants of the product (compact colour biases, pose batch) are checked against this oracle through their
    * reference-layout equivalents (tests/test_gpu_dropin.py); the oracle itself only speaks the reference layouts */
   if (d->flags & ~GH_FLAG_BLEND_W_PER_GAUSSIAN) return GH_ERR_UNSUPPORTED;
+  const double t_begin = gho_now();
+  double t_ser = 0.0, t_mark;
   GhoCtx* c = (GhoCtx*)calloc(1, sizeof(GhoCtx));
   c->dims = *d;
   c->g = (GView*)calloc((size_t)NV * P + 1, sizeof(GView));
@@ -319,6 +343,7 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
     }
   }
   /* radii */
+  t_mark = gho_now();
   if (out->radii) for (long n = 0; n < (long)NV * P; ++n) out->radii[n] = c->g[n].radius;
 
   /* A.2 binning: inclusive scan, emit, stable sort, ranges */
@@ -326,6 +351,55 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
   for (long n = 0; n < (long)NV * P; ++n) { run += c->g[n].tiles; c->offsets[n] = (uint32_t)run; }
   c->D = (int64_t)run;
   c->inst = (Inst*)malloc(sizeof(Inst) * (size_t)(run + 1));
+  t_ser += gho_now() - t_mark;
+  if (g_parallel) {
+    /* baseline mode: bucket the instances by tile (count -> prefix -> scatter), then sort every tile's bucket by the
+     * checker's own comparator (key, emit slot): a total order, so the result equals the global stable sort below */
+    const long NT = (long)NV * tiles;
+    uint32_t* cnt = (uint32_t*)calloc((size_t)NT + 1, sizeof(uint32_t));
+    uint32_t* cur = (uint32_t*)malloc(((size_t)NT + 1) * sizeof(uint32_t));
+#pragma omp parallel for schedule(static)
+    for (long n = 0; n < (long)NV * P; ++n) {
+      const GView* g = &c->g[n];
+      if (!g->tiles) continue;
+      int v = (int)(n / P);
+      for (int ty = g->miny; ty < g->maxy; ++ty)
+        for (int tx = g->minx; tx < g->maxx; ++tx) {
+#pragma omp atomic
+          cnt[(size_t)v * tiles + (size_t)ty * gx + tx]++;
+        }
+    }
+    t_mark = gho_now();
+    uint32_t acc = 0;
+    for (long t = 0; t < NT; ++t) { cur[t] = acc; acc += cnt[t]; }
+    t_ser += gho_now() - t_mark;
+#pragma omp parallel for schedule(static)
+    for (long n = 0; n < (long)NV * P; ++n) {
+      const GView* g = &c->g[n];
+      if (!g->tiles) continue;
+      int v = (int)(n / P);
+      uint32_t off = c->offsets[n] - g->tiles;
+      uint32_t dbits; memcpy(&dbits, &g->depth, 4);
+      for (int ty = g->miny; ty < g->maxy; ++ty)
+        for (int tx = g->minx; tx < g->maxx; ++tx) {
+          uint64_t tile = (uint64_t)v * tiles + (uint64_t)ty * gx + tx;
+          uint32_t pos;
+#pragma omp atomic capture
+          pos = cur[tile]++;
+          c->inst[pos].key = (tile << 32) | dbits; c->inst[pos].slot = off; c->inst[pos].gid = (uint32_t)n;
+          ++off;
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long t = 0; t < NT; ++t) {
+      if (!cnt[t]) continue;
+      uint32_t s0 = cur[t] - cnt[t];
+      qsort(c->inst + s0, (size_t)cnt[t], sizeof(Inst), inst_cmp);
+      c->ranges[2 * t] = s0; c->ranges[2 * t + 1] = cur[t];
+    }
+    free(cnt); free(cur);
+  } else {
+  t_mark = gho_now();
   for (long n = 0; n < (long)NV * P; ++n) {
     const GView* g = &c->g[n];
     if (!g->tiles) continue;
@@ -344,6 +418,8 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
     uint32_t t = (uint32_t)(c->inst[k].key >> 32);
     if (k == 0 || t != (uint32_t)(c->inst[k - 1].key >> 32)) c->ranges[2 * t] = (uint32_t)k;
     if (k == c->D - 1 || t != (uint32_t)(c->inst[k + 1].key >> 32)) c->ranges[2 * t + 1] = (uint32_t)(k + 1);
+  }
+  t_ser += gho_now() - t_mark;
   }
 
   /* A.3 render */
@@ -400,87 +476,23 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
     if (dbg->n_contrib) memcpy(dbg->n_contrib, c->n_contrib, sizeof(uint32_t) * (size_t)NV * H * W);
   }
   *ctx_out = c;
+  g_t_total += gho_now() - t_begin; g_t_serial += t_ser;
   return GH_OK;
 }
 
-/* ------------------------------------------------------------------------------------------- */
-int gho_backward(const GhoCtx* c, const GhInputs* in, const GhGrads* gr) {
-  if (!c || !in || !gr || !gr->dL_dimage) return GH_ERR_INVALID_ARG;
+/* A.5 for one (view, Gaussian) n = v*P + i: sums its instance records, chain rule, adds into the per-Gaussian accumulators.
+ * acc_cw: where the color_w gradient goes (the global array, or a thread's private 48 doubles in baseline mode). */
+typedef struct A5Acc { double *m, *o, *s, *q, *c, *sh, *cb; } A5Acc;
+static void a5_one(const GhoCtx* c, const GhInputs* in, const GhGrads* gr, long n, const double* rec, const A5Acc* A, double* acc_cw) {
   const GhDims* d = &c->dims;
-  const int P = d->P, NV = d->n_views, H = d->H, W = d->W, M = d->M;
-  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, tiles = gx * gy;
-  /* per-instance records: dpx dpy dA dB dC do dr dg db */
-  double* rec = (double*)calloc((size_t)c->D * 9 + 9, sizeof(double));
-
-  /* A.4 render backward: per pixel, back-to-front */
-#pragma omp parallel for schedule(dynamic, 4)
-  for (long t = 0; t < (long)NV * tiles; ++t) {
-    int v = (int)(t / tiles), tt = (int)(t % tiles), ty = tt / gx, tx = tt % gx;
-    const float* bg = in->cams + (size_t)v * GH_CAM_FLOATS + 37;
-    uint32_t s0 = c->ranges[2 * t];
-    const float* dimg = gr->dL_dimage + (size_t)v * 3 * H * W;
-    for (int ly = 0; ly < TILE; ++ly) for (int lx = 0; lx < TILE; ++lx) {
-      int x = tx * TILE + lx, y = ty * TILE + ly;
-      if (x >= W || y >= H) continue;
-      size_t pix = ((size_t)v * H + y) * W + x;
-      float pxf = (float)x, pyf = (float)y;
-      float T_final = c->final_T[pix];
-      uint32_t last = c->n_contrib[pix];
-      float dpix[3] = {dimg[(size_t)0 * H * W + (size_t)y * W + x], dimg[(size_t)1 * H * W + (size_t)y * W + x], dimg[(size_t)2 * H * W + (size_t)y * W + x]};
-      float bg_dot = bg[0] * dpix[0] + bg[1] * dpix[1] + bg[2] * dpix[2];
-      float Tr = T_final, last_alpha = 0.0f, last_col[3] = {0, 0, 0}, accum[3] = {0, 0, 0};
-      for (int64_t j = (int64_t)last - 1; j >= 0; --j) {
-        uint32_t k = s0 + (uint32_t)j;
-        const GView* g = &c->g[c->inst[k].gid];
-        float dx = g->px - pxf, dy = g->py - pyf;
-        float power = -0.5f * (g->A * dx * dx + g->C * dy * dy) - g->B * dx * dy;
-        if (power > 0.0f) continue;
-        float G = gho_exp(power);
-        float alpha = fminf(0.99f, g->opac * G);
-        if (alpha < 1.0f / 255.0f) continue;
-        Tr = Tr / (1.0f - alpha);
-        float dchannel_dcolor = alpha * Tr;
-        float dL_dalpha = 0.0f;
-        double* r = rec + (size_t)c->inst[k].slot * 9;
-        for (int ch = 0; ch < 3; ++ch) {
-          accum[ch] = last_alpha * last_col[ch] + (1.0f - last_alpha) * accum[ch];
-          last_col[ch] = g->rgb[ch];
-          dL_dalpha += (g->rgb[ch] - accum[ch]) * dpix[ch];
-          r[6 + ch] += (double)(dchannel_dcolor * dpix[ch]);
-        }
-        dL_dalpha *= Tr;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
-        float dL_dG = g->opac * dL_dalpha;      /* straight-through the 0.99 clamp (App. A.4-2) */
-        float gdx = G * dx, gdy = G * dy;
-        float dG_ddelx = -gdx * g->A - gdy * g->B;
-        float dG_ddely = -gdy * g->C - gdx * g->B;
-        r[0] += (double)(dL_dG * dG_ddelx);      /* d(delta)/d(px) = +1 */
-        r[1] += (double)(dL_dG * dG_ddely);
-        r[2] += (double)(-0.5f * gdx * dx * dL_dG);
-        r[3] += (double)(-gdx * dy * dL_dG);
-        r[4] += (double)(-0.5f * gdy * dy * dL_dG);
-        r[5] += (double)(G * dL_dalpha);
-      }
-    }
-  }
-
-  /* A.5 preprocess backward: reduce records per (view,Gaussian), chain rule, sum over views */
-  double* acc_m = (double*)calloc((size_t)P * 3 + 3, sizeof(double));
-  double* acc_o = (double*)calloc((size_t)P + 1, sizeof(double));
-  double* acc_s = (double*)calloc((size_t)P * 3 + 3, sizeof(double));
-  double* acc_q = (double*)calloc((size_t)P * 4 + 4, sizeof(double));
-  double* acc_c = (double*)calloc((size_t)P * 3 + 3, sizeof(double));
-  double* acc_sh = (double*)calloc((size_t)P * (M > 0 ? M : 1) * 3 + 3, sizeof(double));
-  double* acc_cb = (double*)calloc((size_t)P * 48 + 48, sizeof(double));
-  int wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? 1 : 0;
-  double* acc_cw = (double*)calloc((wpg ? (size_t)P * 48 : 48) + 48, sizeof(double));
-
-  for (long n = 0; n < (long)NV * P; ++n) {
+  const int P = d->P, H = d->H, W = d->W, M = d->M;
+  const int wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? 1 : 0;
+  double *acc_m = A->m, *acc_o = A->o, *acc_s = A->s, *acc_q = A->q, *acc_c = A->c, *acc_sh = A->sh, *acc_cb = A->cb;
+  {
     int v = (int)(n / P), i = (int)(n % P);
     const GView* g = &c->g[n];
     if (gr->dL_dmeans2D) { gr->dL_dmeans2D[3 * n] = 0; gr->dL_dmeans2D[3 * n + 1] = 0; gr->dL_dmeans2D[3 * n + 2] = 0; }
-    if (!g->tiles) continue;
+    if (!g->tiles) return;
     const float* cam = in->cams + (size_t)v * GH_CAM_FLOATS;
     const float* V = cam; const float* PM = cam + 16;
     double s9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -592,7 +604,107 @@ int gho_backward(const GhoCtx* c, const GhInputs* in, const GhGrads* gr) {
     for (int a2 = 0; a2 < 3; ++a2) acc_m[3 * i + a2] += (double)dm[a2];
     acc_o[i] += (double)g_o;
   }
+}
 
+/* ------------------------------------------------------------------------------------------- */
+int gho_backward(const GhoCtx* c, const GhInputs* in, const GhGrads* gr) {
+  if (!c || !in || !gr || !gr->dL_dimage) return GH_ERR_INVALID_ARG;
+  const GhDims* d = &c->dims;
+  const int P = d->P, NV = d->n_views, H = d->H, W = d->W, M = d->M;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, tiles = gx * gy;
+  const double t_begin = gho_now();
+  double t_ser = 0.0, t_mark;
+  /* per-instance records: dpx dpy dA dB dC do dr dg db */
+  double* rec = (double*)calloc((size_t)c->D * 9 + 9, sizeof(double));
+
+  /* A.4 render backward: per pixel, back-to-front */
+#pragma omp parallel for schedule(dynamic, 4)
+  for (long t = 0; t < (long)NV * tiles; ++t) {
+    int v = (int)(t / tiles), tt = (int)(t % tiles), ty = tt / gx, tx = tt % gx;
+    const float* bg = in->cams + (size_t)v * GH_CAM_FLOATS + 37;
+    uint32_t s0 = c->ranges[2 * t];
+    const float* dimg = gr->dL_dimage + (size_t)v * 3 * H * W;
+    for (int ly = 0; ly < TILE; ++ly) for (int lx = 0; lx < TILE; ++lx) {
+      int x = tx * TILE + lx, y = ty * TILE + ly;
+      if (x >= W || y >= H) continue;
+      size_t pix = ((size_t)v * H + y) * W + x;
+      float pxf = (float)x, pyf = (float)y;
+      float T_final = c->final_T[pix];
+      uint32_t last = c->n_contrib[pix];
+      float dpix[3] = {dimg[(size_t)0 * H * W + (size_t)y * W + x], dimg[(size_t)1 * H * W + (size_t)y * W + x], dimg[(size_t)2 * H * W + (size_t)y * W + x]};
+      float bg_dot = bg[0] * dpix[0] + bg[1] * dpix[1] + bg[2] * dpix[2];
+      float Tr = T_final, last_alpha = 0.0f, last_col[3] = {0, 0, 0}, accum[3] = {0, 0, 0};
+      for (int64_t j = (int64_t)last - 1; j >= 0; --j) {
+        uint32_t k = s0 + (uint32_t)j;
+        const GView* g = &c->g[c->inst[k].gid];
+        float dx = g->px - pxf, dy = g->py - pyf;
+        float power = -0.5f * (g->A * dx * dx + g->C * dy * dy) - g->B * dx * dy;
+        if (power > 0.0f) continue;
+        float G = gho_exp(power);
+        float alpha = fminf(0.99f, g->opac * G);
+        if (alpha < 1.0f / 255.0f) continue;
+        Tr = Tr / (1.0f - alpha);
+        float dchannel_dcolor = alpha * Tr;
+        float dL_dalpha = 0.0f;
+        double* r = rec + (size_t)c->inst[k].slot * 9;
+        for (int ch = 0; ch < 3; ++ch) {
+          accum[ch] = last_alpha * last_col[ch] + (1.0f - last_alpha) * accum[ch];
+          last_col[ch] = g->rgb[ch];
+          dL_dalpha += (g->rgb[ch] - accum[ch]) * dpix[ch];
+          r[6 + ch] += (double)(dchannel_dcolor * dpix[ch]);
+        }
+        dL_dalpha *= Tr;
+        last_alpha = alpha;
+        dL_dalpha += (-T_final / (1.0f - alpha)) * bg_dot;
+        float dL_dG = g->opac * dL_dalpha;      /* straight-through the 0.99 clamp (App. A.4-2) */
+        float gdx = G * dx, gdy = G * dy;
+        float dG_ddelx = -gdx * g->A - gdy * g->B;
+        float dG_ddely = -gdy * g->C - gdx * g->B;
+        r[0] += (double)(dL_dG * dG_ddelx);      /* d(delta)/d(px) = +1 */
+        r[1] += (double)(dL_dG * dG_ddely);
+        r[2] += (double)(-0.5f * gdx * dx * dL_dG);
+        r[3] += (double)(-gdx * dy * dL_dG);
+        r[4] += (double)(-0.5f * gdy * dy * dL_dG);
+        r[5] += (double)(G * dL_dalpha);
+      }
+    }
+  }
+
+  /* A.5 preprocess backward: reduce records per (view,Gaussian), chain rule, sum over views */
+  double* acc_m = (double*)calloc((size_t)P * 3 + 3, sizeof(double));
+  double* acc_o = (double*)calloc((size_t)P + 1, sizeof(double));
+  double* acc_s = (double*)calloc((size_t)P * 3 + 3, sizeof(double));
+  double* acc_q = (double*)calloc((size_t)P * 4 + 4, sizeof(double));
+  double* acc_c = (double*)calloc((size_t)P * 3 + 3, sizeof(double));
+  double* acc_sh = (double*)calloc((size_t)P * (M > 0 ? M : 1) * 3 + 3, sizeof(double));
+  double* acc_cb = (double*)calloc((size_t)P * 48 + 48, sizeof(double));
+  int wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? 1 : 0;
+  double* acc_cw = (double*)calloc((wpg ? (size_t)P * 48 : 48) + 48, sizeof(double));
+
+  const A5Acc A5 = {acc_m, acc_o, acc_s, acc_q, acc_c, acc_sh, acc_cb};
+  if (g_parallel) {
+    /* baseline mode: Gaussians in parallel, the views of a Gaussian in the checker's (ascending) order */
+#pragma omp parallel
+    {
+      double cw_local[48];
+      for (int a = 0; a < 48; ++a) cw_local[a] = 0.0;
+#pragma omp for schedule(static)
+      for (long i = 0; i < (long)P; ++i)
+        for (int v = 0; v < NV; ++v) a5_one(c, in, gr, (long)v * P + i, rec, &A5, wpg ? acc_cw : cw_local);
+      if (!wpg) {
+#pragma omp critical
+        for (int a = 0; a < 48; ++a) acc_cw[a] += cw_local[a];
+      }
+    }
+  } else {
+    t_mark = gho_now();
+    for (long n = 0; n < (long)NV * P; ++n) a5_one(c, in, gr, n, rec, &A5, acc_cw);
+    t_ser += gho_now() - t_mark;
+  }
+
+
+  t_mark = gho_now();
+#pragma omp parallel for schedule(static) if (g_parallel)
   for (int i = 0; i < P; ++i) {
     if (gr->dL_dmeans3D) for (int a = 0; a < 3; ++a) gr->dL_dmeans3D[3 * i + a] = (float)acc_m[3 * i + a];
     if (gr->dL_dopacities) gr->dL_dopacities[i] = (float)acc_o[i];
@@ -610,7 +722,9 @@ int gho_backward(const GhoCtx* c, const GhInputs* in, const GhGrads* gr) {
     for (int i = 0; i < P; ++i) for (int a = 0; a < 3; ++a) s[a] += acc_m[3 * i + a];
     for (int a = 0; a < 3; ++a) gr->dL_dblend_xyz_b[a] = (float)s[a];
   }
+  if (!g_parallel) t_ser += gho_now() - t_mark;
   free(rec); free(acc_m); free(acc_o); free(acc_s); free(acc_q); free(acc_c); free(acc_sh); free(acc_cb); free(acc_cw);
+  g_t_total += gho_now() - t_begin; g_t_serial += t_ser;
   return GH_OK;
 }
 

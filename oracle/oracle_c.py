@@ -48,6 +48,12 @@ def lib() -> C.CDLL:
         _lib.gho_exp_public.restype = C.c_float
         _lib.gho_exp_public.argtypes = [C.c_float]
         _lib.gho_num_threads.restype = C.c_int
+        _lib.gho_set_parallel.restype = None
+        _lib.gho_set_parallel.argtypes = [C.c_int]
+        _lib.gho_get_parallel.restype = C.c_int
+        _lib.gho_timing_reset.restype = None
+        _lib.gho_timing.restype = None
+        _lib.gho_timing.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib.gho_knn.restype = C.c_int
         _lib.gho_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return _lib
@@ -163,6 +169,30 @@ def gho_exp(x: float) -> float:
 
 def num_threads() -> int:
     return int(lib().gho_num_threads())
+
+
+def set_parallel(on: bool) -> None:
+    """Baseline mode (bench.py's cpu_baseline only): emit / sort / chain rule under OpenMP too. The checker default is off."""
+    lib().gho_set_parallel(1 if on else 0)
+
+
+def timing(reset: bool = False):
+    """(seconds inside gho_forward + gho_backward, seconds of that spent in single-threaded sections) since the last reset."""
+    tot, ser = C.c_double(0.0), C.c_double(0.0)
+    lib().gho_timing(C.byref(tot), C.byref(ser))
+    if reset:
+        lib().gho_timing_reset()
+    return tot.value, ser.value
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def knn(points: torch.Tensor, K: int, queries: Optional[torch.Tensor] = None):

@@ -102,3 +102,26 @@ def test_bench_two_gpus_over_rccl():
     strong = _run_bench(2, "--views-per-step", "8", "--scaling", "strong", "--allreduce-grads", backend="nccl")
     assert strong["config"]["final_loss"] == pytest.approx(2 * L1, rel=1e-5)
     assert strong["config"]["grad_l1"] == pytest.approx(2 * G1, rel=1e-4)
+
+
+@pytest.mark.timeout(900)
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` WITHOUT a launcher starts two ranks itself (child processes, before any
+    GPU call), rank 0 prints the one line, and the line counts the ranks that answered a real all-reduce."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--views-per-step", "4", "--steps", "2",
+           "--warmup", "1", "--repeats", "1", "--no-stage-timing", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["ranks"]["world_size"] == 2 and d["config"]["ranks"]["answered_all_reduce"] == 2
+    assert d["config"]["ranks"]["backend"] == "gloo" and "self-launch" in d["config"]["ranks"]["launched_by"]
+    assert d["config"]["views_per_step_total"] == 8
+
+    strong = subprocess.run(cmd + ["--scaling", "strong", "--views-per-step", "8"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=560)
+    assert strong.returncode == 0, strong.stderr[-3000:]
+    ds = _last_json(strong.stdout)
+    si = ds["config"]["strong_scaling"]
+    assert si["views_total"] == 8 and si["views_per_rank"] == 4 and si["measured_ms_per_step"] == pytest.approx(ds["ms_per_step"])

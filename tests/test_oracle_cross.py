@@ -81,3 +81,38 @@ def test_oracle_a_finite_differences_float64():
             fd = (vals[0] - vals[1]) / (2 * h)
             an = float(leaves[ti].grad.reshape(-1)[j])
             assert fd == pytest.approx(an, rel=2e-4, abs=1e-6), (name, j)
+
+
+@pytest.mark.parametrize("use_rgb,blend", [(True, True), (False, True), (True, False)])
+def test_baseline_mode_equals_the_checker(use_rgb, blend):
+    """gho_set_parallel(1) (bench.py's cpu_baseline leg: emit / per-tile sort / chain rule under OpenMP) against the serial
+    checker path: identical lists, image, state; per-Gaussian gradients bit for bit (the views of a Gaussian are summed in the
+    same order); the global (48,) color_w gradient to double-rounding (per-thread partial sums)."""
+    from oracle import oracle_c
+    from tests.helpers import scene_kwargs
+    sc = make_scene("random1k", n_views=3, P=700, use_rgb=use_rgb, blend=blend)
+    kw, bl = scene_kwargs(sc)
+    dimg = dimg_like(3, sc.H, sc.W)
+    res = []
+    for par in (False, True):
+        oracle_c.set_parallel(par)
+        try:
+            oracle_c.timing(reset=True)
+            o = OracleRender(sc.cams(), sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=sc.H, W=sc.W, debug=True, **kw, **bl)
+            g = o.backward(dimg)
+            tot, ser = oracle_c.timing()
+            assert tot > 0 and 0 <= ser <= tot
+            res.append((o.image.clone(), {k: v.clone() for k, v in o.debug.items()}, g, ser / tot))
+            o.close()
+        finally:
+            oracle_c.set_parallel(False)
+    (img0, d0, g0, f0), (img1, d1, g1, f1) = res
+    assert torch.equal(img0, img1)
+    for k in ("sorted_keys", "sorted_gid", "ranges", "final_T", "n_contrib"):
+        assert torch.equal(d0[k], d1[k]), k
+    for k in g0:
+        if k == "color_w" and g0[k].numel() == 48:
+            assert rel_l2(g1[k], g0[k]) < 1e-6
+        else:
+            assert torch.equal(g0[k], g1[k]), k
+    assert f1 <= f0                                   # the baseline mode has less single-threaded time, never more
