@@ -97,17 +97,15 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->n_contrib = take(pix * 4);
   L->inst_grad = take(cap * 4 * GH_REC_G * 4);
   L->inst_flag = take(cap * 4);
-  // what a later gh_forward_refresh reads of a static-lists build: BEFORE everything whose size depends on the colour mode
-  // (M), so that a refresh call with another M still finds them where the build put them
-  L->cull_bound = take(N * 4);
-  L->inst_c = take(cap * 4);
-  L->attr = take(N * 16);
   const bool sh_mode = d->M != 0;
   L->sh_rgb = take(sh_mode ? N * 16 : 0);
   L->dmean_sh = take(sh_mode ? N * 16 : 0);
   L->sh_scratch = take(sh_mode ? ((N * 16 + GH_BLOCK - 1) / GH_BLOCK + 1) * 64 * 4 : 0);   // sized for the pose-batch row count
   L->grad_sums = take(N * 48);
   L->bwd_scratch = take((2 * nblk_pre + 2) * 64 * 4);     // per-block partials of the chain-rule kernel (<= 2N lanes)
+  L->cull_bound = take(N * 4);                            // (a refresh call reads these two of the BUILD's workspace with its OWN
+  L->inst_c = take(cap * 4);                              //  layout: both calls must agree on M == 0 / M != 0, see gh_forward_refresh)
+  L->attr = take(N * 16);
   L->half_counters = take(512);
   L->key_bits = take((gh_proj_blocks(g) + 4) * 8);        // (OR, AND) of the visible depth keys per projection block (+1 word; two
                                                           // halves: + 1 block of rounding + 1 word each)

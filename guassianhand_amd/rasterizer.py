@@ -439,12 +439,12 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         cap = int(g0.dims.max_instances)
         dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
         nbytes = L.gh_workspace_bytes(C.byref(dims))
-        # the library applies THIS call's layout to the owner's workspace: everything a refresh reads of it lies in front of the
-        # arrays sized by the colour mode (gh_workspace_layout), and the owner's workspace must at least span that prefix
-        lay = _abi.GhLayout()
-        L.gh_workspace_layout(C.byref(dims), C.byref(lay))
-        if g0.ws.numel() < lay.attr:
-            raise ValueError("refresh_of: the geometry owner's workspace is smaller than this call's static part")
+        # the library applies THIS call's layout to the owner's workspace, and the arrays a refresh reads of it (cull_bound,
+        # inst_c) lie behind the ones sized by the colour mode (sh_rgb, dmean_sh, sh_scratch: M != 0): the two calls must agree
+        # on it — and the owner's workspace must span this call's layout
+        if (g0.M != 0) != (M != 0) or g0.ws.numel() < nbytes:
+            raise ValueError("refresh_of: the static lists were built in the other colour mode (shs vs colors_precomp); "
+                             "build them again with this call's colour inputs")
         stream = _raw_stream(dev)
         ws = _ws_acquire(dev, nbytes, stream)
         image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)

@@ -276,6 +276,9 @@ int gh_backward_shared(const GhDims* dims, const GhInputs* in, const GhGrads* gr
  * dL_dmeans2D, dL_dscales, dL_drotations, dL_dblend_xyz_b) NULL the per-Gaussian chain rule reduces to sums over the views
  * (the fit trains colour / opacity biases only), and — with precomputed colours, in gh_backward as well — the list walk leaves
  * the position / conic moments out of its sub-records.
+ * Colour mode: the refresh call may bring other colours than the build, but in the SAME mode (both shs, or both
+ * colors_precomp): the library reads the build's workspace with this call's layout, and the arrays behind the SH stage's
+ * scratch move with M == 0 / M != 0 — a caller that switches modes builds the lists again.
  */
 int gh_forward_refresh(const GhDims* dims, const GhInputs* in, const GhOutputs* out, const void* geometry_ws,
                        void* workspace, size_t ws_bytes, void* hip_stream);

@@ -61,8 +61,13 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
                     tanfovx: float, tanfovy: float, bg, H: int, W: int,
                     colors_precomp: Optional[torch.Tensor] = None, shs: Optional[torch.Tensor] = None,
                     sh_degree: int = 0, scale_modifier: float = 1.0, pixel_chunk: int = 2048,
-                    return_aux: bool = False):
-    """Returns (image (3,H,W), radii (P,) int32[, aux dict])."""
+                    return_aux: bool = False, pixel_window=None, checkpoint_chunks: bool = False):
+    """Returns (image (3,H,W), radii (P,) int32[, aux dict]).
+    pixel_window = (x0, y0, x1, y1): evaluate only the pixels x0 <= x < x1, y0 <= y < y1 of the H x W image (the image
+    returned is (3, y1-y0, x1-x0)); everything else — projection, tile rects, tile membership of a pixel — is that of the
+    full image, so the window of a hand-scene render can be checked without the dense P x H x W evaluation.
+    checkpoint_chunks: recompute every pixel chunk in the backward instead of keeping its pixel x Gaussian intermediates
+    (memory of one chunk at a time)."""
     if (shs is None) == (colors_precomp is None):
         raise ValueError("provide exactly one of shs / colors_precomp")
     dt, dev = means3D.dtype, means3D.device
@@ -126,8 +131,11 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
         rgb = torch.clamp_min(eval_sh(sh_degree, shs.to(dt), d) + 0.5, 0.0)
 
     # depth order, stable, ties by index (App. A.2); invalid Gaussians pushed to the end
+    # The sort key of App. A.2 is the FLOAT32 bit pattern of the depth, whatever precision the rest is evaluated in: a float64
+    # run orders by its depth rounded to float32 (ties by index), so that two Gaussians whose depths agree to float32 blend
+    # in the order the published algorithm gives them instead of an order only float64 can see.
     with torch.no_grad():
-        key = torch.where(valid, tz, torch.full_like(tz, float("inf")))
+        key = torch.where(valid, tz.to(torch.float32), torch.full_like(tz, float("inf"), dtype=torch.float32))
         order = torch.sort(key, stable=True).indices
     o_px, o_py = px[order], py[order]
     o_A, o_B, o_C = cA[order], cB[order], cC[order]
@@ -137,10 +145,45 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
     o_minx, o_maxx, o_miny, o_maxy = minx[order], maxx[order], miny[order], maxy[order]
 
     bgc = bg.to(dt)
-    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    wx0, wy0, wx1, wy1 = (0, 0, W, H) if pixel_window is None else [int(v) for v in pixel_window]
+    if not (0 <= wx0 < wx1 <= W and 0 <= wy0 < wy1 <= H):
+        raise ValueError("pixel_window must lie inside the image")
+    ys, xs = torch.meshgrid(torch.arange(wy0, wy1, device=dev), torch.arange(wx0, wx1, device=dev), indexing="ij")
     xs, ys = xs.reshape(-1), ys.reshape(-1)
-    N = H * W
+    N = xs.numel()
     out_rgb, out_T, out_n = [], [], []
+
+    def chunk_colour(X, Y, o_px, o_py, o_A, o_B, o_C, o_op, o_rgb):
+        """Composited colour (n,3) of one pixel chunk — the differentiable part, as a function of the sorted per-Gaussian
+        stage so that it can be checkpointed."""
+        Xf, Yf = X.to(dt)[:, None], Y.to(dt)[:, None]
+        tX, tY = (X // TILE)[:, None], (Y // TILE)[:, None]
+        in_tile = (tX >= o_minx[None]) & (tX < o_maxx[None]) & (tY >= o_miny[None]) & (tY < o_maxy[None]) & o_valid[None]
+        dx = o_px[None, :] - Xf
+        dy = o_py[None, :] - Yf
+        power = -0.5 * (o_A[None] * dx * dx + o_C[None] * dy * dy) - o_B[None] * dx * dy
+        power = torch.where(in_tile, power, torch.zeros_like(power))
+        a_raw = o_op[None, :] * torch.exp(torch.clamp(power, max=0.0))
+        alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()
+        with torch.no_grad():
+            contrib0 = in_tile & (power <= 0) & (alpha >= 1.0 / 255.0)
+        one_minus = torch.where(contrib0, 1.0 - alpha, torch.ones_like(alpha))
+        T_incl = torch.cumprod(one_minus, dim=1)
+        with torch.no_grad():
+            active = contrib0 & (T_incl >= 1e-4)
+        T_excl = torch.cat([torch.ones_like(T_incl[:, :1]), T_incl[:, :-1]], dim=1)
+        wgt = torch.where(active, alpha * T_excl, torch.zeros_like(alpha))
+        final_T = torch.prod(torch.where(active, 1.0 - alpha, torch.ones_like(alpha)), dim=1)
+        return wgt @ o_rgb + final_T[:, None] * bgc[None, :]
+
+    if checkpoint_chunks and not return_aux:
+        from torch.utils.checkpoint import checkpoint
+        for s in range(0, N, pixel_chunk):
+            out_rgb.append(checkpoint(chunk_colour, xs[s:s + pixel_chunk], ys[s:s + pixel_chunk], o_px, o_py, o_A, o_B, o_C, o_op,
+                                      o_rgb, use_reentrant=False))
+        img = torch.cat(out_rgb, dim=0).reshape(wy1 - wy0, wx1 - wx0, 3).permute(2, 0, 1).contiguous()
+        return img, radii
+
     for s in range(0, N, pixel_chunk):
         X = xs[s:s + pixel_chunk]
         Y = ys[s:s + pixel_chunk]
@@ -171,12 +214,12 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
                 last = torch.where(active, pos_in_tile, torch.zeros_like(pos_in_tile)).max(dim=1).values
                 out_T.append(final_T.detach())
                 out_n.append(last)
-    img = torch.cat(out_rgb, dim=0).reshape(H, W, 3).permute(2, 0, 1).contiguous()
+    img = torch.cat(out_rgb, dim=0).reshape(wy1 - wy0, wx1 - wx0, 3).permute(2, 0, 1).contiguous()
     if not return_aux:
         return img, radii
     aux = dict(px=px.detach(), py=py.detach(), depth=tz.detach(), conic=torch.stack([cA, cB, cC], -1).detach(),
                rgb=rgb.detach(), valid=valid, rect=torch.stack([minx, miny, maxx, maxy], -1),
-               final_T=torch.cat(out_T).reshape(H, W), n_contrib=torch.cat(out_n).reshape(H, W),
+               final_T=torch.cat(out_T).reshape(wy1 - wy0, wx1 - wx0), n_contrib=torch.cat(out_n).reshape(wy1 - wy0, wx1 - wx0),
                num_rendered=int(tiles[valid].sum().item()))
     return img, radii, aux
 

@@ -290,6 +290,18 @@ def test_config2_two_hands_blend(dev):
     assert D > 98562
 
 
+def test_two_hands_at_the_reference_render_size_256(dev):
+    """The only render size the reference itself uses: H = W = 256 hard-coded at its one call site (infer_one_shot.py:283-284;
+    512x334 and 1024x1024 are BASELINE.json's). Two hands, 98,562 Gaussians, blend on, the same field of view at half the
+    resolution (f = 650), two ring views."""
+    from guassianhand_amd.scenes import make_scene, ring_cameras
+    sc = make_scene("two_hands", n_views=2)
+    sc.H = sc.W = 256
+    sc.w2c, sc.K = ring_cameras(sc.xyz.mean(0), 2, 256, 256, 650.0)
+    D = compare(sc, dev)
+    assert D > 98562 // 2
+
+
 def test_reference_init_scale(dev):
     """The reference's initial Gaussian size exp(-5) = 6.7 mm (renderer_one_shot.py:165): ~10x more instances."""
     from guassianhand_amd.scenes import make_scene

@@ -132,3 +132,56 @@ def test_gs_activations_reproduce_the_reference_gslayer_forward(fx):
             got = getattr(gm, k).numpy()
             assert got.shape == want.shape, (tag, k)
             assert np.array_equal(got, want), (tag, k, float(np.abs(got - want).max()))
+
+
+def test_helpers_forward_single_view_reproduces_the_reference_calls(fx, monkeypatch):
+    """every drop-in GPU test drives `tests/helpers.forward_single_view`, a restatement of
+    renderer_one_shot.py:259-382. Here it runs on a RECORDING FAKE rasteriser (the same trick that captured the fixture from
+    the reference's own function) and must hand over exactly the tensors, keywords, None-ness and settings the reference's
+    function handed to its rasteriser — call 0 (RGB pass) and call 1 (mask pass), every blend mode."""
+    from types import SimpleNamespace
+    from guassianhand_amd import rasterizer as RZ
+    from tests import helpers
+    calls = []
+
+    class Recorder(torch.nn.Module):
+        def __init__(self, raster_settings):
+            super().__init__()
+            self.raster_settings = raster_settings
+
+        def forward(self, **kw):
+            calls.append((self.raster_settings, kw))
+            rs = self.raster_settings
+            return torch.zeros(3, rs.image_height, rs.image_width), torch.zeros(kw["means3D"].shape[0], dtype=torch.int32)
+
+    monkeypatch.setattr(RZ, "GaussianRasterizer", Recorder)
+    # the camera of the blend fixtures (tests/golden/make_host_fixtures.py): f = 1300, c = (167, 256), w2c = I with t_z = 1
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 1300.0
+    K[0, 2], K[1, 2] = 167.0, 256.0
+    w2c = torch.eye(4)
+    w2c[2, 3] = 1.0
+    cam = cam_mod.Camera.from_w2c(w2c, K, 512, 334, 0.71, 1.42)
+    for name in [str(m) for m in fx["blend_modes"]]:
+        gs_t, bl = _mode_inputs(fx, name)
+        gs = R.GaussianModel(**gs_t)
+        use_rgb = name.startswith("rgb")
+        calls.clear()
+        ret = helpers.forward_single_view(gs, cam, torch.zeros(3), use_rgb=use_rgb, sh_degree=3, **bl)
+        assert len(calls) == int(fx[f"{name}_ncalls"]) == 2
+        assert sorted(ret.keys()) == sorted(str(k) for k in fx[f"{name}_ret_keys"])
+        assert tuple(ret["comp_rgb"].shape) == tuple(fx[f"{name}_ret_rgb_shape"])
+        for ci, (rs, kw) in enumerate(calls):
+            assert sorted(kw.keys()) == sorted(str(k) for k in fx[f"{name}_call{ci}_kwnames"]), (name, ci)
+            assert sorted(k for k, v in kw.items() if v is None) == sorted(str(k) for k in fx[f"{name}_call{ci}_none"]), (name, ci)
+            assert int(rs.sh_degree) == int(fx[f"{name}_call{ci}_sh_degree"])
+            assert np.array_equal(rs.bg.numpy(), fx[f"{name}_call{ci}_bg"])
+            assert [rs.image_height, rs.image_width] == [int(v) for v in fx[f"{name}_call{ci}_hw"]]
+            assert rs._fields == tuple(str(f) for f in fx[f"{name}_call{ci}_settings_fields"])
+            assert rs.prefiltered is False and rs.debug is False and rs.scale_modifier == 1.0
+            for k, v in kw.items():
+                if v is None:
+                    continue
+                want = fx[f"{name}_call{ci}_{k}"]
+                assert str(v.dtype) == str(fx[f"{name}_call{ci}_{k}_dtype"]), (name, ci, k)
+                assert v.shape == want.shape and np.array_equal(v.detach().numpy(), want), (name, ci, k)
