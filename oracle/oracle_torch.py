@@ -61,13 +61,18 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
                     tanfovx: float, tanfovy: float, bg, H: int, W: int,
                     colors_precomp: Optional[torch.Tensor] = None, shs: Optional[torch.Tensor] = None,
                     sh_degree: int = 0, scale_modifier: float = 1.0, pixel_chunk: int = 2048,
-                    return_aux: bool = False, pixel_window=None, checkpoint_chunks: bool = False):
+                    return_aux: bool = False, pixel_window=None, checkpoint_chunks: bool = False,
+                    ambiguity_eps: Optional[float] = None):
     """Returns (image (3,H,W), radii (P,) int32[, aux dict]).
     pixel_window = (x0, y0, x1, y1): evaluate only the pixels x0 <= x < x1, y0 <= y < y1 of the H x W image (the image
     returned is (3, y1-y0, x1-x0)); everything else — projection, tile rects, tile membership of a pixel — is that of the
     full image, so the window of a hand-scene render can be checked without the dense P x H x W evaluation.
     checkpoint_chunks: recompute every pixel chunk in the backward instead of keeping its pixel x Gaussian intermediates
-    (memory of one chunk at a time)."""
+    (memory of one chunk at a time).
+    ambiguity_eps (with checkpoint_chunks): also return a bool mask (h, w) of the pixels at which some discrete decision of
+    App. A.3 sits within that RELATIVE margin of its threshold — alpha against 1/255, power against 0 (|power| <= eps),
+    T (1 - alpha) against 1e-4 (margin 5 eps: a product of up to a thousand factors) — i.e. the pixels where an evaluation in
+    another precision may legitimately decide differently: returns (image, radii, ambiguous)."""
     if (shs is None) == (colors_precomp is None):
         raise ValueError("provide exactly one of shs / colors_precomp")
     dt, dev = means3D.dtype, means3D.device
@@ -174,14 +179,33 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
         T_excl = torch.cat([torch.ones_like(T_incl[:, :1]), T_incl[:, :-1]], dim=1)
         wgt = torch.where(active, alpha * T_excl, torch.zeros_like(alpha))
         final_T = torch.prod(torch.where(active, 1.0 - alpha, torch.ones_like(alpha)), dim=1)
-        return wgt @ o_rgb + final_T[:, None] * bgc[None, :]
+        col = wgt @ o_rgb + final_T[:, None] * bgc[None, :]
+        if ambiguity_eps is None:
+            return col
+        with torch.no_grad():
+            e = float(ambiguity_eps)
+            thr = 1.0 / 255.0
+            near_alpha = in_tile & (power <= e) & ((a_raw - thr).abs() <= e * thr)
+            near_power = in_tile & (power.abs() <= e) & (o_op[None, :] >= thr * (1 - e))
+            alive = torch.cat([torch.ones_like(T_incl[:, :1], dtype=torch.bool), T_incl[:, :-1] >= 1e-4 * (1 - 5 * e)], dim=1)
+            near_stop = contrib0 & alive & ((T_incl - 1e-4).abs() <= 5 * e * 1e-4)
+            # a decision behind the stop cannot matter: only entries the walk can still reach count
+            amb = ((near_alpha | near_power) & alive | near_stop).any(dim=1)
+        return col, amb.to(col.dtype)
 
     if checkpoint_chunks and not return_aux:
         from torch.utils.checkpoint import checkpoint
+        amb_parts = []
         for s in range(0, N, pixel_chunk):
-            out_rgb.append(checkpoint(chunk_colour, xs[s:s + pixel_chunk], ys[s:s + pixel_chunk], o_px, o_py, o_A, o_B, o_C, o_op,
-                                      o_rgb, use_reentrant=False))
+            r = checkpoint(chunk_colour, xs[s:s + pixel_chunk], ys[s:s + pixel_chunk], o_px, o_py, o_A, o_B, o_C, o_op,
+                           o_rgb, use_reentrant=False)
+            if ambiguity_eps is not None:
+                r, am = r
+                amb_parts.append(am.detach() > 0)
+            out_rgb.append(r)
         img = torch.cat(out_rgb, dim=0).reshape(wy1 - wy0, wx1 - wx0, 3).permute(2, 0, 1).contiguous()
+        if ambiguity_eps is not None:
+            return img, radii, torch.cat(amb_parts).reshape(wy1 - wy0, wx1 - wx0)
         return img, radii
 
     for s in range(0, N, pixel_chunk):

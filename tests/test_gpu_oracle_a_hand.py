@@ -31,6 +31,14 @@ ROW_RTOL = 1e-4
 # one float32-vs-float64 threshold flip per million (measured in test_gpu_oracle_a.py) -> allow a proportionate count. (Measured
 # against Oracle B on these windows: none above 1e-4 — a flip deep in a list is weighted by a small transmittance.)
 FLIPS_PER_MILLION_TESTS = 3.0
+# Under a list a thousand entries deep one alpha-vs-1/255 decision taken differently moves the PIXEL by alpha * T * c < 1e-4 (T is
+# small there) — invisible to the image bar — but moves the gradient of a faint Gaussian, which is made of a handful of such
+# terms, by tens of percent (seen: one Gaussian of 15,261, opacity 0.08, row error 19 % with an image error of 6.7e-5). A pixel
+# whose list holds a decision within AMBIGUITY_EPS (relative) of its threshold — evaluated by Oracle A itself, in float64 —
+# is therefore left out of the loss on both sides; the float32 rounding of alpha is ~1e-6 relative, so the margin is 20x that.
+# The fraction of such pixels is printed and bounded.
+AMBIGUITY_EPS = 2e-5
+MAX_AMBIGUOUS_FRACTION = 0.02
 MAX_CANCELLED = 4
 
 
@@ -71,9 +79,10 @@ def _oracle_a_window(sc, win):
     c = sc.cams()[0].to(d)
     means, opac, cols, sh = OT.blend_attributes(leaves["xyz"], leaves["opacity"], leaves["shs"], use_rgb=sc.use_rgb, **bl)
     kw = dict(colors_precomp=cols) if sc.use_rgb else dict(shs=sh, sh_degree=sc.sh_degree)
-    img, _ = OT.rasterize_dense(means, opac, leaves["scaling"], leaves["rotation"], viewmatrix=c[:16].reshape(4, 4),
-                                projmatrix=c[16:32].reshape(4, 4), campos=c[32:35], tanfovx=float(c[35]), tanfovy=float(c[36]),
-                                bg=c[37:40], H=sc.H, W=sc.W, pixel_window=win, checkpoint_chunks=True, pixel_chunk=256, **kw)
+    img, _, amb = OT.rasterize_dense(means, opac, leaves["scaling"], leaves["rotation"], viewmatrix=c[:16].reshape(4, 4),
+                                     projmatrix=c[16:32].reshape(4, 4), campos=c[32:35], tanfovx=float(c[35]), tanfovy=float(c[36]),
+                                     bg=c[37:40], H=sc.H, W=sc.W, pixel_window=win, checkpoint_chunks=True, pixel_chunk=256,
+                                     ambiguity_eps=AMBIGUITY_EPS, **kw)
 
     def backward(dwin):
         (img * dwin.to(d)).sum().backward()
@@ -81,7 +90,7 @@ def _oracle_a_window(sc, win):
         g["colors_precomp" if sc.use_rgb else "shs"] = leaves["shs"].grad
         g.update({k: v.grad for k, v in bl.items()})
         return g
-    return img.detach(), backward
+    return img.detach(), amb, backward
 
 
 # name: (scene config, view of the 2-view ring, window in tiles (tx0, ty0, n) — centre of the hands, where the lists are deepest)
@@ -133,16 +142,20 @@ def test_hand_scene_window_matches_the_dense_float64_autograd_oracle(dev, case):
     # (3) + (4) Oracle A, float64, window pixels only. (Flush-to-zero for the CPU evaluation: the running transmittance under a
     # thousand-deep list underflows into float64 denormals, which cost 50x the time and contribute exactly nothing.)
     ftz = torch.set_flush_denormal(True)
-    img_a, backward_a = _oracle_a_window(sub, win)
-    err = (img_sub[0, :, y0:y1, x0:x1].double() - img_a).abs().amax(dim=0)
+    img_a, ambiguous, backward_a = _oracle_a_window(sub, win)
+    err = (img_sub[0, :, y0:y1, x0:x1].double() - img_a).abs().amax(dim=0)       # the image bar holds on EVERY pixel but counted flips
     flipped = err > IMG_LINF
     n_flip = int(flipped.sum())
+    frac_amb = float(ambiguous.float().mean())
+    print(f"{case}: {int(ambiguous.sum())} of {ambiguous.numel()} pixels ({100 * frac_amb:.2f} %) hold a decision within {AMBIGUITY_EPS:g} of "
+          f"its threshold: left out of the gradient comparison")
+    assert frac_amb <= MAX_AMBIGUOUS_FRACTION
     tests_m = idx.numel() * (y1 - y0) * (x1 - x0) / 1e6 * 0.05            # ~5 % of the (pixel, Gaussian) pairs of a window share a tile rect
     allowed = max(2, int(FLIPS_PER_MILLION_TESTS * tests_m))
     print(f"{case}: image L_inf {float(err[~flipped].max()):.3g} over {int((~flipped).sum())} pixels; {n_flip} pixel(s) with a float32-vs-"
           f"float64 threshold decision (allowed {allowed}), L_inf {float(err[flipped].max()) if n_flip else 0.0:.3g}")
     assert n_flip <= allowed and (n_flip == 0 or float(err[flipped].max()) <= FLIP_LINF)
-    dwin2 = dwin * (~flipped)[None].float()
+    dwin2 = dwin * (~(flipped | ambiguous))[None].float()
     g_a = backward_a(dwin2)
     torch.set_flush_denormal(False)
     dimg2 = torch.zeros(1, 3, H, W)
