@@ -86,8 +86,9 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   }
   L->sort_tables = take(tab * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
-  L->tile_walk = take((size_t)g.NV * g.tiles * 8);       // walked entries [T] + completion counters [T]; directly after
-                                                         // ranges: all cleared by one memset when there is nothing to project
+  L->tile_walk = take((size_t)g.NV * g.tiles * 12);      // walked entries [T] + completion counters [T] + stop positions [T];
+                                                         // directly after ranges: all cleared by one memset when there is
+                                                         // nothing to project
   L->tile_order = take((size_t)g.NV * g.tiles * 4);
   const size_t n_items = (size_t)g.NV * g.tiles + cap / GH_SEGMENT + 4;       // backward work items / checkpoint slots (2 + 2 spare per half)
   L->bwd_items = take(n_items * 8);
@@ -109,6 +110,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->half_counters = take(512);
   L->key_bits = take((gh_proj_blocks(g) + 4) * 8);        // (OR, AND) of the visible depth keys per projection block (+1 word; two
                                                           // halves: + 1 block of rounding + 1 word each)
+  L->tile_bound = take((size_t)g.NV * g.tiles * 4);
   L->total_bytes = off;
   return GH_OK;
 }
@@ -161,7 +163,7 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     o.keys_a += cap0 * 4; o.keys_b += cap0 * 4; o.vals_a += cap0 * 4; o.vals_b += cap0 * 4; o.sorted_slot += cap0 * 4;
     o.inst_r0 += cap0 * 16; o.inst_r1 += cap0 * 16; o.inst_r2 += cap0 * 8;
     o.sort_tables += h ? tab_a * 4 : 0;
-    o.ranges += t0 * 8; o.tile_walk += t0 * 8; o.tile_order += t0 * 4;
+    o.ranges += t0 * 8; o.tile_walk += t0 * 12; o.tile_order += t0 * 4;
     o.bwd_items += h ? items_a * 8 : 0; o.ckpt_rgb += h ? items_a * 256 * 16 : 0;
     o.final_C += p0 * 16; o.final_T += p0 * 4; o.n_contrib += p0 * 4;
     o.inst_grad += cap0 * 4 * GH_REC_G * 4; o.inst_flag += cap0 * 4;
@@ -169,12 +171,14 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     o.grad_sums += n0 * 48;
     o.cull_bound += n0 * 4; o.inst_c += cap0 * 4; o.attr += n0 * 16;
     o.key_bits += h ? (proj_a + 1) * 8 : 0;
+    o.tile_bound += t0 * 4;
     if (h == 0) {
       blk_a = ((size_t)H.g.N + GH_BLOCK - 1) / GH_BLOCK; items_a = (size_t)H.g.n_items; tab_a = gh_sort_table_words(H.g);
       proj_a = gh_proj_blocks(H.g);
     }
     H.in = *in;
     H.in.cams = in->cams + (size_t)H.v0 * GH_CAM_FLOATS;
+    if (in->tile_depth_bound) H.in.tile_depth_bound = in->tile_depth_bound + 2 * t0;     // (depth, block mask) pairs
     if (per_view) {                                       // pose batch: the half's own rows of every per-Gaussian array
       const size_t r0 = n0;
       H.in.means3D = in->means3D + r0 * 3; H.in.opacities = in->opacities + r0;
@@ -224,7 +228,7 @@ __global__ void gh_merge_counters_kernel(const GhCounters* __restrict__ a, const
   if (need > 0xFFFFFFFFull) need = 0xFFFFFFFFull;
   const unsigned long long tot = da + db;
   out->num_rendered = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;
-  out->overflow = (a->overflow | b->overflow) ? 1u : 0u;
+  out->overflow = a->overflow | b->overflow;                // (bit 0: a half exceeded its share; bit 2: depth-bound miss)
   out->reserved[0] = (uint32_t)need;
   out->reserved[1] = 0u;
 }
@@ -241,6 +245,9 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   rc = check_inputs(d, in);
   if (rc != GH_OK) return rc;
   if (!out || !out->image || !workspace) return GH_ERR_INVALID_ARG;
+  if (in->tile_depth_bound && (const float*)out->tile_depth_seen == in->tile_depth_bound) return GH_ERR_INVALID_ARG;
+  // lists that must outlive this call's opacities cannot be truncated by a bound that holds for this call only
+  if (in->tile_depth_bound && (d->flags & GH_FLAG_STATIC_LISTS)) return GH_ERR_UNSUPPORTED;
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
@@ -263,9 +270,11 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
         gh_launch_sh_colour_fwd(&H.d, H.g, &H.in, ws, H.L, sh);
         gh_launch_preprocess_fwd(&H.d, H.g, &H.in, out->radii ? out->radii + (size_t)H.v0 * g.P : nullptr, ws, H.L, sh);
       }
-      if (stages & GH_FWD_BINNING) gh_launch_binning(&H.d, H.g, ws, H.L, sh);
+      if (stages & GH_FWD_BINNING) gh_launch_binning(&H.d, H.g, ws, H.L, sh, H.in.tile_depth_bound ? (const float*)(ws + H.L.tile_bound) : nullptr);
       if (stages & GH_FWD_RENDER)
-        gh_launch_render_fwd(&H.d, H.g, &H.in, out->image + pix0 * 3, out->alpha ? out->alpha + pix0 : nullptr, ws, ws, H.L, sh);
+        gh_launch_render_fwd(&H.d, H.g, &H.in, out->image + pix0 * 3, out->alpha ? out->alpha + pix0 : nullptr, ws, ws, H.L, sh,
+                             out->tile_depth_seen ? out->tile_depth_seen + (size_t)2 * H.v0 * g.tiles : nullptr, out->tile_depth_seen_scale,
+                             out->tile_depth_seen_slack);
     }
     if (!gh_join(S, s)) return GH_ERR_LAUNCH;
     hipLaunchKernelGGL(gh_merge_counters_kernel, dim3(1), dim3(1), 0, s, (const GhCounters*)(ws + hv[0].L.counters),
@@ -279,9 +288,11 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
     gh_launch_preprocess_fwd(d, g, in, out->radii, ws, L, s);
   }
   if (stages & GH_FWD_BINNING) {
-    gh_launch_binning(d, g, ws, L, s);
+    gh_launch_binning(d, g, ws, L, s, in->tile_depth_bound ? (const float*)(ws + L.tile_bound) : nullptr);
   }
-  if (stages & GH_FWD_RENDER) gh_launch_render_fwd(d, g, in, out->image, out->alpha, ws, ws, L, s);
+  if (stages & GH_FWD_RENDER)
+    gh_launch_render_fwd(d, g, in, out->image, out->alpha, ws, ws, L, s, out->tile_depth_seen, out->tile_depth_seen_scale,
+                         out->tile_depth_seen_slack);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 

@@ -469,7 +469,8 @@ __device__ __forceinline__ uint32_t gh_kth_set_bit(uint32_t lo, uint32_t hi, uin
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ slot_begin, float4* __restrict__ geom,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP, uint32_t flags) {
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP, uint32_t flags,
+    const float* __restrict__ tile_depth_bound, const float* __restrict__ depth) {
   constexpr int NW = GH_BLOCK / GH_WAVE;
   __shared__ uint32_t s_w[NW], s_p[NW];
   __shared__ uint32_t s_end[NW][GH_WAVE];               // per wave: inclusive prefix of the lanes' instance counts
@@ -549,6 +550,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     const uint32_t sminx = sr & 255u, sminy = (sr >> 8) & 255u, sw = ((sr >> 16) & 255u) - sminx, sn = sw * ((sr >> 24) - sminy);
     const uint32_t sn_id = (uint32_t)__builtin_amdgcn_readlane((int)n, src), svb = (uint32_t)__builtin_amdgcn_readlane((int)vbase, src);
     uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)(wave_base + x - cnt), src);
+    // (the speculative occlusion bound, exactly as the projection kernel applied it when it counted this Gaussian's tiles)
+    const float stz = tile_depth_bound ? bf(depth[n]) : 0.0f;
     for (uint32_t base = 0; base < sn; base += GH_WAVE) {
       const uint32_t k = base + (uint32_t)lane;
       bool h = false;
@@ -557,6 +560,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
         const uint32_t dy = k / sw;
         ty = sminy + dy; tx = sminx + (k - dy * sw);
         h = gh_block_hit(s0, s1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
+        if (tile_depth_bound) h = h && !(stz > tile_depth_bound[svb + ty * (uint32_t)gx + tx]);
       }
       const uint64_t hm = gh_ballot(h);
       if (h) {
@@ -581,7 +585,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               uint2* __restrict__ ranges, float4* __restrict__ r0,
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
                                                               uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin,
-                                                              float rtiles, float rgx, uint32_t flags, float* __restrict__ inst_c) {
+                                                              float rtiles, float rgx, uint32_t flags, float* __restrict__ inst_c,
+                                                              const float* __restrict__ tile_depth_bound, const float* __restrict__ depth) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
   // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
@@ -637,6 +642,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
         const float4 sbc = make_float4(bf(b.x), (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(sop) : sop, 0.0f, 0.0f);   // as culled
         const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)r, src), sbit = (uint32_t)__builtin_amdgcn_readlane((int)bit, src);
         const uint32_t sminx = sr & 255u, sminy = (sr >> 8) & 255u, sw = ((sr >> 16) & 255u) - sminx;
+        // (speculative occlusion bound: the same `depth > bound` the projection and emit kernels applied)
+        const float stz = tile_depth_bound ? bf(depth[gid]) : 0.0f;
+        const uint32_t svb = (uint32_t)__builtin_amdgcn_readlane((int)(t - tl), src);      // first global tile id of the view
         uint32_t cnt = 0;
         for (uint32_t base = 0; base < sbit; base += GH_WAVE) {
           const uint32_t k = base + (uint32_t)lane;
@@ -644,6 +652,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
           if (k < sbit) {
             const uint32_t dy = k / sw, dx = k - dy * sw;
             h = gh_block_hit(sa, sbc, (float)((sminx + dx) * GH_TILE), (float)((sminy + dy) * GH_TILE), (float)(GH_TILE - 1));
+            if (tile_depth_bound) h = h && !(stz > tile_depth_bound[svb + (sminy + dy) * (uint32_t)gx + (sminx + dx)]);
           }
           cnt += (uint32_t)__popcll(gh_ballot(h));
         }
@@ -652,9 +661,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
     } else if (!small) {                                // (the last, partial wave: lane by lane)
       uint32_t k = 0;
       const float4 bc = make_float4(b.x, (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(b.y) : b.y, 0.0f, 0.0f);   // as culled
+      const float tzl = tile_depth_bound ? depth[gid] : 0.0f;
       for (uint32_t yy = miny; yy < maxy && k < bit; ++yy)
-        for (uint32_t xx = minx; xx < maxx && k < bit; ++xx, ++k)
-          before += gh_block_hit(a, bc, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1)) ? 1u : 0u;
+        for (uint32_t xx = minx; xx < maxx && k < bit; ++xx, ++k) {
+          bool h = gh_block_hit(a, bc, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1));
+          if (tile_depth_bound) h = h && !(tzl > tile_depth_bound[(t - tl) + yy * (uint32_t)gx + xx]);
+          before += h ? 1u : 0u;
+        }
     }
   }
   gh_stream(&sorted_slot[i], slot0 + before);           // (streamed: see gh_stream)
@@ -702,7 +715,7 @@ static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, h
                      (uint32_t*)(ws + L.tile_order));
 }
 
-void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
+void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s, const float* tile_depth_bound) {
   if (g.N == 0) { gh_launch_tile_order(g, ws, L, s); return; }   // ranges are all-empty (memset): any order
   const int nblk_pre = (g.N + GH_BLOCK - 1) / GH_BLOCK;
   GhCounters* ctr = (GhCounters*)(ws + L.counters);
@@ -731,7 +744,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
                      (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (float4*)(ws + L.geom), k_in, v_in, ctr,
-                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags);
+                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags, tile_depth_bound, (const float*)(ws + L.depth));
   if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }    // the emit kernel has written D (it stores nothing past cap)
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
@@ -742,6 +755,6 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
                      (const uint32_t*)(ws + L.slot_begin),
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,   // gh_div_small's range
-                     d->flags, (float*)(ws + L.inst_c));
+                     d->flags, (float*)(ws + L.inst_c), tile_depth_bound, (const float*)(ws + L.depth));
   gh_launch_tile_order(g, ws, L, s);
 }

@@ -51,12 +51,15 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
 // ---- launchers (each enqueues on `s`, never synchronises) --------------------------------------
 void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii,
                               char* ws, const GhLayout& L, hipStream_t s);
-void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s);
+// tile_depth_bound: GhInputs.tile_depth_bound (the kernels that decide list membership for rects without a hit mask repeat the test)
+void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s, const float* tile_depth_bound = nullptr);
 // wg: workspace that owns the geometry / binning arrays (ranges, tile order, inst_r0, sorted_slot, slot_begin, tiles_touched,
 // vals); ws: workspace of this call's own state (colour records, image state, backward scratch). wg == ws for a plain call;
 // they differ for a second call over the same geometry (gh_forward_shared).
+// seen / seen_scale: GhOutputs.tile_depth_seen (optional; full forwards only)
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha,
-                          const char* wg, char* ws, const GhLayout& L, hipStream_t s);
+                          const char* wg, char* ws, const GhLayout& L, hipStream_t s, float* seen = nullptr, float seen_scale = 1.0f,
+                          uint32_t seen_slack = 0u);
 // geom: gh_records_need_geometry(in, gr) — false: the sub-records carry the colour / opacity moments only
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s,

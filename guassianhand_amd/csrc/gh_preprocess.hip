@@ -6,13 +6,33 @@
 #include "gh_internal.h"
 
 // ------------------------------------------------------------------------------------------------
+// Effective occlusion bound of this call from what the previous call reported (GhInputs.tile_depth_bound: (depth, block mask)
+// per tile): a tile keeps its depth when all of its own pixels stopped (a finite depth says so) and every 4x4-pixel block of
+// the eight neighbouring tiles that touches it did too; a neighbour outside the image does not count. One thread per tile.
+__global__ __launch_bounds__(GH_BLOCK) void gh_tile_bound_kernel(const float2* __restrict__ seen, int NV, int gx, int gy,
+                                                                  float* __restrict__ bound) {
+  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int tiles = gx * gy;
+  if (t >= NV * tiles) return;
+  const int v = t / tiles, tl = t - v * tiles, ty = tl / gx, tx = tl - ty * gx;
+  const float2* sv = seen + (size_t)v * tiles;
+  float d = sv[tl].x;
+  auto need = [&](int nx, int ny, uint32_t bits) {      // the neighbour's blocks `bits` must all have stopped
+    if (nx < 0 || ny < 0 || nx >= gx || ny >= gy) return true;
+    return (__float_as_uint(sv[ny * gx + nx].y) & bits) == bits;
+  };
+  const bool ok = need(tx, ty - 1, 0xF000u) && need(tx, ty + 1, 0x000Fu) && need(tx - 1, ty, 0x8888u) && need(tx + 1, ty, 0x1111u) &&
+                  need(tx - 1, ty - 1, 0x8000u) && need(tx + 1, ty - 1, 0x1000u) && need(tx - 1, ty + 1, 0x0008u) && need(tx + 1, ty + 1, 0x0001u);
+  bound[t] = ok ? d : __uint_as_float(0x7F800000u);
+}
+
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     GhInputs in, int P, int NV, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
     const float4* __restrict__ sh_rgb, float4* __restrict__ geom, float* __restrict__ depth,
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk,
-    uint2* __restrict__ key_bits, float rdiv, float* __restrict__ cull_bound_out) {
+    uint2* __restrict__ key_bits, float rdiv, float* __restrict__ cull_bound_out, const float* __restrict__ tile_bound) {
   __shared__ uint2 s_bits[GH_BLOCK / GH_WAVE];
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
@@ -20,7 +40,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
   if (t == 0) {                                        // counters: reserved[0] = element count of the level-1 (depth) sort
     ctr->num_rendered = 0; ctr->overflow = 0; ctr->reserved[0] = (uint32_t)N; ctr->reserved[1] = 0;
   }
-  if (t < T) { ranges[t] = make_uint2(0u, 0u); tile_walk[t] = 0u; tile_walk[T + t] = 0u; }   // per-tile state of the later stages
+  if (t < T) { ranges[t] = make_uint2(0u, 0u); tile_walk[t] = 0u; tile_walk[T + t] = 0u; tile_walk[2 * T + t] = 0u; }   // per-tile state of the later stages
   // Per-lane state that crosses the wave-cooperative tile count below
   uint32_t dkey = 0xFFFFFFFFu;                          // culled Gaussians sort behind everything and emit nothing
   unsigned rect_bits = 0;
@@ -73,11 +93,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
         // ellipse reaches a pixel centre (gh_block_hit, conservative within its margin). A dropped tile holds no pixel
         // that would blend this Gaussian, so images and gradients are unchanged; gh_emit_kernel repeats this test.
         g0 = make_float4(px, py, e.c * dinv, -e.b * dinv); g1 = make_float4(e.a * dinv, op_cull, 0.0f, 0.0f);
+        // Speculative occlusion bound (GhInputs.tile_depth_bound): an instance BEHIND its tile's bound is not listed. The
+        // comparison is `depth > bound` in every kernel that decides membership (here, gh_emit_kernel and gh_ranges_kernel for
+        // rects without a hit mask), so the lists stay consistent; the forward verifies the speculation per pixel.
+        const float* tb = tile_bound ? tile_bound + (size_t)v * (gx * gy) : nullptr;
         if (cnt <= 64) {
           int bit = 0;                                  // row-major position in the rect; rects of <= 64 tiles keep the
           for (int ty = miny; ty < maxy; ++ty)          // hit mask so that the emit kernel does not repeat the tests
             for (int tx = minx; tx < maxx; ++tx, ++bit) {
-              const bool h = gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
+              bool h = gh_block_hit(g0, g1, (float)(tx * GH_TILE), (float)(ty * GH_TILE), (float)(GH_TILE - 1));
+              if (tb) h = h && !(tz > tb[ty * gx + tx]);
               tiles += h ? 1u : 0u;
               if (h) hitmask |= 1ull << bit;
             }
@@ -93,6 +118,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     const float4 s0 = make_float4(bf(g0.x), bf(g0.y), bf(g0.z), bf(g0.w)), s1 = make_float4(bf(g1.x), bf(g1.y), 0.0f, 0.0f);
     const int sminx = __builtin_amdgcn_readlane(minx, src), sminy = __builtin_amdgcn_readlane(miny, src);
     const int sw = __builtin_amdgcn_readlane(maxx, src) - sminx, sn = sw * (__builtin_amdgcn_readlane(maxy, src) - sminy);
+    const float stz = bf(tz);
+    const int sn_idx = __builtin_amdgcn_readlane(n, src);
+    const float* tb = tile_bound ? tile_bound + (size_t)(sn_idx / P) * (gx * gy) : nullptr;
     unsigned cnt = 0;
     for (int base = 0; base < sn; base += GH_WAVE) {
       const int k = base + lane;
@@ -100,6 +128,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
       if (k < sn) {
         const int dy = k / sw, dx = k - dy * sw;
         h = gh_block_hit(s0, s1, (float)((sminx + dx) * GH_TILE), (float)((sminy + dy) * GH_TILE), (float)(GH_TILE - 1));
+        if (tb) h = h && !(stz > tb[(sminy + dy) * gx + (sminx + dx)]);
       }
       cnt += (unsigned)__popcll(gh_ballot(h));
     }
@@ -154,6 +183,12 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
     return;
   }
   int nblk = ((g.N > T ? g.N : T) + GH_BLOCK - 1) / GH_BLOCK;
+  const float* tile_bound = nullptr;
+  if (in->tile_depth_bound) {                          // speculative occlusion bound: neighbourhood test first (one tiny kernel)
+    hipLaunchKernelGGL(gh_tile_bound_kernel, dim3((T + GH_BLOCK - 1) / GH_BLOCK), dim3(GH_BLOCK), 0, s, (const float2*)in->tile_depth_bound,
+                       g.NV, g.gx, g.gy, (float*)(ws + L.tile_bound));
+    tile_bound = (const float*)(ws + L.tile_bound);
+  }
   hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.NV, g.N, g.H, g.W, g.gx, g.gy,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (const float4*)(ws + L.sh_rgb), (float4*)(ws + L.geom),
                      (float*)(ws + L.depth),
@@ -161,7 +196,7 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii,
                      T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk), (uint2*)(ws + L.key_bits),
                      g.N < (1 << 24) ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f,
-                     (float*)(ws + L.cull_bound));
+                     (float*)(ws + L.cull_bound), tile_bound);
 }
 
 // ------------------------------------------------------------------------------------------------

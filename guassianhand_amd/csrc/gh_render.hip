@@ -66,7 +66,14 @@ struct GhPixelFwd {
   float T, C0, C1, C2, A;  // A: accumulated alpha = the mask channel (colour 1, bg 0)
   uint32_t last;
   int done;               // 0 / 1 (kept as int so it can travel through DPP)
+  // SEEN only (GhOutputs.tile_depth_seen): the walk goes on VIRTUALLY behind the stop — nothing is blended — until the
+  // transmittance is below GH_SEEN_T as well: a pixel that ended just under the stop threshold is one rounding away from needing
+  // more of its list, a pixel that also passes the stricter threshold is not.
+  float vT;               // virtual transmittance behind the stop
+  uint32_t stopq;         // 4 * (list position + 1) of the entry that took vT below GH_SEEN_T (this lane's slot only), 0 = none
+  int vdone;              // the virtual walk has ended too
 };
+#define GH_SEEN_T 0.00005f
 
 // (quad_perm gives every lane a source lane, so no `old` value is needed: mov_dpp, not update_dpp(0, ..) — the latter costs a
 // v_mov 0 in front of every use)
@@ -160,7 +167,7 @@ __device__ __forceinline__ void gh_pop4_high(uint64_t& mask, int& j0, int& j1, i
 }
 
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
-template <bool ALPHA>
+template <bool ALPHA, bool SEEN>
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, int blk,
                                                float pxf, float pyf, GhPixelFwd& p, float4* __restrict__ s_col) {
   const uint32_t slot8 = (uint32_t)slot * 8u;
@@ -219,8 +226,38 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
       blend = valid && ((qb & ((2u << slot) - 1u)) == 0u);         // no stop at or before this slot
       w = blend ? w : 0.0f;
       Tn = (qb & 1u) ? p.T : ((qb & 2u) ? P1 : ((qb & 4u) ? P2 : ((qb & 8u) ? P3 : P4)));   // T right before the stop
+      if (SEEN && qb && p.done == 0) {
+        // the virtual walk starts at the stop: transmittance right behind the stopping entry (the later slots of this trip
+        // are left out of it: the virtual stop can only come later for that, never earlier)
+        p.vT = (qb & 1u) ? P1 : ((qb & 2u) ? P2 : ((qb & 4u) ? P3 : P4));
+        if (p.vT < GH_SEEN_T) {
+          p.vdone = 1;
+          if (stopc && (qb & ((1u << slot) - 1u)) == 0u) p.stopq = (uint32_t)(4 * (base + 1)) + (uint32_t)src;
+        }
+      }
       if (qb) p.done = 1;
-      if (__all(p.done != 0)) { finished = true; mask = 0; }        // every pixel of the block is saturated: last trip
+      if (__all((SEEN ? p.vdone : p.done) != 0)) { finished = true; mask = 0; }   // every pixel of the block is saturated: last trip
+    } else if (SEEN) {
+      // pixels between their stop and their virtual stop (wave-uniform test; a few trips per pixel)
+      const bool vlive = p.done != 0 && p.vdone == 0;
+      if (gh_ballot(vlive)) {
+        const float vae = (vlive && ok) ? alpha : 0.0f;
+        const float vf = 1.0f - vae;
+        float V1, V2, V3;
+        gh_quad_prefix3(p.vT, vf, V1, V2, V3);
+        const float Vn = gh_slot_select(p.vT, V1, V2, V3) * vf;      // virtual transmittance right behind this lane's entry
+        const float V4 = gh_quad_bcast<3>(Vn);
+        const int vs = (vae > 0.0f && Vn < GH_SEEN_T) ? 1 : 0;
+        const uint32_t qv = (uint32_t)(gh_quad_bcast_i<0>(vs) | (gh_quad_bcast_i<1>(vs) << 1) | (gh_quad_bcast_i<2>(vs) << 2) |
+                                       (gh_quad_bcast_i<3>(vs) << 3));
+        if (vlive) {
+          if (qv) {
+            p.vdone = 1;
+            if (vs && (qv & ((1u << slot) - 1u)) == 0u) p.stopq = (uint32_t)(4 * (base + 1)) + (uint32_t)src;
+          } else p.vT = V4;
+        }
+        if (__all(p.vdone != 0)) { finished = true; mask = 0; }
+      }
     }
     const float m0 = r * w, m1 = g * w, m2 = bl * w;
     gh_quad_accumulate(p.C0, m0);              // C = (((C + m[slot 0]) + m[slot 1]) + m[slot 2]) + m[slot 3], in list order
@@ -239,13 +276,15 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
 
 // grid = 4 blocks per tile (one per 8x8 quadrant), 4 waves per block (one per 4x4 pixel block); no LDS, no barriers.
 // ALPHA: also accumulate the mask channel (colour 1, bg 0) — SURVEY §8 f-2.
-template <bool ALPHA>
+template <bool ALPHA, bool SEEN>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
     const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
     int tiles, float* __restrict__ image, float* __restrict__ alpha_img, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
-    float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr) {
+    float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const GhCounters* __restrict__ ctr_ro,
+    const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
+    const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth) {
   int v, tx, ty;
   uint32_t item_idx, quad_u;
   gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);
@@ -269,17 +308,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   __shared__ float4 s_col_all[GH_BLOCK / GH_WAVE][GH_WAVE];
   float4* s_col = s_col_all[wid];
   GhPixelFwd p;
-  p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.done = inside ? 0 : 1;
+  p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.stopq = 0; p.done = inside ? 0 : 1;
+  p.vT = 1.0f; p.vdone = p.done;
   if (total > 0 && !__all(p.done != 0)) {
     // two register sets in flight: while one batch is consumed the next one is already being loaded
     GhBatch A, B;
     gh_load_batch(A, r0, r1, r2, lane, total);
     for (int base = 0; base < total; base += 2 * GH_WAVE) {
       gh_load_batch(B, r0, r1, r2, base + GH_WAVE + lane, total);
-      if (gh_fwd_consume<ALPHA>(A, base, total, lane, slot, blk, pxf, pyf, p, s_col)) break;
+      if (gh_fwd_consume<ALPHA, SEEN>(A, base, total, lane, slot, blk, pxf, pyf, p, s_col)) break;
       if (base + GH_WAVE >= total) break;
       gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
-      if (gh_fwd_consume<ALPHA>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p, s_col)) break;
+      if (gh_fwd_consume<ALPHA, SEEN>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p, s_col)) break;
       const int next = base + 2 * GH_WAVE;              // wave-uniform: a checkpoint every GH_SEGMENT entries (rare)
       if ((next % GH_SEGMENT) == 0 && next < total && inside && slot == 0) {
         const size_t ck = ck0 + (size_t)(next / GH_SEGMENT - 1) * 256;
@@ -294,10 +334,26 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint32_t b = (uint32_t)gh_quad_perm_i<0x4E>((int)p.last);      // quad_perm [2,3,0,1]
     p.last = b > p.last ? b : p.last;
   }
+  // Speculative occlusion bound (GhInputs.tile_depth_bound): the tile's list holds nothing behind the bound. A pixel that reached
+  // the early stop inside it looked at nothing further back — its result is the unbounded call's bit for bit; a pixel that ran
+  // off the end of a truncated list may miss entries: it is poisoned below and the call is flagged (overflow bit 2).
+  const bool bounded = tile_depth_bound != nullptr && tile_depth_bound[tile] < __uint_as_float(0x7F800000u);
+  const bool pixel_miss = bounded && inside && p.done == 0;
+  const bool wave_miss = !__all(p.done != 0);       // some in-image pixel of this block never reached the stop
+  // what the NEXT call may rely on: every pixel of the block passed the stricter virtual threshold inside this list
+  const bool wave_unsat = SEEN ? !__all(p.vdone != 0) : wave_miss;
+  if (bounded && wave_miss && lane == 0) atomicOr(&ctr->overflow, 4u);
+  if (SEEN && total == 0 && tid == 0 && quad == 0) {   // empty list: no bound, no block of it stops anything
+    tile_depth_seen[2 * tile] = __uint_as_float(0x7F800000u); tile_depth_seen[2 * tile + 1] = __uint_as_float(0u);
+  }
   if (total > 0) {                                   // walked length of the tile = max n_contrib over its 16 waves
     uint32_t m = p.last;
+    uint32_t sq = p.stopq >> 2;                      // position + 1 of the entry that stopped the lane's pixel
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m; }
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m;
+      const uint32_t u = __shfl_xor(sq, o); sq = u > sq ? u : sq;
+    }
     if (lane == 0) {
       // The LAST of the tile's 16 waves (4 quadrant blocks x 4) appends the tile's backward work items, one per depth
       // segment of the walked prefix: the list is in the order the forward finished the tiles. The backward takes it from
@@ -307,13 +363,39 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       const uint32_t prev_max = __hip_atomic_fetch_max(&tile_walk[tile], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" :: "v"(prev_max) : "memory");
       uint32_t* done = tile_walk + (size_t)gridDim.x / 4;          // completion counters follow the T walk entries
-      const uint32_t prev_done = __hip_atomic_fetch_add(&done[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (prev_done == 4u * (GH_BLOCK / GH_WAVE) - 1u) {
+      if (SEEN) {                                                  // (same ordering discipline: relaxed RMWs, results awaited)
+        uint32_t* stop = done + (size_t)gridDim.x / 4;             // ... and the stop positions follow those
+        const uint32_t ps = __hip_atomic_fetch_max(&stop[tile], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(ps) : "memory");
+      }
+      // bits 0..7 of the completion word count the tile's waves; bit 8 + b = every in-image pixel of block b reached the stop
+      // (each wave adds its own bit once: the sum is the OR)
+      const uint32_t my_bit = (SEEN && !wave_unsat) ? (0x100u << blk) : 0u;
+      const uint32_t prev_done = __hip_atomic_fetch_add(&done[tile], 1u + my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((prev_done & 0xFFu) == 4u * (GH_BLOCK / GH_WAVE) - 1u) {
         const uint32_t w = __hip_atomic_fetch_max(&tile_walk[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // final value
         const uint32_t nseg = (w + GH_SEGMENT - 1u) / GH_SEGMENT;
         if (nseg) {
           const uint32_t pos = __hip_atomic_fetch_add(&ctr->reserved[1], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           for (uint32_t k = 0; k < nseg; ++k) items[pos + k] = make_uint2((uint32_t)tile, k);
+        }
+        if (SEEN) {
+          // every pixel of the tile stopped (and passed the virtual threshold): nothing behind the last entry any of them looked at can matter next time either
+          // (up to the motion margin seen_scale); otherwise no bound for this tile
+          uint32_t* stop = done + (size_t)gridDim.x / 4;
+          const uint32_t sp = __hip_atomic_fetch_max(&stop[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t sat_mask = ((prev_done | my_bit) >> 8) & 0xFFFFu;
+          const bool unsat = sat_mask != 0xFFFFu || sp == 0u;
+          // ... plus `seen_slack` entries: what a pixel that stopped only just finds when it needs a little more next time
+          const uint32_t want = sp + seen_slack;
+          float seen = __uint_as_float(0x7F800000u);
+          if (!unsat) {
+            if (want <= (uint32_t)total) seen = depth[sorted_gid[range.x + want - 1u]] * seen_scale;
+            else if (bounded) seen = tile_depth_bound[tile] * seen_scale;     // this list was cut short itself: widen its bound
+            else seen = depth[sorted_gid[range.x + (uint32_t)total - 1u]] * seen_scale;
+          }
+          tile_depth_seen[2 * tile] = seen;
+          tile_depth_seen[2 * tile + 1] = __uint_as_float(sat_mask);
         }
       }
     }
@@ -327,7 +409,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     float* img = image + (size_t)v * 3 * H * W + (size_t)y * W + x;
     // Device-side overflow guard: with D > max_instances the lists are truncated, so a sync-free caller must never see a
     // plausible image — it gets NaN (and GhCounters.overflow for the host to read whenever it chooses).
-    const float poison = ctr->overflow ? __uint_as_float(0x7FC00000u) : 0.0f;
+    // (a depth-bound miss elsewhere — bit 2 — does not touch this pixel: tiles are independent; this pixel's own miss does)
+    // The capacity / stale-list bits were set by kernels BEFORE this one and are read through a pointer of their own (ctr_ro, the
+    // same address): the only write this kernel makes to the word is the atomic OR of bit 2 above, which these bits do not depend
+    // on — read through `ctr` the load can no longer be a scalar one, and 86 k waves fetching the line the work-list atomics hit
+    // (reserved[1], same 16 bytes) with vector loads cost the kernel 100 us (same-box A/B, round 4: 144 -> 242 us).
+    const float poison = ((ctr_ro->overflow & 3u) || pixel_miss) ? __uint_as_float(0x7FC00000u) : 0.0f;
     img[0] = fmaf(p.T, bg[0], p.C0) + poison;
     img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1) + poison;
     img[(size_t)2 * H * W] = fmaf(p.T, bg[2], p.C2) + poison;
@@ -336,7 +423,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
 }
 
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha, const char* wg, char* ws,
-                          const GhLayout& L, hipStream_t s) {
+                          const GhLayout& L, hipStream_t s, float* seen, float seen_scale, uint32_t seen_slack) {
   const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
   const uint2* ranges = (const uint2*)(wg + L.ranges);
   const uint32_t* order = (const uint32_t*)(wg + L.tile_order);
@@ -345,12 +432,17 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   float* fT = (float*)(ws + L.final_T); uint32_t* nc = (uint32_t*)(ws + L.n_contrib); uint32_t* tw = (uint32_t*)(ws + L.tile_walk);
   float4* ck = (float4*)(ws + L.ckpt_rgb); float4* fC = (float4*)(ws + L.final_C);
   uint2* items = (uint2*)(ws + L.bwd_items); GhCounters* ctr = (GhCounters*)(ws + L.counters);
-  if (alpha)
-    hipLaunchKernelGGL(gh_render_fwd_kernel<true>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr);
-  else
-    hipLaunchKernelGGL(gh_render_fwd_kernel<false>, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr);
+  // the occlusion bound belongs to the call that BUILT the lists (wg == ws); a second call over shared lists has none of its own
+  const float* bound = (wg == ws && in->tile_depth_bound) ? (const float*)(ws + L.tile_bound) : nullptr;
+  if (wg != ws) seen = nullptr;
+  const uint32_t* gid = (const uint32_t*)(wg + L.vals_a); const float* depth = (const float*)(wg + L.depth);
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
+                       g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const GhCounters*)ctr, bound, seen, seen_scale, seen_slack, gid, depth);
+  };
+  // SEEN (GhOutputs.tile_depth_seen wanted): the variant that walks on virtually behind the stop; the plain kernels are untouched
+  if (seen) { if (alpha) launch(gh_render_fwd_kernel<true, true>); else launch(gh_render_fwd_kernel<false, true>); }
+  else { if (alpha) launch(gh_render_fwd_kernel<true, false>); else launch(gh_render_fwd_kernel<false, false>); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -756,7 +848,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_recolour_kernel(GhInputs in, uint
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   const uint32_t D = gctr->num_rendered;
   if (i == 0) { ctr->num_rendered = D; ctr->overflow = gctr->overflow; ctr->reserved[0] = gctr->reserved[0]; ctr->reserved[1] = 0; }
-  if (i < (uint32_t)T) { tile_walk[i] = 0u; tile_walk[T + i] = 0u; }
+  if (i < (uint32_t)T) { tile_walk[i] = 0u; tile_walk[T + i] = 0u; tile_walk[2 * T + i] = 0u; }
   const uint32_t n = D < cap ? D : cap;
   if (i >= n) return;
   inst_flag[i] = 0;
@@ -806,7 +898,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_attr_kernel(GhInputs in, 
                                                                     const float4* __restrict__ sh_rgb, float4* __restrict__ attr,
                                                                     uint32_t* __restrict__ tile_walk, GhCounters* __restrict__ ctr) {
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
-  if (t < T) { tile_walk[t] = 0u; tile_walk[T + t] = 0u; }
+  if (t < T) { tile_walk[t] = 0u; tile_walk[T + t] = 0u; tile_walk[2 * T + t] = 0u; }
   if (t >= N) return;
   const int row = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : t % P;       // n = view * P + row (view-major, as the lists' payload)
   float op = in.opacities[row];

@@ -149,7 +149,11 @@ class _RenderedLoss(torch.autograd.Function):
 
 def _rendered_loss(spec, cams, xyz, opacity, scaling, rotation, shs, *, H, W, use_rgb, sh_degree=3, scale_modifier=1.0, xyz_b=None,
                    opacity_b=None, color_w=None, color_b=None, sync=True, max_instances=None, per_view_gaussians=False,
-                   geometry_cache=None):
+                   geometry_cache=None, depth_bound=None):
+    if depth_bound is not None:                        # rasterizer.DepthBoundCache: moving geometry (see rasterize_views)
+        if geometry_cache is not None:
+            raise ValueError("geometry_cache (static geometry) or depth_bound (moving geometry), not both")
+        geometry_cache = depth_bound
     return _RenderedLoss.apply(spec, geometry_cache, cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier), bool(use_rgb),
                                bool(sync), max_instances, bool(per_view_gaussians), xyz, opacity, scaling, rotation, shs, xyz_b,
                                opacity_b, color_w, color_b)

@@ -51,6 +51,55 @@ class GhStaleGeometryError(GhOverflowError):
     GeometryCache has been cleared, so re-running the step rebuilds the lists."""
 
 
+class GhDepthBoundMiss(GhOverflowError):
+    """A call with a speculative occlusion bound (DepthBoundCache) met a pixel that ran off the end of its truncated tile list: the
+    Gaussians moved further than the margin allows. That pixel is NaN in the returned image; the bound has been dropped, re-run
+    the step (it renders without a bound and produces a fresh one)."""
+
+
+class DepthBoundCache:
+    """Speculative per-tile occlusion bound for loops whose Gaussians move a LITTLE between steps — the one-shot fit's network-
+    side trainables move them every step (infer_one_shot.py:340-343), so the static tile lists of GeometryCache cannot serve it.
+    Every forward through the cache reports, per tile, the depth of the last list entry any pixel looked at (tiles whose pixels
+    all reached the early stop; +inf elsewhere), times (1 + margin); the NEXT forward does not list instances behind it — on the
+    hand scenes more than half of all instances lie behind a saturated surface and were emitted, sorted and gathered for nothing.
+    The forward verifies the speculation per pixel (GhInputs.tile_depth_bound): where it holds the result is the unbounded
+    call's bit for bit; where it fails the pixel is NaN, GhCounters.overflow bit 2 is set and the host re-runs without the bound
+    (sync=True: transparently; sync-free: GhDepthBoundMiss from the backward / check_overflow). Not used inside captured graphs
+    (the two buffers alternate between calls). margin: relative depth margin for the motion between two steps; slack: list
+    entries kept behind the last one any pixel of the tile looked at. refresh_every: a forward that REPORTS a bound runs the
+    kernel variant that walks on behind every pixel's stop until its transmittance has halved again (what tells a robustly
+    saturated tile from one a rounding away from needing its whole list) — 26 % more forward time, measured; the bound is
+    therefore refreshed every refresh_every-th call only and re-used in between (every call still verifies it; the margin has to
+    cover the motion of that many steps)."""
+
+    def __init__(self, margin: float = 2e-3, slack: int = 8, refresh_every: int = 4):
+        self.margin, self.slack, self.refresh_every = float(margin), int(slack), max(1, int(refresh_every))
+        self.bufs, self.key, self.cur, self.valid = None, None, 0, False
+        self.bounded_calls, self.misses, self.age = 0, 0, 0
+
+    def clear(self) -> None:
+        self.valid = False
+
+    def _buffers(self, dev, NV: int, H: int, W: int):
+        """(bound to apply or None, buffer to report into or None) for the next call; advances the cache's state."""
+        key = (dev, NV, H, W)
+        if self.key != key:
+            T = NV * ((W + 15) // 16) * ((H + 15) // 16)
+            self.bufs = (torch.empty(T, 2, dtype=torch.float32, device=dev), torch.empty(T, 2, dtype=torch.float32, device=dev))   # (depth, block mask)
+            self.key, self.cur, self.valid, self.age = key, 0, False, 0
+        if self.valid and self.age + 1 < self.refresh_every:      # re-use the bound, plain kernels
+            self.age += 1
+            self.bounded_calls += 1
+            return self.bufs[self.cur], None
+        bound, seen = (self.bufs[self.cur] if self.valid else None), self.bufs[1 - self.cur]
+        # the buffer this call writes is the next call's bound — also after a miss: a tile whose pixels did not all stop reports
+        # +inf, so what the call leaves behind is a valid bound source either way
+        self.cur, self.valid, self.age = 1 - self.cur, True, 0
+        self.bounded_calls += 1 if bound is not None else 0
+        return bound, seen
+
+
 class GeometryCache:
     """Static geometry for calls that render the SAME Gaussians (means3D, scales, rotations, xyz_b) from the SAME cameras again
     and again while only opacities and colours move — the one-shot fit (infer_one_shot.py:489-524). The first call through a
@@ -99,10 +148,11 @@ _PENDING_MAX = 64
 class _Pending:
     """The asynchronous counter read-back of one sync-free forward. `resolve()` waits for it (normally long done), recycles
     the pinned buffer and remembers the verdict, so that both check_overflow() and the call's own backward can ask."""
-    __slots__ = ("ev", "host", "cap", "key", "done", "d", "over", "stale")
+    __slots__ = ("ev", "host", "cap", "key", "done", "d", "over", "stale", "miss", "dbound")
 
-    def __init__(self, ev, host, cap, key):
+    def __init__(self, ev, host, cap, key, dbound=None):
         self.ev, self.host, self.cap, self.key, self.done, self.d, self.over, self.stale = ev, host, cap, key, False, 0, False, False
+        self.miss, self.dbound = False, dbound
 
     def resolve(self) -> bool:
         """True when the call overflowed its capacity (the learned capacity of its shape is raised then)."""
@@ -116,8 +166,13 @@ class _Pending:
             # each half a large enough share) only sizes the NEXT capacity
             self.over = (c[1] & 0xFFFFFFFF) != 0
             self.stale = (c[1] & 2) != 0
+            self.miss = (c[1] & 4) != 0
+            if self.miss and self.dbound is not None:      # the speculation failed: the re-run of the step renders without a bound
+                self.dbound.clear()
+                self.dbound.misses += 1
+            self.dbound = None
             need = (c[2] & 0xFFFFFFFF) if self.key[-1] else self.d
-            if self.over:                          # stale lists, or lists truncated by an instance overflow: never re-use them
+            if self.over and (c[1] & 3):           # stale lists, or lists truncated by an instance overflow: never re-use them
                 GeometryCache.clear_all()
             if self.over and (c[1] & 1):
                 _capacity[self.key] = max(_capacity.get(self.key, 0), int(max(need, self.d) * 1.5) + 1024)
@@ -129,16 +184,25 @@ class _Pending:
     def message(self) -> str:
         if self.stale:
             return _STALE_MSG
+        if self.miss and not (self.over and self.d > self.cap):
+            return _MISS_MSG
         return (f"tile instances D={self.d} exceeded max_instances={self.cap}; the call returned a NaN image; "
                 "capacity raised, re-run the step")
 
     def error(self) -> GhOverflowError:
-        return (GhStaleGeometryError if self.stale else GhOverflowError)(self.message())
+        if self.stale:
+            return GhStaleGeometryError(self.message())
+        if self.miss and not self.d > self.cap:
+            return GhDepthBoundMiss(self.message())
+        return GhOverflowError(self.message())
 
 
 _STALE_MSG = ("an opacity rose above the bound the static tile lists were built for; the call returned a NaN image; "
               "the geometry caches are cleared, re-run the step (it rebuilds the lists)")
 
+
+_MISS_MSG = ("a pixel ran off the end of a tile list truncated by the speculative occlusion bound (the Gaussians moved further than "
+             "the margin); that pixel is NaN; the bound has been dropped, re-run the step")
 
 _last_D = 0
 _stage_timing = False
@@ -338,7 +402,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                    color_b=None, max_instances: Optional[int] = None, sync: Optional[bool] = True, return_alpha: bool = False,
                    per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None,
                    split_streams: Optional[bool] = None, expect_backward: bool = False, static_lists: bool = False,
-                   refresh_of: Optional["_Ctx"] = None):
+                   refresh_of: Optional["_Ctx"] = None, depth_bound: Optional[DepthBoundCache] = None):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
     with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha.
     per_view_gaussians (pose batch, the batch loop of GS3DRenderer.forward): every per-Gaussian tensor holds NV*P rows and
@@ -355,6 +419,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     per-instance records with ITS opacities and colours (shs or colors_precomp) and walks the lists; forward bit-identical
     to a full call. An opacity above the lists' bound poisons the call (NaN image, GhStaleGeometryError). GeometryCache is
     the policy object on top of the two.
+    depth_bound: a DepthBoundCache (full forwards only): instances behind the previous call's per-tile occlusion depth are
+    not listed; verified by the forward, re-run without the bound on a miss.
     sync: True = read D back (and re-run with a larger capacity if needed); False = never block (check_overflow() is the
     caller's job); None = auto: read D back for the first call of a shape and for calls whose backward will not come
     (expect_backward False), otherwise sync-free with the check at the start of raster_backward."""
@@ -493,6 +559,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
         ctx.pending, ctx.refresh = pending, True
         return image, g0.radii, ctx
+    if depth_bound is not None and (static_lists or _graph_mode or P == 0):
+        depth_bound = None                       # lists that outlive the call / a captured call: no per-call speculation
     while True:
         cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))
         dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
@@ -504,10 +572,13 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
         radii = torch.empty(NV, P, dtype=torch.int32, device=dev)
         alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
+        bound, seen = depth_bound._buffers(dev, NV, H, W) if depth_bound is not None else (None, None)
         inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
                             _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
-                            _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
-        out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha))
+                            _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]), _ptr(bound))
+        out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha), _ptr(seen), 1.0 + (depth_bound.margin if depth_bound is not None else 0.0),
+                             depth_bound.slack if depth_bound is not None else 0)
+
         with _OnDevice(dev):
             fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
             if _stage_timing:
@@ -532,13 +603,19 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             c4 = counters.tolist()                        # the one host read-back, as in the reference wrapper
             d = c4[0] & 0xFFFFFFFF
             _last_D = d
-            over = (c4[1] & 0xFFFFFFFF) != 0
+            over = (c4[1] & 1) != 0
             need = max(d, c4[2] & 0xFFFFFFFF) if split else d   # split: the capacity that gives each half a large enough share
             if over:
                 if max_instances is not None:
                     raise GhOverflowError(f"tile instances D={d} exceed max_instances={cap}")
                 _capacity[key] = int(need * 1.5) + 1024
+                if depth_bound is not None:
+                    depth_bound.clear()                        # (the truncated lists' report is not a bound)
                 continue                                       # (the too-small workspace is simply dropped)
+            if c4[1] & 4:                                      # the occlusion bound missed: the same call again, unbounded
+                depth_bound.clear()
+                depth_bound.misses += 1
+                continue
             if max_instances is None and key not in _capacity:
                 _capacity[key] = max(int(need * 1.5) + 1024, 1 << 16)
         elif _graph_mode:
@@ -553,7 +630,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             host, ev = _free_slots.pop() if _free_slots else (torch.empty(4, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
             host.copy_(counters, non_blocking=True)
             ev.record()
-            pc = _Pending(ev, host, cap, key)
+            pc = _Pending(ev, host, cap, key, depth_bound)
             _pending.append(pc)
             if auto:                                       # an explicit sync=False never blocks: check_overflow() is the caller's job
                 pending = pc
@@ -571,6 +648,8 @@ def cached_raster_forward(cache: Optional[GeometryCache], cams, means3D, opaciti
     sync=True a refresh that finds an opacity above the lists' bound is re-run as a full call, transparently."""
     if cache is None:
         return raster_forward(cams, means3D, opacities, scales, rotations, **kw)
+    if isinstance(cache, DepthBoundCache):         # moving geometry: a speculative occlusion bound instead of static lists
+        return raster_forward(cams, means3D, opacities, scales, rotations, depth_bound=cache, **kw)
     if kw.get("geometry_of") is not None or kw.get("split_streams"):
         raise ValueError("a GeometryCache call takes neither geometry_of nor split_streams")
     xyz_b = kw.get("xyz_b")
@@ -871,7 +950,8 @@ class _RasterizeViews(torch.autograd.Function):
 def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *, H: int, W: int, use_rgb: bool,
                     sh_degree: int = 3, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
                     color_b=None, sync: bool = True, max_instances: Optional[int] = None, return_alpha: bool = False,
-                    per_view_gaussians: bool = False, geometry_cache: Optional[GeometryCache] = None):
+                    per_view_gaussians: bool = False, geometry_cache: Optional[GeometryCache] = None,
+                    depth_bound: Optional[DepthBoundCache] = None):
     """View-batched render with the attribute blend of renderer_one_shot.py:298-334 fused into the kernels.
     per_view_gaussians=True renders a POSE BATCH: the Gaussian tensors hold Nv*P rows and camera v sees rows
     [v*P, (v+1)*P) only — the batch loop of GS3DRenderer.forward (renderer_one_shot.py:615-633) in one launch sequence.
@@ -880,8 +960,13 @@ def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *,
     return_alpha, (images, alpha (Nv,H,W), radii): alpha is the reference's mask render (colour 1, bg 0,
     renderer_one_shot.py:353-380) produced by the same pass as a 4th channel (bit-identical to a separate pass).
     Differentiable w.r.t. xyz, opacity, scaling, rotation, shs and the blend parameters (through image and alpha); only
-    the gradients autograd needs are computed. geometry_cache: see GeometryCache (static Gaussians and cameras).
+    the gradients autograd needs are computed. geometry_cache: see GeometryCache (static Gaussians and cameras);
+    depth_bound: see DepthBoundCache (Gaussians that move a little between steps) — one or the other.
     """
+    if depth_bound is not None:
+        if geometry_cache is not None:
+            raise ValueError("rasterize_views: geometry_cache (static geometry) or depth_bound (moving geometry), not both")
+        geometry_cache = depth_bound
     image, alpha, radii = _RasterizeViews.apply(geometry_cache, cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier),
                                  bool(use_rgb), bool(sync), max_instances, bool(return_alpha), bool(per_view_gaussians), xyz, opacity,
                                  scaling,

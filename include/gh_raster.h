@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define GH_VERSION_MAJOR 0
-#define GH_VERSION_MINOR 4
+#define GH_VERSION_MINOR 5
 
 #define GH_TILE 16           /* tile edge in pixels (binning granularity; fixes which Gaussians a pixel sees) */
 #define GH_CAM_FLOATS 40     /* floats per camera record, see GhCamera */
@@ -111,6 +111,16 @@ typedef struct GhInputs {
   const float* blend_opacity_b; /* (P,)    opacity += opacity_b                   (:306-307) */
   const float* blend_color_w;   /* (48,) or (P,48): RGB: c*w[0:3] + w[3:6] - 1    (:323-324); SH: shs*w (:331-332) */
   const float* blend_color_b;   /* (P,48): RGB: + b[0:3] (:327-328); SH: (shs*w)*w + b (:333-334) */
+  /* Optional speculative occlusion bound (gh_forward only; NULL = none): the array a previous gh_forward of the same views
+     wrote as GhOutputs.tile_depth_seen — (n_views * tiles) pairs (depth as float, block mask as uint32), tile-major inside a
+     view (tile = ty * ceil(W/16) + tx). A tile is bounded when all of its own pixels reached the early stop in that call AND so
+     did every 4x4-pixel block of the eight neighbouring tiles that touches it (a silhouette that moves by up to four pixels
+     cannot uncover a pixel of a bounded tile: an uncovered pixel never stops and needs its whole list).
+     A (Gaussian, tile) instance whose view-space depth is ABOVE the tile's bound is not listed. The forward VERIFIES the
+     speculation: every pixel of a bounded tile must reach the early stop of App. A.3 (T (1 - alpha) < 1e-4) inside the
+     truncated list — then nothing behind the bound could have been looked at and the result is the unbounded call's bit for
+     bit; a pixel that runs off the end of a truncated list gets NaN and GhCounters.overflow |= 4: re-run without the bound. */
+  const float* tile_depth_bound;
 } GhInputs;
 
 typedef struct GhOutputs {
@@ -118,12 +128,29 @@ typedef struct GhOutputs {
   int32_t* radii;  /* (n_views,P)   0 for culled Gaussians */
   float* alpha;    /* (n_views,H,W) or NULL. Accumulated alpha = the reference's mask pass (colour 1, bg 0,
                       renderer_one_shot.py:353-380) produced by the SAME walk as a 4th channel */
+  /* (n_views * tiles) pairs (float, uint32) or NULL: per tile, [0] tile_depth_seen_scale x the depth of the LAST list entry any of
+     its pixels looked at (the entry that stopped its last pixel, plus the slack below) when every pixel of the tile reached the
+     early stop, else +inf (tiles at the silhouette, empty tiles); [1] bit b = every in-image pixel of the tile's 4x4-pixel block b
+     (b = 4 * block row + block column) reached the stop. Fed back as GhInputs.tile_depth_bound of the NEXT step of a loop whose Gaussians move a little
+     between steps (the one-shot fit's network-side trainables move them every step, infer_one_shot.py:340-343), it removes the
+     instances behind a saturated surface — over half of them on the hand scenes — from emit, sort and record gather;
+     tile_depth_seen_scale > 1 is the margin for the motion. Must not alias tile_depth_bound. */
+  float* tile_depth_seen;
+  float tile_depth_seen_scale;
+  /* Slack, in list entries: the depth reported is that of the entry this many positions BEHIND the last one looked at (the
+     list's own last entry if it ends first; the tile's previous bound, scaled, if that list was itself truncated). A pixel whose
+     transmittance ended just below the 1e-4 stop needs a few more entries as soon as anything moves — possibly from the next
+     surface centimetres behind; the slack entries are what it then finds. */
+  uint32_t tile_depth_seen_slack;
 } GhOutputs;
 
 /* Device-side counters written by gh_forward (first bytes of the workspace, see GhLayout.counters). */
 typedef struct GhCounters {
   uint32_t num_rendered; /* D: tile instances emitted (before clamping to max_instances) */
-  uint32_t overflow;     /* 1 if D > max_instances: image/gradients are invalid, re-run with a larger workspace */
+  uint32_t overflow;     /* bit 0: D > max_instances: image / gradients are invalid, re-run with a larger workspace;
+                            bit 1: gh_forward_refresh met an opacity above the bound its lists were built for;
+                            bit 2: a pixel of a tile with a GhInputs.tile_depth_bound ran off the end of its truncated list
+                                   (that pixel is NaN): re-run without the bound */
   uint32_t reserved[2];  /* [0] after a GH_FLAG_SPLIT_STREAMS forward: the max_instances that would have sufficed */
 } GhCounters;
 
@@ -172,7 +199,7 @@ typedef struct GhLayout {
   size_t inst_r2;        /* float2[max_instances]                                   (b, bits: 4x4-block mask of the tile) */
   size_t sort_tables;    /* uint32[...]        per-pass digit tables */
   size_t ranges;         /* uint2 [n_views*tiles] [start,end) into the sorted list */
-  size_t tile_walk;      /* uint32[2][n_views*tiles] list entries actually walked by the forward (max n_contrib of the tile);
+  size_t tile_walk;      /* uint32[3][n_views*tiles] list entries actually walked by the forward (max n_contrib of the tile);
                             forward waves that have finished the tile (the last one appends the tile's backward items) */
   size_t tile_order;     /* uint32[n_views*tiles] forward launch order of the render blocks: longest tile lists first */
   size_t bwd_items;      /* uint2 [n_views*tiles + max_instances/GH_SEGMENT + 2] backward work items (tile, depth segment) in the order the
@@ -201,6 +228,8 @@ typedef struct GhLayout {
                             share of max_instances) */
   size_t key_bits;       /* uint2[projection blocks] (OR, AND) over the depth-key bits of the block's visible Gaussians: a depth-sort
                             pass whose digit is the same in every key (OR & ~AND has no bit in it) degenerates to a copy */
+  size_t tile_bound;     /* float[n_views*tiles] the effective occlusion bound of this call (GhInputs.tile_depth_bound after the
+                            neighbourhood test; +inf = unbounded), read by every kernel that decides list membership */
 } GhLayout;
 
 /* Library version: major<<16 | minor. */

@@ -25,15 +25,15 @@ def test_library_exports_every_declared_symbol(gh_lib_path):
     for sym in header_symbols():
         assert hasattr(L, sym), sym
     _abi.declare(L)
-    assert L.gh_version() == (0 << 16) | 4
+    assert L.gh_version() == (0 << 16) | 5
 
 
 def test_struct_sizes_match_header():
     # GhDims: 6 int32 + float + uint32 + int64
     assert C.sizeof(_abi.GhDims) == 40
-    assert C.sizeof(_abi.GhInputs) == 11 * 8
+    assert C.sizeof(_abi.GhInputs) == 12 * 8
     assert C.sizeof(_abi.GhGrads) == 14 * 8
-    assert C.sizeof(_abi.GhOutputs) == 3 * 8
+    assert C.sizeof(_abi.GhOutputs) == 5 * 8          # 4 pointers + (float, uint32)
     assert C.sizeof(_abi.GhCounters) == 16
     assert C.sizeof(_abi.GhLayout) == len(_abi.LAYOUT_FIELDS) * 8
 
