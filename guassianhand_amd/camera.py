@@ -74,7 +74,9 @@ def pack_camera(viewmatrix, projmatrix, campos, tanfovx, tanfovy, bg) -> torch.T
         tf[1].fill_(ty)
         prefix = torch.cat([viewmatrix.reshape(16).float(), projmatrix.reshape(16).float(), campos.reshape(3).float(), tf])
         _pack_cache = (viewmatrix, projmatrix, campos, (viewmatrix._version, projmatrix._version, campos._version, tx, ty), prefix)
-    return torch.cat([prefix, bg.reshape(3).float().to(dev)]).reshape(1, GH_CAM_FLOATS)
+    if bg.dtype is not torch.float32 or bg.device != dev or bg.dim() != 1:
+        bg = bg.reshape(3).float().to(dev)
+    return torch.cat((prefix, bg)).reshape(1, GH_CAM_FLOATS)
 
 
 def pack_cameras_from_w2c(w2cs: torch.Tensor, Ks: torch.Tensor, H: int, W: int, bg: torch.Tensor) -> torch.Tensor:

@@ -313,15 +313,20 @@ __device__ __forceinline__ void gh_sum_records(uint32_t o0, uint32_t o1, const f
     const uint32_t f = fl;
     if (sl + 1 < o1) fl = inst_flag[sl + 1];             // the next slot's flags travel while this slot's records are summed
     GhF3 r[4][3];
+#ifdef GH_ABL_HALFREC      // timing ablation only (results invalid): what the chain rule costs when an instance has two sub-records
+#define GH_ABL_NQ 2
+#else
+#define GH_ABL_NQ 4
+#endif
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < GH_ABL_NQ; ++q) {
       if ((f >> (8 * q)) & 1u) {
-        const GhF3* p = (const GhF3*)(inst_grad + ((size_t)sl * 4 + q) * GH_REC_G);
+        const GhF3* p = (const GhF3*)(inst_grad + ((size_t)sl * GH_ABL_NQ + q) * GH_REC_G);
         r[q][0] = p[0]; r[q][1] = p[1]; r[q][2] = p[2];
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < GH_ABL_NQ; ++q) {
       if ((f >> (8 * q)) & 1u) {
         acc[0] += (double)r[q][0].x; acc[1] += (double)r[q][0].y; acc[2] += (double)r[q][0].z;
         acc[3] += (double)r[q][1].x; acc[4] += (double)r[q][1].y; acc[5] += (double)r[q][1].z;

@@ -791,9 +791,15 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
           for (int q = GEOM ? 0 : 5; q < GH_REC; ++q) s9[q] += a9[q];
         }
       }
+#ifdef GH_ABL_HALFREC      // timing ablation only (results invalid): two sub-record slots per instance, half the quadrants write
+      if (any && quad < 2) {
+        const uint32_t sl = slots[seg_lo + k * GH_WAVE + lane];
+        GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 2 + quad) * GH_REC_G);
+#else
       if (any) {
         const uint32_t sl = slots[seg_lo + k * GH_WAVE + lane];
         GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC_G);
+#endif
         if (GEOM) {
           rec[0] = GhF3{s9[0], s9[1], s9[2]};
           rec[1] = GhF3{s9[3], s9[4], s9[5]};

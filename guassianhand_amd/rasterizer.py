@@ -865,6 +865,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 g["opacities"].reshape(s[4]), g["scales"].reshape(s[5]), g["rotations"].reshape(s[6]), None, None, None)
 
 
+def _any_global_hook() -> bool:
+    m = torch.nn.modules.module
+    f = getattr(m, "_has_any_global_hook", None)
+    if f is not None:
+        return bool(f())
+    return bool(getattr(m, "_global_forward_hooks", None) or getattr(m, "_global_forward_pre_hooks", None) or
+                getattr(m, "_global_backward_hooks", None) or getattr(m, "_global_backward_pre_hooks", None))
+
+
 class GaussianRasterizer(nn.Module):
     """Same constructor / call keywords / 2-tuple return as the module the reference imports at
     tgs/models/renderer_one_shot.py:3 and calls at :338-346 and :372-379."""
@@ -895,9 +904,18 @@ class GaussianRasterizer(nn.Module):
         # needs_input_grad ignores torch.no_grad())
         expect_backward = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (means3D, means2D, shs, colors_precomp, opacities, scales, rotations))
-        with torch.autocast(device_type=means3D.device.type, enabled=False):
-            return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                             self.raster_settings, self.sync, expect_backward)
+        # (The reference wraps the call in torch.autocast(dtype=float32), renderer_one_shot.py:337. Nothing below is an autocast-
+        # eligible torch op — tensors go to the C-ABI as raw pointers after an explicit float32 check in _prep — so no
+        # autocast(enabled=False) context is entered here: it cost 6 us per call for nothing.)
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                         self.raster_settings, self.sync, expect_backward)
+
+    # nn.Module.__call__ runs the hook machinery around forward(); this module never has hooks worth 3 us per call on a path
+    # that is called twice per view (hooks registered by a caller are honoured: fall back to the full protocol then)
+    def __call__(self, *args, **kwargs):
+        if self._forward_hooks or self._forward_pre_hooks or self._backward_hooks or self._backward_pre_hooks or _any_global_hook():
+            return super().__call__(*args, **kwargs)
+        return self.forward(*args, **kwargs)
 
 
 # ---------------------------------------------------------------------------------------------------
