@@ -259,6 +259,9 @@ def main():
     ap.add_argument("--split-streams", default="off", choices=["off", "on", "auto"],
                     help="GH_FLAG_SPLIT_STREAMS: render the step's views as two halves on two HIP streams inside the library "
                          "(bit-identical results); auto = from 4 views of more than half a megapixel per rank up")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="EXPERIMENT: capture this many copies of the step on as many streams and replay them round-robin, so that "
+                         "consecutive (independent) steps overlap on the GPU; 1 = steps strictly one after the other (the contract's default)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="timed windows of --steps steps each; `value` / `ms_per_step` are the FIRST window's (the contract's exactly-K "
                          "steps), the others are reported as repeat statistics")
@@ -391,6 +394,7 @@ def main():
     # launch sequence is ~45 small kernels, and enqueueing them one by one leaves the result at the mercy of the host
     # (0.5 ms per step on a quiet box, several ms on a busy one). Collectives stay outside the graph.
     graph, g_loss, graph_note = None, None, None
+    pipe = []
     if not args.no_graph:
         try:                                             # the leaves' AccumulateGrad nodes were created on the default stream
             torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -411,6 +415,19 @@ def main():
             for _ in range(max(1, args.warmup)):         # warm-up of the replay path itself (clocks, graph upload): untimed
                 graph.replay()
             torch.cuda.synchronize()
+            pipe = []
+            if args.pipeline > 1 and world == 1:
+                for _ in range(args.pipeline):
+                    st = torch.cuda.Stream()
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        local_step(sync=False).backward(seed)          # this stream's workspaces
+                        gph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gph, stream=st, capture_error_mode="thread_local"):
+                            gl = local_step(sync=False)
+                            gl.backward(seed)
+                    pipe.append((st, gph, gl))
+                torch.cuda.synchronize()
         except Exception as e:                           # capture is an optimisation of the enqueue path, never a requirement
             graph, g_loss, graph_note = None, None, f"graph capture failed ({type(e).__name__}: {e}); eager steps"
             R.set_graph_mode(False)
@@ -432,8 +449,13 @@ def main():
         barrier()
         t0 = time.perf_counter()
         pending, loss = None, None
-        for _ in range(args.steps):
-            if graph is not None:
+        for k in range(args.steps):
+            if graph is not None and args.pipeline > 1 and world == 1:
+                st, gph, gl = pipe[k % len(pipe)]
+                with torch.cuda.stream(st):
+                    gph.replay()
+                loss = gl
+            elif graph is not None:
                 loss, pending = replay_step(pending)
             else:
                 loss = step(sync=False)
@@ -560,6 +582,7 @@ def main():
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
                        "split_streams": bool(V >= 2 and (R._split_policy is True or (
                            R._split_policy == "auto" and V >= 4 and H * W > R._SPLIT_AUTO_MIN_PIXELS))),
+                       "pipelined_steps": args.pipeline,
                        "hip_graph": graph is not None, "timed_steps": "HIP graph replay of one captured step" if graph is not None
                        else "eager kernel-by-kernel enqueue" + (f" [{graph_note}]" if graph_note else "")},
             "roofline": roofline, "stages": stages,

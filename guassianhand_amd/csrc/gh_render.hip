@@ -354,7 +354,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m;
       const uint32_t u = __shfl_xor(sq, o); sq = u > sq ? u : sq;
     }
+#ifdef GH_ABL_NOEND     // timing ablation only (the backward gets no work list): what the per-wave end-of-tile atomics cost the forward
+    if (false) {
+#else
     if (lane == 0) {
+#endif
       // The LAST of the tile's 16 waves (4 quadrant blocks x 4) appends the tile's backward work items, one per depth
       // segment of the walked prefix: the list is in the order the forward finished the tiles. The backward takes it from
       // the end, so the tiles that ran longest start first; the order only affects scheduling, never results.
