@@ -64,7 +64,7 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-PROFILE_TAG = "r3"        # profiles/<tag>_pmc_*.json: the committed counter passes this build's bench lines quote
+PROFILE_TAG = "r4"        # profiles/<tag>_pmc_*.json: the committed counter passes this build's bench lines quote
 
 
 def workload_key(args, V: int):

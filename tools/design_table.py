@@ -4,7 +4,7 @@
 tests/test_docs.py asserts DESIGN.md holds exactly this block for the committed profiles."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r3"
+TAG = "r4"
 BEGIN, END = "<!-- BEGIN GENERATED: tools/design_table.py -->", "<!-- END GENERATED -->"
 
 
