@@ -10,6 +10,7 @@ GH_FLAG_BLEND_COLOR_B_RGB = 2
 GH_FLAG_PER_VIEW_GAUSSIANS = 4
 GH_FLAG_SPLIT_STREAMS = 8
 GH_FLAG_STATIC_LISTS = 16
+GH_FLAG_DEPTH24 = 32
 
 GH_OK = 0
 GH_ERR_INVALID_ARG = -1

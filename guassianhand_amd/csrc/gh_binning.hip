@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w
 // (gh_preprocess_fwd_kernel; key_bits[n_bits] receives the word). Computed ONCE, by block (0, 0) of the first pass's histogram
 // kernel; every later pass reads the word: a pass whose digit has no varying bit is the identity (its histogram kernel exits,
 // its scatter kernel copies). Keys that were left out of the (OR, AND) — Gaussians that emit no instance — may land anywhere.
-__device__ __forceinline__ void gh_store_varying_bits(uint2* __restrict__ key_bits, int n_bits) {
+__device__ __forceinline__ void gh_store_varying_bits(uint2* __restrict__ key_bits, int n_bits, uint32_t* __restrict__ wide_flag) {
   __shared__ uint32_t s_or[GH_BLOCK / GH_WAVE], s_and[GH_BLOCK / GH_WAVE];
   uint32_t o = 0u, a = 0xFFFFFFFFu;
   for (int i = threadIdx.x; i < n_bits; i += GH_BLOCK) { const uint2 b = key_bits[i]; o |= b.x; a &= b.y; }
@@ -60,8 +60,12 @@ __device__ __forceinline__ void gh_store_varying_bits(uint2* __restrict__ key_bi
   for (int k = 32; k > 0; k >>= 1) { o |= __shfl_xor(o, k); a &= __shfl_xor(a, k); }
   if ((threadIdx.x & 63) == 0) { s_or[threadIdx.x >> 6] = o; s_and[threadIdx.x >> 6] = a; }
   __syncthreads();
-  if (threadIdx.x == 0)
-    key_bits[n_bits].x = (s_or[0] | s_or[1] | s_or[2] | s_or[3]) & ~(s_and[0] & s_and[1] & s_and[2] & s_and[3]);
+  if (threadIdx.x == 0) {
+    const uint32_t varying = (s_or[0] | s_or[1] | s_or[2] | s_or[3]) & ~(s_and[0] & s_and[1] & s_and[2] & s_and[3]);
+    key_bits[n_bits].x = varying;
+    // GH_FLAG_DEPTH24: this sort has no pass for the top byte — it must not vary (one thread per call: no contention)
+    if (wide_flag && (varying >> 24) != 0u) atomicOr(wide_flag, 8u);
+  }
   __syncthreads();
 }
 __device__ __forceinline__ bool gh_digit_varies(const uint2* __restrict__ key_bits, int n_bits, int shift, uint32_t dmask) {
@@ -74,9 +78,9 @@ template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
                                                                   uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
                                                                   uint32_t* __restrict__ table, const uint2* __restrict__ key_bits,
-                                                                  int n_bits) {
+                                                                  int n_bits, uint32_t* __restrict__ wide_flag) {
   __shared__ uint32_t s_hist[MAXD];
-  if (key_bits && shift == 0 && blockIdx.x == 0 && blockIdx.y == 0) gh_store_varying_bits((uint2*)key_bits, n_bits);
+  if (key_bits && shift == 0 && blockIdx.x == 0 && blockIdx.y == 0) gh_store_varying_bits((uint2*)key_bits, n_bits, wide_flag);
   if (!gh_digit_varies(key_bits, n_bits, shift, dmask)) return;       // the scatter of this pass is a plain copy
   const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
   const uint32_t seg = blockIdx.y, nblk = gridDim.x, ndig = dmask + 1u;
@@ -91,10 +95,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t*
   }
   for (uint32_t d = threadIdx.x; d < ndig; d += GH_BLOCK) s_hist[d] = 0;
   __syncthreads();
+  // One LDS atomic per RUN of equal digits in lane order, not per key: after an earlier pass (or with keys that arrive grouped,
+  // like the tile partition's high digit: view-major instances) neighbouring lanes carry the same digit and 64 same-address LDS
+  // atomics serialise (the second tile pass's histogram took 12.3 us where the first took 5.6).
+  const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const uint32_t idx = base + j * GH_BLOCK + threadIdx.x;
-    if (idx < n) atomicAdd(&s_hist[(k[j] >> shift) & dmask], 1u);
+    const uint32_t dg = idx < n ? ((k[j] >> shift) & dmask) : 0xFFFFFFFFu;       // the tail's lanes form a run of their own
+    const uint32_t prev = (uint32_t)__shfl_up((int)dg, 1);
+    const bool head = lane == 0 || dg != prev;
+    const uint64_t after = (gh_ballot(head) >> lane) >> 1;                       // run heads behind this lane
+    if (head && idx < n) atomicAdd(&s_hist[dg], after ? (uint32_t)__builtin_ctzll(after) + 1u : (uint32_t)(64 - lane));
   }
   __syncthreads();
   for (uint32_t d = threadIdx.x; d < ndig; d += GH_BLOCK) {
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
 template <int ITEMS>
 static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr,
                             uint32_t cap, int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s,
-                            const uint2* key_bits, int n_bits) {
+                            const uint2* key_bits, int n_bits, uint32_t* wide_flag) {
   const size_t per_seg = seg_len ? seg_len : cap;
   const int nblk = (int)((per_seg + GH_BLOCK * ITEMS - 1) / (GH_BLOCK * ITEMS));
   if (nblk == 0 || segs == 0) return;
@@ -359,7 +371,7 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
     const uint32_t dmask = (1u << nbits) - 1u, ndig = dmask + 1u;
     uint32_t* tot = table + (size_t)ndig * nblk;
     const dim3 gb(nblk, 1), gs(ndig, 1), blk(GH_BLOCK);
-    hipLaunchKernelGGL((gh_radix_hist_kernel<4, 1024, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, 0, dmask, table, key_bits, n_bits);
+    hipLaunchKernelGGL((gh_radix_hist_kernel<4, 1024, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, 0, dmask, table, key_bits, n_bits, wide_flag);
     hipLaunchKernelGGL(gh_radix_scan_kernel<4>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
     hipLaunchKernelGGL((gh_radix_scatter_kernel<4, 1024, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
                        0, dmask, nbits, table, tot, key_bits, n_bits);
@@ -376,11 +388,11 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
     uint32_t* tot = table + (size_t)segs * ndig * nblk;
     const dim3 gb(nblk, segs), gs(ndig, segs), blk(GH_BLOCK);
     if (nblk <= 128) {                                   // short segments: no scan kernel (see gh_radix_scatter_kernel)
-      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits);
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag);
       hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
                          lo, dmask, hi - lo, table, tot, key_bits, n_bits);
     } else {
-      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits);
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag);
       hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
       hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
                          lo, dmask, hi - lo, table, tot, key_bits, n_bits);
@@ -419,17 +431,18 @@ int gh_radix_passes(size_t cap, int nbits) {
 }
 
 void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
-                      int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s, const uint2* key_bits, int n_bits) {
+                      int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s, const uint2* key_bits, int n_bits,
+                      uint32_t* wide_flag) {
   const size_t per_seg = seg_len ? seg_len : cap;
   const int items = gh_radix_items(per_seg, segs, seg_len != 0u);
-  if (items == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
-  else if (items == 8) gh_radix_sort_t<8>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
-  else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits);
+  if (items == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits, wide_flag);
+  else if (items == 8) gh_radix_sort_t<8>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits, wide_flag);
+  else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits, wide_flag);
 }
 
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                    int nbits, uint32_t* table, hipStream_t s) {
-  gh_radix_sort_ex(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, 0u, 1, table, s, nullptr, 0);
+  gh_radix_sort_ex(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, 0u, 1, table, s, nullptr, 0, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   if (blockIdx.x == gridDim.x - 1 && tid == 0) {        // the last block knows the instance total D
     const uint32_t total = blk_off + blk_sum;
     ctr->num_rendered = total;
-    ctr->overflow = total > cap ? 1u : 0u;
+    if (total > cap) atomicOr(&ctr->overflow, 1u);          // (the projection kernel cleared the word; bit 3 may already be set)
   }
   const uint32_t wave_base = blk_off + woff, wave_total = s_w[wid];
   if (i < N) slot_begin[n] = wave_base + x - cnt;
@@ -727,9 +740,11 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* dv_in = (uint32_t*)(ws + L.depth_vals_a); uint32_t* dv_out = (uint32_t*)(ws + L.depth_vals_b);
   const int T = g.NV * g.tiles;
   const int n_proj_blocks = ((g.N > T ? g.N : T) + GH_BLOCK - 1) / GH_BLOCK;          // grid of gh_preprocess_fwd_kernel
-  gh_radix_sort_ex(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, 32, (uint32_t)g.P, g.NV, table, s,
-                   (const uint2*)(ws + L.key_bits), n_proj_blocks);
-  const uint32_t* perm = dv_in;                       // 4 passes: the result is back in the *_a buffers
+  // GH_FLAG_DEPTH24: three passes (the top byte is asserted constant and checked by the first histogram kernel), else four
+  const bool d24 = (d->flags & GH_FLAG_DEPTH24) != 0;
+  gh_radix_sort_ex(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, d24 ? 24 : 32, (uint32_t)g.P, g.NV, table, s,
+                   (const uint2*)(ws + L.key_bits), n_proj_blocks, d24 ? &ctr->overflow : nullptr);
+  const uint32_t* perm = dv_in;                       // (the sort swaps the pointers: four passes end in the *_a buffers, three in *_b)
 
   // level 2: emit in depth order
   const uint32_t* tiles_touched = (const uint32_t*)(ws + L.tiles_touched);

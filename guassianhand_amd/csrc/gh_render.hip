@@ -418,7 +418,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     // same address): the only write this kernel makes to the word is the atomic OR of bit 2 above, which these bits do not depend
     // on — read through `ctr` the load can no longer be a scalar one, and 86 k waves fetching the line the work-list atomics hit
     // (reserved[1], same 16 bytes) with vector loads cost the kernel 100 us (same-box A/B, round 4: 144 -> 242 us).
-    const float poison = ((ctr_ro->overflow & 3u) || pixel_miss) ? __uint_as_float(0x7FC00000u) : 0.0f;
+    const float poison = ((ctr_ro->overflow & 11u) || pixel_miss) ? __uint_as_float(0x7FC00000u) : 0.0f;   // (bits 0, 1, 3: the whole call is invalid)
     img[0] = fmaf(p.T, bg[0], p.C0) + poison;
     img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1) + poison;
     img[(size_t)2 * H * W] = fmaf(p.T, bg[2], p.C2) + poison;

@@ -417,6 +417,10 @@ class CapturedFitStep:
             if c4[1] & 2:                                          # stale static lists (an opacity above their bound): not a capacity matter
                 R.GeometryCache.clear_all()
                 raise R.GhStaleGeometryError(R._STALE_MSG + " [inside the captured fit step: the next replay() rebuilds and re-captures]")
+            if c4[1] & 8:                                          # GH_FLAG_DEPTH24 did not hold: four depth-sort passes for this shape
+                R._depth24[key] = False
+                R.GeometryCache.clear_all()
+                raise R.GhOverflowError(R._DEPTH24_MSG + " [inside the captured fit step: construct a new CapturedFitStep]")
             if (c4[1] & 0xFFFFFFFF) != 0:                          # the device-side flag decides (a split call's reserved[0] only sizes)
                 need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
                 R._capacity[key] = max(R._capacity.get(key, 0), int(need * 1.5) + 1024)

@@ -140,6 +140,12 @@ class GeometryCache:
 # ---------------------------------------------------------------------------------------------------
 # capacity policy for the data-dependent instance count D
 _capacity: Dict[Tuple[int, int, int, int], int] = {}
+# GH_FLAG_DEPTH24 (three depth-sort passes instead of four: two launches less per forward) is tried for every call shape until a
+# call of that shape reports that the top byte of its visible depths does vary (GhCounters.overflow bit 3): visible depths that
+# straddle a factor-4 boundary such as 0.5 m or 2 m. Like the instance capacity, the verdict is learned per shape.
+_depth24: Dict[Tuple[int, int, int, int, bool], bool] = {}
+_DEPTH24_MSG = ("the visible depths span more than the 24 key bits the three-pass depth sort covers; the call returned a NaN image; "
+                "the four-pass sort is used for this call shape from now on, re-run the step")
 _pending = []      # _Pending records of sync-free calls not yet checked
 _free_slots = []   # recycled (pinned 4-int buffer, event) pairs: a sync-free call allocates neither
 _PENDING_MAX = 64
@@ -167,6 +173,8 @@ class _Pending:
             self.over = (c[1] & 0xFFFFFFFF) != 0
             self.stale = (c[1] & 2) != 0
             self.miss = (c[1] & 4) != 0
+            if c[1] & 8:                                   # GH_FLAG_DEPTH24 did not hold: four passes for this shape from now on
+                _depth24[self.key] = False
             if self.miss and self.dbound is not None:      # the speculation failed: the re-run of the step renders without a bound
                 self.dbound.clear()
                 self.dbound.misses += 1
@@ -186,6 +194,8 @@ class _Pending:
             return _STALE_MSG
         if self.miss and not (self.over and self.d > self.cap):
             return _MISS_MSG
+        if not self.d > self.cap and _depth24.get(self.key, True) is False and not self.stale and not self.miss:
+            return _DEPTH24_MSG
         return (f"tile instances D={self.d} exceeded max_instances={self.cap}; the call returned a NaN image; "
                 "capacity raised, re-run the step")
 
@@ -303,6 +313,9 @@ def check_overflow(block: bool = True, keep_recent: int = 0) -> None:
         if c4[1] & 2:                                  # a static-geometry replay met an opacity above its lists' bound
             GeometryCache.clear_all()
             raise GhStaleGeometryError(_STALE_MSG + " [inside a captured graph: capture again]")
+        if c4[1] & 8:                                  # GH_FLAG_DEPTH24 did not hold for a captured call
+            _depth24[key] = False
+            raise GhOverflowError(_DEPTH24_MSG + " [inside a captured graph: capture again]")
         if (c4[1] & 0xFFFFFFFF) != 0:                  # the device-side flag decides; reserved[0] of a split call sizes the next capacity
             need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
             _capacity[key] = max(_capacity.get(key, 0), int(need * 1.5) + 1024)
@@ -561,8 +574,10 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         return image, g0.radii, ctx
     if depth_bound is not None and (static_lists or _graph_mode or P == 0):
         depth_bound = None                       # lists that outlive the call / a captured call: no per-call speculation
+    base_flags = flags
     while True:
         cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))
+        flags = base_flags | (_abi.GH_FLAG_DEPTH24 if _depth24.get(key, True) else 0)
         dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
         nbytes = L.gh_workspace_bytes(C.byref(dims))
         if nbytes == 0:
@@ -603,6 +618,11 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             c4 = counters.tolist()                        # the one host read-back, as in the reference wrapper
             d = c4[0] & 0xFFFFFFFF
             _last_D = d
+            if c4[1] & 8:                                      # the three-pass depth sort does not cover this call's depths
+                _depth24[key] = False
+                if depth_bound is not None:
+                    depth_bound.clear()
+                continue
             over = (c4[1] & 1) != 0
             need = max(d, c4[2] & 0xFFFFFFFF) if split else d   # split: the capacity that gives each half a large enough share
             if over:
@@ -791,7 +811,7 @@ def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
     return dict(counters=v(lay.counters, 16, torch.int32, 4), g0=geom[:, 0:4], g1=geom[:, 4:8], gb=geom[:, 8],
                 depth=v(lay.depth, N * 4, torch.float32, N), rect=v(lay.rect, N * 4, torch.int32, N),
                 tiles_touched=v(lay.tiles_touched, N * 4, torch.int32, N), slot_begin=v(lay.slot_begin, N * 4, torch.int32, N),
-                depth_order=v(lay.depth_vals_a, N * 4, torch.int32, N),
+                depth_order=v(lay.depth_vals_b if (ctx.dims.flags & _abi.GH_FLAG_DEPTH24) else lay.depth_vals_a, N * 4, torch.int32, N),
                 sorted_tile=v(lay.keys_a, cap * 4, torch.int32, cap), sorted_slot=v(lay.sorted_slot, cap * 4, torch.int32, cap),
                 sorted_gid=v(lay.vals_a, cap * 4, torch.int32, cap),
                 inst_r2=v(lay.inst_r2, cap * 8, torch.int32, cap, 2),

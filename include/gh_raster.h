@@ -68,6 +68,12 @@ typedef enum GhStatus {
                                            opacity o as max(2, 2 o), so the lists hold every tile the Gaussian can reach while
                                            its opacity stays <= that bound. Images and gradients are those of the plain call
                                            (a tile that holds no contributing pixel changes nothing): only D is larger. */
+#define GH_FLAG_DEPTH24 32u             /* the caller expects the depth keys of the Gaussians that emit instances to differ in their
+                                           low 24 bits only (all visible depths inside one factor-4 range such as [0.5, 2) m — the top
+                                           byte of the float, sign + 7 exponent bits, is the same): the per-view depth sort then runs
+                                           three 8-bit passes instead of four (the fourth would be a copy: two launches less per
+                                           forward). Verified on the device before the sort; if the top byte does vary the call sets
+                                           GhCounters.overflow bit 3 and returns a NaN image: re-run without the flag. */
 #define GH_FLAG_SPLIT_STREAMS 8u        /* n_views >= 2: the views are rendered as two independent halves (views [0, n/2) and
                                            [n/2, n)), the second on a HIP stream of the library's own, forked from and joined
                                            back into the caller's stream inside every call (graph-capturable): the drain of one
@@ -150,7 +156,8 @@ typedef struct GhCounters {
   uint32_t overflow;     /* bit 0: D > max_instances: image / gradients are invalid, re-run with a larger workspace;
                             bit 1: gh_forward_refresh met an opacity above the bound its lists were built for;
                             bit 2: a pixel of a tile with a GhInputs.tile_depth_bound ran off the end of its truncated list
-                                   (that pixel is NaN): re-run without the bound */
+                                   (that pixel is NaN): re-run without the bound;
+                            bit 3: GH_FLAG_DEPTH24 did not hold (NaN image): re-run without the flag */
   uint32_t reserved[2];  /* [0] after a GH_FLAG_SPLIT_STREAMS forward: the max_instances that would have sufficed */
 } GhCounters;
 

@@ -302,6 +302,35 @@ def test_two_hands_at_the_reference_render_size_256(dev):
     assert D > 98562 // 2
 
 
+def test_depth_ranges_wider_than_the_three_pass_sort(dev):
+    """GH_FLAG_DEPTH24 (three depth-sort passes, tried first for every call shape) covers visible depths whose float bit patterns
+    share their top byte, e.g. everything in [0.5, 2) m. A scene that straddles 0.5 m and 2 m must still come out bit-exact: the
+    device flags the call (overflow bit 3), a sync call re-runs with four passes transparently, the shape remembers; a sync-free
+    call returns NaN and raises at the check."""
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=2, P=1500)
+    sc.xyz[:, 2] = sc.xyz[:, 2] * 9.0 + 0.25                  # camera at z = -1: depths 0.35 .. 2.15 m
+    sc.scaling = sc.scaling * 2.0
+    key = R.capacity_key(sc.P, 2, sc.H, sc.W)
+    R._depth24.pop(key, None)
+    compare(sc, dev)                                          # sync=True: flagged, re-run, bit-exact against the oracle
+    assert R._depth24.get(key) is False
+    # sync-free with the flag forced back on: NaN image + an error at the check, and the shape is demoted again
+    R._depth24.pop(key, None)
+    s = sc.to(dev)
+    img, _, _ = R.raster_forward(sc.cams().to(dev), s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W, sync=False,
+                                 colors_precomp=s.shs.squeeze(1))
+    with pytest.raises(R.GhOverflowError, match="24 key bits"):
+        R.check_overflow()
+    assert bool(torch.isnan(img).all()) and R._depth24.get(key) is False
+    # a scene inside one factor-4 range keeps the three-pass sort
+    sc2 = make_scene("random1k", n_views=2, P=1500, seed=5)
+    sc2.H, sc2.W = 96, 80
+    compare(sc2, dev)
+    assert R._depth24.get(R.capacity_key(sc2.P, 2, 96, 80), True) is True
+
+
 def test_reference_init_scale(dev):
     """The reference's initial Gaussian size exp(-5) = 6.7 mm (renderer_one_shot.py:165): ~10x more instances."""
     from guassianhand_amd.scenes import make_scene
