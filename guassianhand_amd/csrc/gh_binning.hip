@@ -202,7 +202,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t idx = wave_base + r * GH_WAVE + lane;
     key[r] = idx < n ? keys_in[idx] : ~0u;
+#ifdef GH_ABL_NOVALS       // timing ablation only (results invalid): what a keys-only (packed key | payload) partition pass would cost
+    val[r] = SELF ? (idx < n ? vals_in[idx] : 0u) : 0u;
+#else
     val[r] = idx < n ? vals_in[idx] : 0u;
+#endif
   }
 
   // digit base = exclusive scan over digits of tot[] + this block's row prefix
@@ -347,7 +351,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
       const uint32_t dg = (k >> shift) & dmask;
       const uint32_t dst = s_base[dg] + (e - s_lbase[dg]);
       keys_out[dst] = k;
+#ifdef GH_ABL_NOVALS
+      if (SELF) vals_out[dst] = s_val[e];
+#else
       vals_out[dst] = s_val[e];
+#endif
     }
   }
 }
