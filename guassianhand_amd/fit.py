@@ -63,7 +63,7 @@ def fit_loss(comp_rgb, comp_mask, gt_rgb, gt_mask, bbox_mask=None, lambda_l1: fl
 class OneShotFit(nn.Module):
     def __init__(self, gs: GaussianModel, uv: torch.Tensor, *, use_rgb: bool = True, sh_degree: int = 3,
                  map_hw: Sequence[int] = (1024, 2048), lr: float = 0.01, render_fn: Optional[Callable] = None,
-                 active_texels: Optional[bool] = None, static_geometry: Optional[bool] = None):
+                 active_texels: Optional[bool] = None, static_geometry: Optional[bool] = None, occlusion_bound: bool = False):
         super().__init__()
         self.gs = GaussianModel(*[t.detach() for t in gs])          # frozen network outputs
         self.register_buffer("uv", uv.detach().float())
@@ -83,8 +83,16 @@ class OneShotFit(nn.Module):
         # Any other camera tensor, image size or a changed `_version` of a geometry tensor rebuilds automatically; after an
         # in-place change through `.data` call invalidate_geometry(). (The reference's map_bias / identity codes move the
         # Gaussians themselves, infer_one_shot.py:340-343: a fit that trains them passes static_geometry=False.)
+        # occlusion_bound=True is the policy for the OTHER kind of fit — Gaussians that move a little every step through
+        # update_gaussians() (network-side trainables): static lists cannot serve it, the previous step's verified per-tile occlusion
+        # depth can (rasterizer.DepthBoundCache: the instances behind it are not listed; exact by verification).
         self._geom_cache = None
-        if (static_geometry if static_geometry is not None else (render_fn is None and gs.xyz.is_cuda)):
+        if occlusion_bound:
+            if static_geometry:
+                raise ValueError("OneShotFit: static_geometry (frozen Gaussians) or occlusion_bound (moving Gaussians), not both")
+            from .rasterizer import DepthBoundCache
+            self._geom_cache = DepthBoundCache()
+        elif (static_geometry if static_geometry is not None else (render_fn is None and gs.xyz.is_cuda)):
             from .rasterizer import GeometryCache
             self._geom_cache = GeometryCache()
         self.keep_boundary_grads, self.boundary_grads, self.last_reg = False, None, None
@@ -183,7 +191,9 @@ class OneShotFit(nn.Module):
         if gs.xyz.shape != self.gs.xyz.shape:
             raise ValueError("update_gaussians: the number of Gaussians is fixed (the UV lookup is indexed by it)")
         self.gs = GaussianModel(*[t.detach() for t in gs])
-        self.invalidate_geometry()
+        from .rasterizer import DepthBoundCache
+        if not isinstance(self._geom_cache, DepthBoundCache):      # (an occlusion bound survives a small move: that is its purpose)
+            self.invalidate_geometry()
 
     def invalidate_geometry(self) -> None:
         """Forget the static tile lists (after modifying a geometry tensor in place through `.data`)."""
@@ -388,11 +398,11 @@ class CapturedFitStep:
         # here: were it only the cache's (cleared by any overflow in the process, invalidate_geometry(), update_gaussians()),
         # its workspace would go back to the pool and the next forward of that size would overwrite the lists under the graph.
         gc = self.fit._geom_cache
-        self._geom = None if gc is None else gc.ctx
+        self._geom = getattr(gc, "ctx", None)                     # (a DepthBoundCache holds no lists and is not used inside graphs)
 
     def _stale(self) -> bool:
         gc = self.fit._geom_cache
-        return gc is not None and gc.ctx is not self._geom
+        return gc is not None and hasattr(gc, "ctx") and gc.ctx is not self._geom
 
     def replay(self) -> torch.Tensor:
         if self._lr() != self.lr:

@@ -90,6 +90,22 @@ def test_forward_rejects_bad_arguments_before_touching_the_gpu(gh_lib_path):
     assert L.gh_forward(C.byref(d), C.byref(inp3), C.byref(_abi.GhOutputs(one, one, None)), one, 16, None) == _abi.GH_ERR_WORKSPACE_SMALL
 
 
+def test_occlusion_bound_arguments_are_validated_before_any_launch(gh_lib_path):
+    """GhInputs.tile_depth_bound / GhOutputs.tile_depth_seen (v0.5): the report must not alias the bound, and lists that outlive
+    the call (GH_FLAG_STATIC_LISTS) cannot be truncated by a per-call bound."""
+    L = C.CDLL(gh_lib_path)
+    _abi.declare(L)
+    one, two = C.c_void_p(256), C.c_void_p(512)
+    d = _abi.GhDims(10, 1, 64, 64, 0, 0, 1.0, 0, 100)
+    inp = _abi.GhInputs(one, one, one, one, one, None, one, None, None, None, None, two)
+    out = _abi.GhOutputs(one, one, None, two, 1.002, 8)
+    assert L.gh_forward(C.byref(d), C.byref(inp), C.byref(out), one, 1 << 30, None) == _abi.GH_ERR_INVALID_ARG
+    ds = _abi.GhDims(10, 1, 64, 64, 0, 0, 1.0, _abi.GH_FLAG_STATIC_LISTS, 100)
+    out2 = _abi.GhOutputs(one, one, None, None, 1.0, 0)
+    assert L.gh_forward(C.byref(ds), C.byref(inp), C.byref(out2), one, 1 << 30, None) == _abi.GH_ERR_UNSUPPORTED
+    assert _abi.GH_FLAG_DEPTH24 == 32
+
+
 def test_product_has_no_cpu_fallback():
     """CPU tensors must raise (a silent CPU path would void the parity claims)."""
     import torch

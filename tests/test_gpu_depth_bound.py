@@ -124,3 +124,35 @@ def test_bound_with_split_streams_and_alpha(dev):
         img, _, c = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, sync=True, split_streams=split, depth_bound=cache, **kw)
         assert torch.equal(img, img0) and torch.equal(c.alpha, a0)
     assert cache.bounded_calls == 2 and cache.misses == 0
+
+
+def test_fit_whose_gaussians_move_every_step_with_the_occlusion_bound(dev):
+    """The reference's own fit moves the Gaussians every step (network-side trainables, infer_one_shot.py:340-343):
+    OneShotFit(occlusion_bound=True) + update_gaussians() per step takes exactly the steps of the plain full path."""
+    from guassianhand_amd import fit as F
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.renderer import GaussianModel
+    from tests.helpers import tiny_fit_problem
+    pb = tiny_fit_problem(P=4000, n_views=4, hw=(96, 96), device=dev)
+    g = torch.Generator().manual_seed(8)
+    gt_rgb = torch.rand(4, 96, 96, 3, generator=g).to(dev)
+    gt_mask = (torch.rand(4, 96, 96, generator=g) > 0.5).float().to(dev)
+    args = (pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
+    gs = pb["gs"]
+    gs = GaussianModel(gs.xyz, (gs.opacity * 0 + 0.8), gs.rotation, gs.scaling * 3.0, gs.shs)     # opaque enough for tiles to saturate
+    a = F.OneShotFit(gs, pb["uv"], map_hw=pb["map_hw"], static_geometry=False)
+    b = F.OneShotFit(gs, pb["uv"], map_hw=pb["map_hw"], occlusion_bound=True)
+    assert isinstance(b._geom_cache, R.DepthBoundCache)
+    xyz = gs.xyz.clone()
+    for step in range(7):
+        xyz = xyz + 5e-5 * torch.randn(xyz.shape, generator=g).to(dev)
+        moved = GaussianModel(xyz, gs.opacity, gs.rotation, gs.scaling, gs.shs)
+        a.update_gaussians(moved)
+        b.update_gaussians(moved)
+        la, lb = a.step(*args, sync=True), b.step(*args, sync=True)
+        assert float(la) == float(lb), step
+        for k in a._adam:
+            assert torch.equal(a._adam[k].param, b._adam[k].param), (step, k)
+    assert b._geom_cache.bounded_calls >= 5
+    print("bounded calls", b._geom_cache.bounded_calls, "misses", b._geom_cache.misses)
+    R.check_overflow()
