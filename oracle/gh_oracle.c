@@ -356,47 +356,73 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
     /* baseline mode: bucket the instances by tile (count -> prefix -> scatter), then sort every tile's bucket by the
      * checker's own comparator (key, emit slot): a total order, so the result equals the global stable sort below */
     const long NT = (long)NV * tiles;
+    const long NG = (long)NV * P;
+#ifdef _OPENMP
+    extern int omp_get_max_threads(void);
+    extern int omp_get_thread_num(void);
+    const int nth = omp_get_max_threads();
+#else
+    const int nth = 1;
+#endif
+    /* thread-private tile counters (no atomics: 128 threads hammering 672 counters is slower than one thread): thread k owns
+     * Gaussians [NG k / nth, NG (k+1) / nth), counts their instances per tile, then writes them at its own offsets */
     uint32_t* cnt = (uint32_t*)calloc((size_t)NT + 1, sizeof(uint32_t));
     uint32_t* cur = (uint32_t*)malloc(((size_t)NT + 1) * sizeof(uint32_t));
-#pragma omp parallel for schedule(static)
-    for (long n = 0; n < (long)NV * P; ++n) {
-      const GView* g = &c->g[n];
-      if (!g->tiles) continue;
-      int v = (int)(n / P);
-      for (int ty = g->miny; ty < g->maxy; ++ty)
-        for (int tx = g->minx; tx < g->maxx; ++tx) {
-#pragma omp atomic
-          cnt[(size_t)v * tiles + (size_t)ty * gx + tx]++;
-        }
+    uint32_t* lc = (uint32_t*)calloc((size_t)nth * (size_t)NT + 1, sizeof(uint32_t));
+#pragma omp parallel num_threads(nth)
+    {
+#ifdef _OPENMP
+      const int k = omp_get_thread_num();
+#else
+      const int k = 0;
+#endif
+      uint32_t* mine = lc + (size_t)k * NT;
+      for (long n = NG * k / nth; n < NG * (k + 1) / nth; ++n) {
+        const GView* g = &c->g[n];
+        if (!g->tiles) continue;
+        int v = (int)(n / P);
+        for (int ty = g->miny; ty < g->maxy; ++ty)
+          for (int tx = g->minx; tx < g->maxx; ++tx) mine[(size_t)v * tiles + (size_t)ty * gx + tx]++;
+      }
     }
     t_mark = gho_now();
     uint32_t acc = 0;
-    for (long t = 0; t < NT; ++t) { cur[t] = acc; acc += cnt[t]; }
-    t_ser += gho_now() - t_mark;
-#pragma omp parallel for schedule(static)
-    for (long n = 0; n < (long)NV * P; ++n) {
-      const GView* g = &c->g[n];
-      if (!g->tiles) continue;
-      int v = (int)(n / P);
-      uint32_t off = c->offsets[n] - g->tiles;
-      uint32_t dbits; memcpy(&dbits, &g->depth, 4);
-      for (int ty = g->miny; ty < g->maxy; ++ty)
-        for (int tx = g->minx; tx < g->maxx; ++tx) {
-          uint64_t tile = (uint64_t)v * tiles + (uint64_t)ty * gx + tx;
-          uint32_t pos;
-#pragma omp atomic capture
-          pos = cur[tile]++;
-          c->inst[pos].key = (tile << 32) | dbits; c->inst[pos].slot = off; c->inst[pos].gid = (uint32_t)n;
-          ++off;
-        }
+    for (long t = 0; t < NT; ++t) {
+      cur[t] = acc;
+      for (int k = 0; k < nth; ++k) { uint32_t x = lc[(size_t)k * NT + t]; lc[(size_t)k * NT + t] = acc; acc += x; cnt[t] += x; }
     }
-#pragma omp parallel for schedule(dynamic, 4)
+    t_ser += gho_now() - t_mark;
+#pragma omp parallel num_threads(nth)
+    {
+#ifdef _OPENMP
+      const int k = omp_get_thread_num();
+#else
+      const int k = 0;
+#endif
+      uint32_t* mine = lc + (size_t)k * NT;
+      for (long n = NG * k / nth; n < NG * (k + 1) / nth; ++n) {
+        const GView* g = &c->g[n];
+        if (!g->tiles) continue;
+        int v = (int)(n / P);
+        uint32_t off = c->offsets[n] - g->tiles;
+        uint32_t dbits; memcpy(&dbits, &g->depth, 4);
+        for (int ty = g->miny; ty < g->maxy; ++ty)
+          for (int tx = g->minx; tx < g->maxx; ++tx) {
+            uint64_t tile = (uint64_t)v * tiles + (uint64_t)ty * gx + tx;
+            uint32_t pos = mine[tile]++;
+            c->inst[pos].key = (tile << 32) | dbits; c->inst[pos].slot = off; c->inst[pos].gid = (uint32_t)n;
+            ++off;
+          }
+      }
+    }
+#pragma omp parallel for schedule(dynamic, 1)
     for (long t = 0; t < NT; ++t) {
       if (!cnt[t]) continue;
-      uint32_t s0 = cur[t] - cnt[t];
+      uint32_t s0 = cur[t];
       qsort(c->inst + s0, (size_t)cnt[t], sizeof(Inst), inst_cmp);
-      c->ranges[2 * t] = s0; c->ranges[2 * t + 1] = cur[t];
+      c->ranges[2 * t] = s0; c->ranges[2 * t + 1] = s0 + cnt[t];
     }
+    free(lc);
     free(cnt); free(cur);
   } else {
   t_mark = gho_now();
@@ -730,6 +756,16 @@ int gho_backward(const GhoCtx* c, const GhInputs* in, const GhGrads* gr) {
 
 /* exposed so tests can check the reproducible exp against libm */
 float gho_exp_public(float x) { return gho_exp(x); }
+/* number of OpenMP threads of the following calls (bench.py's cpu_baseline picks the count that is fastest on the host it runs on:
+ * a container's CPU share is usually far smaller than the host's core count) */
+void gho_set_num_threads(int n) {
+#ifdef _OPENMP
+  extern void omp_set_num_threads(int);
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 int gho_num_threads(void) {
 #ifdef _OPENMP
   extern int omp_get_max_threads(void);

@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
         _lib.gho_exp_public.restype = C.c_float
         _lib.gho_exp_public.argtypes = [C.c_float]
         _lib.gho_num_threads.restype = C.c_int
+        _lib.gho_set_num_threads.restype = None
+        _lib.gho_set_num_threads.argtypes = [C.c_int]
         _lib.gho_set_parallel.restype = None
         _lib.gho_set_parallel.argtypes = [C.c_int]
         _lib.gho_get_parallel.restype = C.c_int
@@ -169,6 +171,10 @@ def gho_exp(x: float) -> float:
 
 def num_threads() -> int:
     return int(lib().gho_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    lib().gho_set_num_threads(int(n))
 
 
 def set_parallel(on: bool) -> None:
