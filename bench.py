@@ -101,6 +101,31 @@ def pmc_profile(kind: str, kernel: str, args, V: int):
     return ent, f"profiles/{name}.json (offline rocprofv3 --pmc passes, source {doc['source_hash']})"
 
 
+def effective_cpus() -> int:
+    """CPUs this process can actually use: the affinity mask and the cgroup CPU quota, not the host's core count (a container
+    on the GPU box sees 256 host CPUs and owns a share of 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(round(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(round(q / per))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
     """The CPU restatement on the host cores: a reported baseline only. Default: the C oracle (oracle/gh_oracle.c, OpenMP over
     tiles). torch_reference (BASELINE configs[0], `--config random1k`): the literal "PyTorch CPU autograd reference" — the dense
@@ -111,7 +136,7 @@ def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
     dimg = torch.randn(1, 3, s.H, s.W, generator=g) / (3 * s.H * s.W)
     if torch_reference:
         from oracle import oracle_torch as OT
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(effective_cpus())          # (not the host's core count: oversubscribing a container's share is slower)
         c = cams[0]
         n, t0 = 0, time.perf_counter()
         while True:
@@ -128,8 +153,8 @@ def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
                 break
         from oracle import oracle_c
         return {"value": n / dt, "unit": "renders/s", "cores": torch.get_num_threads(), "kind": "port",
-                "threads": torch.get_num_threads(), "host_cpus": os.cpu_count(), "cpu_model": oracle_c.cpu_model(),
-                "serial_fraction": None,
+                "threads": torch.get_num_threads(), "host_cpus": os.cpu_count(), "effective_cpus": effective_cpus(),
+                "cpu_model": oracle_c.cpu_model(), "serial_fraction": None,
                 "sample": f"{n} fwd+bwd renders of view 0 of the same workload ({dt:.1f} s), oracle/oracle_torch.py: dense PyTorch CPU "
                           "autograd (BASELINE configs[0]'s reference)"}
     from oracle import oracle_c
@@ -158,7 +183,7 @@ def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
     oracle_c.set_parallel(True)
     try:
         sweep = {}
-        cands = sorted({t for t in (4, 8, 16, 32, 64, 128, default_threads) if 1 <= t <= max(default_threads, os.cpu_count() or 1)})
+        cands = sorted({t for t in (4, 8, 16, 32, 64, 128, default_threads, effective_cpus()) if 1 <= t <= max(default_threads, os.cpu_count() or 1)})
         per = max(0.8, min(2.0, 0.35 * seconds / max(1, len(cands))))
         for t in cands:
             oracle_c.set_num_threads(t)
@@ -171,7 +196,7 @@ def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
         oracle_c.set_parallel(False)
         oracle_c.set_num_threads(default_threads)
     return {"value": n / t_lib, "unit": "renders/s", "cores": best, "kind": "port",
-            "threads": best, "host_cpus": os.cpu_count(), "cpu_model": oracle_c.cpu_model(),
+            "threads": best, "host_cpus": os.cpu_count(), "effective_cpus": effective_cpus(), "cpu_model": oracle_c.cpu_model(),
             "serial_fraction": t_ser / t_lib if t_lib > 0 else None,
             "value_by_wall_clock": n / dt, "thread_sweep_renders_per_s": {str(k): round(v, 2) for k, v in sweep.items()},
             "sample": f"{n} fwd+bwd renders of view 0 of the same workload ({dt:.1f} s), oracle/gh_oracle.c in its baseline mode: "
