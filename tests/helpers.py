@@ -118,3 +118,22 @@ def forward_single_view(gs, viewpoint_camera, background_color: torch.Tensor, re
                                           scales=gs.scaling, rotations=gs.rotation, cov3D_precomp=None)
         ret["comp_mask"] = rendered_mask.permute(1, 2, 0)
     return ret
+
+
+def limit_torch_threads_to_the_cpu_share():
+    """torch's CPU thread pool defaults to the HOST's core count; inside a container with a CPU quota (the GPU box: 256 host CPUs,
+    a share of 16) that oversubscribes and dense CPU work — the float64 Oracle A — runs orders of magnitude slower."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(round(int(q[0]) / int(q[1])))))
+    except (OSError, ValueError, IndexError):
+        pass
+    torch.set_num_threads(max(1, n))
+    return n

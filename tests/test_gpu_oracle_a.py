@@ -36,7 +36,9 @@ ROW_RTOL = 1e-4
 def dev():
     assert torch.cuda.is_available()
     from guassianhand_amd import _lib
+    from tests.helpers import limit_torch_threads_to_the_cpu_share
     _lib.lib()
+    limit_torch_threads_to_the_cpu_share()          # Oracle A runs on the host's CPUs: use the share this process owns
     return torch.device("cuda:0")
 
 
