@@ -593,7 +593,7 @@ def main():
                         "alg_bytes_per_launch": ab[dom], "ms_per_launch": stage_ms[dom],
                         "timing": f"HIP events around the stage entry points, {args.steps} eager steps run right after the timed steps",
                         # what actually bounds the kernel (it is not bandwidth): vector-ALU issue and the LDS pipe, from the
-                        # committed SQ counter passes — arithmetic in profiles/r3_pmc_sq*.json
+                        # committed SQ counter passes — arithmetic in profiles/r4_pmc_sq*.json
                         "secondary": sq["secondary"] if sq else None, "secondary_source": sq_src}
         out = {
             "metric": "fwd+bwd renders/sec @512x334, ~100k Gaussians", "value": value, "unit": "renders/s",
