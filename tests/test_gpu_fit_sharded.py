@@ -186,3 +186,42 @@ def test_sharded_fit_over_rccl():
         assert res[r]["losses"] == pytest.approx(losses, rel=1e-5)
         assert _close(res[r]["state"], st)
     assert all(torch.equal(res[1]["state"][k], res[0]["state"][k]) for k in st)
+
+
+@pytest.mark.timeout(300)
+def test_rccl_loads_and_reduces_the_gradient_block_in_a_world_of_one():
+    """No lease of this build has had two GPUs, so the two-rank RCCL tests above have only ever skipped. What CAN run on one GPU: the
+    "nccl" backend (= RCCL on ROCm) initialised for a world of one, an all-reduce of a buffer of the fit's gradient-block size
+    issued on a side stream behind producer work exactly as dist.allreduce_block issues it, and a barrier — RCCL's library load,
+    communicator creation and stream ordering on this software stack. (A one-rank all-reduce moves nothing over xGMI: it says
+    nothing about scaling.)"""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["GH_ROOT"])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%s" % os.environ["GH_PORT"], rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+n = 4 + 48 + 4 * 98562                                   # [4 caller floats | color_w | opacity_b | color_b (P,3)]: the fit's prefix
+block = torch.arange(n, dtype=torch.float32, device="cuda") * 1e-3
+want = block.clone()
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    work = dist.all_reduce(block, op=dist.ReduceOp.SUM, async_op=True)
+work.wait()
+torch.cuda.current_stream().wait_stream(side)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(block, want), "a one-rank sum must leave the block unchanged"
+print("rccl world-of-one ok", torch.cuda.nccl.version())
+dist.destroy_process_group()
+'''
+    from tests.test_gpu_bench import _free_port
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GH_ROOT=root, GH_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0 and "rccl world-of-one ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
