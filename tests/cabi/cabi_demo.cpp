@@ -8,7 +8,9 @@
 // out:  float image[NV*3*H*W]; int32 radii[NV*P]; uint32 D; float dmeans3D[P*3], dopacities[P], dscales[P*3],
 //       drotations[P*4], dcolors[P*3];
 //       then the SECOND call over the same geometry (gh_forward_shared / gh_backward_shared with colour 1, the reference's
-//       mask pass, renderer_one_shot.py:372-379): float mask_image[NV*3*H*W], float dopacities_mask[P]
+//       mask pass, renderer_one_shot.py:372-379): float mask_image[NV*3*H*W], float dopacities_mask[P];
+//       then (v0.5) a forward that REPORTS a per-tile occlusion bound and one that APPLIES it (GhOutputs.tile_depth_seen ->
+//       GhInputs.tile_depth_bound), with GH_FLAG_DEPTH24: float bounded_image[NV*3*H*W], uint32 D_bounded, uint32 overflow_bits
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -103,6 +105,28 @@ int main(int argc, char** argv) {
   if (rc != GH_OK) { std::fprintf(stderr, "gh_backward: %d\n", rc); return 3; }
   CHECK(hipStreamSynchronize(stream));
 
+  // speculative occlusion bound + three-pass depth sort, from plain C++: report, then apply (a workspace of its own)
+  const int tiles = ((W + GH_TILE - 1) / GH_TILE) * ((H + GH_TILE - 1) / GH_TILE);
+  float *seen_a, *seen_b, *image3; void* ws3 = nullptr;
+  CHECK(hipMalloc((void**)&seen_a, (size_t)NV * tiles * 8)); CHECK(hipMalloc((void**)&seen_b, (size_t)NV * tiles * 8));
+  CHECK(hipMalloc((void**)&image3, (size_t)NV * 3 * H * W * 4));
+  GhDims dims3 = dims;
+  dims3.flags |= GH_FLAG_DEPTH24;
+  const size_t ws3_bytes = gh_workspace_bytes(&dims3);
+  CHECK(hipMalloc(&ws3, ws3_bytes));
+  GhOutputs out3 = {image3, nullptr, nullptr, seen_a, 1.002f, 8u};
+  int rc3 = gh_forward(&dims3, &in, &out3, ws3, ws3_bytes, stream);
+  if (rc3 != GH_OK) { std::fprintf(stderr, "gh_forward (report): %d\n", rc3); return 3; }
+  GhInputs in3 = in;
+  in3.tile_depth_bound = seen_a;
+  out3.tile_depth_seen = seen_b;
+  rc3 = gh_forward(&dims3, &in3, &out3, ws3, ws3_bytes, stream);
+  if (rc3 != GH_OK) { std::fprintf(stderr, "gh_forward (bounded): %d\n", rc3); return 3; }
+  GhCounters ctr3;
+  CHECK(hipMemcpyAsync(&ctr3, ws3, sizeof ctr3, hipMemcpyDeviceToHost, stream));
+  CHECK(hipStreamSynchronize(stream));
+  std::printf("bounded forward: instances %u (unbounded %u), overflow bits %u\n", ctr3.num_rendered, D, ctr3.overflow);
+
   FILE* o = std::fopen(argv[2], "wb");
   if (!o) return 1;
   auto wr = [&](const void* d, size_t bytes) {
@@ -115,6 +139,8 @@ int main(int argc, char** argv) {
   wr(gr.dL_dmeans3D, (size_t)P * 12); wr(gr.dL_dopacities, (size_t)P * 4); wr(gr.dL_dscales, (size_t)P * 12);
   wr(gr.dL_drotations, (size_t)P * 16); wr(gr.dL_dcolors, (size_t)P * 12);
   wr(image2, (size_t)NV * 3 * H * W * 4); wr(gr2.dL_dopacities, (size_t)P * 4);
+  wr(image3, (size_t)NV * 3 * H * W * 4);
+  std::fwrite(&ctr3.num_rendered, 4, 1, o); std::fwrite(&ctr3.overflow, 4, 1, o);
   std::fclose(o);
   std::printf("ok\n");
   return 0;

@@ -60,7 +60,12 @@ def test_cpp_driver_matches_python_host_and_oracle(tmp_path, gh_lib_path):
              "colors_precomp": take(P * 3, np.float32).reshape(P, 3)}
     mask_image = take(2 * 3 * H * W, np.float32).reshape(2, 3, H, W)
     mask_dop = take(P, np.float32)
+    bounded_image = take(2 * 3 * H * W, np.float32).reshape(2, 3, H, W)
+    D_bounded, overflow_bits = int(take(1, np.uint32)[0]), int(take(1, np.uint32)[0])
     assert off == raw.size
+    # v0.5 from plain C++: a forward that applies the occlusion bound another forward reported, with the three-pass depth sort —
+    # verified on the device (no flag set), never more instances, the same image bit for bit
+    assert overflow_bits == 0 and 0 < D_bounded <= D and torch.equal(bounded_image, image)
 
     # the same call through the Python host (ctypes + torch memory): identical bits
     dev = torch.device("cuda:0")
