@@ -91,7 +91,7 @@ class OneShotFit(nn.Module):
             if static_geometry:
                 raise ValueError("OneShotFit: static_geometry (frozen Gaussians) or occlusion_bound (moving Gaussians), not both")
             from .rasterizer import DepthBoundCache
-            self._geom_cache = DepthBoundCache()
+            self._geom_cache = DepthBoundCache()      # (ignored by calls of fewer than four 512x334 views' worth of pixels)
         elif (static_geometry if static_geometry is not None else (render_fn is None and gs.xyz.is_cuda)):
             from .rasterizer import GeometryCache
             self._geom_cache = GeometryCache()

@@ -71,10 +71,12 @@ class DepthBoundCache:
     kernel variant that walks on behind every pixel's stop until its transmittance has halved again (what tells a robustly
     saturated tile from one a rounding away from needing its whole list) — 26 % more forward time, measured; the bound is
     therefore refreshed every refresh_every-th call only and re-used in between (every call still verifies it; the margin has to
-    cover the motion of that many steps)."""
+    cover the motion of that many steps). min_pixels: calls that render fewer pixels in all ignore the cache (the launch floors of a
+    small call leave nothing for the bound to win: one 512x334 view 240 -> 257 us with it)."""
 
-    def __init__(self, margin: float = 2e-3, slack: int = 8, refresh_every: int = 4):
+    def __init__(self, margin: float = 2e-3, slack: int = 8, refresh_every: int = 4, min_pixels: int = 4 * 512 * 334):
         self.margin, self.slack, self.refresh_every = float(margin), int(slack), max(1, int(refresh_every))
+        self.min_pixels = int(min_pixels)        # calls smaller than this render without a bound (measured: one or two 512x334 views lose)
         self.bufs, self.key, self.cur, self.valid = None, None, 0, False
         self.bounded_calls, self.misses, self.age = 0, 0, 0
 
@@ -572,8 +574,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
         ctx.pending, ctx.refresh = pending, True
         return image, g0.radii, ctx
-    if depth_bound is not None and (static_lists or _graph_mode or P == 0):
-        depth_bound = None                       # lists that outlive the call / a captured call: no per-call speculation
+    if depth_bound is not None and (static_lists or _graph_mode or P == 0 or NV * H * W < depth_bound.min_pixels):
+        depth_bound = None                       # lists that outlive the call / a captured call / a small call: no per-call speculation
     base_flags = flags
     while True:
         cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))

@@ -44,7 +44,7 @@ def test_bound_hit_is_exact_and_halves_the_lists(dev, config, nv):
     s = make_scene(config, n_views=nv).to(dev)
     cams = s.cams()
     img0, radii0, D0, st0, g0 = _render(s, cams, s.xyz, None)
-    cache = R.DepthBoundCache(refresh_every=1)
+    cache = R.DepthBoundCache(refresh_every=1, min_pixels=0)
     img1, _, D1, _, _ = _render(s, cams, s.xyz, cache, want_grads=False)         # first call: no bound yet, reports one
     assert torch.equal(img1, img0) and D1 == D0 and cache.valid and cache.bounded_calls == 0
     img2, radii2, D2, st2, g2 = _render(s, cams, s.xyz, cache)                     # second call: bounded
@@ -66,7 +66,7 @@ def test_moving_gaussians_every_step_equals_the_unbounded_render(dev):
     from guassianhand_amd.scenes import make_scene
     s = make_scene("two_hands", n_views=2).to(dev)
     cams = s.cams()
-    cache = R.DepthBoundCache(refresh_every=3)       # report a bound every third call, re-use it in between
+    cache = R.DepthBoundCache(refresh_every=3, min_pixels=0)       # report a bound every third call, re-use it in between
     g = torch.Generator().manual_seed(5)
     xyz = s.xyz.clone()
     ratios = []
@@ -91,7 +91,7 @@ def test_a_wrong_bound_is_caught(dev):
     s = make_scene("two_hands", n_views=1).to(dev)
     cams = s.cams()
     img0, _, D0, _, _ = _render(s, cams, s.xyz, None, want_grads=False)
-    cache = R.DepthBoundCache(refresh_every=1)
+    cache = R.DepthBoundCache(refresh_every=1, min_pixels=0)
     _render(s, cams, s.xyz, cache, want_grads=False)
     cache.bufs[cache.cur][:, 0].mul_(0.98)                      # 2 cm nearer at 1 m: in front of the surface the pixels stop on
     img1, _, D1, _, _ = _render(s, cams, s.xyz, cache, want_grads=False)          # sync=True
@@ -119,7 +119,7 @@ def test_bound_with_split_streams_and_alpha(dev):
               return_alpha=True)
     img0, _, c0 = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, sync=True, **kw)
     a0 = c0.alpha.clone()
-    cache = R.DepthBoundCache(refresh_every=2)
+    cache = R.DepthBoundCache(refresh_every=2, min_pixels=0)
     for split in (True, True, False):
         img, _, c = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, sync=True, split_streams=split, depth_bound=cache, **kw)
         assert torch.equal(img, img0) and torch.equal(c.alpha, a0)
@@ -143,6 +143,7 @@ def test_fit_whose_gaussians_move_every_step_with_the_occlusion_bound(dev):
     a = F.OneShotFit(gs, pb["uv"], map_hw=pb["map_hw"], static_geometry=False)
     b = F.OneShotFit(gs, pb["uv"], map_hw=pb["map_hw"], occlusion_bound=True)
     assert isinstance(b._geom_cache, R.DepthBoundCache)
+    b._geom_cache.min_pixels = 0                         # (this test's images are far below the size from which the policy applies the bound)
     xyz = gs.xyz.clone()
     for step in range(7):
         xyz = xyz + 5e-5 * torch.randn(xyz.shape, generator=g).to(dev)
@@ -156,3 +157,13 @@ def test_fit_whose_gaussians_move_every_step_with_the_occlusion_bound(dev):
     assert b._geom_cache.bounded_calls >= 5
     print("bounded calls", b._geom_cache.bounded_calls, "misses", b._geom_cache.misses)
     R.check_overflow()
+
+
+def test_small_calls_ignore_the_cache(dev):
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.scenes import make_scene
+    s = make_scene("two_hands", n_views=1, P=20000).to(dev)
+    cache = R.DepthBoundCache()                           # default policy: nothing below four 512x334 views' worth of pixels
+    for _ in range(3):
+        _render(s, s.cams(), s.xyz, cache, want_grads=False)
+    assert cache.bounded_calls == 0 and not cache.valid

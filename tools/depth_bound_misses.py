@@ -9,7 +9,7 @@ s = make_scene("two_hands", n_views=V).to(dev)
 cams = s.cams()
 kw = dict(H=s.H, W=s.W, colors_precomp=s.shs.squeeze(1), xyz_b=s.xyz_b, opacity_b=s.opacity_b, color_w=s.color_w, color_b=s.color_b)
 g = torch.Generator().manual_seed(3)
-cache = R.DepthBoundCache(margin=2e-3, slack=32)
+cache = R.DepthBoundCache(margin=2e-3, slack=32, min_pixels=0)
 xyz = s.xyz.clone()
 R.raster_forward(cams, xyz, s.opacity, s.scaling, s.rotation, sync=True, depth_bound=cache, **kw)
 gx, gy = (s.W + 15) // 16, (s.H + 15) // 16

@@ -61,7 +61,7 @@ def run(cache):
     return Ds[-1], st, e0.elapsed_time(e1) / K, missed
 
 
-for name, cache in (("no bound", None), ("occlusion bound", R.DepthBoundCache(margin=margin, slack=slack, refresh_every=refresh))):
+for name, cache in (("no bound", None), ("occlusion bound", R.DepthBoundCache(margin=margin, slack=slack, refresh_every=refresh, min_pixels=0))):
     if (mode == "none" and cache is not None) or (mode == "bound" and cache is None):
         continue
     D, st, wall, missed = run(cache)

@@ -44,7 +44,7 @@ for it in range(n):
     cams = sc.cams().to(dev)
     bl = {k: getattr(s, k) for k in ("xyz_b", "opacity_b", "color_w", "color_b") if getattr(s, k) is not None}
     kw = dict(colors_precomp=s.shs.squeeze(1)) if use_rgb else dict(shs=s.shs, sh_degree=sc.sh_degree)
-    cache = R.DepthBoundCache(margin=rnd.choice([5e-4, 2e-3]), slack=rnd.choice([0, 8]), refresh_every=rnd.choice([1, 2, 3]))
+    cache = R.DepthBoundCache(margin=rnd.choice([5e-4, 2e-3]), slack=rnd.choice([0, 8]), refresh_every=rnd.choice([1, 2, 3]), min_pixels=0)
     xyz = s.xyz.clone()
     sigma = motion * rnd.choice([0.0, 2e-5, 2e-4])
     for step in range(5):
