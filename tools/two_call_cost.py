@@ -26,11 +26,14 @@ def fused():
     out = render_views(gs, sc.w2c, sc.K, sc.H, sc.W, sc.bg, color_w=sc.color_w, xyz_b=sc.xyz_b, color_b=sc.color_b,
                        opacity_b=sc.opacity_b, use_rgb=True, sync=False)
     (out["comp_rgb"].mean() + out["comp_mask"].mean()).backward()
-def t(fn, n=10):
-    fn(); fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+def t(fn, n=30):
+    for _ in range(4): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
+    global enq
+    enq = (time.perf_counter() - t0) / n * 1e3
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-a = t(ref_protocol); b = t(fused)
+a = t(ref_protocol); a_enq = enq; b = t(fused)
 R.check_overflow()
-print(f"reference protocol (8 views x 2 rasteriser calls through the drop-in): {a:.3f} ms = {a / 8:.3f} ms per view fwd+bwd")
+print(f"reference protocol (8 views x 2 rasteriser calls through the drop-in): {a:.3f} ms = {a / 8:.3f} ms per view fwd+bwd (host enqueue {a_enq / 8:.3f})")
 print(f"fused batched form (8 views, RGB+alpha in one pass, sync-free): {b:.3f} ms = {b / 8:.3f} ms per view fwd+bwd")
