@@ -1,0 +1,28 @@
+"""A short, fixed-seed run of the feature-matrix fuzz (tools/fuzz_features.py): random scene shapes x colour modes x blend subsets x
+call variants (plain, split streams, static lists + refresh, shared geometry, occlusion bound, pose batch) against the C oracle —
+forward bit-exact, gradients within the north star's tolerances (a float64 dense evaluation referees where two float32 programs
+disagree on ill-conditioned scenes). The long runs are in profiles/r4_fuzz_features.txt."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_feature_matrix_fuzz_fixed_seed():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_features.py"), "160", "7"], capture_output=True, text=True,
+                       timeout=550, cwd=ROOT)
+    tail = "\n".join(r.stdout.splitlines()[-12:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("feature fuzz:")]
+    assert summary, tail
+    print(summary[0])
+    assert "; 0 findings" in summary[0], tail
+    # every variant was drawn
+    import ast
+    counts = ast.literal_eval(summary[0].split("): ", 1)[1].split("; ")[0])
+    assert all(v > 0 for v in counts.values()), counts
