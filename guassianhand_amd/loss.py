@@ -127,6 +127,8 @@ class _RenderedLoss(torch.autograd.Function):
         else:
             raise ValueError(kind)
         ctx.rctx, ctx.dimg, ctx.dal, ctx.use_rgb = rctx, dimg, dal, use_rgb
+        # (the backward kernels re-read the inputs through the context's pointers: autograd's version check, as in rasterizer.py)
+        ctx.save_for_backward(*[t for t in (cams, xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b) if t is not None])
         ctx.set_materialize_grads(False)             # no image-sized zero tensors for the outputs that carry no gradient
         ctx.shapes = [None if t is None else t.shape for t in (xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b)]
         alpha = rctx.alpha if rctx.alpha is not None else image.new_zeros(0)
@@ -136,6 +138,7 @@ class _RenderedLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _gi, _ga, _gr):
         from . import rasterizer as R
+        ctx.saved_tensors
         g = R.raster_backward(ctx.rctx, ctx.dimg, want_means2D=False, dL_dalpha=ctx.dal, grad_scale=g_loss,
                               want=R._wanted(ctx.needs_input_grad[11:20], ctx.use_rgb))
         ctx.rctx = None

@@ -869,6 +869,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         if _reuse_geometry and parent is None:
             _geom_last = (tuple(weakref.ref(o) for o in objs), vals, weakref.ref(rctx))
         ctx.rctx = rctx
+        # the backward kernels read these tensors again, through the pointers the context holds: registering them makes autograd
+        # raise its usual "modified by an inplace operation" error when one of them was written between forward and backward,
+        # as it does for the reference extension (which saves them) — instead of gradients of a scene that never existed
+        ctx.save_for_backward(*[t for t in (means3D, sh, colors_precomp, opacities, scales, rotations) if t is not None])
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape,
                       None if colors_precomp is None else colors_precomp.shape, opacities.shape, scales.shape,
                       rotations.shape)
@@ -878,6 +882,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_image, _grad_radii):
+        ctx.saved_tensors                                  # (version check of the inputs, see forward)
         g = raster_backward(ctx.rctx, grad_image)
         ctx.rctx = None
         s = ctx.shapes
@@ -964,6 +969,7 @@ class _RasterizeViews(torch.autograd.Function):
                                                    return_alpha=want_alpha, per_view_gaussians=per_view, **kw)
         ctx.rctx = rctx
         ctx.use_rgb = use_rgb
+        ctx.save_for_backward(*[t for t in (cams, xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b) if t is not None])
         ctx.shapes = [None if t is None else t.shape for t in (xyz, opacity, scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b)]
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)             # an unused output (image or alpha) arrives as None, not as a zero image
@@ -974,6 +980,7 @@ class _RasterizeViews(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_image, grad_alpha, _gr):
+        ctx.saved_tensors                                  # inputs written in place since the forward: autograd's own error (see _RasterizeGaussians)
         if ctx.rctx.alpha is None:
             grad_alpha = None
         g = raster_backward(ctx.rctx, grad_image, want_means2D=False, dL_dalpha=grad_alpha,

@@ -405,3 +405,41 @@ def test_default_dropin_inference_call_reruns_transparently(dev):
         Rz.check_overflow()
     finally:
         Rz.set_geometry_reuse(True)
+
+
+def test_backward_after_an_inplace_update_of_an_input_raises_like_the_reference(dev):
+    """The backward kernels read the call's input tensors again (through pointers the context keeps). The reference extension saves
+    its inputs with `save_for_backward`, so PyTorch raises when one of them was written in place between forward and backward; the
+    drop-in, the view-batched Function and the render+loss node register theirs too — the same error instead of gradients that mix
+    the old tile lists with the new values. A write to a tensor the call did not read is no error."""
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.loss import rendered_l1_loss
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=2, P=600, use_rgb=True, blend=False)
+    img, _, t = _reference_style_call(sc, dev)
+    with torch.no_grad():
+        t["scales"].mul_(1.01)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        img.sum().backward()
+    # an untouched call still works afterwards, and its gradients are the oracle-checked ones of the other tests
+    img, _, t = _reference_style_call(sc, dev)
+    with torch.no_grad():
+        t["means2D"].add_(1.0)                               # never read by the rasteriser
+    img.sum().backward()
+    assert t["means3D"].grad is not None and bool(torch.isfinite(t["means3D"].grad).all())
+
+    s = sc.to(dev)
+    cams = s.cams().contiguous()
+    target = torch.rand(2, 3, sc.H, sc.W, device=dev)
+    for form in ("views", "loss"):
+        p = {k: getattr(s, k).clone().requires_grad_(True) for k in ("xyz", "opacity", "scaling", "rotation", "shs")}
+        pos = (cams, p["xyz"], p["opacity"], p["scaling"], p["rotation"], p["shs"])
+        if form == "views":
+            out = R.rasterize_views(*pos, H=sc.H, W=sc.W, use_rgb=True)[0].sum()
+        else:
+            out = rendered_l1_loss(*pos, target, H=sc.H, W=sc.W, use_rgb=True)[0]
+        with torch.no_grad():
+            p["opacity"].mul_(0.9)
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            out.backward()
+    R.check_overflow()

@@ -26,3 +26,20 @@ def test_feature_matrix_fuzz_fixed_seed():
     import ast
     counts = ast.literal_eval(summary[0].split("): ", 1)[1].split("; ")[0])
     assert all(v > 0 for v in counts.values()), counts
+
+
+@pytest.mark.timeout(600)
+def test_dropin_sequence_fuzz_fixed_seed():
+    """tools/fuzz_dropin.py: random sequences of drop-in calls (RGB + mask pass reuse, backwards in any order and long after later
+    renders, in-place updates, replaced leaves, pool clears, all sync modes) — every image bit-equal to the oracle on the values the
+    call saw, every gradient within tolerance, and a backward over inputs written in place since its forward raises autograd's error."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_dropin.py"), "60", "5"], capture_output=True, text=True, timeout=550, cwd=ROOT)
+    tail = "\n".join(r.stdout.splitlines()[-12:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("drop-in sequence fuzz:")]
+    assert summary, tail
+    print(summary[0])
+    assert summary[0].endswith("; 0 findings"), tail
+    import ast
+    st = ast.literal_eval(summary[0].split("): ", 1)[1].rsplit("; ", 1)[0])
+    assert st["mask_passes"] > 50 and st["late_backwards"] > 50 and st.get("stale_backwards", 0) > 10, st

@@ -1,0 +1,192 @@
+"""Stateful fuzz of the drop-in `GaussianRasterizer` (the module the reference imports, renderer_one_shot.py:3): random SEQUENCES of calls.
+
+The per-call arithmetic is covered by tools/fuzz_features.py; what this exercises is the state around it — the mask-pass reuse of the
+previous call's geometry (matched by tensor identity and `_version`), pooled workspaces, contexts that outlive later calls, sync modes.
+Per iteration a small scene with leaf tensors and three cameras of different image sizes, then 8-20 random actions:
+    render (RGB pass, often followed by the mask pass over the same objects; under autograd or torch.no_grad(); sync None / True / False)
+    backward of ANY earlier output still alive (in any order, e.g. the RGB pass of view 0 after two later renders of other views)
+    drop an output without a backward, update leaves in place (`no_grad` + `add_`: bumps `_version`), replace leaf objects,
+    check_overflow / clear_workspace_pool
+A backward whose inputs were updated in place since its forward must raise autograd's "modified by an inplace operation" error (the
+reference extension saves its inputs, so PyTorch raises there too). Every image is compared bit for bit with the C oracle on the values the call saw; every backward's leaf gradients with the oracle's
+backward on that call's snapshot (rel-L2 <= 2e-5, element-wise <= 2e-3).   usage: fuzz_dropin.py [n_iterations] [seed]"""
+import math, os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from guassianhand_amd import rasterizer as R
+from guassianhand_amd.camera import Camera, pack_camera
+from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from guassianhand_amd.scenes import make_scene
+from oracle.oracle_c import OracleRender
+from tests.helpers import rel_l2, max_rel
+
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
+rnd = random.Random(seed)
+dev = torch.device("cuda:0")
+stats = dict(renders=0, mask_passes=0, backwards=0, late_backwards=0, drops=0, updates=0, replaced=0, no_grad_renders=0)
+bad = []
+LEAVES = ("xyz", "opacity", "scaling", "rotation", "colour")
+
+
+def one(it):
+    rnd.seed(seed * 1000003 + it)
+    P = rnd.choice([40, 300, 1200])
+    rgb = rnd.random() < 0.6
+    sc = make_scene("random1k", n_views=3, P=P, use_rgb=rgb, blend=False, seed=rnd.randint(0, 10 ** 6))
+    sizes = [(rnd.randint(20, 130), rnd.randint(20, 130)) for _ in range(3)]
+    cams = [Camera.from_w2c(sc.w2c[v].to(dev), sc.K[v].to(dev), sizes[v][0], sizes[v][1]) for v in range(3)]
+    bg = torch.rand(3, generator=torch.Generator().manual_seed(it)).to(dev)
+    leaf = dict(xyz=sc.xyz, opacity=sc.opacity, scaling=sc.scaling, rotation=sc.rotation, colour=sc.shs.squeeze(1) if rgb else sc.shs)
+    leaf = {k: v.to(dev).clone().requires_grad_(True) for k, v in leaf.items()}
+    deg = 0 if rgb else rnd.randint(0, 3)
+    live = []
+    trace = []
+    tag = lambda: f"it {it} P={P} {'rgb' if rgb else 'sh%d' % deg} sizes={sizes}: " + " > ".join(trace[-8:])
+
+    def settings(v, bg_, deg_):
+        c = cams[v]
+        return GaussianRasterizationSettings(image_height=sizes[v][0], image_width=sizes[v][1], tanfovx=math.tan(c.FoVx * 0.5),
+                                             tanfovy=math.tan(c.FoVy * 0.5), bg=bg_, scale_modifier=1.0, viewmatrix=c.world_view_transform,
+                                             projmatrix=c.full_proj_transform.float(), sh_degree=deg_, campos=c.camera_center, prefiltered=False, debug=False)
+
+    def oracle_of(snap, v, mask):
+        c = cams[v]
+        cam = pack_camera(c.world_view_transform, c.full_proj_transform.float(), c.camera_center, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5),
+                          torch.zeros(3, device=dev) if mask else bg).cpu()
+        kw = dict(colors_precomp=torch.ones(P, 3)) if mask else (dict(colors_precomp=snap["colour"]) if rgb else dict(shs=snap["colour"], sh_degree=deg))
+        return OracleRender(cam, snap["xyz"], snap["opacity"], snap["scaling"], snap["rotation"], H=sizes[v][0], W=sizes[v][1], **kw)
+
+    def render():
+        v = rnd.randrange(3)
+        sync = rnd.choice([None, None, True, False])
+        grad = rnd.random() < 0.8
+        with_mask = rnd.random() < 0.7
+        snap = {k: x.detach().cpu().clone() for k, x in leaf.items()}
+        trace.append(f"render(v{v},sync={sync},{'grad' if grad else 'no_grad'}{',+mask' if with_mask else ''})")
+        means2D = torch.zeros_like(leaf["xyz"], requires_grad=True)
+        with torch.enable_grad() if grad else torch.no_grad():
+            kw = dict(colors_precomp=leaf["colour"]) if rgb else dict(shs=leaf["colour"])
+            img, radii = GaussianRasterizer(settings(v, bg, deg), sync=sync)(means3D=leaf["xyz"], means2D=means2D, opacities=leaf["opacity"],
+                                                                         scales=leaf["scaling"], rotations=leaf["rotation"], cov3D_precomp=None, **kw)
+            stats["renders"] += 1
+            stats["no_grad_renders"] += 0 if grad else 1
+            outs = [(img, False)]
+            if with_mask:
+                ones = torch.ones_like(leaf["xyz"])
+                m, _ = GaussianRasterizer(settings(v, torch.zeros(3, device=dev), 0), sync=sync)(
+                    means3D=leaf["xyz"], means2D=means2D, colors_precomp=ones, opacities=leaf["opacity"], scales=leaf["scaling"],
+                    rotations=leaf["rotation"], cov3D_precomp=None)
+                stats["mask_passes"] += 1
+                outs.append((m, True))
+        for out, mask in outs:
+            o = oracle_of(snap, v, mask)
+            assert torch.equal(out.detach().cpu(), o.image[0]), tag() + (" (mask image)" if mask else " (image)")
+            if not mask:
+                assert torch.equal(radii.cpu(), o.radii[0]), tag() + " (radii)"
+            o.close()
+            if grad and rnd.random() < 0.8:
+                deps = [x for k, x in leaf.items() if not (mask and k == "colour")]
+                live.append(dict(out=out, mask=mask, v=v, snap=snap, born=len(trace), deps=[(x, x._version) for x in deps]))
+
+    def backward():
+        if not live:
+            return
+        e = live.pop(rnd.randrange(len(live)))
+        late = len(trace) - e["born"]
+        trace.append(f"backward({'mask' if e['mask'] else 'rgb'} of v{e['v']}, {late} actions later)")
+        stats["backwards"] += 1
+        stats["late_backwards"] += 1 if late >= 2 else 0
+        for x in leaf.values():
+            x.grad = None
+        H, W = sizes[e["v"]]
+        dimg = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(it * 131 + len(trace)))
+        if any(x._version != ver for x, ver in e["deps"]):
+            # an input of that call was written in place since: autograd's error, as with the reference extension (which saves its inputs)
+            stats["stale_backwards"] = stats.get("stale_backwards", 0) + 1
+            try:
+                (e["out"] * dimg[0].to(dev)).sum().backward()
+            except RuntimeError as err:
+                assert "modified by an inplace operation" in str(err), tag() + f" (unexpected error text: {err})"
+                return
+            raise AssertionError(tag() + " (a backward over inputs that were modified in place did not raise)")
+        (e["out"] * dimg[0].to(dev)).sum().backward()
+        o = oracle_of(e["snap"], e["v"], e["mask"])
+        og = o.backward(dimg)
+        o.close()
+        names = dict(xyz="means3D", opacity="opacities", scaling="scales", rotation="rotations", colour="colors_precomp" if rgb else "shs")
+        for k, x in leaf.items():
+            if e["mask"] and k == "colour":
+                assert x.grad is None or float(x.grad.abs().max()) == 0.0, tag() + " (colour gradient from a mask pass)"
+                continue
+            if x.grad is None:                                # the leaf object was replaced after this call: its gradient went to the old object
+                continue
+            a, b = x.grad.detach().cpu(), og[names[k]].reshape(x.shape)
+            if float(b.abs().max()) == 0.0:
+                assert float(a.abs().max()) == 0.0, tag() + f" ({k})"
+                continue
+            l2, mr = rel_l2(a, b), max_rel(a, b)
+            assert l2 <= 2e-5 and mr <= 2e-3, (tag(), k, l2, mr)
+
+    def drop():
+        if live:
+            e = live.pop(rnd.randrange(len(live)))
+            trace.append(f"drop({'mask' if e['mask'] else 'rgb'} of v{e['v']})")
+            stats["drops"] += 1
+
+    def update():
+        ks = rnd.sample(LEAVES, rnd.randint(1, 3))
+        trace.append("update(" + ",".join(ks) + ")")
+        stats["updates"] += 1
+        with torch.no_grad():
+            for k in ks:
+                if k == "opacity":
+                    leaf[k].mul_(0.9 + 0.1 * rnd.random())
+                elif k == "rotation":
+                    leaf[k].add_(0.05 * torch.randn_like(leaf[k]))
+                elif k == "scaling":
+                    leaf[k].mul_(1.0 + 0.1 * (rnd.random() - 0.5))
+                else:
+                    leaf[k].add_((0.003 if k == "xyz" else 0.05) * torch.randn_like(leaf[k]))
+
+    def replace():
+        k = rnd.choice(LEAVES)
+        trace.append(f"replace({k})")
+        stats["replaced"] += 1
+        leaf[k] = leaf[k].detach().clone().requires_grad_(True)
+
+    def housekeeping():
+        what = rnd.choice(["check", "check_nb", "pool"])
+        trace.append(what)
+        if what == "check":
+            R.check_overflow()
+        elif what == "check_nb":
+            R.check_overflow(block=False)
+        else:
+            R.clear_workspace_pool()
+
+    actions = [render] * 5 + [backward] * 4 + [drop, update, update, replace, housekeeping]
+    for _ in range(rnd.randint(8, 20)):
+        rnd.choice(actions)()
+    while live:                                                 # whatever is still alive gets its backward at the end
+        backward()
+    R.check_overflow()
+
+
+t0 = time.time()
+for it in (only or range(n_iter)):
+    try:
+        one(it)
+    except AssertionError as e:
+        bad.append(str(e)[:700])
+        print("MISMATCH", bad[-1], flush=True)
+    except Exception as e:
+        bad.append(f"it {it}: {type(e).__name__}: {e}"[:700])
+        print("ERROR", bad[-1], flush=True)
+    if (it + 1) % 50 == 0:
+        print(f"{it + 1} iterations, {len(bad)} findings, {time.time() - t0:.0f} s", flush=True)
+torch.cuda.synchronize()
+print(f"drop-in sequence fuzz: {n_iter} iterations (seed {seed}): {stats}; {len(bad)} findings")
+for b in bad[:20]:
+    print("  ", b)
