@@ -405,16 +405,18 @@ class CapturedFitStep:
         return gc is not None and hasattr(gc, "ctx") and gc.ctx is not self._geom
 
     def replay(self) -> torch.Tensor:
-        if self._lr() != self.lr:
-            self._capture()
-        elif self._stale():
+        if self._stale():
             # the cache was cleared or rebuilt since the capture: the graph would render the OLD lists (kept alive above, so
             # not a fault — but not what the fit holds now). This step runs as a regular one (it rebuilds the lists), then capture again.
+            # (Checked BEFORE the learning rate: a capture over an empty cache records the BUILD — a full forward — and every replay
+            # of that graph would rebuild the lists instead of refreshing them; found by tools/fuzz_fit.py.)
             from . import rasterizer as R
-            loss = self.fit.step(*self.args, sync=True).detach().clone()   # THIS replay's step, run eagerly
+            loss = self.fit.step(*self.args, sync=True).detach().clone()   # THIS replay's step, run eagerly (at the current learning rate)
             R.check_overflow()
             self._capture()
             return loss
+        if self._lr() != self.lr:
+            self._capture()
         self.graph.replay()
         return self.loss
 

@@ -362,3 +362,41 @@ def test_captured_fit_step_replays_the_eager_fit(dev):
             assert torch.equal(x, y), k
         assert int(b.step_state[0]) == n_steps and int(b.step_state[1]) == 0
         assert int(a.step_state[0]) == n_steps
+
+
+def test_a_milestone_on_a_dropped_cache_recaptures_a_refresh_not_a_build(dev):
+    """Found by tools/fuzz_fit.py: when the static lists were dropped (GeometryCache.clear_all(): any overflow in the process does
+    that) AND the epoch count crossed a learning-rate milestone before the next replay, CapturedFitStep re-captured first — over
+    an empty cache, so the graph recorded the BUILD (a full forward) and every later replay rebuilt the lists instead of refreshing
+    them (slower, and the gradients of a build and of a refresh differ in the last bit). The stale check now comes first: that
+    replay runs eagerly (it rebuilds), then the refresh is captured — the replays are the eager fit's steps again, bit for bit."""
+    from guassianhand_amd import fit as F
+    from guassianhand_amd import rasterizer as R
+    pb = tiny_fit_problem(P=600, n_views=4, hw=(64, 80), device=dev)
+    mk = lambda: F.OneShotFit(pb["gs"], pb["uv"], map_hw=pb["map_hw"])
+    g = torch.Generator().manual_seed(9)
+    gt_rgb = torch.rand(4, 64, 80, 3, generator=g).to(dev)
+    gt_mask = (torch.rand(4, 64, 80, generator=g) > 0.5).float().to(dev)
+    args = (pb["w2c"], pb["K"], pb["H"], pb["W"], pb["bg"], gt_rgb, gt_mask)
+    eager, f = mk(), mk()
+    for i in range(2):
+        eager.step(*args, sync=(i == 0))
+    cap = f.captured(*args)
+    for _ in range(3):
+        eager.step(*args, sync=False)
+        cap.replay()
+    R.GeometryCache.clear_all()
+    for fit_ in (eager, f):
+        fit_.end_epoch()
+        fit_.end_epoch()                                                # epoch 2 is a milestone: the rate halves
+    losses_e, losses_c = [], []
+    for _ in range(5):
+        losses_e.append(float(eager.step(*args, sync=False)))
+        losses_c.append(float(cap.replay()))
+    cap.check()
+    R.check_overflow()
+    assert losses_c == losses_e
+    assert f._geom_cache.builds == eager._geom_cache.builds == 2
+    for k in eager._adam:
+        for name in ("param", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(getattr(eager._adam[k], name), getattr(f._adam[k], name)), (k, name)

@@ -43,3 +43,17 @@ def test_dropin_sequence_fuzz_fixed_seed():
     import ast
     st = ast.literal_eval(summary[0].split("): ", 1)[1].rsplit("; ", 1)[0])
     assert st["mask_passes"] > 50 and st["late_backwards"] > 50 and st.get("stale_backwards", 0) > 10, st
+
+
+@pytest.mark.timeout(600)
+def test_fit_sequence_fuzz_fixed_seed():
+    """tools/fuzz_fit.py: the one-shot fit in its three execution modes (static lists eager, static lists as replayed HIP graph, full
+    path) through random schedules of steps, learning-rate milestones, moved Gaussians, dropped caches, pool clears and unrelated
+    renders — eager and captured hold the same bits after every event, the full path agrees to float32 accumulation."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_fit.py"), "80", "6"], capture_output=True, text=True, timeout=550, cwd=ROOT)
+    tail = "\n".join(r.stdout.splitlines()[-12:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("fit sequence fuzz:")]
+    assert summary, tail
+    print(summary[0])
+    assert "; 0 findings" in summary[0], tail
