@@ -137,3 +137,27 @@ def limit_torch_threads_to_the_cpu_share():
         pass
     torch.set_num_threads(max(1, n))
     return n
+
+
+def float64_grads(cams_, xyz, opacity, scaling, rotation, shs, use_rgb, sh_degree, blend, dimg_, H, W):
+    """The same gradients from Oracle A (dense float64 autograd, oracle/oracle_torch.py): the referee between two float32 programs."""
+    from oracle import oracle_torch as OT
+    d = torch.float64
+    leaves = {n: x.to(d).clone().requires_grad_(True) for n, x in dict(xyz=xyz, opacity=opacity.reshape(-1, 1), scaling=scaling, rotation=rotation, shs=shs).items()}
+    bl = {k: v.to(d).clone().requires_grad_(True) for k, v in blend.items()}
+    cams_ = cams_.to(d)
+    tot = 0
+    for v in range(cams_.shape[0]):
+        c = cams_[v]
+        means, opac, cols, sh = OT.blend_attributes(leaves["xyz"], leaves["opacity"], leaves["shs"], use_rgb=use_rgb,
+                                                    **{k: (x.reshape(-1, 1) if k == "opacity_b" else x) for k, x in bl.items()})
+        kw = dict(colors_precomp=cols) if use_rgb else dict(shs=sh, sh_degree=sh_degree)
+        img, _ = OT.rasterize_dense(means, opac, leaves["scaling"], leaves["rotation"], viewmatrix=c[:16].reshape(4, 4),
+                                    projmatrix=c[16:32].reshape(4, 4), campos=c[32:35], tanfovx=float(c[35]), tanfovy=float(c[36]),
+                                    bg=c[37:40], H=H, W=W, **kw)
+        tot = tot + (img * dimg_[v].to(d)).sum()
+    tot.backward()
+    out = dict(means3D=leaves["xyz"].grad, opacities=leaves["opacity"].grad, scales=leaves["scaling"].grad, rotations=leaves["rotation"].grad)
+    out["colors_precomp" if use_rgb else "shs"] = leaves["shs"].grad
+    out.update({k: v.grad for k, v in bl.items()})
+    return {k: (torch.zeros_like(leaves["xyz"][:0]) if v is None else v) for k, v in out.items()}

@@ -57,3 +57,20 @@ def test_fit_sequence_fuzz_fixed_seed():
     assert summary, tail
     print(summary[0])
     assert "; 0 findings" in summary[0], tail
+
+
+@pytest.mark.timeout(600)
+def test_geometry_cache_sequence_fuzz_fixed_seed():
+    """tools/fuzz_cache.py: `rasterize_views` through one shared GeometryCache while everything around it changes (in-place updates of
+    what the static lists do and do not depend on, colour mode, SH degree, sizes, camera sets, blend terms, opacities lifted above
+    the lists' culling bound, cleared caches and pools): every render bit-equal to the oracle, hit or build."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cache.py"), "40", "5"], capture_output=True, text=True, timeout=550, cwd=ROOT)
+    tail = "\n".join(r.stdout.splitlines()[-12:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("geometry-cache sequence fuzz:")]
+    assert summary, tail
+    print(summary[0])
+    assert summary[0].endswith("; 0 findings"), tail
+    import ast
+    st = ast.literal_eval(summary[0].split("): ", 1)[1].rsplit("; ", 1)[0])
+    assert st["hits"] > 100 and st["builds"] > 50, st

@@ -1,0 +1,215 @@
+"""Sequence fuzz of `rasterize_views` through ONE shared `GeometryCache` (static tile lists, gh_forward_refresh).
+
+A cache hit must be indistinguishable from a full call. Per iteration a small scene in both colour modes, two camera sets, then 10-24
+random actions between renders: in-place updates of what the lists do NOT depend on (opacities, colours, blend biases: still a hit,
+and the image must follow), in-place updates / replacements of what they DO depend on (positions, scales, rotations, xyz_b, cameras:
+a miss), switches of the colour mode, SH degree, image size, camera set, blend terms coming and going and changing form
+((48,) <-> (P,48) weights), an opacity bias that lifts opacities above the lists' culling bound (the refresh poisons itself and the
+call is re-run as a build), cache.clear(), GeometryCache.clear_all(), pool clears. Every render: image (and fused alpha) bit-equal to
+the C oracle on the current values, gradients of all inputs within tolerance.   usage: fuzz_cache.py [n_iterations] [seed]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from guassianhand_amd import rasterizer as R
+from guassianhand_amd.scenes import make_scene, ring_cameras
+from guassianhand_amd.camera import pack_cameras_from_w2c
+from oracle.oracle_c import OracleRender
+from tests.helpers import float64_grads, rel_l2, max_rel
+
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
+rnd = random.Random(seed)
+dev = torch.device("cuda:0")
+stats = dict(renders=0, hits=0, builds=0, stale_rebuilds=0, backwards=0)
+bad = []
+
+
+def one(it):
+    rnd.seed(seed * 1000003 + it)
+    P = rnd.choice([60, 400, 1500])
+    g = torch.Generator().manual_seed(it)
+    sc_rgb = make_scene("random1k", n_views=3, P=P, use_rgb=True, blend=True, seed=rnd.randint(0, 10 ** 6))
+    sc_sh = make_scene("random1k", n_views=3, P=P, use_rgb=False, blend=True, seed=rnd.randint(0, 10 ** 6))
+    T = lambda x: x.to(dev).clone().requires_grad_(True)
+    st = dict(xyz=T(sc_rgb.xyz), opacity=T(sc_rgb.opacity * 0.8), scaling=T(sc_rgb.scaling), rotation=T(sc_rgb.rotation),
+              rgb=T(sc_rgb.shs), sh=T(sc_sh.shs),
+              xyz_b=T(0.003 * torch.randn(3, generator=g)), opacity_b=T(sc_rgb.opacity_b), color_w=T(sc_rgb.color_w),
+              color_wp=T(1 + 0.05 * torch.randn(P, 48, generator=g)), color_b=T(sc_rgb.color_b))
+    on = dict(xyz_b=rnd.random() < 0.6, opacity_b=rnd.random() < 0.6, color_w=rnd.random() < 0.6, color_b=rnd.random() < 0.6)
+    mode = dict(use_rgb=rnd.random() < 0.5, deg=3, wpg=False, alpha=rnd.random() < 0.5)
+    size = [rnd.randint(24, 110), rnd.randint(24, 110)]
+    camsets = []
+    for k in range(2):
+        nv = rnd.randint(1, 3)
+        w2c, K = ring_cameras(torch.zeros(3), nv, 128, 128, 325.0 * (1.0 + 0.2 * k))
+        camsets.append((w2c, K))
+    cam_i = [0]
+    cam_cache = {}
+    cache = R.GeometryCache()
+    trace = []
+    tag = lambda: f"it {it} P={P}: " + " > ".join(trace[-10:])
+    synced_shapes = set()
+
+    def cams_now():
+        key = (cam_i[0], size[0], size[1])
+        if key not in cam_cache:                                   # one tensor OBJECT per (camera set, size): the cache matches objects
+            w2c, K = camsets[cam_i[0]]
+            cam_cache[key] = pack_cameras_from_w2c(w2c, K, size[0], size[1], torch.tensor([0.1, 0.2, 0.3])).to(dev).contiguous()
+        return cam_cache[key]
+
+    def blend_now(cpu=False):
+        out = {}
+        f = (lambda x: x.detach().cpu()) if cpu else (lambda x: x)
+        if on["xyz_b"]: out["xyz_b"] = f(st["xyz_b"])
+        if on["opacity_b"]: out["opacity_b"] = f(st["opacity_b"])
+        if on["color_w"]: out["color_w"] = f(st["color_wp"] if mode["wpg"] else st["color_w"])
+        if on["color_b"] and (mode["use_rgb"] or on["color_w"]): out["color_b"] = f(st["color_b"])      # SH: b needs w (:334)
+        return out
+
+    def render():
+        cams = cams_now()
+        NV, (H, W) = cams.shape[0], size
+        shape_key = (NV, H, W, mode["use_rgb"])
+        sync = True if shape_key not in synced_shapes else rnd.random() < 0.6
+        synced_shapes.add(shape_key)
+        col = st["rgb"] if mode["use_rgb"] else st["sh"]
+        h0, b0 = cache.hits, cache.builds
+        trace.append(f"render({'rgb' if mode['use_rgb'] else 'sh%d' % mode['deg']},{NV}v,{H}x{W},blend={sorted(blend_now())},alpha={mode['alpha']},sync={sync})")
+        for x in st.values():
+            x.grad = None
+        out = R.rasterize_views(cams, st["xyz"], st["opacity"], st["scaling"], st["rotation"], col, H=H, W=W, use_rgb=mode["use_rgb"],
+                                sh_degree=mode["deg"], sync=sync, return_alpha=mode["alpha"], geometry_cache=cache, **blend_now())
+        img = out[0]
+        stats["renders"] += 1
+        stats["hits"] += cache.hits - h0
+        stats["builds"] += cache.builds - b0
+        if cache.hits - h0 and cache.builds - b0:
+            stats["stale_rebuilds"] += 1
+        trace[-1] += f"[{'hit' if cache.hits - h0 and not cache.builds - b0 else 'build'}]"
+        cpu = lambda x: x.detach().cpu()
+        kw = dict(colors_precomp=cpu(col).squeeze(1)) if mode["use_rgb"] else dict(shs=cpu(col), sh_degree=mode["deg"])
+        o = OracleRender(cpu(cams), cpu(st["xyz"]), cpu(st["opacity"]), cpu(st["scaling"]), cpu(st["rotation"]), H=H, W=W, **kw, **blend_now(cpu=True))
+        assert torch.equal(cpu(img), o.image), tag() + " (image)"
+        dimg = torch.randn(NV, 3, H, W, generator=torch.Generator().manual_seed(it * 977 + len(trace)))
+        loss = (img * dimg.to(dev)).sum()
+        if mode["alpha"]:
+            cm = cpu(cams).clone(); cm[:, 37:40] = 0
+            om = OracleRender(cm, cpu(st["xyz"]), cpu(st["opacity"]), cpu(st["scaling"]), cpu(st["rotation"]), H=H, W=W, colors_precomp=torch.ones(P, 3),
+                              **{k: v for k, v in blend_now(cpu=True).items() if k in ("xyz_b", "opacity_b")})
+            assert torch.equal(cpu(out[1]), om.image[:, 0]), tag() + " (alpha)"
+            om.close()
+        loss.backward()
+        stats["backwards"] += 1
+        og = o.backward(dimg)
+        o.close()
+        ref64 = [None]
+        pairs = dict(xyz="means3D", opacity="opacities", scaling="scales", rotation="rotations")
+        pairs["rgb" if mode["use_rgb"] else "sh"] = "colors_precomp" if mode["use_rgb"] else "shs"
+        for k in blend_now():
+            pairs[("color_wp" if mode["wpg"] else "color_w") if k == "color_w" else k] = k
+        for mine, theirs in pairs.items():
+            a, b = st[mine].grad, og[theirs]
+            assert a is not None, tag() + f" (no gradient for {mine})"
+            a = cpu(a).reshape(b.shape)
+            if float(b.abs().max()) == 0.0:
+                assert float(a.abs().max()) == 0.0, tag() + f" ({mine})"
+                continue
+            l2, mr = rel_l2(a, b), max_rel(a, b)
+            if not (l2 <= 2e-5 and mr <= 3e-3):
+                # two float32 programs disagree beyond the usual bar (tiny images, opacities lifted above 1, sums over all Gaussians):
+                # the float64 dense evaluation says which one is off
+                if ref64[0] is None:
+                    bl64 = blend_now(cpu=True)
+                    ref64[0] = float64_grads(cpu(cams), cpu(st["xyz"]), cpu(st["opacity"]), cpu(st["scaling"]), cpu(st["rotation"]), cpu(col),
+                                             mode["use_rgb"], mode["deg"], bl64, dimg, H, W)
+                r = ref64[0][theirs].reshape(b.shape).double()
+                e_hip, e_orc = rel_l2(a, r), rel_l2(b, r)
+                stats["refereed"] = stats.get("refereed", 0) + 1
+                print(f"referee {tag()[-160:]} {mine}: vs float32 oracle {l2:.2e} / {mr:.2e}; against float64: HIP {e_hip:.2e}, oracle {e_orc:.2e}", flush=True)
+                # float32 accumulation through deep stacks (P = 1,500 in 100 x 100 pixels, opacities lifted to the 0.99 clamp) leaves the
+                # HIP path 1e-5 from float64 where the oracle (double accumulators in its chain rule) is at 2e-6; the sums over ALL
+                # Gaussians (xyz_b, the (48,) weights) cancel and sit ten times higher for both
+                bar = 5e-4 if theirs in ("xyz_b", "color_w") and b.numel() <= 48 else 5e-5
+                assert e_hip <= bar or e_hip <= 5.0 * e_orc, (tag(), mine, l2, mr, e_hip, e_orc)
+
+    def act():
+        a = rnd.choice(["colour", "colour", "opacity", "bias", "geom", "geom_replace", "cams_inplace", "mode", "deg", "size", "camset", "blend", "wpg",
+                        "alpha", "lift", "clear", "clear_all", "pool"])
+        trace.append(a)
+        with torch.no_grad():
+            if a == "colour":
+                (st["rgb"] if mode["use_rgb"] else st["sh"]).add_(0.05 * torch.randn_like(st["rgb"] if mode["use_rgb"] else st["sh"]))
+            elif a == "opacity":
+                st["opacity"].mul_(0.85 + 0.15 * rnd.random())
+            elif a == "bias":
+                st["opacity_b"].add_(0.01 * torch.randn_like(st["opacity_b"])); st["color_b"].add_(0.01 * torch.randn_like(st["color_b"]))
+                st["color_w"].add_(0.01 * torch.randn_like(st["color_w"])); st["color_wp"].add_(0.01 * torch.randn_like(st["color_wp"]))
+            elif a == "geom":
+                k = rnd.choice(["xyz", "scaling", "rotation", "xyz_b"])
+                trace[-1] += f"({k})"
+                if k == "scaling": st[k].mul_(1.0 + 0.1 * (rnd.random() - 0.5))
+                else: st[k].add_((0.05 if k == "rotation" else 0.002) * torch.randn_like(st[k]))
+            elif a == "cams_inplace":
+                cams_now()[:, 37:40].add_(0.05)                       # the background colour lives in the camera record: version bump -> miss
+            elif a == "lift":
+                # an opacity bias that lifts some opacities above the culling bound of lists built earlier (max(2, 2 o)): the refresh
+                # poisons itself (GhCounters.overflow bit 1), the sync=True call re-runs as a build; the oracle clamps nothing either
+                on["opacity_b"] = True
+                idx = torch.randperm(P, generator=g)[: max(1, P // 50)].to(dev)
+                st["opacity_b"].view(-1)[idx] += 2.2
+                synced_shapes.clear()                                # (the next render of every shape is a sync=True one)
+        if a == "geom_replace":
+            k = rnd.choice(["xyz", "scaling", "rotation"])
+            trace[-1] += f"({k})"
+            st[k] = st[k].detach().clone().requires_grad_(True)
+        elif a == "mode":
+            mode["use_rgb"] = not mode["use_rgb"]
+        elif a == "deg":
+            mode["deg"] = rnd.randint(0, 3)
+        elif a == "size":
+            size[0], size[1] = rnd.randint(24, 110), rnd.randint(24, 110)
+        elif a == "camset":
+            cam_i[0] ^= 1
+        elif a == "blend":
+            k = rnd.choice(sorted(on))
+            on[k] = not on[k]
+            trace[-1] += f"({k}={on[k]})"
+        elif a == "wpg":
+            mode["wpg"] = not mode["wpg"]
+        elif a == "alpha":
+            mode["alpha"] = not mode["alpha"]
+        elif a == "clear":
+            cache.clear()
+        elif a == "clear_all":
+            R.GeometryCache.clear_all()
+        elif a == "pool":
+            R.clear_workspace_pool()
+
+    render()
+    for _ in range(rnd.randint(10, 24)):
+        if rnd.random() < 0.55:
+            render()
+        else:
+            act()
+    render()
+    R.check_overflow()
+
+
+t0 = time.time()
+for it in (only or range(n_iter)):
+    try:
+        one(it)
+    except AssertionError as e:
+        bad.append(str(e)[:900])
+        print("MISMATCH", bad[-1], flush=True)
+    except Exception as e:
+        bad.append(f"it {it}: {type(e).__name__}: {e}"[:900])
+        print("ERROR", bad[-1], flush=True)
+        R.GeometryCache.clear_all()
+    if (it + 1) % 50 == 0:
+        print(f"{it + 1} iterations, {len(bad)} findings, {time.time() - t0:.0f} s", flush=True)
+torch.cuda.synchronize()
+print(f"geometry-cache sequence fuzz: {n_iter} iterations (seed {seed}): {stats}; {len(bad)} findings")
+for b in bad[:20]:
+    print("  ", b)

@@ -13,7 +13,7 @@ import torch
 from guassianhand_amd import rasterizer as R
 from guassianhand_amd.scenes import make_scene
 from oracle.oracle_c import OracleRender
-from tests.helpers import rel_l2, max_rel
+from tests.helpers import float64_grads, rel_l2, max_rel
 
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -76,30 +76,6 @@ def blend_kw(sc, t=lambda x: x, b3=False):
     if b3 and "color_b" in out:
         out["color_b"] = out["color_b"][:, :3].contiguous()          # GH_FLAG_BLEND_COLOR_B_RGB: the three columns RGB mode reads
     return out
-
-
-def float64_grads(cams_, xyz, opacity, scaling, rotation, shs, use_rgb, sh_degree, blend, dimg_, H, W):
-    """The same gradients from Oracle A (dense float64 autograd, oracle/oracle_torch.py): the referee between two float32 programs."""
-    from oracle import oracle_torch as OT
-    d = torch.float64
-    leaves = {n: x.to(d).clone().requires_grad_(True) for n, x in dict(xyz=xyz, opacity=opacity.reshape(-1, 1), scaling=scaling, rotation=rotation, shs=shs).items()}
-    bl = {k: v.to(d).clone().requires_grad_(True) for k, v in blend.items()}
-    cams_ = cams_.to(d)
-    tot = 0
-    for v in range(cams_.shape[0]):
-        c = cams_[v]
-        means, opac, cols, sh = OT.blend_attributes(leaves["xyz"], leaves["opacity"], leaves["shs"], use_rgb=use_rgb,
-                                                    **{k: (x.reshape(-1, 1) if k == "opacity_b" else x) for k, x in bl.items()})
-        kw = dict(colors_precomp=cols) if use_rgb else dict(shs=sh, sh_degree=sh_degree)
-        img, _ = OT.rasterize_dense(means, opac, leaves["scaling"], leaves["rotation"], viewmatrix=c[:16].reshape(4, 4),
-                                    projmatrix=c[16:32].reshape(4, 4), campos=c[32:35], tanfovx=float(c[35]), tanfovy=float(c[36]),
-                                    bg=c[37:40], H=H, W=W, **kw)
-        tot = tot + (img * dimg_[v].to(d)).sum()
-    tot.backward()
-    out = dict(means3D=leaves["xyz"].grad, opacities=leaves["opacity"].grad, scales=leaves["scaling"].grad, rotations=leaves["rotation"].grad)
-    out["colors_precomp" if use_rgb else "shs"] = leaves["shs"].grad
-    out.update({k: v.grad for k, v in bl.items()})
-    return {k: (torch.zeros_like(leaves["xyz"][:0]) if v is None else v) for k, v in out.items()}
 
 
 refereed = [0, 0]          # [gradient tensors sent to the referee, of which the HIP path was the worse of the two float32 programs]
