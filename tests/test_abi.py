@@ -141,3 +141,40 @@ def test_python_mirror_follows_the_header_field_by_field():
     for name, val in flags.items():
         if name != "GH_FLAG_NONE":
             assert getattr(_abi, name) == int(val), name
+
+
+def test_workspace_layout_properties_over_random_dims(gh_lib_path):
+    """gh_workspace_layout over 2,000 random dimension sets (all flag combinations, degenerate sizes): accepted dims give a layout whose
+    offsets ascend in struct order in 256-byte steps and end inside total_bytes; the size grows with the instance capacity; rejected
+    dims give 0 bytes; nothing crashes (pure host arithmetic, no GPU)."""
+    import random
+    L = C.CDLL(gh_lib_path)
+    _abi.declare(L)
+    rnd = random.Random(7)
+    flag_bits = (_abi.GH_FLAG_BLEND_W_PER_GAUSSIAN, _abi.GH_FLAG_BLEND_COLOR_B_RGB, _abi.GH_FLAG_PER_VIEW_GAUSSIANS, _abi.GH_FLAG_SPLIT_STREAMS,
+                 _abi.GH_FLAG_STATIC_LISTS, _abi.GH_FLAG_DEPTH24)
+    ok = 0
+    for _ in range(2000):
+        P = rnd.choice([0, 1, 2, 255, 256, 257, 1000, 98562, rnd.randint(0, 300000)])
+        NV = rnd.choice([1, 2, 3, 8, 32, rnd.randint(1, 64)])
+        H, W = (rnd.choice([1, 15, 16, 17, 334, 512, 1024, rnd.randint(1, 4080)]) for _ in range(2))
+        M = rnd.choice([0, 0, 1, 4, 9, 16])
+        flags = 0
+        for b in flag_bits:
+            flags |= b if rnd.random() < 0.3 else 0
+        cap = rnd.choice([0, 1, 63, 64, 65, 2047, 2048, 2049, 10 ** 6, rnd.randint(0, 2 * 10 ** 7)])
+        d = _abi.GhDims(P, NV, H, W, rnd.randint(0, 3), M, 1.0, flags, cap)
+        lay = _abi.GhLayout()
+        rc = L.gh_workspace_layout(C.byref(d), C.byref(lay))
+        nbytes = L.gh_workspace_bytes(C.byref(d))
+        if rc != 0:
+            assert rc in (_abi.GH_ERR_INVALID_ARG, _abi.GH_ERR_UNSUPPORTED) and nbytes == 0
+            continue
+        ok += 1
+        offs = [getattr(lay, f) for f in _abi.LAYOUT_FIELDS[1:]]
+        assert offs == sorted(offs), (P, NV, H, W, M, flags, cap)
+        assert all(o % 256 == 0 for o in offs) and offs[-1] <= lay.total_bytes == nbytes
+        assert lay.keys_b - lay.keys_a >= 4 * cap and lay.vals_b - lay.vals_a >= 4 * cap
+        d2 = _abi.GhDims(P, NV, H, W, d.sh_degree, M, 1.0, flags, cap + 4096)
+        assert L.gh_workspace_bytes(C.byref(d2)) >= nbytes
+    assert ok > 1000
