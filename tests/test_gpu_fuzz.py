@@ -74,3 +74,17 @@ def test_geometry_cache_sequence_fuzz_fixed_seed():
     import ast
     st = ast.literal_eval(summary[0].split("): ", 1)[1].rsplit("; ", 1)[0])
     assert st["hits"] > 100 and st["builds"] > 50, st
+
+
+@pytest.mark.timeout(600)
+def test_depth_bound_cache_sequence_fuzz_fixed_seed():
+    """The same schedule through a DepthBoundCache on dense opaque scenes: whatever changed since the bound was reported (positions by
+    centimetres, cameras, sizes, colour mode), a bounded call is the unbounded call bit for bit or a verified miss that is re-run."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cache.py"), "30", "8", "--depth-bound"], capture_output=True, text=True,
+                       timeout=550, cwd=ROOT)
+    tail = "\n".join(r.stdout.splitlines()[-12:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("depth-bound-cache sequence fuzz:")]
+    assert summary, tail
+    print(summary[0])
+    assert summary[0].endswith("; 0 findings"), tail

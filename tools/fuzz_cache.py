@@ -5,7 +5,8 @@ random actions between renders: in-place updates of what the lists do NOT depend
 and the image must follow), in-place updates / replacements of what they DO depend on (positions, scales, rotations, xyz_b, cameras:
 a miss), switches of the colour mode, SH degree, image size, camera set, blend terms coming and going and changing form
 ((48,) <-> (P,48) weights), an opacity bias that lifts opacities above the lists' culling bound (the refresh poisons itself and the
-call is re-run as a build), cache.clear(), GeometryCache.clear_all(), pool clears. Every render: image (and fused alpha) bit-equal to
+call is re-run as a build), cache.clear(), GeometryCache.clear_all(), pool clears. With --depth-bound the same schedule runs through a
+DepthBoundCache instead (every change is legal there: the forward verifies the bound, a miss is re-run without it). Every render: image (and fused alpha) bit-equal to
 the C oracle on the current values, gradients of all inputs within tolerance.   usage: fuzz_cache.py [n_iterations] [seed]"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +20,7 @@ from tests.helpers import float64_grads, rel_l2, max_rel
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
+DEPTH_BOUND = "--depth-bound" in sys.argv      # the same schedule through a DepthBoundCache (speculative occlusion bound, verified by the forward)
 rnd = random.Random(seed)
 dev = torch.device("cuda:0")
 stats = dict(renders=0, hits=0, builds=0, stale_rebuilds=0, backwards=0)
@@ -36,6 +38,10 @@ def one(it):
               rgb=T(sc_rgb.shs), sh=T(sc_sh.shs),
               xyz_b=T(0.003 * torch.randn(3, generator=g)), opacity_b=T(sc_rgb.opacity_b), color_w=T(sc_rgb.color_w),
               color_wp=T(1 + 0.05 * torch.randn(P, 48, generator=g)), color_b=T(sc_rgb.color_b))
+    if DEPTH_BOUND:                                # dense opaque stacks: most tiles saturate, so there are bounds to apply — and to miss
+        with torch.no_grad():
+            st["scaling"].mul_(rnd.choice([2.0, 4.0]))
+            st["opacity"].copy_(0.6 + 0.39 * torch.rand(P, 1, generator=g).to(dev))
     on = dict(xyz_b=rnd.random() < 0.6, opacity_b=rnd.random() < 0.6, color_w=rnd.random() < 0.6, color_b=rnd.random() < 0.6)
     mode = dict(use_rgb=rnd.random() < 0.5, deg=3, wpg=False, alpha=rnd.random() < 0.5)
     size = [rnd.randint(24, 110), rnd.randint(24, 110)]
@@ -46,7 +52,9 @@ def one(it):
         camsets.append((w2c, K))
     cam_i = [0]
     cam_cache = {}
-    cache = R.GeometryCache()
+    cache = R.DepthBoundCache(min_pixels=0, refresh_every=rnd.choice([1, 2, 4]), margin=rnd.choice([2e-3, 2e-2])) if DEPTH_BOUND else R.GeometryCache()
+    if DEPTH_BOUND:
+        cache.hits = cache.builds = 0
     trace = []
     tag = lambda: f"it {it} P={P}: " + " > ".join(trace[-10:])
     synced_shapes = set()
@@ -78,8 +86,23 @@ def one(it):
         trace.append(f"render({'rgb' if mode['use_rgb'] else 'sh%d' % mode['deg']},{NV}v,{H}x{W},blend={sorted(blend_now())},alpha={mode['alpha']},sync={sync})")
         for x in st.values():
             x.grad = None
-        out = R.rasterize_views(cams, st["xyz"], st["opacity"], st["scaling"], st["rotation"], col, H=H, W=W, use_rgb=mode["use_rgb"],
-                                sh_degree=mode["deg"], sync=sync, return_alpha=mode["alpha"], geometry_cache=cache, **blend_now())
+        call = lambda sync_: R.rasterize_views(cams, st["xyz"], st["opacity"], st["scaling"], st["rotation"], col, H=H, W=W, use_rgb=mode["use_rgb"],
+                                               sh_degree=mode["deg"], sync=sync_, return_alpha=mode["alpha"],
+                                               **({"depth_bound": cache} if DEPTH_BOUND else {"geometry_cache": cache}), **blend_now())
+        if DEPTH_BOUND:
+            m0, bc0 = cache.misses, cache.bounded_calls
+            try:
+                out = call(sync)
+                if not sync:
+                    R.check_overflow()                              # a sync-free call whose bound missed says so here (NaN pixels until then)
+            except R.GhOverflowError:
+                stats["sync_free_misses"] = stats.get("sync_free_misses", 0) + 1
+                out = call(True)
+            stats["bound_misses"] = stats.get("bound_misses", 0) + cache.misses - m0
+            cache.hits += 1 if cache.bounded_calls > bc0 else 0     # "hit" = a call that applied a bound
+            cache.builds += 0 if cache.bounded_calls > bc0 else 1
+        else:
+            out = call(sync)
         img = out[0]
         stats["renders"] += 1
         stats["hits"] += cache.hits - h0
@@ -149,7 +172,7 @@ def one(it):
                 k = rnd.choice(["xyz", "scaling", "rotation", "xyz_b"])
                 trace[-1] += f"({k})"
                 if k == "scaling": st[k].mul_(1.0 + 0.1 * (rnd.random() - 0.5))
-                else: st[k].add_((0.05 if k == "rotation" else 0.002) * torch.randn_like(st[k]))
+                else: st[k].add_((0.05 if k == "rotation" else rnd.choice([0.002, 0.002, 0.03] if DEPTH_BOUND else [0.002])) * torch.randn_like(st[k]))
             elif a == "cams_inplace":
                 cams_now()[:, 37:40].add_(0.05)                       # the background colour lives in the camera record: version bump -> miss
             elif a == "lift":
@@ -210,6 +233,6 @@ for it in (only or range(n_iter)):
     if (it + 1) % 50 == 0:
         print(f"{it + 1} iterations, {len(bad)} findings, {time.time() - t0:.0f} s", flush=True)
 torch.cuda.synchronize()
-print(f"geometry-cache sequence fuzz: {n_iter} iterations (seed {seed}): {stats}; {len(bad)} findings")
+print(f"{'depth-bound' if DEPTH_BOUND else 'geometry'}-cache sequence fuzz: {n_iter} iterations (seed {seed}): {stats}; {len(bad)} findings")
 for b in bad[:20]:
     print("  ", b)
