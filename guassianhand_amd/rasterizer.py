@@ -156,11 +156,12 @@ _PENDING_MAX = 64
 class _Pending:
     """The asynchronous counter read-back of one sync-free forward. `resolve()` waits for it (normally long done), recycles
     the pinned buffer and remembers the verdict, so that both check_overflow() and the call's own backward can ask."""
-    __slots__ = ("ev", "host", "cap", "key", "done", "d", "over", "stale", "miss", "dbound")
+    __slots__ = ("ev", "host", "cap", "key", "done", "d", "over", "stale", "miss", "dbound", "told")
 
     def __init__(self, ev, host, cap, key, dbound=None):
         self.ev, self.host, self.cap, self.key, self.done, self.d, self.over, self.stale = ev, host, cap, key, False, 0, False, False
         self.miss, self.dbound = False, dbound
+        self.told = False          # the caller has been given this record's error (a look at the counters by the geometry-reuse check is not that)
 
     def resolve(self) -> bool:
         """True when the call overflowed its capacity (the learned capacity of its shape is raised then)."""
@@ -202,6 +203,7 @@ class _Pending:
                 "capacity raised, re-run the step")
 
     def error(self) -> GhOverflowError:
+        self.told = True
         if self.stale:
             return GhStaleGeometryError(self.message())
         if self.miss and not self.d > self.cap:
@@ -327,6 +329,8 @@ def check_overflow(block: bool = True, keep_recent: int = 0) -> None:
     n_old = len(_pending) - keep_recent if keep_recent > 0 else 0
     for i, pc in enumerate(_pending):
         if pc.done:
+            if pc.over and not pc.told:                    # resolved by somebody who did not report it (the geometry-reuse check)
+                bad = pc
             continue
         if not block and i >= n_old and not pc.ev.query():
             keep.append(pc)
@@ -403,7 +407,7 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 class _Ctx:
     __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "rows", "stream", "alpha",
-                 "parent", "radii", "pending", "refresh", "__weakref__")
+                 "parent", "radii", "pending", "verdict", "refresh", "__weakref__")
 
     def __del__(self):
         try:
@@ -510,6 +514,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
         ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
         ctx.pending = g0.pending                 # the overflow flag is the geometry owner's
+        ctx.verdict = g0.verdict
         ctx.refresh = False
         return image, g0.radii, ctx           # same geometry, same radii; an overflow is the first call's (NaN image here too)
     if refresh_of is not None:
@@ -572,7 +577,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         ctx = _Ctx()
         ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
         ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
-        ctx.pending, ctx.refresh = pending, True
+        ctx.pending, ctx.refresh, ctx.verdict = pending, True, None
         return image, g0.radii, ctx
     if depth_bound is not None and (static_lists or _graph_mode or P == 0 or NV * H * W < depth_bound.min_pixels):
         depth_bound = None                       # lists that outlive the call / a captured call / a small call: no per-call speculation
@@ -608,7 +613,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             raise RuntimeError(f"gh_forward failed: {_abi.status_name(rc)}")
         counters = ws[:16].view(torch.int32)
         _last_ws = ws
-        pending, auto = None, sync is None
+        pending, auto, verdict = None, sync is None, None
         if sync is None:
             # auto: read D back once per shape to size the capacity, then sync-free — but only for calls whose backward will
             # come (it checks this call's counters before it produces a gradient, see raster_backward). A call outside
@@ -654,6 +659,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             ev.record()
             pc = _Pending(ev, host, cap, key, depth_bound)
             _pending.append(pc)
+            verdict = pc
             if auto:                                       # an explicit sync=False never blocks: check_overflow() is the caller's job
                 pending = pc
         break
@@ -661,6 +667,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
     ctx.b_rgb, ctx.rows = b_rgb, rows
     ctx.alpha, ctx.parent, ctx.radii, ctx.stream, ctx.pending, ctx.refresh = alpha, None, radii, stream, pending, False
+    ctx.verdict = verdict                                  # the counter read-back of a sync-free call, whoever is to ask for it
     return image, radii, ctx
 
 
@@ -861,6 +868,12 @@ class _RasterizeGaussians(torch.autograd.Function):
             g, _geom_last = _geom_last, None
             if g is not None and sh is None and g[1] == vals and all(a() is b for a, b in zip(g[0], objs)):
                 parent = g[2]()                    # alive until its backward has run
+                # never the lists of a call that overflowed: its verdict is known when its counters were read already (the caller
+                # has been told, and this IS the re-run the message asks for — found by tools/fuzz_dropin.py --shrink), and a call
+                # that reads D back itself (sync=True, or an inference call) asks now
+                p = None if parent is None else parent.verdict
+                if p is not None and (p.done or sync is True or (sync is None and not expect_backward)) and p.resolve():
+                    parent = None
         image, radii, rctx = raster_forward(
             cams, means3D, opacities, scales, rotations, H=int(rs.image_height), W=int(rs.image_width),
             shs=sh, colors_precomp=colors_precomp, sh_degree=int(rs.sh_degree),

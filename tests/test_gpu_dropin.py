@@ -443,3 +443,55 @@ def test_backward_after_an_inplace_update_of_an_input_raises_like_the_reference(
         with pytest.raises(RuntimeError, match="modified by an inplace operation"):
             out.backward()
     R.check_overflow()
+
+
+def test_the_rerun_after_an_overflow_does_not_walk_the_overflowed_lists(dev):
+    """Found by tools/fuzz_dropin.py --shrink: a sync-free call overflows its instance capacity (NaN image), check_overflow() says so
+    and raises the capacity — and the re-run the message asks for, made with the same tensor objects and precomputed colours while the
+    failed output is still alive, was taken for the MASK pass of the failed call (same objects, same camera, directly after a full
+    call) and re-walked its truncated lists: NaN again, even with sync=True. A call whose counters are known to have overflowed (or
+    are read now, by a call that reads D back anyway) is never a geometry parent."""
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=1, P=1200, use_rgb=True, blend=False)
+
+    def render(sync):
+        from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+        rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg,
+                                           scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform.float(),
+                                           sh_degree=0, campos=cam.camera_center, prefiltered=False, debug=False)
+        return GaussianRasterizer(rs, sync=sync)(means3D=t["xyz"], means2D=torch.zeros_like(t["xyz"], requires_grad=True), opacities=t["opacity"],
+                                                 scales=t["scaling"], rotations=t["rotation"], colors_precomp=t["colour"], cov3D_precomp=None)[0]
+
+    from guassianhand_amd.camera import Camera
+    H, W = 110, 66
+    cam = Camera.from_w2c(sc.w2c[0].to(dev), sc.K[0].to(dev), H, W)
+    bg = torch.zeros(3, device=dev)
+    t = {k: v.to(dev).clone().requires_grad_(True) for k, v in dict(xyz=sc.xyz, opacity=sc.opacity, scaling=sc.scaling, rotation=sc.rotation,
+                                                                   colour=sc.shs.squeeze(1)).items()}
+    ref = render(True).detach().clone()
+    key = R.capacity_key(sc.P, 1, H, W)
+    saved = R._capacity[key]
+    try:
+        R._capacity[key] = max(64, R.last_num_rendered() // 3)
+        failed = render(False)                                   # sync-free: overflows, NaN image, nobody has looked yet
+        assert bool(torch.isnan(failed).any())
+        with pytest.raises(R.GhOverflowError):
+            R.check_overflow()
+        assert R._capacity[key] > R.last_num_rendered()
+        again = render(True)                                     # `failed` is still alive: its lists must not be walked again
+        assert torch.equal(again.detach(), ref)
+        # the verdict not yet read: a call that reads D back itself asks before it shares
+        R._capacity[key] = max(64, R.last_num_rendered() // 3)
+        R.set_geometry_reuse(True)                               # (forget `again`: the next call is a full one, not its mask pass)
+        failed2 = render(False)
+        again2 = render(True)
+        assert torch.equal(again2.detach(), ref) and bool(torch.isnan(failed2).any())
+        with pytest.raises(R.GhOverflowError):
+            R.check_overflow()
+    finally:
+        R._capacity[key] = max(saved, R._capacity.get(key, 0))
+        try:
+            R.check_overflow()
+        except R.GhOverflowError:
+            pass

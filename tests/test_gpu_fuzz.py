@@ -31,9 +31,9 @@ def test_feature_matrix_fuzz_fixed_seed():
 @pytest.mark.timeout(600)
 def test_dropin_sequence_fuzz_fixed_seed():
     """tools/fuzz_dropin.py: random sequences of drop-in calls (RGB + mask pass reuse, backwards in any order and long after later
-    renders, in-place updates, replaced leaves, pool clears, all sync modes) — every image bit-equal to the oracle on the values the
+    renders, in-place updates, replaced leaves, pool clears, all sync modes, learned instance capacities cut at random: overflow + recovery) — every image bit-equal to the oracle on the values the
     call saw, every gradient within tolerance, and a backward over inputs written in place since its forward raises autograd's error."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_dropin.py"), "60", "5"], capture_output=True, text=True, timeout=550, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_dropin.py"), "60", "5", "--shrink"], capture_output=True, text=True, timeout=550, cwd=ROOT)
     tail = "\n".join(r.stdout.splitlines()[-12:])
     assert r.returncode == 0, tail + r.stderr[-2000:]
     summary = [l for l in r.stdout.splitlines() if l.startswith("drop-in sequence fuzz:")]
