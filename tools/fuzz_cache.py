@@ -20,6 +20,7 @@ from tests.helpers import float64_grads, rel_l2, max_rel
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
+SHRINK = "--shrink" in sys.argv               # also cut the learned instance capacities at random (overflow + recovery through the caches)
 DEPTH_BOUND = "--depth-bound" in sys.argv      # the same schedule through a DepthBoundCache (speculative occlusion bound, verified by the forward)
 rnd = random.Random(seed)
 dev = torch.device("cuda:0")
@@ -29,6 +30,12 @@ bad = []
 
 def one(it):
     rnd.seed(seed * 1000003 + it)
+    if SHRINK:
+        try:
+            R.check_overflow()
+        except R.GhOverflowError:
+            pass
+        R._capacity.clear()
     P = rnd.choice([60, 400, 1500])
     g = torch.Generator().manual_seed(it)
     sc_rgb = make_scene("random1k", n_views=3, P=P, use_rgb=True, blend=True, seed=rnd.randint(0, 10 ** 6))
@@ -101,6 +108,13 @@ def one(it):
             stats["bound_misses"] = stats.get("bound_misses", 0) + cache.misses - m0
             cache.hits += 1 if cache.bounded_calls > bc0 else 0     # "hit" = a call that applied a bound
             cache.builds += 0 if cache.bounded_calls > bc0 else 1
+        elif SHRINK and not sync:
+            try:
+                out = call(False)
+                R.check_overflow()                                  # an overflowed sync-free call (NaN image) says so here
+            except R.GhOverflowError:
+                stats["overflows_recovered"] = stats.get("overflows_recovered", 0) + 1
+                out = call(True)
         else:
             out = call(sync)
         img = out[0]
@@ -158,7 +172,7 @@ def one(it):
 
     def act():
         a = rnd.choice(["colour", "colour", "opacity", "bias", "geom", "geom_replace", "cams_inplace", "mode", "deg", "size", "camset", "blend", "wpg",
-                        "alpha", "lift", "clear", "clear_all", "pool"])
+                        "alpha", "lift", "clear", "clear_all", "pool"] + (["shrink", "shrink"] if SHRINK else []))
         trace.append(a)
         with torch.no_grad():
             if a == "colour":
@@ -202,6 +216,12 @@ def one(it):
             mode["wpg"] = not mode["wpg"]
         elif a == "alpha":
             mode["alpha"] = not mode["alpha"]
+        elif a == "shrink":
+            k = rnd.choice([2, 5, 50])
+            trace[-1] += f"(/{k})"
+            stats["shrinks"] = stats.get("shrinks", 0) + 1
+            for key in list(R._capacity):
+                R._capacity[key] = max(64, R._capacity[key] // k)
         elif a == "clear":
             cache.clear()
         elif a == "clear_all":
