@@ -46,12 +46,20 @@ def one(it):
     cams = [Camera.from_w2c(sc.w2c[v].to(dev), sc.K[v].to(dev), sizes[v][0], sizes[v][1]) for v in range(3)]
     bg = torch.rand(3, generator=torch.Generator().manual_seed(it)).to(dev)
     leaf = dict(xyz=sc.xyz, opacity=sc.opacity, scaling=sc.scaling, rotation=sc.rotation, colour=sc.shs.squeeze(1) if rgb else sc.shs)
+    # sometimes the positions and opacities reach the rasteriser as NON-CONTIGUOUS views of wider leaves (columns 1:4 of a (P,5) tensor,
+    # column 1:2 of a (P,3) one): the wrapper makes its contiguous copy, the gradient must come back through the view
+    strided = rnd.random() < 0.3
+    if strided:
+        leaf["xyz"] = torch.cat([torch.zeros(P, 1), leaf["xyz"], torch.ones(P, 1)], 1)
+        leaf["opacity"] = torch.cat([torch.zeros(P, 1), leaf["opacity"], torch.ones(P, 1)], 1)
     leaf = {k: v.to(dev).clone().requires_grad_(True) for k, v in leaf.items()}
+    cols = dict(xyz=slice(1, 4), opacity=slice(1, 2)) if strided else {}
+    arg = lambda k, src=None: (src or leaf)[k][:, cols[k]] if k in cols else (src or leaf)[k]
     deg = 0 if rgb else rnd.randint(0, 3)
     live = []
     trace = []
     shrunk = [False]
-    tag = lambda: f"it {it} P={P} {'rgb' if rgb else 'sh%d' % deg} sizes={sizes}: " + " > ".join(trace[-8:])
+    tag = lambda: f"it {it} P={P} {'rgb' if rgb else 'sh%d' % deg}{' strided' if strided else ''} sizes={sizes}: " + " > ".join(trace[-8:])
 
     def settings(v, bg_, deg_):
         c = cams[v]
@@ -68,20 +76,21 @@ def one(it):
 
     def render(force=None):
         v, sync, grad, with_mask = force or (rnd.randrange(3), rnd.choice([None, None, True, False]), rnd.random() < 0.8, rnd.random() < 0.7)
-        snap = {k: x.detach().cpu().clone() for k, x in leaf.items()}
+        snap = {k: arg(k).detach().cpu().clone() for k in leaf}
         trace.append(f"render(v{v},sync={sync},{'grad' if grad else 'no_grad'}{',+mask' if with_mask else ''})")
-        means2D = torch.zeros_like(leaf["xyz"], requires_grad=True)
         with torch.enable_grad() if grad else torch.no_grad():
+            a_xyz, a_op = arg("xyz"), arg("opacity")                 # (the same view objects for the RGB pass and the mask pass)
+            means2D = torch.zeros_like(a_xyz, requires_grad=True)
             kw = dict(colors_precomp=leaf["colour"]) if rgb else dict(shs=leaf["colour"])
-            img, radii = GaussianRasterizer(settings(v, bg, deg), sync=sync)(means3D=leaf["xyz"], means2D=means2D, opacities=leaf["opacity"],
+            img, radii = GaussianRasterizer(settings(v, bg, deg), sync=sync)(means3D=a_xyz, means2D=means2D, opacities=a_op,
                                                                          scales=leaf["scaling"], rotations=leaf["rotation"], cov3D_precomp=None, **kw)
             stats["renders"] += 1
             stats["no_grad_renders"] += 0 if grad else 1
             outs = [(img, False)]
             if with_mask:
-                ones = torch.ones_like(leaf["xyz"])
+                ones = torch.ones_like(a_xyz)
                 m, _ = GaussianRasterizer(settings(v, torch.zeros(3, device=dev), 0), sync=sync)(
-                    means3D=leaf["xyz"], means2D=means2D, colors_precomp=ones, opacities=leaf["opacity"], scales=leaf["scaling"],
+                    means3D=a_xyz, means2D=means2D, colors_precomp=ones, opacities=a_op, scales=leaf["scaling"],
                     rotations=leaf["rotation"], cov3D_precomp=None)
                 stats["mask_passes"] += 1
                 outs.append((m, True))
@@ -151,7 +160,12 @@ def one(it):
                 continue
             if x.grad is None:                                # the leaf object was replaced after this call: its gradient went to the old object
                 continue
-            a, b = x.grad.detach().cpu(), og[names[k]].reshape(x.shape)
+            gx = x.grad.detach().cpu()
+            if k in cols:
+                rest = torch.cat([gx[:, :cols[k].start], gx[:, cols[k].stop:]], 1)
+                assert float(rest.abs().max()) == 0.0, tag() + f" (gradient in the columns of {k} the rasteriser never saw)"
+                gx = gx[:, cols[k]]
+            a, b = gx, og[names[k]].reshape(gx.shape)
             if float(b.abs().max()) == 0.0:
                 assert float(a.abs().max()) == 0.0, tag() + f" ({k})"
                 continue
