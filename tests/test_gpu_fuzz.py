@@ -88,3 +88,19 @@ def test_depth_bound_cache_sequence_fuzz_fixed_seed():
     assert summary, tail
     print(summary[0])
     assert summary[0].endswith("; 0 findings"), tail
+
+
+@pytest.mark.timeout(600)
+def test_size_class_fuzz_fixed_seed():
+    """tools/fuzz_sizes.py: scenes drawn to select the code paths the launch logic picks BY SIZE (4 / 8 / 16 keys per thread in either
+    sort, scan-free or row-scan histograms, three or four depth passes, 2 ... 17 tile bits, images up to 255 tiles wide, up to 5e7
+    instances): image and radii bit-equal to the oracle's in every draw."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sizes.py"), "45", "2"], capture_output=True, text=True, timeout=550, cwd=ROOT)
+    tail = "\n".join(r.stdout.splitlines()[-8:])
+    assert r.returncode == 0, tail + r.stderr[-2000:]
+    summary = [l for l in r.stdout.splitlines() if l.startswith("size-class fuzz:")]
+    assert summary, tail
+    print(summary[0])
+    assert summary[0].endswith("; 0 findings"), tail
+    assert "tile-partition keys/thread [4, 8, 16]" in summary[0] and "depth-sort keys/thread [4, 8]" in summary[0], summary[0]
+    assert "scan-free histogram [False, True]" in summary[0] and "depth24 [False, True]" in summary[0], summary[0]

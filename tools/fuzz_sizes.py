@@ -1,0 +1,131 @@
+"""Size-class fuzz: the HIP path against the C oracle on scenes that select the DIFFERENT code paths the launch logic picks by size.
+
+tools/fuzz_features.py covers the feature matrix at P <= 2,500, where every radix pass runs with 4 keys per thread, every segment
+fits the scan-free histogram form and the tile ids fit one or two narrow passes. What is chosen by size (gh_binning.hip, gh_api.hip):
+    depth sort     4 / 8 keys per thread (total keys >= 2^19), blocks per view <= 128 (every block sums the histogram rows itself)
+                   or more (row-scan kernel), three passes (GH_FLAG_DEPTH24 holds) or four (visible depths straddle a factor-4 boundary)
+    tile partition 4 / 8 / 16 keys per thread (capacity 2^21, 2^25), one 1024-digit pass (9-10 tile bits of ONE view), two or three
+                   8-bit passes (up to 17 tile bits: 32 views of 1024^2), row scans of more than 1024 blocks (two sweeps)
+    render         lists of a few entries ... tens of thousands per tile, images up to 255 tiles wide
+Each iteration draws P in 1 ... 400,000, 1-32 views, images from 16^2 to 4080 pixels wide, a camera distance that keeps or breaks the
+24-bit depth assumption, and a scale distribution that sets the instances per Gaussian (D up to ~2e7); image and radii must be
+bit-equal to the oracle's (run in its OpenMP mode, which is bit-identical to the checker mode: tests/test_oracle_cross.py), gradients
+within 3e-4 rel-L2 when D <= 4e6 (a path check, not an accuracy bar: fuzz_features.py has those).   usage: fuzz_sizes.py [n_iterations] [seed]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from guassianhand_amd import rasterizer as R
+from guassianhand_amd.camera import pack_cameras_from_w2c
+from guassianhand_amd.scenes import ring_cameras
+from oracle import oracle_c
+from oracle.oracle_c import OracleRender
+from tests.helpers import rel_l2, limit_torch_threads_to_the_cpu_share
+
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
+rnd = random.Random(seed)
+dev = torch.device("cuda:0")
+limit_torch_threads_to_the_cpu_share()
+oracle_c.set_parallel(True)
+oracle_c.set_num_threads(torch.get_num_threads())
+bad = []
+seen = dict(items_depth=set(), self_hist=set(), depth24=set(), tile_bits=set(), items_tile=set(), max_D=0)
+
+
+def one(it):
+    rnd.seed(seed * 1000003 + it)
+    g = torch.Generator().manual_seed(it)
+    cls = rnd.choice(["tiny", "small", "mid", "mid", "large", "wide", "many_views", "dense"] * 3 + ["huge"])
+    if cls == "tiny":
+        P, NV, H, W = rnd.choice([1, 2, 63, 64, 65, 255, 257]), rnd.randint(1, 3), rnd.randint(16, 64), rnd.randint(16, 64)
+    elif cls == "small":
+        P, NV, H, W = rnd.randint(1000, 20000), rnd.randint(1, 4), rnd.randint(64, 400), rnd.randint(64, 400)
+    elif cls == "mid":
+        P, NV, H, W = rnd.randint(50000, 140000), rnd.randint(1, 8), rnd.choice([334, 512, 640]), rnd.choice([334, 512, 640])
+    elif cls == "large":
+        P, NV, H, W = rnd.randint(150000, 400000), rnd.randint(1, 3), rnd.choice([512, 1024]), rnd.choice([512, 1024])
+    elif cls == "wide":
+        P, NV, H, W = rnd.randint(2000, 30000), 1, rnd.choice([16, 64, 200]), rnd.choice([2048, 4080])
+        if rnd.random() < 0.5:
+            H, W = W, H
+    elif cls == "many_views":
+        P, NV, H, W = rnd.randint(2000, 20000), rnd.choice([9, 16, 32]), rnd.choice([256, 512, 1024]), rnd.choice([256, 512, 1024])
+    elif cls == "huge":                                       # > 2^25 instances: the tile partition runs with 16 keys per thread
+        P, NV, H, W = rnd.randint(100000, 200000), rnd.randint(4, 8), 512, rnd.choice([334, 512])
+    else:                                                     # dense: many instances per Gaussian
+        P, NV, H, W = rnd.randint(20000, 80000), rnd.randint(1, 4), rnd.choice([334, 512]), rnd.choice([334, 512])
+    radius = rnd.choice([0.6, 1.0, 1.0, 1.7, 2.2, 6.0])       # [0.5, 2) is one 24-bit depth range: 1.7 / 2.2 with extent 0.5 straddle 2.0
+    ext = rnd.choice([0.2, 0.5]) * min(1.0, radius)
+    f = 0.9 * max(H, W) * radius / ext * rnd.choice([0.5, 1.0])
+    xyz = (torch.rand(P, 3, generator=g) - 0.5) * ext
+    base = ext / max(1.0, P ** (1 / 3)) * (4.0 if cls in ("dense", "huge") else rnd.choice([0.3, 1.0, 2.0]))
+    # keep the expected instance count under ~1.5e7 (the oracle walks every one of them on the host's cores); "huge": ~4.5e7
+    limit = 4.5e7 if cls == "huge" else 1.5e7
+    sigma_px = base * f / radius
+    est = P * NV * min((6.0 * sigma_px / 16.0 + 1.0) ** 2, ((W + 15) // 16) * ((H + 15) // 16))
+    base *= max(0.02, (limit / est) ** 0.5) if (est > limit or cls == "huge") else 1.0
+    scaling = base * torch.exp(0.5 * torch.randn(P, 3, generator=g))
+    rot = torch.randn(P, 4, generator=g); rot = rot / rot.norm(dim=1, keepdim=True)
+    opacity = torch.sigmoid(1.5 * torch.randn(P, 1, generator=g)) * rnd.choice([0.3, 1.0])
+    use_rgb = rnd.random() < 0.7
+    col = torch.rand(P, 3, generator=g) if use_rgb else torch.cat([0.5 + 0.3 * torch.randn(P, 1, 3, generator=g), 0.2 * torch.randn(P, 15, 3, generator=g)], 1)
+    w2c, K = ring_cameras(torch.zeros(3), NV, H, W, f, radius=radius)
+    cams = pack_cameras_from_w2c(w2c, K, H, W, torch.tensor([0.05, 0.1, 0.15]))
+    tag = f"it {it} {cls} P={P} NV={NV} {H}x{W} radius={radius} ext={ext:.2f} f={f:.0f} scale={base:.2e} {'rgb' if use_rgb else 'sh3'}"
+    kw = dict(colors_precomp=col) if use_rgb else dict(shs=col, sh_degree=3)
+    t0 = time.time()
+    o = OracleRender(cams, xyz, opacity, scaling, rot, H=H, W=W, **kw)
+    t_or = time.time() - t0
+    kwg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    img, radii, ctx = R.raster_forward(cams.to(dev), xyz.to(dev), opacity.to(dev), scaling.to(dev), rot.to(dev), H=H, W=W, sync=True, **kwg)
+    D = R.last_num_rendered()
+    key = (P, NV, H, W, False)
+    d24 = R._depth24.get(key, True)
+    tiles = NV * ((W + 15) // 16) * ((H + 15) // 16)
+    tb = max(1, (tiles - 1).bit_length())
+    cap = int(ctx.dims.max_instances)
+    seen["items_depth"].add(8 if P * NV >= (1 << 19) else 4)
+    seen["self_hist"].add((P + 256 * (8 if P * NV >= (1 << 19) else 4) - 1) // (256 * (8 if P * NV >= (1 << 19) else 4)) <= 128)
+    seen["depth24"].add(bool(d24)); seen["tile_bits"].add(tb)
+    seen["items_tile"].add(4 if cap <= (1 << 21) else (8 if cap <= (1 << 25) else 16))
+    seen["max_D"] = max(seen["max_D"], D)
+    print(f"{tag}: D={D} cap={cap} tile bits {tb} depth24={d24} oracle {t_or:.1f} s", flush=True)
+    assert torch.equal(radii.cpu(), o.radii), tag + " (radii)"
+    same = torch.equal(img.cpu(), o.image)
+    if not same:
+        d = (img.cpu() - o.image)
+        raise AssertionError(tag + f" (image: {int((d != 0).sum())} values differ, {int(torch.isnan(d).sum())} NaN, max {float(d[~torch.isnan(d)].abs().max()):.3g})")
+    if D <= 4_000_000:
+        dimg = torch.randn(NV, 3, H, W, generator=g)
+        og = o.backward(dimg)
+        gr = R.raster_backward(ctx, dimg.to(dev), want_means2D=False)
+        for k, b in og.items():
+            if k == "means2D":
+                continue
+            a = gr[k].cpu().reshape(b.shape)
+            assert bool(torch.isfinite(a).all()), tag + f" ({k} not finite)"
+            if float(b.abs().max()) > 0:
+                l2 = rel_l2(a, b)
+                assert l2 <= 3e-4, (tag, k, l2)
+    o.close()
+    del img, radii, ctx
+    R.clear_workspace_pool()
+    torch.cuda.empty_cache()
+
+
+t0 = time.time()
+for it in (only or range(n_iter)):
+    try:
+        one(it)
+    except AssertionError as e:
+        bad.append(str(e)[:600]); print("MISMATCH", bad[-1], flush=True)
+    except Exception as e:
+        bad.append(f"it {it}: {type(e).__name__}: {e}"[:600]); print("ERROR", bad[-1], flush=True)
+        R.clear_workspace_pool(); torch.cuda.empty_cache()
+R.check_overflow()
+print(f"size-class fuzz: {n_iter} iterations (seed {seed}) in {time.time() - t0:.0f} s; paths seen: depth-sort keys/thread {sorted(seen['items_depth'])}, "
+      f"scan-free histogram {sorted(seen['self_hist'])}, depth24 {sorted(seen['depth24'])}, tile bits {sorted(seen['tile_bits'])}, "
+      f"tile-partition keys/thread {sorted(seen['items_tile'])}, largest D {seen['max_D']}; {len(bad)} findings")
+for b in bad[:20]:
+    print("  ", b)
