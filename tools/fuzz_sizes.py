@@ -74,13 +74,32 @@ def one(it):
     cams = pack_cameras_from_w2c(w2c, K, H, W, torch.tensor([0.05, 0.1, 0.15]))
     tag = f"it {it} {cls} P={P} NV={NV} {H}x{W} radius={radius} ext={ext:.2f} f={f:.0f} scale={base:.2e} {'rgb' if use_rgb else 'sh3'}"
     kw = dict(colors_precomp=col) if use_rgb else dict(shs=col, sh_degree=3)
+    # the call variant: plain | the views as two halves on two streams | the fused attribute blend | static lists + a refresh with
+    # other opacities and colours (compared on the refreshed values)
+    variant = rnd.choice(["plain", "plain", "split", "blend", "static_refresh"])
+    if variant == "split" and NV < 2:
+        variant = "plain"
+    bl = {}
+    if variant == "blend":
+        bl = dict(xyz_b=0.01 * ext * torch.randn(3, generator=g), opacity_b=0.02 * torch.randn(P, 1, generator=g),
+                  color_w=1 + 0.05 * torch.randn(48, generator=g), color_b=0.02 * torch.randn(P, 48, generator=g))
+    tag += f" {variant}"
+    todev = lambda d_: {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in d_.items()}
+    geo = (cams.to(dev), xyz.to(dev), opacity.to(dev), scaling.to(dev), rot.to(dev))
+    if variant == "static_refresh":
+        _, _, ctx0 = R.raster_forward(*geo, H=H, W=W, sync=True, static_lists=True, **todev(kw))
+        opacity = (opacity * (0.3 + 0.7 * torch.rand(P, 1, generator=g))).clamp(max=1.0)
+        col = col + 0.1 * torch.randn(col.shape, generator=g)
+        kw = dict(colors_precomp=col) if use_rgb else dict(shs=col, sh_degree=3)
     t0 = time.time()
-    o = OracleRender(cams, xyz, opacity, scaling, rot, H=H, W=W, **kw)
+    o = OracleRender(cams, xyz, opacity, scaling, rot, H=H, W=W, **kw, **bl)
     t_or = time.time() - t0
-    kwg = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
-    img, radii, ctx = R.raster_forward(cams.to(dev), xyz.to(dev), opacity.to(dev), scaling.to(dev), rot.to(dev), H=H, W=W, sync=True, **kwg)
+    if variant == "static_refresh":
+        img, radii, ctx = R.raster_forward(geo[0], geo[1], opacity.to(dev), geo[3], geo[4], H=H, W=W, sync=True, refresh_of=ctx0, **todev(kw))
+    else:
+        img, radii, ctx = R.raster_forward(*geo, H=H, W=W, sync=True, split_streams=(variant == "split"), **todev(kw), **todev(bl))
     D = R.last_num_rendered()
-    key = (P, NV, H, W, False)
+    key = (P, NV, H, W, variant == "split")
     d24 = R._depth24.get(key, True)
     tiles = NV * ((W + 15) // 16) * ((H + 15) // 16)
     tb = max(1, (tiles - 1).bit_length())
@@ -109,6 +128,7 @@ def one(it):
                 l2 = rel_l2(a, b)
                 assert l2 <= 3e-4, (tag, k, l2)
     o.close()
+    ctx0 = None
     del img, radii, ctx
     R.clear_workspace_pool()
     torch.cuda.empty_cache()
