@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.timeout(600)
 def test_feature_matrix_fuzz_fixed_seed():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_features.py"), "160", "7"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_features.py"), "110", "7"], capture_output=True, text=True,
                        timeout=550, cwd=ROOT)
     tail = "\n".join(r.stdout.splitlines()[-12:])
     assert r.returncode == 0, tail + r.stderr[-2000:]
@@ -64,7 +64,7 @@ def test_geometry_cache_sequence_fuzz_fixed_seed():
     """tools/fuzz_cache.py: `rasterize_views` through one shared GeometryCache while everything around it changes (in-place updates of
     what the static lists do and do not depend on, colour mode, SH degree, sizes, camera sets, blend terms, opacities lifted above
     the lists' culling bound, cleared caches and pools): every render bit-equal to the oracle, hit or build."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cache.py"), "40", "5"], capture_output=True, text=True, timeout=550, cwd=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cache.py"), "25", "5"], capture_output=True, text=True, timeout=550, cwd=ROOT)
     tail = "\n".join(r.stdout.splitlines()[-12:])
     assert r.returncode == 0, tail + r.stderr[-2000:]
     summary = [l for l in r.stdout.splitlines() if l.startswith("geometry-cache sequence fuzz:")]
@@ -73,14 +73,14 @@ def test_geometry_cache_sequence_fuzz_fixed_seed():
     assert summary[0].endswith("; 0 findings"), tail
     import ast
     st = ast.literal_eval(summary[0].split("): ", 1)[1].rsplit("; ", 1)[0])
-    assert st["hits"] > 100 and st["builds"] > 50, st
+    assert st["hits"] > 60 and st["builds"] > 30, st
 
 
 @pytest.mark.timeout(600)
 def test_depth_bound_cache_sequence_fuzz_fixed_seed():
     """The same schedule through a DepthBoundCache on dense opaque scenes: whatever changed since the bound was reported (positions by
     centimetres, cameras, sizes, colour mode), a bounded call is the unbounded call bit for bit or a verified miss that is re-run."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cache.py"), "30", "8", "--depth-bound"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cache.py"), "16", "8", "--depth-bound"], capture_output=True, text=True,
                        timeout=550, cwd=ROOT)
     tail = "\n".join(r.stdout.splitlines()[-12:])
     assert r.returncode == 0, tail + r.stderr[-2000:]
