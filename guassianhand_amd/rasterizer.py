@@ -940,6 +940,14 @@ class GaussianRasterizer(nn.Module):
         if cov3D_precomp is not None:
             raise NotImplementedError("cov3D_precomp is never passed by the reference "
                                       "(renderer_one_shot.py:313, :346) and is not supported")
+        if means3D.shape[0] == 0:
+            # No Gaussians. The published wrapper skips the kernels then (`if(P != 0)` around the rasteriser call in the extension's
+            # RasterizeGaussiansCUDA — third-party source, not in the reference tree) and returns the image it allocated: ZEROS, not the
+            # background. The drop-in returns what the published module returns; the C-ABI / raster_forward composite the background
+            # over nothing (T = 1), which is what App. A's formulas give. Connected to the graph so that a backward yields empty gradients.
+            rs = self.raster_settings
+            img = torch.zeros(3, int(rs.image_height), int(rs.image_width), dtype=torch.float32, device=means3D.device)
+            return img + 0.0 * means3D.sum(), torch.zeros(0, dtype=torch.int32, device=means3D.device)
         # will a backward come? (decided here: inside an autograd Function's forward the grad mode is always off, and
         # needs_input_grad ignores torch.no_grad())
         expect_backward = torch.is_grad_enabled() and any(

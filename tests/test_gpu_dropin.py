@@ -495,3 +495,33 @@ def test_the_rerun_after_an_overflow_does_not_walk_the_overflowed_lists(dev):
             R.check_overflow()
         except R.GhOverflowError:
             pass
+
+
+def test_no_gaussians(dev):
+    """P = 0. The C-ABI composites the background over nothing (T = 1 everywhere: App. A's formulas) and its backward produces empty
+    gradients; the drop-in module returns what the published wrapper returns for an empty model — the zero image it allocated, the
+    kernels skipped — and stays differentiable (empty gradients)."""
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from guassianhand_amd.camera import Camera
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("random1k", n_views=2, P=10)
+    cams = sc.cams().to(dev)
+    z = lambda *s: torch.zeros(*s, device=dev)
+    img, radii, ctx = R.raster_forward(cams, z(0, 3), z(0, 1), z(0, 3), z(0, 4), H=40, W=56, colors_precomp=z(0, 3))
+    bg = cams[:, 37:40]
+    assert img.shape == (2, 3, 40, 56) and radii.shape == (2, 0)
+    assert torch.equal(img, bg[:, :, None, None].expand(2, 3, 40, 56))
+    g = R.raster_backward(ctx, torch.randn(2, 3, 40, 56, device=dev), want_means2D=False)
+    assert all(v.numel() == 0 for v in g.values())
+    cam = Camera.from_w2c(sc.w2c[0].to(dev), sc.K[0].to(dev), 40, 56)
+    rs = GaussianRasterizationSettings(image_height=40, image_width=56, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                                       bg=torch.ones(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                                       projmatrix=cam.full_proj_transform.float(), sh_degree=0, campos=cam.camera_center, prefiltered=False, debug=False)
+    xyz = z(0, 3).requires_grad_(True)
+    out, rad = GaussianRasterizer(rs)(means3D=xyz, means2D=z(0, 3), opacities=z(0, 1), colors_precomp=z(0, 3), scales=z(0, 3), rotations=z(0, 4),
+                                      cov3D_precomp=None)
+    assert out.shape == (3, 40, 56) and float(out.detach().abs().max()) == 0.0 and rad.numel() == 0
+    out.sum().backward()
+    assert xyz.grad is not None and xyz.grad.shape == (0, 3)
+    R.check_overflow()
