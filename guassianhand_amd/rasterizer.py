@@ -958,6 +958,14 @@ class GaussianRasterizer(nn.Module):
         return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                          self.raster_settings, self.sync, expect_backward)
 
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """The published module's frustum test (its `mark_visible`: a point is visible when its view-space depth exceeds 0.2 — the
+        near cull of App. A.1; the reference never calls it). (P,) bool, no gradient. A handful of torch ops on the caller's device:
+        not part of the render path."""
+        with torch.no_grad():
+            vm = self.raster_settings.viewmatrix.to(positions.dtype)      # row-vector convention: p_view = [x y z 1] @ viewmatrix
+            return (positions[:, 0] * vm[0, 2] + positions[:, 1] * vm[1, 2] + positions[:, 2] * vm[2, 2] + vm[3, 2]) > 0.2
+
     # nn.Module.__call__ runs the hook machinery around forward(); this module never has hooks worth 3 us per call on a path
     # that is called twice per view (hooks registered by a caller are honoured: fall back to the full protocol then)
     def __call__(self, *args, **kwargs):

@@ -185,3 +185,31 @@ def test_helpers_forward_single_view_reproduces_the_reference_calls(fx, monkeypa
                 want = fx[f"{name}_call{ci}_{k}"]
                 assert str(v.dtype) == str(fx[f"{name}_call{ci}_{k}_dtype"]), (name, ci, k)
                 assert v.shape == want.shape and np.array_equal(v.detach().numpy(), want), (name, ci, k)
+
+
+def test_mark_visible_is_the_near_cull_of_the_projection(fx):
+    """GaussianRasterizer.markVisible (published module API; the reference never calls it): view-space depth > 0.2, evaluated with
+    the row-vector view matrix the reference builds (renderer_one_shot.py:96) — on the fixture cameras it agrees with the radii the
+    oracle's projection stage produces for tiny opaque Gaussians (radius > 0 needs more than the depth test, so: invisible by this test
+    => radius 0)."""
+    from guassianhand_amd.camera import Camera
+    from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle.oracle_c import OracleRender
+    from guassianhand_amd.camera import pack_camera
+    import math
+    g = torch.Generator().manual_seed(0)
+    w2c = torch.eye(4)
+    w2c[2, 3] = 0.5                                               # camera half a metre behind the origin, looking down +z
+    K = torch.tensor([[100.0, 0, 32, 0], [0, 100.0, 32, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    cam = Camera.from_w2c(w2c, K, 64, 64)
+    rs = GaussianRasterizationSettings(64, 64, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.zeros(3), 1.0, cam.world_view_transform,
+                                       cam.full_proj_transform.float(), 0, cam.camera_center, False, False)
+    pts = (torch.rand(400, 3, generator=g) - 0.5) * torch.tensor([0.2, 0.2, 1.6])      # depths -0.3 ... 1.3: both sides of 0.2
+    vis = GaussianRasterizer(rs).markVisible(pts)
+    assert vis.dtype == torch.bool and vis.shape == (400,) and 0 < int(vis.sum()) < 400
+    depth = pts[:, 2] + 0.5
+    assert torch.equal(vis, depth > 0.2)
+    o = OracleRender(pack_camera(rs.viewmatrix, rs.projmatrix, rs.campos, rs.tanfovx, rs.tanfovy, rs.bg), pts, torch.full((400, 1), 0.9),
+                     torch.full((400, 3), 0.01), torch.tensor([[1.0, 0, 0, 0]]).repeat(400, 1), H=64, W=64, colors_precomp=torch.rand(400, 3, generator=g))
+    assert not bool((o.radii[0][~vis] > 0).any())
+    assert bool((o.radii[0][vis] > 0).any())
