@@ -5,7 +5,8 @@ random actions between renders: in-place updates of what the lists do NOT depend
 and the image must follow), in-place updates / replacements of what they DO depend on (positions, scales, rotations, xyz_b, cameras:
 a miss), switches of the colour mode, SH degree, image size, camera set, blend terms coming and going and changing form
 ((48,) <-> (P,48) weights), an opacity bias that lifts opacities above the lists' culling bound (the refresh poisons itself and the
-call is re-run as a build), cache.clear(), GeometryCache.clear_all(), pool clears. With --depth-bound the same schedule runs through a
+call is re-run as a build), cache.clear(), GeometryCache.clear_all(), pool clears; a third of the renders go through the fused render + L1-loss
+autograd node (loss.rendered_l1_loss) instead of rasterize_views. With --depth-bound the same schedule runs through a
 DepthBoundCache instead (every change is legal there: the forward verifies the bound, a miss is re-run without it). Every render: image (and fused alpha) bit-equal to
 the C oracle on the current values, gradients of all inputs within tolerance.   usage: fuzz_cache.py [n_iterations] [seed]"""
 import os, random, sys, time
@@ -93,7 +94,16 @@ def one(it):
         trace.append(f"render({'rgb' if mode['use_rgb'] else 'sh%d' % mode['deg']},{NV}v,{H}x{W},blend={sorted(blend_now())},alpha={mode['alpha']},sync={sync})")
         for x in st.values():
             x.grad = None
-        call = lambda sync_: R.rasterize_views(cams, st["xyz"], st["opacity"], st["scaling"], st["rotation"], col, H=H, W=W, use_rgb=mode["use_rgb"],
+        fused = (not mode["alpha"]) and rnd.random() < 0.35      # render + L1 loss as ONE autograd node (loss.rendered_l1_loss) through the same cache
+        target = torch.rand(NV, 3, H, W, generator=torch.Generator().manual_seed(it * 31 + len(trace)))
+        if fused:
+            trace[-1] += "+l1"
+            from guassianhand_amd.loss import rendered_l1_loss
+            call = lambda sync_: (lambda r_: (r_[1], r_[2], r_[0]))(rendered_l1_loss(
+                cams, st["xyz"], st["opacity"], st["scaling"], st["rotation"], col, target.to(dev), H=H, W=W, use_rgb=mode["use_rgb"],
+                sh_degree=mode["deg"], sync=sync_, **({"depth_bound": cache} if DEPTH_BOUND else {"geometry_cache": cache}), **blend_now()))
+        else:
+            call = lambda sync_: R.rasterize_views(cams, st["xyz"], st["opacity"], st["scaling"], st["rotation"], col, H=H, W=W, use_rgb=mode["use_rgb"],
                                                sh_degree=mode["deg"], sync=sync_, return_alpha=mode["alpha"],
                                                **({"depth_bound": cache} if DEPTH_BOUND else {"geometry_cache": cache}), **blend_now())
         if DEPTH_BOUND:
@@ -128,8 +138,16 @@ def one(it):
         kw = dict(colors_precomp=cpu(col).squeeze(1)) if mode["use_rgb"] else dict(shs=cpu(col), sh_degree=mode["deg"])
         o = OracleRender(cpu(cams), cpu(st["xyz"]), cpu(st["opacity"]), cpu(st["scaling"]), cpu(st["rotation"]), H=H, W=W, **kw, **blend_now(cpu=True))
         assert torch.equal(cpu(img), o.image), tag() + " (image)"
-        dimg = torch.randn(NV, 3, H, W, generator=torch.Generator().manual_seed(it * 977 + len(trace)))
-        loss = (img * dimg.to(dev)).sum()
+        if fused:
+            # the node's loss is mean|img - target| (its value checked against torch on the bit-equal image), its image gradient sign / N
+            loss = out[2] * 3.0
+            ref_loss = (o.image - target).abs().mean()
+            lv = float(out[2].detach())
+            assert abs(lv - float(ref_loss)) <= 1e-6 * max(1.0, float(ref_loss)), tag() + f" (fused L1 loss {lv} vs {float(ref_loss)})"
+            dimg = 3.0 * torch.sign(o.image - target) / o.image.numel()
+        else:
+            dimg = torch.randn(NV, 3, H, W, generator=torch.Generator().manual_seed(it * 977 + len(trace)))
+            loss = (img * dimg.to(dev)).sum()
         if mode["alpha"]:
             cm = cpu(cams).clone(); cm[:, 37:40] = 0
             om = OracleRender(cm, cpu(st["xyz"]), cpu(st["opacity"]), cpu(st["scaling"]), cpu(st["rotation"]), H=H, W=W, colors_precomp=torch.ones(P, 3),
