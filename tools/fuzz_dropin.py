@@ -6,7 +6,8 @@ Per iteration a small scene with leaf tensors and three cameras of different ima
     render (RGB pass, often followed by the mask pass over the same objects; under autograd or torch.no_grad(); sync None / True / False)
     backward of ANY earlier output still alive (in any order, e.g. the RGB pass of view 0 after two later renders of other views)
     drop an output without a backward, update leaves in place (`no_grad` + `add_`: bumps `_version`), replace leaf objects,
-    check_overflow / clear_workspace_pool; with --shrink also cuts of the learned instance capacities (overflow + recovery)
+    check_overflow / clear_workspace_pool; with --shrink also cuts of the learned instance capacities (overflow + recovery); with
+    --streams every render goes to the null stream or one of two side streams
 A backward whose inputs were updated in place since its forward must raise autograd's "modified by an inplace operation" error (the
 reference extension saves its inputs, so PyTorch raises there too). Every image is compared bit for bit with the C oracle on the values the call saw; every backward's leaf gradients with the oracle's
 backward on that call's snapshot (rel-L2 <= 2e-5, element-wise <= 2e-3).   usage: fuzz_dropin.py [n_iterations] [seed]"""
@@ -23,6 +24,7 @@ from tests.helpers import rel_l2, max_rel
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
+STREAMS = "--streams" in sys.argv     # renders on the null stream and on two side streams, at random
 SHRINK = "--shrink" in sys.argv      # also cut the learned instance capacities at random: overflow detection and recovery in every sync mode
 rnd = random.Random(seed)
 dev = torch.device("cuda:0")
@@ -59,6 +61,7 @@ def one(it):
     live = []
     trace = []
     shrunk = [False]
+    streams = [None, torch.cuda.Stream(), torch.cuda.Stream()] if STREAMS else []
     tag = lambda: f"it {it} P={P} {'rgb' if rgb else 'sh%d' % deg}{' strided' if strided else ''} sizes={sizes}: " + " > ".join(trace[-8:])
 
     def settings(v, bg_, deg_):
@@ -78,7 +81,14 @@ def one(it):
         v, sync, grad, with_mask = force or (rnd.randrange(3), rnd.choice([None, None, True, False]), rnd.random() < 0.8, rnd.random() < 0.7)
         snap = {k: arg(k).detach().cpu().clone() for k in leaf}
         trace.append(f"render(v{v},sync={sync},{'grad' if grad else 'no_grad'}{',+mask' if with_mask else ''})")
-        with torch.enable_grad() if grad else torch.no_grad():
+        # on the null stream or on one of two side streams (ordered against the null stream, where the updates happen): workspaces are
+        # pooled per stream, the mask-pass reuse is per stream, the backward runs on the forward's stream
+        st_ = rnd.choice(streams) if STREAMS else None
+        if st_ is not None:
+            trace[-1] += f"@s{[id(x) for x in streams].index(id(st_))}"
+            st_.wait_stream(torch.cuda.current_stream())
+        import contextlib
+        with (torch.cuda.stream(st_) if st_ is not None else contextlib.nullcontext()), (torch.enable_grad() if grad else torch.no_grad()):
             a_xyz, a_op = arg("xyz"), arg("opacity")                 # (the same view objects for the RGB pass and the mask pass)
             means2D = torch.zeros_like(a_xyz, requires_grad=True)
             kw = dict(colors_precomp=leaf["colour"]) if rgb else dict(shs=leaf["colour"])
@@ -94,6 +104,8 @@ def one(it):
                     rotations=leaf["rotation"], cov3D_precomp=None)
                 stats["mask_passes"] += 1
                 outs.append((m, True))
+        if st_ is not None:
+            torch.cuda.current_stream().wait_stream(st_)
         nan_outs = [o_ for o_, _m in outs if bool(torch.isnan(o_).any())]
         if nan_outs:
             # an instance-capacity overflow (the `shrink` action): the device-side guard returned a NaN image. Legal only where the
