@@ -270,7 +270,7 @@ static void geo_forward(const GhDims* d, const GhInputs* in, const float* cam, i
 /* ------------------------------------------------------------------------------------------- */
 int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCtx** ctx_out, GhoDebug* dbg) {
   if (!d || !in || !out || !ctx_out) return GH_ERR_INVALID_ARG;
-  if ((in->shs != NULL) == (in->colors_precomp != NULL)) return GH_ERR_INVALID_ARG;
+  if (d->P != 0 && (in->shs != NULL) == (in->colors_precomp != NULL)) return GH_ERR_INVALID_ARG;   /* (P = 0: nothing is read, the background only) */
   const int P = d->P, NV = d->n_views, H = d->H, W = d->W;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, tiles = gx * gy;
   if (gx > 255 || gy > 255 || d->sh_degree > 3) return GH_ERR_UNSUPPORTED;

@@ -24,6 +24,7 @@ from tests.helpers import rel_l2, limit_torch_threads_to_the_cpu_share
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
+FORCE_CLASS = next((a.split("=")[1] for a in sys.argv if a.startswith("--class=")), None)      # e.g. --class=tiny (P in {0, 1, 2, 63 ... 257})
 rnd = random.Random(seed)
 dev = torch.device("cuda:0")
 limit_torch_threads_to_the_cpu_share()
@@ -37,8 +38,9 @@ def one(it):
     rnd.seed(seed * 1000003 + it)
     g = torch.Generator().manual_seed(it)
     cls = rnd.choice(["tiny", "small", "mid", "mid", "large", "wide", "many_views", "dense"] * 3 + ["huge"])
+    cls = FORCE_CLASS or cls
     if cls == "tiny":
-        P, NV, H, W = rnd.choice([1, 2, 63, 64, 65, 255, 257]), rnd.randint(1, 3), rnd.randint(16, 64), rnd.randint(16, 64)
+        P, NV, H, W = rnd.choice([0, 1, 2, 63, 64, 65, 255, 257]), rnd.randint(1, 3), rnd.randint(16, 64), rnd.randint(16, 64)
     elif cls == "small":
         P, NV, H, W = rnd.randint(1000, 20000), rnd.randint(1, 4), rnd.randint(64, 400), rnd.randint(64, 400)
     elif cls == "mid":
@@ -121,6 +123,9 @@ def one(it):
         gr = R.raster_backward(ctx, dimg.to(dev), want_means2D=False)
         for k, b in og.items():
             if k == "means2D":
+                continue
+            if b.numel() == 0:                                  # (P = 0: empty gradients on both sides)
+                assert gr[k].numel() == 0, tag + f" ({k}: a gradient for no Gaussians)"
                 continue
             a = gr[k].cpu().reshape(b.shape)
             assert bool(torch.isfinite(a).all()), tag + f" ({k} not finite)"
