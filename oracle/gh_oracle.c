@@ -267,6 +267,14 @@ static void geo_forward(const GhDims* d, const GhInputs* in, const float* cam, i
   o->det = fmaf(o->a, o->c, -(o->b * o->b));
 }
 
+/* float -> int as the GPU converts (v_cvt_i32_f32): truncation, NaN -> 0, saturation at the int range */
+static inline int f2i(float x) {
+  if (x != x) return 0;
+  if (x >= 2147483648.0f) return 2147483647;
+  if (x <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)x;
+}
+
 /* ------------------------------------------------------------------------------------------- */
 int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCtx** ctx_out, GhoDebug* dbg) {
   if (!d || !in || !out || !ctx_out) return GH_ERR_INVALID_ARG;
@@ -295,20 +303,23 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
     GView* g = &c->g[n];
     memset(g, 0, sizeof(*g));
     Geo e; geo_forward(d, in, cam, i, &e);
-    if (e.tz <= 0.2f) continue;
+    /* Non-finite inputs: the published code is undefined there (a NaN radius cast to int; a radius of INT_MIN makes BOTH rect
+     * extents negative and their product positive). The checker stays defined by doing what the GPU's conversions do — NaN -> 0,
+     * saturation (f2i below) — and by culling a NaN depth like the kernels' `tz > 0.2` test; for finite inputs nothing changes. */
+    if (!(e.tz > 0.2f)) continue;
     if (e.det == 0.0f) continue;
     float dinv = 1.0f / e.det;
     float mid = 0.5f * (e.a + e.c);
     float sq = sqrtf(fmaxf(0.1f, fmaf(mid, mid, -e.det)));
     float lam1 = mid + sq, lam2 = mid - sq;
-    int radius = (int)ceilf(3.0f * sqrtf(fmaxf(lam1, lam2)));
+    int radius = f2i(ceilf(3.0f * sqrtf(fmaxf(lam1, lam2))));
     float ndcx = e.hx * e.winv, ndcy = e.hy * e.winv;
     float px = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
     float py = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
-    int minx = (int)((px - (float)radius) / (float)TILE); minx = minx < 0 ? 0 : (minx > gx ? gx : minx);
-    int miny = (int)((py - (float)radius) / (float)TILE); miny = miny < 0 ? 0 : (miny > gy ? gy : miny);
-    int maxx = (int)((px + (float)radius + (float)(TILE - 1)) / (float)TILE); maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
-    int maxy = (int)((py + (float)radius + (float)(TILE - 1)) / (float)TILE); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
+    int minx = f2i((px - (float)radius) / (float)TILE); minx = minx < 0 ? 0 : (minx > gx ? gx : minx);
+    int miny = f2i((py - (float)radius) / (float)TILE); miny = miny < 0 ? 0 : (miny > gy ? gy : miny);
+    int maxx = f2i((px + (float)radius + (float)(TILE - 1)) / (float)TILE); maxx = maxx < 0 ? 0 : (maxx > gx ? gx : maxx);
+    int maxy = f2i((py + (float)radius + (float)(TILE - 1)) / (float)TILE); maxy = maxy < 0 ? 0 : (maxy > gy ? gy : maxy);
     if ((maxx - minx) * (maxy - miny) <= 0) continue;
     g->radius = radius; g->minx = minx; g->miny = miny; g->maxx = maxx; g->maxy = maxy;
     g->tiles = (uint32_t)((maxx - minx) * (maxy - miny));
