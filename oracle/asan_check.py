@@ -18,5 +18,24 @@ for par, cfg, kw in ((0, "random1k", dict(n_views=2, blend=True)), (0, "random1k
     g = o.backward(dimg_like(sc.w2c.shape[0], sc.H, sc.W))
     o.close()
     print("baseline mode" if par else "checker", cfg, kw, "instances", o.num_rendered, "sum|dL/dxyz|", float(g["means3D"].abs().sum()))
+# non-finite Gaussians (NaN / +-inf positions, scales, rotations, opacities, colours; P = 0): undefined in the published algorithm, defined
+# here by the GPU's float -> int conversions (f2i) — no out-of-range conversion, no heap damage, in either mode
+nan, inf = float("nan"), float("inf")
+for par in (0, 1):
+    oracle_c.set_parallel(bool(par))
+    sc = make_scene("random1k", n_views=2, P=400, use_rgb=True, blend=False)
+    for j, (attr, val) in enumerate((("xyz", nan), ("xyz", inf), ("xyz", -inf), ("scaling", nan), ("scaling", inf), ("scaling", 0.0), ("rotation", nan),
+                                     ("rotation", inf), ("rotation", 0.0), ("opacity", nan), ("opacity", inf), ("shs", nan), ("shs", inf))):
+        t = getattr(sc, attr).clone()
+        t[3 + 7 * j] = val
+        setattr(sc, attr, t)
+    o = oracle_c.OracleRender(sc.cams(), sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=sc.H, W=sc.W, debug=True, colors_precomp=sc.shs.squeeze(1))
+    o.backward(dimg_like(2, sc.H, sc.W))
+    o.close()
+    z = lambda *s_: torch.zeros(*s_)
+    o = oracle_c.OracleRender(sc.cams(), z(0, 3), z(0, 1), z(0, 3), z(0, 4), H=sc.H, W=sc.W, colors_precomp=z(0, 3))
+    o.backward(dimg_like(2, sc.H, sc.W))
+    o.close()
+    print("baseline mode" if par else "checker", "non-finite Gaussians and an empty scene: clean")
 idx, d = oracle_c.knn(torch.rand(3000, 3), 100)
 print("knn", tuple(idx.shape), "clean")
