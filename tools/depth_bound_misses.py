@@ -1,3 +1,5 @@
+"""How often, and where, the speculative occlusion bound (DepthBoundCache) misses on a moving-geometry loop of the hand scenes: per-step misses,
+the tiles concerned and what margin / slack would have held (the measurements behind the virtual walk and the neighbourhood erosion of DESIGN.md 5e)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
