@@ -78,9 +78,37 @@ def one(it):
     kw = dict(colors_precomp=col) if use_rgb else dict(shs=col, sh_degree=3)
     # the call variant: plain | the views as two halves on two streams | the fused attribute blend | static lists + a refresh with
     # other opacities and colours (compared on the refreshed values)
-    variant = rnd.choice(["plain", "plain", "split", "blend", "static_refresh"])
+    variant = rnd.choice(["plain", "plain", "split", "blend", "static_refresh", "pose_batch"])
     if variant == "split" and NV < 2:
         variant = "plain"
+    if variant == "pose_batch" and (NV < 2 or NV * P > 1_500_000 or P == 0):
+        variant = "plain"
+    if variant == "pose_batch":
+        # NV different Gaussian sets in one launch sequence (GH_FLAG_PER_VIEW_GAUSSIANS): every per-Gaussian tensor holds NV * P rows;
+        # compared view by view with the oracle's render of that view's rows
+        xs = torch.cat([xyz + 0.02 * ext * v * torch.randn(P, 3, generator=g) for v in range(NV)])
+        ops = torch.cat([(opacity * (0.5 + 0.5 * torch.rand(P, 1, generator=g))) for _ in range(NV)])
+        rep = lambda x: x.repeat(NV, *([1] * (x.dim() - 1)))
+        sc_all, rot_all, col_all = rep(scaling), rep(rot), rep(col)
+        kw_all = dict(colors_precomp=col_all) if use_rgb else dict(shs=col_all, sh_degree=3)
+        tag += " pose_batch"
+        imgp, radp, ctxp = R.raster_forward(cams.to(dev), xs.to(dev), ops.to(dev), sc_all.to(dev), rot_all.to(dev), H=H, W=W, sync=True,
+                                            per_view_gaussians=True, **{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw_all.items()})
+        Dp = R.last_num_rendered()
+        seen["max_D"] = max(seen["max_D"], Dp)
+        seen["pose_batches"] = seen.get("pose_batches", 0) + 1
+        print(f"{tag}: D={Dp} rows={NV * P}", flush=True)
+        for v in range(NV):
+            sl = slice(v * P, (v + 1) * P)
+            kv = dict(colors_precomp=col_all[sl]) if use_rgb else dict(shs=col_all[sl], sh_degree=3)
+            ov = OracleRender(cams[v:v + 1], xs[sl], ops[sl], sc_all[sl], rot_all[sl], H=H, W=W, **kv)
+            assert torch.equal(imgp[v].cpu(), ov.image[0]) and torch.equal(radp[v].cpu(), ov.radii[0]), tag + f" (view {v})"
+            ov.close()
+        gp = R.raster_backward(ctxp, torch.randn(NV, 3, H, W, generator=g).to(dev), want_means2D=False)
+        assert all(bool(torch.isfinite(x).all()) for x in gp.values()), tag + " (gradient not finite)"
+        del imgp, radp, ctxp, gp
+        R.clear_workspace_pool(); torch.cuda.empty_cache()
+        return
     bl = {}
     if variant == "blend":
         bl = dict(xyz_b=0.01 * ext * torch.randn(3, generator=g), opacity_b=0.02 * torch.randn(P, 1, generator=g),
@@ -167,6 +195,6 @@ R.check_overflow()
 print(f"size-class fuzz: {n_iter} iterations (seed {seed}) in {time.time() - t0:.0f} s; paths seen: depth-sort keys/thread {sorted(seen['items_depth'])}, "
       f"scan-free histogram {sorted(seen['self_hist'])}, depth24 {sorted(seen['depth24'])}, tile bits {sorted(seen['tile_bits'])}, "
       f"tile-partition keys/thread {sorted(seen['items_tile'])}, largest D {seen['max_D']}, {seen.get('big_bwd', 0)} backward passes above 4e6 instances "
-      f"checked split against unsplit; {len(bad)} findings")
+      f"checked split against unsplit, {seen.get('pose_batches', 0)} pose batches; {len(bad)} findings")
 for b in bad[:20]:
     print("  ", b)
