@@ -116,3 +116,15 @@ def test_baseline_mode_equals_the_checker(use_rgb, blend):
         else:
             assert torch.equal(g0[k], g1[k]), k
     assert f1 <= f0                                   # the baseline mode has less single-threaded time, never more
+
+
+def test_c_oracle_against_the_float64_dense_oracle_over_the_feature_matrix():
+    """tools/fuzz_oracles_cpu.py, 250 fixed-seed draws: the C oracle (what the HIP path is bit-equal to) against Oracle A (dense float64
+    autograd from the behavioural spec) over RGB / SH degree 0-3 x M x every blend subset and form x off-grid sizes — the checker's
+    formulas, not only its typing. (6,000 draws: profiles/r4_fuzz_oracles_cpu.txt.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_oracles_cpu.py"), "250", "3"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("oracle-vs-oracle fuzz")]
+    assert line and ": 0 findings" in line[0], r.stdout[-2000:]

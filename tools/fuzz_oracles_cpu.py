@@ -1,0 +1,113 @@
+"""CPU-only fuzz of the CHECKER: the C oracle (float32, tiles, sort keys, hand-written chain rule — what the HIP path is bit-equal to) against
+Oracle A (dense float64 PyTorch autograd written from the behavioural spec, no tiles, no sort keys) over the feature matrix.
+
+The GPU fuzzers prove the HIP path equals the C oracle; this one asks whether the C oracle's FORMULAS are right wherever the two programs
+can be compared: random small scenes x RGB / SH degree 0-3 with M in {1,4,9,16} x every subset of the blend terms in their (48,) /
+(P,48) forms x off-grid image sizes and off-centre cameras. Image: L_inf <= 1e-4 outside pixels where float32 and float64 take a
+threshold decision differently (alpha vs 1/255, T vs 1e-4: Oracle A marks the pixels where a decision sits within 2e-5 of its threshold; counted,
+bounded); gradients: rel-L2 <= 2e-4 (float32 against float64 on
+scenes of a few hundred Gaussians), with the pixels of a flipped decision left out on both sides.   usage: fuzz_oracles_cpu.py [n] [seed]"""
+import os, random, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from guassianhand_amd.scenes import make_scene
+from oracle.oracle_c import OracleRender
+from oracle import oracle_torch as OT
+from tests.helpers import rel_l2
+
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rnd = random.Random(seed)
+bad, flips_total, worst, amb_total = [], 0, {"img": 0.0, "grad": 0.0}, [0]
+
+
+def one(it):
+    global flips_total
+    rnd.seed(seed * 1000003 + it)
+    g = torch.Generator().manual_seed(it)
+    P, NV = rnd.choice([1, 5, 40, 150, 300]), rnd.randint(1, 2)
+    rgb = rnd.random() < 0.5
+    sc = make_scene("random1k", n_views=NV, P=P, use_rgb=rgb, blend=True, seed=rnd.randint(0, 10 ** 6))
+    sc.H, sc.W = rnd.randint(16, 48), rnd.randint(16, 48)              # the intrinsics stay those of 128x128: off-centre principal point
+    if rnd.random() < 0.5:
+        sc.scaling = sc.scaling * rnd.choice([0.5, 2.0, 4.0])
+    deg = 0
+    if not rgb:
+        deg = rnd.randint(0, 3)
+        M = rnd.choice([m for m in (1, 4, 9, 16) if m >= (deg + 1) ** 2])
+        sc.shs = sc.shs[:, :M].contiguous()
+    sc.sh_degree = deg
+    sc.xyz_b = None if rnd.random() < 0.4 else 0.004 * torch.randn(3, generator=g)
+    if rnd.random() < 0.4: sc.opacity_b = None
+    if rnd.random() < 0.4: sc.color_w = None
+    elif rnd.random() < 0.5: sc.color_w = 1 + 0.05 * torch.randn(P, 48, generator=g)
+    if rnd.random() < 0.4: sc.color_b = None
+    if not rgb and (sc.shs.shape[1] != 16 or sc.color_w is None):
+        sc.color_b = None
+    if not rgb and sc.shs.shape[1] != 16:
+        sc.color_w = None
+    sc.bg = torch.rand(3, generator=g)
+    blend = {k: getattr(sc, k) for k in ("xyz_b", "opacity_b", "color_w", "color_b") if getattr(sc, k) is not None}
+    tag = f"it {it} P={P} NV={NV} {sc.H}x{sc.W} {'rgb' if rgb else 'sh%d/M%d' % (deg, sc.shs.shape[1])} blend={sorted(blend)}" + \
+          (" w(P,48)" if sc.color_w is not None and sc.color_w.numel() != 48 else "")
+    cams = sc.cams()
+    kw = dict(colors_precomp=sc.shs.squeeze(1)) if rgb else dict(shs=sc.shs, sh_degree=deg)
+    o = OracleRender(cams, sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=sc.H, W=sc.W, **kw, **blend)
+    # Oracle A, float64
+    d = torch.float64
+    leaves = {n: getattr(sc, n).to(d).clone().requires_grad_(True) for n in ("xyz", "opacity", "scaling", "rotation", "shs")}
+    bl = {k: v.to(d).clone().requires_grad_(True) for k, v in blend.items()}
+    imgs, ambs = [], []
+    for v in range(NV):
+        c = cams[v].to(d)
+        means, opac, cols, sh = OT.blend_attributes(leaves["xyz"], leaves["opacity"], leaves["shs"], use_rgb=rgb, **bl)
+        ckw = dict(colors_precomp=cols) if rgb else dict(shs=sh, sh_degree=deg)
+        img, _, amb = OT.rasterize_dense(means, opac, leaves["scaling"], leaves["rotation"], viewmatrix=c[:16].reshape(4, 4), projmatrix=c[16:32].reshape(4, 4),
+                                         campos=c[32:35], tanfovx=float(c[35]), tanfovy=float(c[36]), bg=c[37:40], H=sc.H, W=sc.W,
+                                         checkpoint_chunks=True, ambiguity_eps=2e-5, **ckw)
+        imgs.append(img)
+        ambs.append(amb)
+    img_a = torch.stack(imgs)
+    err = (o.image.double() - img_a.detach()).abs().amax(dim=1)
+    # pixels at which a discrete decision of App. A.3 sits within 2e-5 (relative) of its threshold in float64: float32 may decide the
+    # other way there; such a pixel may move by one faint entry in the image and is left out of the gradient comparison on both sides
+    ambiguous = torch.stack(ambs)
+    amb_total[0] += int(ambiguous.sum())
+    assert float(ambiguous.float().mean()) <= 0.05, tag + " (more than 5 % ambiguous pixels)"
+    flipped = (err > 1e-4) | ambiguous
+    nf = int((err > 1e-4).sum())
+    flips_total += nf
+    worst["img"] = max(worst["img"], float(err[~flipped].max()) if bool((~flipped).any()) else 0.0)
+    assert nf <= max(2, int(0.002 * flipped.numel())), tag + f" ({nf} pixels beyond 1e-4: more than threshold decisions explain; worst {float(err.max()):.3g})"
+    assert nf == 0 or float(err[flipped].max()) <= 2e-2, tag + f" (a flipped pixel differs by {float(err[flipped].max()):.3g})"
+    dimg = torch.randn(NV, 3, sc.H, sc.W, generator=g) * (~flipped)[:, None].float()
+    (img_a * dimg.to(d)).sum().backward()
+    ga = dict(means3D=leaves["xyz"].grad, opacities=leaves["opacity"].grad, scales=leaves["scaling"].grad, rotations=leaves["rotation"].grad)
+    ga["colors_precomp" if rgb else "shs"] = leaves["shs"].grad
+    ga.update({k: v.grad for k, v in bl.items()})
+    gb = o.backward(dimg)
+    o.close()
+    for k, a in ga.items():
+        b = gb[k].double().reshape(a.shape)
+        if float(a.abs().max()) < 1e-12:
+            assert float(b.abs().max()) <= 1e-6, tag + f" ({k}: the float64 gradient is zero, the oracle's is not)"
+            continue
+        l2 = rel_l2(b, a)
+        worst["grad"] = max(worst["grad"], l2)
+        # (rel-L2 of the tensor, or — scenes where one or two faint Gaussians are all that is visible, whose gradient is a cancelling sum
+        # of a few pixel terms of 1e-2 — an absolute 1e-6 on gradients whose upstream dL/dimage is N(0, 1))
+        assert l2 <= 2e-4 or float((a - b).abs().max()) <= 1e-6, (tag, k, l2, float((a - b).abs().max()))
+
+
+t0 = time.time()
+for it in range(n_iter):
+    try:
+        one(it)
+    except AssertionError as e:
+        bad.append(str(e)[:500]); print("MISMATCH", bad[-1], flush=True)
+    if (it + 1) % 50 == 0:
+        print(f"{it + 1} iterations, {len(bad)} findings, {time.time() - t0:.0f} s", flush=True)
+print(f"oracle-vs-oracle fuzz (CPU): {n_iter} iterations (seed {seed}): {len(bad)} findings; {flips_total} pixels beyond 1e-4, {amb_total[0]} pixels left out as ambiguous (a decision within 2e-5 of its threshold); "
+      f"worst image L_inf elsewhere {worst['img']:.2e}, worst gradient rel-L2 {worst['grad']:.2e}")
+for b in bad[:15]:
+    print("  ", b)
