@@ -274,3 +274,4 @@ torch.cuda.synchronize()
 print(f"{'depth-bound' if DEPTH_BOUND else 'geometry'}-cache sequence fuzz: {n_iter} iterations (seed {seed}): {stats}; {len(bad)} findings")
 for b in bad[:20]:
     print("  ", b)
+sys.exit(1 if bad else 0)

@@ -255,3 +255,4 @@ torch.cuda.synchronize()
 print(f"drop-in sequence fuzz: {n_iter} iterations (seed {seed}): {stats}; {len(bad)} findings")
 for b in bad[:20]:
     print("  ", b)
+sys.exit(1 if bad else 0)

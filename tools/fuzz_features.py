@@ -286,3 +286,4 @@ print(f"feature fuzz: {n_iter} iterations (seed {seed}): {count}; {len(bad)} fin
 print("worst gradient deviation from the (float32) oracle by scene distribution, rel-L2 / element-wise: " + "; ".join(f"{m} {w[0]:.1e} / {w[1]:.1e}" for m, w in worst_by.items()))
 for b in bad[:20]:
     print("  ", b)
+sys.exit(1 if bad else 0)

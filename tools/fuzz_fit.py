@@ -149,3 +149,4 @@ torch.cuda.synchronize()
 print(f"fit sequence fuzz: {n_iter} iterations (seed {seed}): {stats}; {len(bad)} findings; static vs full path: largest first-moment difference {worst_moment[0]:.2e} of the moment's scale")
 for b in bad[:20]:
     print("  ", b)
+sys.exit(1 if bad else 0)

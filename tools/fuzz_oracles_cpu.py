@@ -111,3 +111,4 @@ print(f"oracle-vs-oracle fuzz (CPU): {n_iter} iterations (seed {seed}): {len(bad
       f"worst image L_inf elsewhere {worst['img']:.2e}, worst gradient rel-L2 {worst['grad']:.2e}")
 for b in bad[:15]:
     print("  ", b)
+sys.exit(1 if bad else 0)

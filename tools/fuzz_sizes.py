@@ -198,3 +198,4 @@ print(f"size-class fuzz: {n_iter} iterations (seed {seed}) in {time.time() - t0:
       f"checked split against unsplit, {seen.get('pose_batches', 0)} pose batches; {len(bad)} findings")
 for b in bad[:20]:
     print("  ", b)
+sys.exit(1 if bad else 0)
