@@ -5,6 +5,7 @@ Three fits of the same small problem are driven through the same random schedule
     B  static geometry, every step a replay of the captured HIP graph (re-captured at learning-rate milestones, eager + re-capture
        when the lists it was captured on were dropped)
     C  full path every step (static_geometry=False)
+    D  full path through a DepthBoundCache (occlusion_bound=True: the policy for Gaussians that move every step) — must take C's steps
 Events: steps, epoch ends (learning-rate milestones), update_gaussians() with Gaussians that moved a little, invalidate_geometry(),
 GeometryCache.clear_all() (what an overflow anywhere in the process does), clear_workspace_pool(), unrelated renders of other sizes in
 between (they compete for pooled workspaces). After every event batch: A and B hold the SAME bits (parameters, both Adam moments,
@@ -45,11 +46,16 @@ def one(it):
         gs = GaussianModel(gs.xyz, gs.opacity, gs.rotation, gs.scaling, shs)
     mk = lambda static: F.OneShotFit(gs, pb["uv"], map_hw=pb["map_hw"], use_rgb=use_rgb, static_geometry=static)
     A, B, C = mk(True), mk(True), mk(False)
+    # D: the policy for Gaussians that move every step — full forwards through a DepthBoundCache (speculative occlusion bound, verified by
+    # the forward, re-run on a miss); made to apply to these small renders too
+    D = F.OneShotFit(gs, pb["uv"], map_hw=pb["map_hw"], use_rgb=use_rgb, static_geometry=False, occlusion_bound=True)
+    D._geom_cache.min_pixels, D._geom_cache.refresh_every = 0, rnd.choice([1, 2, 4])
+    ld = []
     trace = []
     tag = lambda: f"it {it} P={P} {hw} {'rgb' if use_rgb else 'sh3'}: " + " > ".join(trace[-14:])
     la, lb, lc = [], [], []
     # B's construction runs two regular steps: the others take them too
-    for f, ls in ((A, la), (C, lc)):
+    for f, ls in ((A, la), (C, lc), (D, ld)):
         for i in range(2):
             ls.append(float(f.step(*args, sync=(i == 0))))
     cap = B.captured(*args)
@@ -77,6 +83,12 @@ def one(it):
             q = float(torch.quantile(diff[:1 << 22].float(), 0.99)) if diff.numel() else 0.0
             assert q <= 1e-3, tag() + f" (static vs full path: {k}, 99th percentile of |diff| {q:.3g}, max {float(diff.max()):.3g})"
         assert la[2:] == lb, tag() + f" (losses eager static vs captured: {la[-3:]} vs {lb[-3:]})"
+        for x, y in zip(lc, ld):                                  # the occlusion bound is exact: the full path's losses
+            assert abs(x - y) <= 2e-6 * max(1.0, abs(x)), tag() + f" (loss full path {x} vs occlusion-bound fit {y})"
+        for k in C._adam:
+            dq = (C._adam[k].param - D._adam[k].param).abs().reshape(-1)
+            qd = float(torch.quantile(dq[:1 << 22].float(), 0.99)) if dq.numel() else 0.0
+            assert qd <= 1e-3 and int(C._adam[k].step_state[0]) == int(D._adam[k].step_state[0]), tag() + f" (full path vs occlusion-bound fit: {k}, 99th percentile {qd:.3g})"
         for x, y in zip(la, lc):
             assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), tag() + f" (loss static {x} vs full {y})"
 
@@ -88,6 +100,7 @@ def one(it):
             for _i in range(k):
                 la.append(float(A.step(*args, sync=rnd.random() < 0.3)))
                 lc.append(float(C.step(*args, sync=rnd.random() < 0.3)))
+                ld.append(float(D.step(*args, sync=True)))
                 g0 = cap.graph
                 lb.append(float(cap.replay()))
                 stats["recaptures"] += 0 if cap.graph is g0 else 1
@@ -97,7 +110,7 @@ def one(it):
             k = rnd.randint(1, 6)
             trace.append(f"end_epoch x{k}")
             stats["epoch_ends"] += k
-            for f in (A, B, C):
+            for f in (A, B, C, D):
                 for _i in range(k):
                     f.end_epoch()
         elif ev == "move":
@@ -106,12 +119,12 @@ def one(it):
             cur = A.gs
             d = 0.002 * torch.randn(cur.xyz.shape, generator=g).to(dev)
             new = GaussianModel(cur.xyz + d, cur.opacity, cur.rotation, cur.scaling, cur.shs)
-            for f in (A, B, C):
+            for f in (A, B, C, D):
                 f.update_gaussians(new)
         elif ev == "invalidate":
             trace.append("invalidate_geometry")
             stats["invalidations"] += 1
-            for f in (A, B, C):
+            for f in (A, B, C, D):
                 f.invalidate_geometry()
         elif ev == "clear_all":
             trace.append("GeometryCache.clear_all")
@@ -131,6 +144,8 @@ def one(it):
         compare()
     cap.check()
     R.check_overflow()
+    stats["bounded_calls"] = stats.get("bounded_calls", 0) + D._geom_cache.bounded_calls
+    stats["bound_misses"] = stats.get("bound_misses", 0) + D._geom_cache.misses
 
 
 t0 = time.time()
