@@ -117,7 +117,7 @@ def one(it):
             trace.append("update_gaussians")
             stats["moves"] += 1
             cur = A.gs
-            d = 0.002 * torch.randn(cur.xyz.shape, generator=g).to(dev)
+            d = rnd.choice([0.002, 0.002, 0.05]) * torch.randn(cur.xyz.shape, generator=g).to(dev)      # (5 cm: the occlusion bound of fit D misses)
             new = GaussianModel(cur.xyz + d, cur.opacity, cur.rotation, cur.scaling, cur.shs)
             for f in (A, B, C, D):
                 f.update_gaussians(new)
