@@ -111,6 +111,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->key_bits = take((gh_proj_blocks(g) + 4) * 8);        // (OR, AND) of the visible depth keys per projection block (+1 word; two
                                                           // halves: + 1 block of rounding + 1 word each)
   L->tile_bound = take((size_t)g.NV * g.tiles * 4);
+  L->block_tiles = take((gh_proj_blocks(g) + 4) * 4);     // (two halves: + 1 block of rounding + 1 spare word each)
   L->total_bytes = off;
   return GH_OK;
 }
@@ -171,6 +172,7 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     o.grad_sums += n0 * 48;
     o.cull_bound += n0 * 4; o.inst_c += cap0 * 4; o.attr += n0 * 16;
     o.key_bits += h ? (proj_a + 1) * 8 : 0;
+    o.block_tiles += h ? (proj_a + 1) * 4 : 0;
     o.tile_bound += t0 * 4;
     if (h == 0) {
       blk_a = ((size_t)H.g.N + GH_BLOCK - 1) / GH_BLOCK; items_a = (size_t)H.g.n_items; tab_a = gh_sort_table_words(H.g);

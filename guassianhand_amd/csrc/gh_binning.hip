@@ -455,23 +455,50 @@ void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*
 
 // ------------------------------------------------------------------------------------------------
 // Level 2: walk the Gaussians in depth order.
-// Per-block sums of tiles-touched in depth-sorted order.
-__global__ __launch_bounds__(GH_BLOCK) void gh_count_sorted_kernel(int N, const uint32_t* __restrict__ perm,
+// Per-block sums of tiles-touched in depth-sorted order (the emit kernel's slot scan) — and, in the same launch, the RECORD slots:
+// thread i here is thread i of the projection kernel (same block size), whose blocks left their instance counts in block_tiles;
+// every block adds up the counts of the blocks before it (coalesced L2 reads) and scans its own 256 counts, so slot_begin[n]
+// = number of instances of all (view, Gaussian) pairs in front of n in the projection kernel's thread order. The backward's
+// sub-records live there: the chain-rule kernel walks the pairs in that order and reads one contiguous stretch per wave.
+__global__ __launch_bounds__(GH_BLOCK) void gh_count_sorted_kernel(int N, int P, int NV, float rdiv, const uint32_t* __restrict__ perm,
                                                                     const uint32_t* __restrict__ tiles_touched,
-                                                                    uint32_t* __restrict__ block_sums) {
+                                                                    uint32_t* __restrict__ block_sums,
+                                                                    const uint32_t* __restrict__ block_tiles,
+                                                                    uint32_t* __restrict__ slot_begin) {
   __shared__ unsigned s_wsum[GH_BLOCK / GH_WAVE];
-  const int i = blockIdx.x * GH_BLOCK + threadIdx.x;
+  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE], s_p[GH_BLOCK / GH_WAVE];
+  const int tid = threadIdx.x;
+  const int i = blockIdx.x * GH_BLOCK + tid;
   const unsigned c = i < N ? tiles_touched[perm[i]] : 0u;
+  // (view, Gaussian) of projection thread i: Gaussian-major, views adjacent (NV == 0: row-major, the pose batch)
+  uint32_t n = 0u;
+  if (i < N) {
+    if (NV == 0) n = (uint32_t)i;
+    else { const uint32_t r = rdiv > 0.0f ? gh_div_small((uint32_t)i, (uint32_t)NV, rdiv) : (uint32_t)i / (uint32_t)NV; n = ((uint32_t)i - r * (uint32_t)NV) * (uint32_t)P + r; }
+  }
+  const uint32_t ct = i < N ? tiles_touched[n] : 0u;
+  uint32_t part = 0;
+  const uint32_t blk = blockIdx.x;
+  for (uint32_t b = tid; b < blk; b += 4 * GH_BLOCK) {
+    const uint32_t b1 = b + GH_BLOCK, b2 = b + 2 * GH_BLOCK, b3 = b + 3 * GH_BLOCK;    // four loads in flight per trip
+    const uint32_t v0 = block_tiles[b], v1 = b1 < blk ? block_tiles[b1] : 0u, v2 = b2 < blk ? block_tiles[b2] : 0u,
+                   v3 = b3 < blk ? block_tiles[b3] : 0u;
+    part += (v0 + v1) + (v2 + v3);
+  }
+  part = gh_wave_sum_u32(part);
   const unsigned ws = gh_wave_sum_u32(c);
-  if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = ws;
-  __syncthreads();
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  if ((tid & 63) == 0) { s_wsum[tid >> 6] = ws; s_p[tid >> 6] = part; }
+  uint32_t total;
+  const uint32_t excl = gh_block_excl_scan(ct, s_w, &total);        // (two barriers: s_wsum / s_p are visible behind them)
+  if (tid == 0) block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  if (i < N) slot_begin[n] = ((s_p[0] + s_p[1]) + (s_p[2] + s_p[3])) + excl;
 }
 
 // One thread per (view, Gaussian) IN DEPTH ORDER: block-local scan -> first emit slot of the Gaussian, then one
 // instance per tile of its rect that passes the exact ellipse/tile test (the same test that counted them in the
 // projection kernel), row-major: key = global tile id, payload = view*P+gaussian.
-// A Gaussian's instances occupy consecutive slots [slot_begin, slot_begin + tiles): the backward sums its records there.
+// A Gaussian's instances occupy consecutive emit slots (the stable partition below reads them in this order); the backward's
+// sub-records live at the RECORD slots gh_count_sorted_kernel numbered, not here.
 // The instances are written by the WAVE, not by their Gaussian's lane: the 64 Gaussians of a wave own one contiguous run of
 // slots; lane l of trip j takes slot 64 j + l of the run, finds its Gaussian (binary search over the wave's prefix sums in
 // LDS) and the tile (the k-th set bit of the Gaussian's hit mask) — coalesced stores and ceil(run / 64) trips, where one
@@ -489,7 +516,7 @@ __device__ __forceinline__ uint32_t gh_kth_set_bit(uint32_t lo, uint32_t hi, uin
 
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
-    const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ slot_begin, float4* __restrict__ geom,
+    const uint32_t* __restrict__ block_sums, float4* __restrict__ geom,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP, uint32_t flags,
     const float* __restrict__ tile_depth_bound, const float* __restrict__ depth) {
   constexpr int NW = GH_BLOCK / GH_WAVE;
@@ -536,7 +563,6 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     if (total > cap) atomicOr(&ctr->overflow, 1u);          // (the projection kernel cleared the word; bit 3 may already be set)
   }
   const uint32_t wave_base = blk_off + woff, wave_total = s_w[wid];
-  if (i < N) slot_begin[n] = wave_base + x - cnt;
   // the wave's run of slots, 64 per trip
   for (uint32_t j = 0; j < wave_total; j += GH_WAVE) {
     const uint32_t sl = j + (uint32_t)lane;
@@ -629,14 +655,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   const uint32_t gid = vals[i];
   const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line: record, tile rect, tile hit mask
   const float4 a = grec[0], b = grec[1], c = grec[2];
-  const uint32_t slot0 = slot_begin[gid];            // first emit slot (4-byte gather from an L2-sized array; keeping it
-                                                     // in the geometry line cost the emit kernel a scattered line write)
+  const uint32_t slot0 = slot_begin[gid];            // first record slot (4-byte gather from an L2-sized array)
   const float cb = c.x;
   uint32_t tl, ty;                                     // tile inside the view, its row
   if (rtiles > 0.0f) { tl = t - gh_div_small(t, (uint32_t)tiles, rtiles) * (uint32_t)tiles; ty = gh_div_small(tl, (uint32_t)gx, rgx); }
   else { tl = t % (uint32_t)tiles; ty = tl / (uint32_t)gx; }
   const uint32_t tx = tl - ty * (uint32_t)gx;
-  // emit slot of (gid, tile): the Gaussian's instances were emitted row-major over the HIT tiles of its rect
+  // record slot of (gid, tile): the Gaussian's slots are numbered row-major over the HIT tiles of its rect
   const uint32_t r = __float_as_uint(c.y);
   const uint32_t minx = r & 255u, miny = (r >> 8) & 255u, maxx = (r >> 16) & 255u, maxy = r >> 24;
   const uint32_t bit = (ty - miny) * (maxx - minx) + (tx - minx);
@@ -691,7 +716,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
         }
     }
   }
-  gh_stream(&sorted_slot[i], slot0 + before);           // (streamed: see gh_stream)
+  // (D > max_instances: the lists are a truncated, invalid set and record slots run up to D - 1: keep the backward's stores inside)
+  const uint32_t rslot = slot0 + before;
+  gh_stream(&sorted_slot[i], rslot < cap ? rslot : cap - 1u);           // (streamed: see gh_stream)
   const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
   gh_stream(&r0[i], a); gh_stream(&r1[i], b); gh_stream(&r2[i], make_float2(cb, __uint_as_float(m)));
   if (flags & GH_FLAG_STATIC_LISTS) gh_stream(&inst_c[i], b.x);   // the conic's C again, compact: what gh_forward_refresh reads of r1
@@ -756,8 +783,10 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
 
   // level 2: emit in depth order
   const uint32_t* tiles_touched = (const uint32_t*)(ws + L.tiles_touched);
-  hipLaunchKernelGGL(gh_count_sorted_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, perm, tiles_touched,
-                     (uint32_t*)(ws + L.block_sums));
+  const bool per_view = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
+  hipLaunchKernelGGL(gh_count_sorted_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, per_view ? 0 : g.NV,
+                     g.N < (1 << 24) && !per_view ? 1.0f / (float)g.NV : 0.0f, perm, tiles_touched,
+                     (uint32_t*)(ws + L.block_sums), (const uint32_t*)(ws + L.block_tiles), (uint32_t*)(ws + L.slot_begin));
   // level 3: stable partition by tile id; an odd number of passes starts in the b buffers so the result is in *_a
   const int tile_passes = gh_radix_passes((size_t)g.cap, g.tile_bits);
   uint32_t* ka = (uint32_t*)(ws + L.keys_a); uint32_t* kb = (uint32_t*)(ws + L.keys_b);
@@ -766,7 +795,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* k_in = start_b ? kb : ka; uint32_t* k_out = start_b ? ka : kb;
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
-                     (const uint32_t*)(ws + L.block_sums), (uint32_t*)(ws + L.slot_begin), (float4*)(ws + L.geom), k_in, v_in, ctr,
+                     (const uint32_t*)(ws + L.block_sums), (float4*)(ws + L.geom), k_in, v_in, ctr,
                      g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags, tile_depth_bound, (const float*)(ws + L.depth));
   if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }    // the emit kernel has written D (it stores nothing past cap)
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);

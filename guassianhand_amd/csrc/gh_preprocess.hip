@@ -32,8 +32,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk,
-    uint2* __restrict__ key_bits, float rdiv, float* __restrict__ cull_bound_out, const float* __restrict__ tile_bound) {
+    uint2* __restrict__ key_bits, float rdiv, float* __restrict__ cull_bound_out, const float* __restrict__ tile_bound,
+    uint32_t* __restrict__ block_tiles) {
   __shared__ uint2 s_bits[GH_BLOCK / GH_WAVE];
+  __shared__ uint32_t s_tiles[GH_BLOCK / GH_WAVE];
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
   uint32_t k_or = 0u, k_and = 0xFFFFFFFFu;              // bits of this thread's depth key if its Gaussian emits instances
@@ -164,14 +166,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     if (radii) radii[n] = radius;
     if (tiles > 0) { k_or = dkey; k_and = dkey; }     // only Gaussians that emit instances need to be in depth order
   }
-  // (OR, AND) of the block's keys: the depth sort skips a digit no two keys differ in (views at ~1 m: the top byte)
+  // (OR, AND) of the block's keys: the depth sort skips a digit no two keys differ in (views at ~1 m: the top byte); and the
+  // block's instance count: record slots are numbered in THIS kernel's thread order (gh_count_sorted_kernel scans the sums)
+  uint32_t tsum = t < N ? tiles : 0u;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { k_or |= __shfl_xor(k_or, o); k_and &= __shfl_xor(k_and, o); }
-  if ((threadIdx.x & 63) == 0) s_bits[threadIdx.x >> 6] = make_uint2(k_or, k_and);
+  for (int o = 32; o > 0; o >>= 1) { k_or |= __shfl_xor(k_or, o); k_and &= __shfl_xor(k_and, o); tsum += __shfl_xor(tsum, o); }
+  if ((threadIdx.x & 63) == 0) { s_bits[threadIdx.x >> 6] = make_uint2(k_or, k_and); s_tiles[threadIdx.x >> 6] = tsum; }
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) {
     key_bits[blockIdx.x] = make_uint2(s_bits[0].x | s_bits[1].x | s_bits[2].x | s_bits[3].x,
                                       s_bits[0].y & s_bits[1].y & s_bits[2].y & s_bits[3].y);
+    block_tiles[blockIdx.x] = (s_tiles[0] + s_tiles[1]) + (s_tiles[2] + s_tiles[3]);
+  }
 }
 
 void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, int32_t* radii, char* ws,
@@ -196,7 +202,7 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii,
                      T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk), (uint2*)(ws + L.key_bits),
                      g.N < (1 << 24) ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f,
-                     (float*)(ws + L.cull_bound), tile_bound);
+                     (float*)(ws + L.cull_bound), tile_bound, (uint32_t*)(ws + L.block_tiles));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -210,22 +216,28 @@ __device__ __forceinline__ void gh_block_acc(float (*s_part)[64], int slot, floa
 // One thread per Gaussian; loops the views so gradients w.r.t. view-independent attributes are summed
 // in registers/own memory in a fixed order (no atomics, bitwise reproducible).
 // (SH colours only — with precomputed colours the chain-rule kernel sums the records itself, gh_sum_records.)
-// Fixed-order sum of every Gaussian's per-(instance, quadrant) gradient sub-records; its instances are the
-// consecutive emit slots [slot_begin, slot_begin + tiles). Few registers, so the reads run at full occupancy; the
-// chain-rule kernel then reads the 9 sums coalesced. Gaussians are taken in INDEX order: slot_begin / tiles_touched /
-// the 48-byte sums are then coalesced and only the stretch of sub-records is a random (but contiguous) read; walking
-// them in depth order (contiguous sub-records, three scattered per-Gaussian accesses) measured 10 us slower.
-__global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, uint32_t cap,
+// Fixed-order sum of every Gaussian's per-(instance, quadrant) gradient sub-records; they sit at the consecutive record slots
+// [slot_begin, slot_begin + tiles). Few registers, so the reads run at full occupancy; the chain-rule kernel then reads the 9 sums
+// coalesced. The (view, Gaussian) pairs are taken in the order their record slots are numbered (round 5: the projection kernel's
+// thread order, gh_count_sorted_kernel), so neighbouring quads read neighbouring stretches of sub-records (1024x1024 SH3: 111 ->
+// 104 us; with slots in emit = depth order the stretches were scattered).
+__global__ __launch_bounds__(GH_BLOCK) void gh_record_sum_kernel(int N, int P, int NV, float rdiv, uint32_t cap,
                                                                   const uint32_t* __restrict__ slot_begin,
                                                                   const uint32_t* __restrict__ tiles_touched,
                                                                   const float* __restrict__ inst_grad,
                                                                   const uint32_t* __restrict__ inst_flag, float4* __restrict__ gsum) {
   // FOUR lanes per (view, Gaussian), one per quadrant: the quad reads the 144 contiguous bytes of an instance's four
   // sub-records.
+  // Quads walk the (view, Gaussian) pairs in the order the record slots are numbered (the projection kernel's thread order:
+  // Gaussian-major, views adjacent; NV == 0: row-major, the pose batch), so neighbouring quads read neighbouring slots.
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   const int j = t >> 2, q = t & 3;
   const bool live = j < N;                              // whole quads are live or not; no early return (DPP below)
-  const uint32_t n = live ? (uint32_t)j : 0u;
+  uint32_t n = 0u;
+  if (live) {
+    if (NV == 0) n = (uint32_t)j;
+    else { const uint32_t i = rdiv > 0.0f ? gh_div_small((uint32_t)j, (uint32_t)NV, rdiv) : (uint32_t)j / (uint32_t)NV; n = ((uint32_t)j - i * (uint32_t)NV) * (uint32_t)P + i; }
+  }
   uint32_t o0 = 0, o1 = 0;
   if (live) {
     o0 = slot_begin[n]; o1 = o0 + tiles_touched[n];
@@ -635,17 +647,18 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   // 164 us). The image size decides, so every call of a shape (and both halves of a split call) takes the same path.
   const bool rgb = in->colors_precomp != nullptr;
   const bool fused = rgb && (size_t)g.H * (size_t)g.W <= ((size_t)1 << 19);
+  const bool halves = v_split >= 0;                      // a split call: the second half's instance arrays start cap_a entries in
   auto kern = rgb ? (fused ? (geom ? gh_preprocess_bwd_kernel<true, true, true> : gh_preprocess_bwd_kernel<true, false, true>)
                            : (geom ? gh_preprocess_bwd_kernel<true, true, false> : gh_preprocess_bwd_kernel<true, false, false>))
                   : (geom ? gh_preprocess_bwd_kernel<false, true, false> : gh_preprocess_bwd_kernel<false, false, false>);
   const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
   if ((parts & GH_PBWD_RECORD_SUM) && !fused)
-    hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, (uint32_t)g.cap,
+    hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, g.P, per_view ? 0 : g.NV,
+                       g.N < (1 << 24) && !per_view ? 1.0f / (float)g.NV : 0.0f, (uint32_t)g.cap,
                        (const uint32_t*)(wg + L.slot_begin), (const uint32_t*)(wg + L.tiles_touched),
                        (const float*)(ws + L.inst_grad), (const uint32_t*)(ws + L.inst_flag), (float4*)(ws + L.grad_sums));
   if (!(parts & GH_PBWD_CHAIN)) return;
   const int nblk_sh = gh_launch_sh_colour_bwd(d, g, in, gr, wg, ws, L, s);     // SH mode only; no-op with colors_precomp
-  const bool halves = v_split >= 0;                      // a split call: the second half's instance arrays start cap_a entries in
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, *gr, g.P, g.NV, g.H, g.W,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, lg,
                      (const uint32_t*)(wg + L.tiles_touched), (const float4*)(ws + L.dmean_sh),

@@ -2,8 +2,10 @@
 
 Same names, argument meaning and outputs as the reference for the part of `GS3DRenderer` that sits on
 the hot path: `GaussianModel` (:114-119), the GSLayer activations (:191-214) and the per-view loop of
-`forward_single_batch` (:494-510) with its Gaussian selection (:468-477, `select_gaussians`). The feature networks above it (attention, MLPs, UV lookups) are out
-of scope and stay in the reference.
+`forward_single_batch` (:494-510) with its Gaussian selection (:468-477, `select_gaussians`), and the composition of the
+whole of `forward_single_batch` (:448-512) over the reference's own sub-modules (`forward_single_batch`,
+`fused_renderer_cls`). The feature networks above it (attention, MLPs) are out of scope and stay in the
+reference: they are taken as callables of the renderer object.
 
 `render_views(...)` is the MI355X form of the per-view loop: all views in one launch sequence, blend fused into the
 kernels. The reference's own protocol (blend in torch, two `GaussianRasterizer` calls per view) needs nothing from this
@@ -141,3 +143,82 @@ def render_views(gs: GaussianModel, w2cs: torch.Tensor, intrinsics: torch.Tensor
     out["image_chw"], out["alpha"] = img, alpha        # the rasteriser's own layouts (consumed by loss.fit_image_loss)
     out["3dgs"] = gs
     return out
+
+
+# ---- forward_single_batch (renderer_one_shot.py:448-512), composed -------------------------------------------------------
+def _lookup_uv_map(self, vert_uv: torch.Tensor, param_chw: torch.Tensor) -> torch.Tensor:
+    """`self.query_triplane_texture(vert_uv, param.unsqueeze(0).unsqueeze(0)).squeeze(0)` (renderer_one_shot.py:420-446 at the
+    call sites :489-492) for vert_uv (1,N,2): positions rescaled from [-radius_texture, radius_texture] to [-1, 1]
+    (`scale_tensor`, tgs/utils/ops.py:23-34), bilinear, align_corners=True, zeros outside -> (N,C).
+    The map arrives as the reference's (C,Hm,Wm) parameter; the kernel reads it channel-last, so a parameter whose MEMORY is
+    (Hm,Wm,C) — `nn.Parameter(torch.zeros(Hm, Wm, C)).permute(2, 0, 1)` — is read in place, any other layout through one copy.
+    UVs that carry a gradient (a differentiable `get_uvd` in full training) take torch's grid_sample, which differentiates
+    w.r.t. the grid as well; the one-shot fit's UVs do not (infer_one_shot.py:340-343 trains maps, not UVs)."""
+    from .uvmap import uv_sample
+    r = float(getattr(self.cfg, "radius_texture", 1.0))
+    pos = vert_uv[0]
+    pos = (pos - (-r)) / (r - (-r))
+    pos = pos * (1 - (-1)) + (-1)
+    if pos.requires_grad or not param_chw.is_cuda:
+        out = F.grid_sample(param_chw[None], pos[None, :, None, :], align_corners=True, mode="bilinear")
+        return out[0, :, :, 0].transpose(0, 1)
+    if pos.shape[0] == 0:
+        return param_chw.new_zeros(0, param_chw.shape[0])
+    return uv_sample(param_chw.permute(1, 2, 0), pos)
+
+
+def forward_single_batch(self, gs_hidden_features: torch.Tensor, query_points: torch.Tensor, w2cs: torch.Tensor,
+                         intrinsics: torch.Tensor, height: int, width: int, znear, zfar,
+                         background_color: Optional[torch.Tensor], color_w=None, xyz_b=None, color_b=None, opacity_b=None,
+                         vert3d_uv=None, face_uv=None, face_uv_xy=None):
+    """GS3DRenderer.forward_single_batch (renderer_one_shot.py:448-512) with the reference's signature, over the reference's
+    own sub-modules taken from `self` as callables — `gs_valid` (:468), `vert_pos_refinement` (:474), `forward_gs` (:478),
+    `threshold_low` / `threshold_high`, `cfg.scaling_modifier` / `cfg.sh_degree` / `cfg.radius_texture`,
+    `gs_net.cfg.use_rgb` — and `get_uvd` (livehand.input_encoder, :481; `self.get_uvd` if the object carries one):
+
+        validity prune (> threshold_low)  U  duplicate-and-refine (> threshold_high)      select_gaussians: one read-back (:469-473)
+        cat(valid, refined copies) / cat(valid features, copied features)                 :476-477
+        forward_gs -> GaussianModel                                                       :478
+        get_uvd -> UVs normalised to [-1, 1] (u / 1, v / 0.5)                             :481-486
+        color_b / opacity_b maps looked up at the UVs                                     gh_uv_sample_forward (:489-492)
+        all views in ONE launch sequence, blend fused, RGB + mask in one walk             render_views (:494-503)
+        dict of stacked (Nv,H,W,3) maps + "3dgs"                                          :505-510
+
+    znear / zfar are accepted and ignored exactly as the reference's Camera ignores them (:99-100 forces 0.01 / 1000)."""
+    if_gs_valid = self.gs_valid(gs_hidden_features, query_points)
+    pts_valid, feat_valid, pts_copied, feat_copied = select_gaussians(if_gs_valid.squeeze(1), query_points, gs_hidden_features,
+                                                                      self.threshold_low, self.threshold_high)
+    pts_copied = self.vert_pos_refinement(feat_copied, pts_copied)
+    pts = torch.cat([pts_valid, pts_copied], dim=-2)
+    feats = torch.cat([feat_valid, feat_copied], dim=-2)
+    gs = self.forward_gs(feats, pts)
+
+    get_uvd = getattr(self, "get_uvd", None)
+    if get_uvd is None:
+        from livehand.input_encoder import get_uvd          # the reference's own dependency (renderer_one_shot.py:19)
+    vert_uv, _vert_d, _ = get_uvd(pts, vert3d_uv[0], face_uv, face_uv_xy)
+    vert_uv = vert_uv.unsqueeze(0)
+    vert_uv[..., 0] = 2.0 * (vert_uv[..., 0] / 1) - 1.0
+    vert_uv[..., 1] = 2.0 * (vert_uv[..., 1] / 0.5) - 1.0
+    if color_b is not None:
+        color_b = _lookup_uv_map(self, vert_uv, color_b)
+    if opacity_b is not None:
+        opacity_b = _lookup_uv_map(self, vert_uv, opacity_b)
+
+    nv = w2cs.shape[0]
+    bg = background_color if background_color is not None else torch.zeros(3, dtype=torch.float32, device=pts.device)
+    out = render_views(GaussianModel(gs.xyz, gs.opacity, gs.rotation, gs.scaling, gs.shs), w2cs, intrinsics, int(height), int(width), bg,
+                       ret_mask=True, color_w=color_w, xyz_b=xyz_b, color_b=color_b, opacity_b=opacity_b,
+                       use_rgb=bool(self.gs_net.cfg.use_rgb), sh_degree=int(self.cfg.sh_degree),
+                       scaling_modifier=float(self.cfg.scaling_modifier))
+    return {"comp_rgb": out["comp_rgb"], "comp_rgb_bg": bg.unsqueeze(0).expand(nv, -1) if nv else bg.new_zeros(0, 3),
+            "comp_mask": out["comp_mask"], "3dgs": gs}
+
+
+def fused_renderer_cls(base):
+    """The reference's plugin seam (`renderer_cls`, config/config_one_shot.yaml:175, resolved by tgs.find,
+    tgs/__init__.py:4-9): a subclass of the given `GS3DRenderer` whose forward_single_batch is the composed MI355X path
+    above; everything else — configure(), the feature fetch, SelfAttn, the batch loop of forward() (:514-648) — is the
+    base class's. `guassianhand_amd.tgs_renderer.GS3DRenderer` is this class over tgs.models.renderer_one_shot.GS3DRenderer."""
+    return type(base.__name__, (base,), {"forward_single_batch": forward_single_batch, "__module__": __name__,
+                                         "__doc__": f"{base.__module__}.{base.__name__} with the MI355X forward_single_batch"})

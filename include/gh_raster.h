@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define GH_VERSION_MAJOR 0
-#define GH_VERSION_MINOR 5
+#define GH_VERSION_MINOR 6
 
 #define GH_TILE 16           /* tile edge in pixels (binning granularity; fixes which Gaussians a pixel sees) */
 #define GH_CAM_FLOATS 40     /* floats per camera record, see GhCamera */
@@ -194,13 +194,17 @@ typedef struct GhLayout {
   size_t rect;           /* uint32[n_views*P]  minx | miny<<8 | maxx<<16 | maxy<<24 (tile units) */
   size_t clamped;        /* uint8 [n_views*P]  SH colour clamp flags (bit ch) */
   size_t tiles_touched;  /* uint32[n_views*P]  tiles of the rect the alpha >= 1/255 ellipse reaches (exact tile culling); 0 = none */
-  size_t slot_begin;     /* uint32[n_views*P]  first emit slot of the Gaussian; its instances are [begin, begin+tiles) */
+  size_t slot_begin;     /* uint32[n_views*P]  first RECORD slot of the (view, Gaussian): the backward's sub-records of its instances are
+                            [begin, begin+tiles), row-major over the hit tiles of its rect. Record slots are numbered in the order
+                            the per-Gaussian kernels walk the (view, Gaussian) pairs — Gaussian-major, the views of a row adjacent
+                            (pose batch: row-major) — so that the chain rule's wave reads one contiguous stretch of sub-records */
   size_t depth_keys_a, depth_keys_b; /* uint32[n_views*P] level-1 sort: depth bits (0xFFFFFFFF when culled); result in _a */
   size_t depth_vals_a, depth_vals_b; /* uint32[n_views*P] level-1 payload: view*P + gaussian; depth order in _a */
   size_t block_sums;     /* uint32[...]        scan scratch */
   size_t keys_a, keys_b; /* uint32[max_instances] level-3 sort: global tile id; sorted result in keys_a */
   size_t vals_a, vals_b; /* uint32[max_instances] payload view*P + gaussian; sorted result in vals_a */
-  size_t sorted_slot;    /* uint32[max_instances] sorted position -> emit slot (where the backward puts its record) */
+  size_t sorted_slot;    /* uint32[max_instances] sorted position -> record slot (where the backward puts its sub-records): a permutation
+                            of 0 .. D-1 */
   size_t inst_r0;        /* float4[max_instances] sorted per-instance render record (px, py, conicA, conicB) */
   size_t inst_r1;        /* float4[max_instances]                                   (conicC, opacity, r, g)  */
   size_t inst_r2;        /* float2[max_instances]                                   (b, bits: 4x4-block mask of the tile) */
@@ -237,6 +241,7 @@ typedef struct GhLayout {
                             pass whose digit is the same in every key (OR & ~AND has no bit in it) degenerates to a copy */
   size_t tile_bound;     /* float[n_views*tiles] the effective occlusion bound of this call (GhInputs.tile_depth_bound after the
                             neighbourhood test; +inf = unbounded), read by every kernel that decides list membership */
+  size_t block_tiles;    /* uint32[projection blocks] instances counted by each block of the projection kernel (record-slot scan) */
 } GhLayout;
 
 /* Library version: major<<16 | minor. */

@@ -1,4 +1,5 @@
 """Shared helpers for the parity tests (oracle = checker, HIP path = thing under test)."""
+import math
 import torch
 
 from guassianhand_amd.scenes import make_scene
@@ -161,3 +162,67 @@ def float64_grads(cams_, xyz, opacity, scaling, rotation, shs, use_rgb, sh_degre
     out["colors_precomp" if use_rgb else "shs"] = leaves["shs"].grad
     out.update({k: v.grad for k, v in bl.items()})
     return {k: (torch.zeros_like(leaves["xyz"][:0]) if v is None else v) for k, v in out.items()}
+
+
+# ---- stand-ins for the sub-modules forward_single_batch calls (renderer_one_shot.py:448-512) -------------------------------
+# Shared by tests/golden/make_batch_fixture.py (which hands them to the REFERENCE's own forward_single_batch) and by
+# tests/test_gpu_single_batch.py (which hands them to the composed path): the networks themselves are out of scope, what is
+# pinned is the composition around them. Weights come from a fixed seed; the validity score is read straight from feature
+# column 0, so that the two thresholds decide on bit-identical values on every device.
+class BatchStandIns:
+    C = 12                               # feature channels
+
+    def __init__(self, device="cpu", use_rgb=True, seed=11):
+        g = torch.Generator().manual_seed(seed)
+        mk = lambda *s: (0.4 * torch.randn(*s, generator=g)).to(device)
+        self.W = {"xyz": mk(self.C, 3), "scaling": 0.5 * mk(self.C, 3), "rotation": mk(self.C, 4), "opacity": 3.0 * mk(self.C, 1),
+                  "shs": mk(self.C, 3 if use_rgb else 48)}
+        self.Wr = mk(self.C, 3)
+        self.use_rgb = use_rgb
+        self.threshold_low, self.threshold_high = 0.1, 0.9
+
+    def gs_valid(self, feat, pts):
+        return feat[:, 0:1]
+
+    def vert_pos_refinement(self, feat, pts):
+        return pts + 0.003 * torch.tanh(feat @ self.Wr)
+
+    def forward_gs(self, feat, pts):
+        from guassianhand_amd.renderer import gs_activations
+        raw = {k: feat @ w for k, w in self.W.items()}
+        raw["scaling"] = raw["scaling"] - 5.0
+        return gs_activations(raw, pts, use_rgb=self.use_rgb)
+
+    @staticmethod
+    def get_uvd(pts, vert3d_uv0, face_uv, face_uv_xy):
+        """(uv in [0,1] x [0,0.5], distance, intermediates) like livehand.input_encoder.get_uvd's return triple."""
+        uv = torch.stack([torch.sigmoid(25.0 * pts[:, 0]), 0.5 * torch.sigmoid(25.0 * pts[:, 1])], 1)
+        return uv.detach(), pts[:, 2].detach(), None
+
+    def namespace(self, device, sh_degree=3, scaling_modifier=1.0, radius_texture=1.0):
+        """The attributes forward_single_batch / forward_single_view read of the renderer object."""
+        from types import SimpleNamespace
+        return SimpleNamespace(gs_valid=self.gs_valid, vert_pos_refinement=self.vert_pos_refinement, forward_gs=self.forward_gs,
+                               threshold_low=self.threshold_low, threshold_high=self.threshold_high, device=torch.device(device),
+                               cfg=SimpleNamespace(scaling_modifier=scaling_modifier, sh_degree=sh_degree, radius_texture=radius_texture),
+                               gs_net=SimpleNamespace(cfg=SimpleNamespace(use_rgb=self.use_rgb)), get_uvd=self.get_uvd)
+
+
+def batch_inputs(N=400, n_views=2, H=64, W=48, map_hw=(16, 32), seed=5):
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.rand(N, BatchStandIns.C, generator=g)
+    feat[:, 0] = torch.rand(N, generator=g)
+    feat[:, 0][(feat[:, 0] - 0.1).abs() < 1e-4] = 0.2          # keep the score off the thresholds
+    feat[:, 0][(feat[:, 0] - 0.9).abs() < 1e-4] = 0.8
+    pts = 0.05 * torch.randn(N, 3, generator=g)
+    K = torch.eye(4).repeat(n_views, 1, 1)
+    K[:, 0, 0] = K[:, 1, 1] = 180.0
+    K[:, 0, 2], K[:, 1, 2] = W / 2.0, H / 2.0
+    w2c = torch.eye(4).repeat(n_views, 1, 1)
+    for v in range(n_views):
+        a = 0.35 * v
+        w2c[v, :3, :3] = torch.tensor([[math.cos(a), 0.0, math.sin(a)], [0.0, 1.0, 0.0], [-math.sin(a), 0.0, math.cos(a)]])
+        w2c[v, :3, 3] = torch.tensor([0.01 * v, -0.01, 1.0])
+    return dict(feat=feat, pts=pts, w2cs=w2c, Ks=K, H=H, W=W, bg=torch.tensor([0.1, 0.2, 0.3]),
+                color_w=1 + 0.05 * torch.randn(48, generator=g), xyz_b=0.004 * torch.randn(3, generator=g),
+                color_b=0.05 * torch.randn(48, *map_hw, generator=g), opacity_b=0.05 * torch.randn(1, *map_hw, generator=g))

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(gh_lib_path):
     for sym in header_symbols():
         assert hasattr(L, sym), sym
     _abi.declare(L)
-    assert L.gh_version() == (0 << 16) | 5
+    assert L.gh_version() == (0 << 16) | 6
 
 
 def test_struct_sizes_match_header():
