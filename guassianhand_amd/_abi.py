@@ -11,6 +11,8 @@ GH_FLAG_PER_VIEW_GAUSSIANS = 4
 GH_FLAG_SPLIT_STREAMS = 8
 GH_FLAG_STATIC_LISTS = 16
 GH_FLAG_DEPTH24 = 32
+GH_COUNTER_ERROR_MASK = 15     # GhCounters.overflow bits 0-3: errors
+GH_COUNTER_DEPTH24_OK = 16     # bit 4: information (the depth keys' top byte did not vary)
 
 GH_OK = 0
 GH_ERR_INVALID_ARG = -1
@@ -60,7 +62,7 @@ class GhAdamTensor(C.Structure):
 LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "depth", "rect", "clamped",
                  "tiles_touched", "slot_begin", "depth_keys_a", "depth_keys_b", "depth_vals_a", "depth_vals_b",
                  "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "sorted_slot", "inst_r0", "inst_r1", "inst_r2",
-                 "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "cull_bound", "inst_c", "attr", "half_counters", "key_bits", "tile_bound", "block_tiles")
+                 "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "cull_bound", "inst_c", "attr", "half_counters", "key_bits", "tile_bound", "block_tiles", "render_guard")
 
 
 class GhLayout(C.Structure):

@@ -112,6 +112,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
                                                           // halves: + 1 block of rounding + 1 word each)
   L->tile_bound = take((size_t)g.NV * g.tiles * 4);
   L->block_tiles = take((gh_proj_blocks(g) + 4) * 4);     // (two halves: + 1 block of rounding + 1 spare word each)
+  L->render_guard = take(512);                            // one word (+ a second, 256 bytes on, for the other half of a split call)
   L->total_bytes = off;
   return GH_OK;
 }
@@ -173,6 +174,7 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     o.cull_bound += n0 * 4; o.inst_c += cap0 * 4; o.attr += n0 * 16;
     o.key_bits += h ? (proj_a + 1) * 8 : 0;
     o.block_tiles += h ? (proj_a + 1) * 4 : 0;
+    o.render_guard += (size_t)h * 256;
     o.tile_bound += t0 * 4;
     if (h == 0) {
       blk_a = ((size_t)H.g.N + GH_BLOCK - 1) / GH_BLOCK; items_a = (size_t)H.g.n_items; tab_a = gh_sort_table_words(H.g);
@@ -230,7 +232,8 @@ __global__ void gh_merge_counters_kernel(const GhCounters* __restrict__ a, const
   if (need > 0xFFFFFFFFull) need = 0xFFFFFFFFull;
   const unsigned long long tot = da + db;
   out->num_rendered = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;
-  out->overflow = a->overflow | b->overflow;                // (bit 0: a half exceeded its share; bit 2: depth-bound miss)
+  // errors: either half's (bit 0: a half exceeded its share; bit 2: depth-bound miss; ...); the depth-key information bit: both halves'
+  out->overflow = ((a->overflow | b->overflow) & GH_COUNTER_ERROR_MASK) | (a->overflow & b->overflow & GH_COUNTER_DEPTH24_OK);
   out->reserved[0] = (uint32_t)need;
   out->reserved[1] = 0u;
 }

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w
 // (gh_preprocess_fwd_kernel; key_bits[n_bits] receives the word). Computed ONCE, by block (0, 0) of the first pass's histogram
 // kernel; every later pass reads the word: a pass whose digit has no varying bit is the identity (its histogram kernel exits,
 // its scatter kernel copies). Keys that were left out of the (OR, AND) — Gaussians that emit no instance — may land anywhere.
-__device__ __forceinline__ void gh_store_varying_bits(uint2* __restrict__ key_bits, int n_bits, uint32_t* __restrict__ wide_flag) {
+__device__ __forceinline__ void gh_store_varying_bits(uint2* __restrict__ key_bits, int n_bits, uint32_t* __restrict__ wide_flag, bool nbits24) {
   __shared__ uint32_t s_or[GH_BLOCK / GH_WAVE], s_and[GH_BLOCK / GH_WAVE];
   uint32_t o = 0u, a = 0xFFFFFFFFu;
   for (int i = threadIdx.x; i < n_bits; i += GH_BLOCK) { const uint2 b = key_bits[i]; o |= b.x; a &= b.y; }
@@ -63,8 +63,12 @@ __device__ __forceinline__ void gh_store_varying_bits(uint2* __restrict__ key_bi
   if (threadIdx.x == 0) {
     const uint32_t varying = (s_or[0] | s_or[1] | s_or[2] | s_or[3]) & ~(s_and[0] & s_and[1] & s_and[2] & s_and[3]);
     key_bits[n_bits].x = varying;
-    // GH_FLAG_DEPTH24: this sort has no pass for the top byte — it must not vary (one thread per call: no contention)
-    if (wide_flag && (varying >> 24) != 0u) atomicOr(wide_flag, 8u);
+    // The top byte of the keys: when it does not vary the caller learns that GH_FLAG_DEPTH24 holds for this call (information bit);
+    // when it does and this sort has no pass for it (nbits24), the call is invalid (one thread per call: no contention)
+    if (wide_flag) {
+      if ((varying >> 24) == 0u) atomicOr(wide_flag, GH_COUNTER_DEPTH24_OK);
+      else if (nbits24) atomicOr(wide_flag, 8u);
+    }
   }
   __syncthreads();
 }
@@ -78,9 +82,9 @@ template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
                                                                   uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
                                                                   uint32_t* __restrict__ table, const uint2* __restrict__ key_bits,
-                                                                  int n_bits, uint32_t* __restrict__ wide_flag) {
+                                                                  int n_bits, uint32_t* __restrict__ wide_flag, int total_bits) {
   __shared__ uint32_t s_hist[MAXD];
-  if (key_bits && shift == 0 && blockIdx.x == 0 && blockIdx.y == 0) gh_store_varying_bits((uint2*)key_bits, n_bits, wide_flag);
+  if (key_bits && shift == 0 && blockIdx.x == 0 && blockIdx.y == 0) gh_store_varying_bits((uint2*)key_bits, n_bits, wide_flag, total_bits <= 24);
   if (!gh_digit_varies(key_bits, n_bits, shift, dmask)) return;       // the scatter of this pass is a plain copy
   const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
   const uint32_t seg = blockIdx.y, nblk = gridDim.x, ndig = dmask + 1u;
@@ -202,11 +206,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   for (int r = 0; r < ITEMS; ++r) {
     const uint32_t idx = wave_base + r * GH_WAVE + lane;
     key[r] = idx < n ? keys_in[idx] : ~0u;
-#ifdef GH_ABL_NOVALS       // timing ablation only (results invalid): what a keys-only (packed key | payload) partition pass would cost
-    val[r] = SELF ? (idx < n ? vals_in[idx] : 0u) : 0u;
-#else
     val[r] = idx < n ? vals_in[idx] : 0u;
-#endif
   }
 
   // digit base = exclusive scan over digits of tot[] + this block's row prefix
@@ -351,11 +351,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
       const uint32_t dg = (k >> shift) & dmask;
       const uint32_t dst = s_base[dg] + (e - s_lbase[dg]);
       keys_out[dst] = k;
-#ifdef GH_ABL_NOVALS
-      if (SELF) vals_out[dst] = s_val[e];
-#else
       vals_out[dst] = s_val[e];
-#endif
     }
   }
 }
@@ -379,7 +375,7 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
     const uint32_t dmask = (1u << nbits) - 1u, ndig = dmask + 1u;
     uint32_t* tot = table + (size_t)ndig * nblk;
     const dim3 gb(nblk, 1), gs(ndig, 1), blk(GH_BLOCK);
-    hipLaunchKernelGGL((gh_radix_hist_kernel<4, 1024, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, 0, dmask, table, key_bits, n_bits, wide_flag);
+    hipLaunchKernelGGL((gh_radix_hist_kernel<4, 1024, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, 0, dmask, table, key_bits, n_bits, wide_flag, nbits);
     hipLaunchKernelGGL(gh_radix_scan_kernel<4>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
     hipLaunchKernelGGL((gh_radix_scatter_kernel<4, 1024, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
                        0, dmask, nbits, table, tot, key_bits, n_bits);
@@ -396,11 +392,11 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
     uint32_t* tot = table + (size_t)segs * ndig * nblk;
     const dim3 gb(nblk, segs), gs(ndig, segs), blk(GH_BLOCK);
     if (nblk <= 128) {                                   // short segments: no scan kernel (see gh_radix_scatter_kernel)
-      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag);
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag, nbits);
       hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
                          lo, dmask, hi - lo, table, tot, key_bits, n_bits);
     } else {
-      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag);
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag, nbits);
       hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
       hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
                          lo, dmask, hi - lo, table, tot, key_bits, n_bits);
@@ -560,7 +556,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   if (blockIdx.x == gridDim.x - 1 && tid == 0) {        // the last block knows the instance total D
     const uint32_t total = blk_off + blk_sum;
     ctr->num_rendered = total;
-    if (total > cap) atomicOr(&ctr->overflow, 1u);          // (the projection kernel cleared the word; bit 3 may already be set)
+    // (the projection kernel cleared the word; bits 3 / 4 may already be set; a BINNING-only re-run clears a stale bit 0)
+    if (total > cap) atomicOr(&ctr->overflow, 1u); else atomicAnd(&ctr->overflow, ~1u);
   }
   const uint32_t wave_base = blk_off + woff, wave_total = s_w[wid];
   // the wave's run of slots, 64 per trip
@@ -731,10 +728,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
 // order up to differences between the views' r-th tiles. The order only affects scheduling, never results; the order
 // inside a bucket is arbitrary. (The backward's order comes from the forward itself: gh_render_fwd_kernel.)
 __global__ __launch_bounds__(GH_BLOCK) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int tiles, int NV,
-                                                                  uint32_t* __restrict__ order) {
+                                                                  uint32_t* __restrict__ order, const GhCounters* __restrict__ ctr,
+                                                                  uint32_t* __restrict__ render_guard) {
   __shared__ uint32_t s_cnt[256];
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   const int tid = threadIdx.x, v = blockIdx.x;
+  // the last kernel in front of the render: the error bits as they stand now, in a word of their own (the render kernel's waves
+  // read it through the scalar cache; its own atomics go to the counters' line)
+  if (v == 0 && tid == 0) *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK;
   ranges += (size_t)v * tiles;
   s_cnt[tid] = 0;
   __syncthreads();
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_tile_order_kernel(const uint2* __
 
 static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
   hipLaunchKernelGGL(gh_tile_order_kernel, dim3(g.NV), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges), g.tiles, g.NV,
-                     (uint32_t*)(ws + L.tile_order));
+                     (uint32_t*)(ws + L.tile_order), (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard));
 }
 
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s, const float* tile_depth_bound) {
@@ -778,7 +779,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   // GH_FLAG_DEPTH24: three passes (the top byte is asserted constant and checked by the first histogram kernel), else four
   const bool d24 = (d->flags & GH_FLAG_DEPTH24) != 0;
   gh_radix_sort_ex(dk_in, dv_in, dk_out, dv_out, &ctr->reserved[0], (uint32_t)g.N, d24 ? 24 : 32, (uint32_t)g.P, g.NV, table, s,
-                   (const uint2*)(ws + L.key_bits), n_proj_blocks, d24 ? &ctr->overflow : nullptr);
+                   (const uint2*)(ws + L.key_bits), n_proj_blocks, &ctr->overflow);
   const uint32_t* perm = dv_in;                       // (the sort swaps the pointers: four passes end in the *_a buffers, three in *_b)
 
   // level 2: emit in depth order

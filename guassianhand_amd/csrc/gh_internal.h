@@ -87,7 +87,8 @@ int gh_radix_passes(size_t cap, int nbits);
 // key_bits / n_bits: optional per-producer-block (OR, AND) of the key bits: a pass whose digit no two keys differ in is a copy.
 void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
                       int nbits, uint32_t seg_len, int segs, uint32_t* table, hipStream_t s, const uint2* key_bits = nullptr,
-                      int n_bits = 0, uint32_t* wide_flag = nullptr);    // wide_flag: |= 8 when a key bit above 23 varies (GH_FLAG_DEPTH24)
+                      int n_bits = 0, uint32_t* wide_flag = nullptr);    // wide_flag (needs key_bits): |= GH_COUNTER_DEPTH24_OK when no key bit
+                                                                         // above 23 varies, |= 8 when one does and nbits <= 24
 size_t gh_radix_table_words(size_t per_segment, int segs);
 void gh_launch_sh_colour_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, char* ws, const GhLayout& L, hipStream_t s);
 // wg: workspace whose tiles_touched (visibility of a (view, Gaussian)) counts — the geometry owner's

@@ -10,7 +10,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_l1_loss_kernel(const float4* __re
                                                                const GhCounters* __restrict__ guard) {
   __shared__ float s_w[GH_BLOCK / GH_WAVE];
   float acc = 0.0f;
-  if (guard && guard->overflow) grad_scale = 0.0f;       // the image is invalid (instance overflow): no gradient leaves here
+  if (guard && (guard->overflow & GH_COUNTER_ERROR_MASK)) grad_scale = 0.0f;       // the image is invalid (instance overflow): no gradient leaves here
   auto sgn = [](float d) { return d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); };      // torch.sign: sign(0) = 0
   for (size_t i = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * GH_BLOCK) {
     const float4 a = img[i], b = gt[i];
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_partials_sum_kernel(const float* 
   s = gh_wave_sum_to63(s);
   if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) out[0] = (guard && guard->overflow) ? __uint_as_float(0x7FC00000u) : scale * (((s_w[0] + s_w[1]) + s_w[2]) + s_w[3]);
+  if (threadIdx.x == 0) out[0] = (guard && (guard->overflow & GH_COUNTER_ERROR_MASK)) ? __uint_as_float(0x7FC00000u) : scale * (((s_w[0] + s_w[1]) + s_w[2]) + s_w[3]);
 }
 
 extern "C" int gh_l1_loss(const float* image, const float* target, size_t n, float* loss_out, float* dL_dimage, float* partials,
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_fit_loss_kernel(const float* __re
   __shared__ float s_w[GH_BLOCK / GH_WAVE];
   float acc = 0.0f;
   const size_t npix = (size_t)NV * HW;
-  const float live = (guard && guard->overflow) ? 0.0f : 1.0f;   // instance overflow: invalid images, no gradient leaves here
+  const float live = (guard && (guard->overflow & GH_COUNTER_ERROR_MASK)) ? 0.0f : 1.0f;   // instance overflow: invalid images, no gradient leaves here
   for (size_t i = (size_t)blockIdx.x * GH_BLOCK + threadIdx.x; i < npix; i += (size_t)gridDim.x * GH_BLOCK) {
     const size_t v = rHW > 0.0f ? (size_t)gh_div_small((uint32_t)i, (uint32_t)HW, rHW) : i / HW, p = i - v * HW;   // (no 64-bit division per pixel)
     const bool in_box = bbox ? bbox[i] != 0.0f : true;

@@ -186,6 +186,7 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   if (g.N == 0) {                                      // nothing to project: only the counters and per-tile state
     (void)hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s);
     (void)hipMemsetAsync(ws + L.ranges, 0, L.tile_order - L.ranges, s);
+    (void)hipMemsetAsync(ws + L.render_guard, 0, 4, s);      // (a refresh call over nothing goes straight to the render)
     return;
   }
   int nblk = ((g.N > T ? g.N : T) + GH_BLOCK - 1) / GH_BLOCK;
@@ -325,20 +326,15 @@ __device__ __forceinline__ void gh_sum_records(uint32_t o0, uint32_t o1, const f
     const uint32_t f = fl;
     if (sl + 1 < o1) fl = inst_flag[sl + 1];             // the next slot's flags travel while this slot's records are summed
     GhF3 r[4][3];
-#ifdef GH_ABL_HALFREC      // timing ablation only (results invalid): what the chain rule costs when an instance has two sub-records
-#define GH_ABL_NQ 2
-#else
-#define GH_ABL_NQ 4
-#endif
 #pragma unroll
-    for (int q = 0; q < GH_ABL_NQ; ++q) {
+    for (int q = 0; q < 4; ++q) {
       if ((f >> (8 * q)) & 1u) {
-        const GhF3* p = (const GhF3*)(inst_grad + ((size_t)sl * GH_ABL_NQ + q) * GH_REC_G);
+        const GhF3* p = (const GhF3*)(inst_grad + ((size_t)sl * 4 + q) * GH_REC_G);
         r[q][0] = p[0]; r[q][1] = p[1]; r[q][2] = p[2];
       }
     }
 #pragma unroll
-    for (int q = 0; q < GH_ABL_NQ; ++q) {
+    for (int q = 0; q < 4; ++q) {
       if ((f >> (8 * q)) & 1u) {
         acc[0] += (double)r[q][0].x; acc[1] += (double)r[q][0].y; acc[2] += (double)r[q][0].z;
         acc[3] += (double)r[q][1].x; acc[4] += (double)r[q][1].y; acc[5] += (double)r[q][1].z;

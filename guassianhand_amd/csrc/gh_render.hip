@@ -282,8 +282,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
     int tiles, float* __restrict__ image, float* __restrict__ alpha_img, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
-    float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const GhCounters* __restrict__ ctr_ro,
-    const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
+    float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const uint32_t* __restrict__ render_guard,
+    uint32_t guard_mask, const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
     const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth) {
   int v, tx, ty;
   uint32_t item_idx, quad_u;
@@ -354,11 +354,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       const uint32_t t = __shfl_xor(m, o); m = t > m ? t : m;
       const uint32_t u = __shfl_xor(sq, o); sq = u > sq ? u : sq;
     }
-#ifdef GH_ABL_NOEND     // timing ablation only (the backward gets no work list): what the per-wave end-of-tile atomics cost the forward
-    if (false) {
-#else
     if (lane == 0) {
-#endif
       // The LAST of the tile's 16 waves (4 quadrant blocks x 4) appends the tile's backward work items, one per depth
       // segment of the walked prefix: the list is in the order the forward finished the tiles. The backward takes it from
       // the end, so the tiles that ran longest start first; the order only affects scheduling, never results.
@@ -414,11 +410,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     // Device-side overflow guard: with D > max_instances the lists are truncated, so a sync-free caller must never see a
     // plausible image — it gets NaN (and GhCounters.overflow for the host to read whenever it chooses).
     // (a depth-bound miss elsewhere — bit 2 — does not touch this pixel: tiles are independent; this pixel's own miss does)
-    // The capacity / stale-list bits were set by kernels BEFORE this one and are read through a pointer of their own (ctr_ro, the
-    // same address): the only write this kernel makes to the word is the atomic OR of bit 2 above, which these bits do not depend
-    // on — read through `ctr` the load can no longer be a scalar one, and 86 k waves fetching the line the work-list atomics hit
-    // (reserved[1], same 16 bytes) with vector loads cost the kernel 100 us (same-box A/B, round 4: 144 -> 242 us).
-    const float poison = ((ctr_ro->overflow & 11u) || pixel_miss) ? __uint_as_float(0x7FC00000u) : 0.0f;   // (bits 0, 1, 3: the whole call is invalid)
+    // The capacity / stale-list / depth-key bits were set by kernels BEFORE this one; the kernel in front of this one left them in
+    // a word of their own (GhLayout.render_guard), read here through the scalar cache. The only write this kernel makes to the
+    // counters' line is the atomic OR of bit 2 above and the work-list atomics (reserved[1]): a plain load of THAT line cannot be a
+    // scalar one, and 86 k waves fetching it with vector loads cost the kernel 100 us (same-box A/B, round 4: 144 -> 242 us).
+    // guard_mask: bits 0, 1, 3 (the whole call is invalid); a second call over shared lists also takes bit 2 of the call that
+    // built them — it has no bound of its own to verify, and lists a miss truncated are not its lists either.
+    const float poison = ((*render_guard & guard_mask) || pixel_miss) ? __uint_as_float(0x7FC00000u) : 0.0f;
     img[0] = fmaf(p.T, bg[0], p.C0) + poison;
     img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1) + poison;
     img[(size_t)2 * H * W] = fmaf(p.T, bg[2], p.C2) + poison;
@@ -437,12 +435,14 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   float4* ck = (float4*)(ws + L.ckpt_rgb); float4* fC = (float4*)(ws + L.final_C);
   uint2* items = (uint2*)(ws + L.bwd_items); GhCounters* ctr = (GhCounters*)(ws + L.counters);
   // the occlusion bound belongs to the call that BUILT the lists (wg == ws); a second call over shared lists has none of its own
-  const float* bound = (wg == ws && in->tile_depth_bound) ? (const float*)(ws + L.tile_bound) : nullptr;
+  // (and with nothing to project the bound kernel never ran: there is no bound to read)
+  const float* bound = (wg == ws && in->tile_depth_bound && g.N > 0) ? (const float*)(ws + L.tile_bound) : nullptr;
   if (wg != ws) seen = nullptr;
   const uint32_t* gid = (const uint32_t*)(wg + L.vals_a); const float* depth = (const float*)(wg + L.depth);
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
-                       g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const GhCounters*)ctr, bound, seen, seen_scale, seen_slack, gid, depth);
+                       g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const uint32_t*)(ws + L.render_guard),
+                       wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, depth);
   };
   // SEEN (GhOutputs.tile_depth_seen wanted): the variant that walks on virtually behind the stop; the plain kernels are untouched
   if (seen) { if (alpha) launch(gh_render_fwd_kernel<true, true>); else launch(gh_render_fwd_kernel<false, true>); }
@@ -795,15 +795,9 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
           for (int q = GEOM ? 0 : 5; q < GH_REC; ++q) s9[q] += a9[q];
         }
       }
-#ifdef GH_ABL_HALFREC      // timing ablation only (results invalid): two sub-record slots per instance, half the quadrants write
-      if (any && quad < 2) {
-        const uint32_t sl = slots[seg_lo + k * GH_WAVE + lane];
-        GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 2 + quad) * GH_REC_G);
-#else
       if (any) {
         const uint32_t sl = slots[seg_lo + k * GH_WAVE + lane];
         GhF3* rec = (GhF3*)(inst_grad + ((size_t)sl * 4 + quad) * GH_REC_G);
-#endif
         if (GEOM) {
           rec[0] = GhF3{s9[0], s9[1], s9[2]};
           rec[1] = GhF3{s9[3], s9[4], s9[5]};
@@ -854,10 +848,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_recolour_kernel(GhInputs in, uint
                                                                 const float4* __restrict__ g_r1, const float2* __restrict__ g_r2,
                                                                 float4* __restrict__ r1, float2* __restrict__ r2,
                                                                 uint32_t* __restrict__ inst_flag, uint32_t* __restrict__ tile_walk,
-                                                                GhCounters* __restrict__ ctr) {
+                                                                GhCounters* __restrict__ ctr, uint32_t* __restrict__ render_guard) {
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   const uint32_t D = gctr->num_rendered;
-  if (i == 0) { ctr->num_rendered = D; ctr->overflow = gctr->overflow; ctr->reserved[0] = gctr->reserved[0]; ctr->reserved[1] = 0; }
+  if (i == 0) {
+    ctr->num_rendered = D; ctr->overflow = gctr->overflow; ctr->reserved[0] = gctr->reserved[0]; ctr->reserved[1] = 0;
+    *render_guard = gctr->overflow & GH_COUNTER_ERROR_MASK;        // (this is the kernel in front of the render, see gh_render_fwd_kernel)
+  }
   if (i < (uint32_t)T) { tile_walk[i] = 0u; tile_walk[T + i] = 0u; tile_walk[2 * T + i] = 0u; }
   const uint32_t n = D < cap ? D : cap;
   if (i >= n) return;
@@ -879,7 +876,8 @@ void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, co
   hipLaunchKernelGGL(gh_recolour_kernel, dim3(nblk > 0 ? nblk : 1), dim3(GH_BLOCK), 0, s, *in, d->flags, g.P, T, (uint32_t)g.cap,
                      (const GhCounters*)(wg + L.counters), (const uint32_t*)(wg + L.vals_a), (const float4*)(wg + L.inst_r1),
                      (const float2*)(wg + L.inst_r2), (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2),
-                     (uint32_t*)(ws + L.inst_flag), (uint32_t*)(ws + L.tile_walk), (GhCounters*)(ws + L.counters));
+                     (uint32_t*)(ws + L.inst_flag), (uint32_t*)(ws + L.tile_walk), (GhCounters*)(ws + L.counters),
+                     (uint32_t*)(ws + L.render_guard));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -925,8 +923,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_instance_kernel(uint32_t 
                                                                         const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                                         const float4* __restrict__ g_r0, const float* __restrict__ g_c,
                                                                         const float4* __restrict__ attr, float4* __restrict__ r1,
-                                                                        float2* __restrict__ r2, uint32_t* __restrict__ inst_flag) {
+                                                                        float2* __restrict__ r2, uint32_t* __restrict__ inst_flag,
+                                                                        const GhCounters* __restrict__ ctr, uint32_t* __restrict__ render_guard) {
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
+  // the kernel in front of the render (gh_refresh_attr_kernel, complete by now, may have raised bit 1): the error bits in their own word
+  if (i == 0) *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK;
   const uint32_t D = gctr->num_rendered;
   const uint32_t n = D < cap ? D : cap;
   if (i >= n) return;
@@ -957,5 +958,6 @@ void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, con
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,
                      (const GhCounters*)(wg + L.counters), (const uint32_t*)(wg + L.keys_a), (const uint32_t*)(wg + L.vals_a),
                      (const float4*)(wg + L.inst_r0), (const float*)(wg + L.inst_c), (const float4*)(ws + L.attr),
-                     (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag));
+                     (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
+                     (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard));
 }

@@ -200,7 +200,7 @@ __device__ __forceinline__ void gh_adam_block(const GhAdamOne& T, int b, int hos
   // of the bias correction then lives on the device too: step_state[0] = steps applied so far, read by every block when it
   // starts; the block that FINISHES last (a ticket in step_state[1]) writes the new count — every other block has read the old
   // one by then. No host value changes from launch to launch, so a captured step replays correctly.
-  const bool skip = guard && guard->overflow != 0u;
+  const bool skip = guard && (guard->overflow & GH_COUNTER_ERROR_MASK) != 0u;
   int t = host_step;
   if (T.step_state) t = __hip_atomic_load(&T.step_state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   // bias corrections in double, as torch.optim.Adam's Python arithmetic — by ONE thread per block

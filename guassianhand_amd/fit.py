@@ -278,7 +278,7 @@ class OneShotFit(nn.Module):
         ovf = None
         if world > 1 and self.color_w.is_cuda:
             ovf = torch.zeros((), device=self.color_w.device) if local_guard is None else \
-                local_guard.view(torch.int32)[1].ne(0).float()
+                (local_guard.view(torch.int32)[1] & 15).ne(0).float()      # the error bits (GH_COUNTER_ERROR_MASK); bit 4 is information
         blk = None
         if use_block:
             from . import rasterizer as R
@@ -390,7 +390,7 @@ class CapturedFitStep:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss = self.fit.step(*self.args, sync=False)    # (capturing enqueues nothing: this is not a step)
-            self.counters = list(R._graph_counters.values())
+            self.counters = R.graph_counters()
         finally:
             R.set_graph_mode(False)
         self.lr = self._lr()
@@ -425,16 +425,9 @@ class CapturedFitStep:
         from . import rasterizer as R
         for counters, cap, key in self.counters:
             c4 = counters.tolist()
-            d = c4[0] & 0xFFFFFFFF
-            if c4[1] & 2:                                          # stale static lists (an opacity above their bound): not a capacity matter
-                R.GeometryCache.clear_all()
-                raise R.GhStaleGeometryError(R._STALE_MSG + " [inside the captured fit step: the next replay() rebuilds and re-captures]")
-            if c4[1] & 8:                                          # GH_FLAG_DEPTH24 did not hold: four depth-sort passes for this shape
-                R._depth24[key] = False
-                R.GeometryCache.clear_all()
-                raise R.GhOverflowError(R._DEPTH24_MSG + " [inside the captured fit step: construct a new CapturedFitStep]")
-            if (c4[1] & 0xFFFFFFFF) != 0:                          # the device-side flag decides (a split call's reserved[0] only sizes)
-                need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
-                R._capacity[key] = max(R._capacity.get(key, 0), int(need * 1.5) + 1024)
-                R.GeometryCache.clear_all()                        # lists truncated by the overflow must not be refreshed again
-                raise R.GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside the captured fit step")
+            # stale static lists (an opacity above their bound) / GH_FLAG_DEPTH24 not holding / an instance overflow: the rasteriser
+            # learns what the word says (capacity, verdicts, caches cleared) and raises the matching error
+            R.report_counter_word(key, c4[1], c4[0] & 0xFFFFFFFF, cap, c4[2] & 0xFFFFFFFF, dev=counters.device,
+                                  where=(" [inside the captured fit step: the next replay() rebuilds and re-captures]" if (c4[1] & 2) else
+                                         " [inside the captured fit step: construct a new CapturedFitStep]" if (c4[1] & 8) else
+                                         " inside the captured fit step"))

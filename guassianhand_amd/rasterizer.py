@@ -16,6 +16,7 @@ there is no PyTorch/CPU fallback — a missing library or a CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import weakref
 from typing import Dict, NamedTuple, Optional, Tuple
 
@@ -78,18 +79,30 @@ class DepthBoundCache:
         self.margin, self.slack, self.refresh_every = float(margin), int(slack), max(1, int(refresh_every))
         self.min_pixels = int(min_pixels)        # calls smaller than this render without a bound (measured: one or two 512x334 views lose)
         self.bufs, self.key, self.cur, self.valid = None, None, 0, False
+        self._cams, self._cams_version = None, None
         self.bounded_calls, self.misses, self.age = 0, 0, 0
 
     def clear(self) -> None:
         self.valid = False
 
-    def _buffers(self, dev, NV: int, H: int, W: int):
-        """(bound to apply or None, buffer to report into or None) for the next call; advances the cache's state."""
-        key = (dev, NV, H, W)
-        if self.key != key:
+    def _buffers(self, dev, NV: int, H: int, W: int, key=None):
+        """(bound to apply or None, buffer to report into or None) for the next call; advances the cache's state.
+        key = (P, per_view, packed camera tensor): a bound reported for OTHER cameras, another Gaussian count or the other
+        Gaussian layout says nothing about this call (it would stay exact — the forward verifies — but miss on nearly every
+        tile: a re-render under sync=True, a skipped step under sync=False), so the cache starts over when any of them changes.
+        The cameras are identified by the tensor OBJECT and its version: pass the same packed tensor (camera.pack_cameras_from_w2c)
+        every step for the bound to carry over."""
+        P, per_view, cams = key if key is not None else (None, None, None)
+        cam_ref = self._cams() if self._cams is not None else None
+        same_cams = cams is None or (cam_ref is cams and self._cams_version == cams._version)
+        full = (dev, NV, H, W, P, per_view)
+        if self.key != full or not same_cams:
             T = NV * ((W + 15) // 16) * ((H + 15) // 16)
-            self.bufs = (torch.empty(T, 2, dtype=torch.float32, device=dev), torch.empty(T, 2, dtype=torch.float32, device=dev))   # (depth, block mask)
-            self.key, self.cur, self.valid, self.age = key, 0, False, 0
+            if self.key is None or self.key[:4] != full[:4]:
+                self.bufs = (torch.empty(T, 2, dtype=torch.float32, device=dev), torch.empty(T, 2, dtype=torch.float32, device=dev))   # (depth, block mask)
+            self.key, self.cur, self.valid, self.age = full, 0, False, 0
+            self._cams = None if cams is None else weakref.ref(cams)
+            self._cams_version = None if cams is None else cams._version
         if self.valid and self.age + 1 < self.refresh_every:      # re-use the bound, plain kernels
             self.age += 1
             self.bounded_calls += 1
@@ -140,56 +153,122 @@ class GeometryCache:
 
 
 # ---------------------------------------------------------------------------------------------------
-# capacity policy for the data-dependent instance count D
-_capacity: Dict[Tuple[int, int, int, int], int] = {}
-# GH_FLAG_DEPTH24 (three depth-sort passes instead of four: two launches less per forward) is tried for every call shape until a
-# call of that shape reports that the top byte of its visible depths does vary (GhCounters.overflow bit 3): visible depths that
-# straddle a factor-4 boundary such as 0.5 m or 2 m. Like the instance capacity, the verdict is learned per shape.
-_depth24: Dict[Tuple[int, int, int, int, bool], bool] = {}
+# What the rasteriser remembers between calls. Two kinds, kept apart (round 5):
+#   * _DeviceState — per DEVICE, behind one re-entrant lock: learned instance capacities, the GH_FLAG_DEPTH24 verdicts, outstanding
+#     counter read-backs, the workspace pool, the geometry record of the two-call protocol, graph-mode counters, the latest
+#     workspace / gradient block. Two devices in one process share nothing; two threads on one device (autograd runs `backward` on
+#     a thread of its own) take the lock around every read-modify-write of it.
+#   * _Policy — process-wide SWITCHES a program sets once (graph mode, split-stream policy, geometry reuse, stage timing): plain
+#     configuration, no per-call state.
+# The module attributes earlier rounds' tests and tools read (`_capacity`, `_depth24`, `_geom_last`, `_graph_counters`, `_pending`,
+# `_split_policy` ...) resolve to the CURRENT device's state through the module __getattr__ at the end of this file.
+class _DeviceState:
+    def __init__(self, index: int):
+        self.index = index
+        self.lock = threading.RLock()
+        # capacity policy for the data-dependent instance count D: call shape -> learned max_instances
+        self.capacity: Dict[Tuple[int, int, int, int, bool], int] = {}
+        # GH_FLAG_DEPTH24 (three depth-sort passes instead of four: two launches less per forward) per call shape. The flag is a
+        # speculation the device can only answer with a NaN image, so it is used ONLY for a shape a read-back has shown it to hold
+        # for (GhCounters.overflow bit 4, reported by every full forward, also one made WITHOUT the flag): absent = unknown = four
+        # passes; True = observed to hold; False = observed to fail once (bit 3, or bit 4 missing): four passes from then on.
+        self.depth24: Dict[Tuple[int, int, int, int, bool], bool] = {}
+        self.pending = []        # _Pending records of sync-free calls not yet checked
+        self.free_slots = []     # recycled (pinned 4-int buffer, event) pairs: a sync-free call allocates neither
+        self.last_D = 0
+        self.last_ws = None      # workspace of the most recent forward (its first 16 bytes are the GhCounters)
+        self.graph_counters = {} # workspace address -> (device view of GhCounters, cap, key) of forwards issued in graph mode
+        self.ws_pool: Dict[Tuple[int, int], list] = {}
+        self.geom_last = None    # (identity objects, values, weakref to the context) of the latest full drop-in forward
+        self.last_grad_block = None
+        self.stage_events = []   # (stage name, start event, end event)
+
+
+class _Policy:
+    graph_mode = False
+    split = False                # False | True | "auto"
+    reuse_geometry = True
+    stage_timing = False
+
+
+_policy = _Policy()
+_states: Dict[int, _DeviceState] = {}
+_states_lock = threading.Lock()
+
+
+def _dev_index(dev=None) -> int:
+    if dev is None:
+        return torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if isinstance(dev, int):
+        return dev
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def _state(dev=None) -> _DeviceState:
+    """The rasteriser's state for `dev` (a torch.device, an index, or None = the current device)."""
+    i = _dev_index(dev)
+    st = _states.get(i)
+    if st is None:
+        with _states_lock:
+            st = _states.setdefault(i, _DeviceState(i))
+    return st
+
+
+def _learn_depth24(st: _DeviceState, key, flags_word: int) -> None:
+    """Update the GH_FLAG_DEPTH24 verdict of a call shape from a counter word that has been read back."""
+    if flags_word & 8:
+        st.depth24[key] = False
+    elif flags_word & _abi.GH_COUNTER_DEPTH24_OK:
+        st.depth24.setdefault(key, True)
+    elif not (flags_word & 1):             # a complete call whose depths' top byte varies (truncated lists prove nothing)
+        st.depth24[key] = False
+
+
 _DEPTH24_MSG = ("the visible depths span more than the 24 key bits the three-pass depth sort covers; the call returned a NaN image; "
                 "the four-pass sort is used for this call shape from now on, re-run the step")
-_pending = []      # _Pending records of sync-free calls not yet checked
-_free_slots = []   # recycled (pinned 4-int buffer, event) pairs: a sync-free call allocates neither
 _PENDING_MAX = 64
 
 
 class _Pending:
     """The asynchronous counter read-back of one sync-free forward. `resolve()` waits for it (normally long done), recycles
     the pinned buffer and remembers the verdict, so that both check_overflow() and the call's own backward can ask."""
-    __slots__ = ("ev", "host", "cap", "key", "done", "d", "over", "stale", "miss", "dbound", "told")
+    __slots__ = ("st", "ev", "host", "cap", "key", "done", "d", "over", "stale", "miss", "wide", "dbound", "told", "learn24")
 
-    def __init__(self, ev, host, cap, key, dbound=None):
-        self.ev, self.host, self.cap, self.key, self.done, self.d, self.over, self.stale = ev, host, cap, key, False, 0, False, False
-        self.miss, self.dbound = False, dbound
+    def __init__(self, st, ev, host, cap, key, dbound=None, learn24=True):
+        self.st, self.ev, self.host, self.cap, self.key, self.done, self.d, self.over, self.stale = st, ev, host, cap, key, False, 0, False, False
+        self.miss, self.wide, self.dbound = False, False, dbound
+        self.learn24 = learn24     # a full forward (the depth sort ran): its counter word says whether GH_FLAG_DEPTH24 holds
         self.told = False          # the caller has been given this record's error (a look at the counters by the geometry-reuse check is not that)
 
     def resolve(self) -> bool:
         """True when the call overflowed its capacity (the learned capacity of its shape is raised then)."""
-        global _last_D
-        if not self.done:
-            self.ev.synchronize()
-            c = self.host.tolist()
-            self.d = c[0] & 0xFFFFFFFF
-            _last_D = self.d
-            # overflowed = the device-side flag, nothing else; a split call's reserved[0] (the max_instances that would give
-            # each half a large enough share) only sizes the NEXT capacity
-            self.over = (c[1] & 0xFFFFFFFF) != 0
-            self.stale = (c[1] & 2) != 0
-            self.miss = (c[1] & 4) != 0
-            if c[1] & 8:                                   # GH_FLAG_DEPTH24 did not hold: four passes for this shape from now on
-                _depth24[self.key] = False
-            if self.miss and self.dbound is not None:      # the speculation failed: the re-run of the step renders without a bound
-                self.dbound.clear()
-                self.dbound.misses += 1
-            self.dbound = None
-            need = (c[2] & 0xFFFFFFFF) if self.key[-1] else self.d
-            if self.over and (c[1] & 3):           # stale lists, or lists truncated by an instance overflow: never re-use them
-                GeometryCache.clear_all()
-            if self.over and (c[1] & 1):
-                _capacity[self.key] = max(_capacity.get(self.key, 0), int(max(need, self.d) * 1.5) + 1024)
-            _free_slots.append((self.host, self.ev))
-            self.host = self.ev = None
-            self.done = True
+        st = self.st
+        with st.lock:
+            if not self.done:
+                self.ev.synchronize()
+                c = self.host.tolist()
+                self.d = c[0] & 0xFFFFFFFF
+                st.last_D = self.d
+                # overflowed = the device-side error bits, nothing else; a split call's reserved[0] (the max_instances that would
+                # give each half a large enough share) only sizes the NEXT capacity
+                self.over = (c[1] & _abi.GH_COUNTER_ERROR_MASK) != 0
+                self.stale = (c[1] & 2) != 0
+                self.miss = (c[1] & 4) != 0
+                self.wide = (c[1] & 8) != 0                    # GH_FLAG_DEPTH24 did not hold: four passes for this shape from now on
+                if self.learn24:
+                    _learn_depth24(st, self.key, c[1])
+                if self.miss and self.dbound is not None:      # the speculation failed: the re-run of the step renders without a bound
+                    self.dbound.clear()
+                    self.dbound.misses += 1
+                self.dbound = None
+                need = (c[2] & 0xFFFFFFFF) if self.key[-1] else self.d
+                if self.over and (c[1] & 3):           # stale lists, or lists truncated by an instance overflow: never re-use them
+                    GeometryCache.clear_all()
+                if self.over and (c[1] & 1):
+                    st.capacity[self.key] = max(st.capacity.get(self.key, 0), int(max(need, self.d) * 1.5) + 1024)
+                st.free_slots.append((self.host, self.ev))
+                self.host = self.ev = None
+                self.done = True
         return self.over
 
     def message(self) -> str:
@@ -197,7 +276,7 @@ class _Pending:
             return _STALE_MSG
         if self.miss and not (self.over and self.d > self.cap):
             return _MISS_MSG
-        if not self.d > self.cap and _depth24.get(self.key, True) is False and not self.stale and not self.miss:
+        if not self.d > self.cap and self.wide and not self.stale and not self.miss:
             return _DEPTH24_MSG
         return (f"tile instances D={self.d} exceeded max_instances={self.cap}; the call returned a NaN image; "
                 "capacity raised, re-run the step")
@@ -218,43 +297,37 @@ _STALE_MSG = ("an opacity rose above the bound the static tile lists were built 
 _MISS_MSG = ("a pixel ran off the end of a tile list truncated by the speculative occlusion bound (the Gaussians moved further than "
              "the margin); that pixel is NaN; the bound has been dropped, re-run the step")
 
-_last_D = 0
-_stage_timing = False
-_stage_events = []   # (stage name, start event, end event)
+
+def last_guard(dev=None):
+    """Device view of the GhCounters of the most recent forward on `dev` (None = the current device): the `guard` argument of
+    gh_l1_loss / gh_fit_loss / gh_adam_reg_step (device-side overflow guard). Holds that workspace alive until the next forward."""
+    ws = _state(dev).last_ws
+    return None if ws is None else ws[:16]
 
 
-_last_ws = None      # workspace of the most recent forward (its first 16 bytes are the GhCounters)
-
-
-def last_guard():
-    """Device view of the GhCounters of the most recent forward: the `guard` argument of gh_l1_loss / gh_fit_loss /
-    gh_adam_reg_step (device-side overflow guard). Holds that workspace alive until the next forward."""
-    return None if _last_ws is None else _last_ws[:16]
-
-
-def last_num_rendered() -> int:
+def last_num_rendered(dev=None) -> int:
     """Tile instances D of the most recent forward whose counters have been read back."""
-    return _last_D
+    return _state(dev).last_D
 
 
 def enable_stage_timing(on: bool) -> None:
     """Bracket every pipeline stage with HIP events on the launch stream (bench.py's roofline leg)."""
-    global _stage_timing
-    _stage_timing = bool(on)
+    _policy.stage_timing = bool(on)
     if on:
-        _stage_events.clear()
+        for st in list(_states.values()):
+            st.stage_events.clear()
 
 
 def stage_timing_summary() -> Dict[str, float]:
-    """Average milliseconds per launch of each stage since enable_stage_timing(True)."""
+    """Average milliseconds per launch of each stage since enable_stage_timing(True) (current device)."""
     torch.cuda.synchronize()
     acc: Dict[str, list] = {}
-    for name, e0, e1 in _stage_events:
+    for name, e0, e1 in _state().stage_events:
         acc.setdefault(name, []).append(e0.elapsed_time(e1))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-def _run_stages(fn, args, stages):
+def _run_stages(st: _DeviceState, fn, args, stages):
     """Call a *_stages entry point once per stage with events in between (same stream, same order)."""
     rc = 0
     for name, bit in stages:
@@ -262,27 +335,31 @@ def _run_stages(fn, args, stages):
         e0.record()
         rc = fn(*args, C.c_uint32(bit))
         e1.record()
-        _stage_events.append((name, e0, e1))
+        st.stage_events.append((name, e0, e1))
         if rc != 0:
             break
     return rc
-
-
-_graph_mode = False
-_graph_counters = {}   # workspace address -> device view of GhCounters of forwards issued in graph mode (read back by check_overflow)
 
 
 def set_graph_mode(on: bool) -> None:
     """Graph mode: sync-free forwards issue no counter read-back at all (nothing but kernel launches and async
     memsets reaches the stream), so a whole step can be captured with torch.cuda.CUDAGraph / hipGraph.
     check_overflow() then reads the counters of the captured workspaces directly."""
-    global _graph_mode
-    _graph_mode = bool(on)
+    _policy.graph_mode = bool(on)
     if not on:
-        _graph_counters.clear()
+        for st in list(_states.values()):
+            with st.lock:
+                st.graph_counters.clear()
 
 
-_split_policy = False       # False | True | "auto"
+def graph_counters(dev=None):
+    """[(device view of GhCounters, max_instances, call-shape key)] of the forwards issued in graph mode on `dev` so far — what a
+    capture keeps to check its replays (fit.CapturedFitStep)."""
+    st = _state(dev)
+    with st.lock:
+        return list(st.graph_counters.values())
+
+
 _SPLIT_AUTO_MIN_PIXELS = 1 << 19   # "auto": where the split measured a gain (1024x1024 x 8 views: +4.9 %; 512x334: 8 views -1 %, 16 views +0.8 %)
 
 
@@ -290,10 +367,9 @@ def set_split_streams(mode) -> None:
     """Module policy for calls that do not say (split_streams=None): False = one stream, True = split whenever n_views >= 2,
     "auto" = split where it measured a gain: four or more views of more than half a megapixel each (GH_FLAG_SPLIT_STREAMS;
     results are bit-identical either way)."""
-    global _split_policy
     if mode not in (False, True, "auto"):
         raise ValueError("set_split_streams: False, True or 'auto'")
-    _split_policy = mode
+    _policy.split = mode
 
 
 def capacity_key(P: int, NV: int, H: int, W: int, split: bool = False):
@@ -305,68 +381,82 @@ def _initial_capacity(P: int, NV: int) -> int:
     return max(1 << 16, 8 * P * NV)
 
 
-def check_overflow(block: bool = True, keep_recent: int = 0) -> None:
-    """Verify every outstanding sync-free forward fitted its capacity (raises GhOverflowError). block=False only looks at
-    read-backs that have arrived — except that all but the `keep_recent` latest calls are waited for regardless (they
-    finished long ago), which bounds how late an overflow can surface."""
-    global _pending, _last_D
-    for counters, cap, key in list(_graph_counters.values()):   # graph mode: workspaces are static, read them directly
-        c4 = counters.tolist()
-        d = c4[0] & 0xFFFFFFFF
-        _last_D = d
-        if c4[1] & 2:                                  # a static-geometry replay met an opacity above its lists' bound
+def report_counter_word(key, flags_word: int, d: int, cap: int, reserved0: int = 0, dev=None, where: str = "") -> None:
+    """Act on a GhCounters.overflow word read back from a workspace the caller holds itself (a captured graph's, see
+    fit.CapturedFitStep.check): learn what it says (capacity, GH_FLAG_DEPTH24 verdict, stale caches) and raise the matching error."""
+    st = _state(dev)
+    with st.lock:
+        st.last_D = d
+        _learn_depth24(st, key, flags_word)
+        if flags_word & 2:                                  # a static-geometry replay met an opacity above its lists' bound
             GeometryCache.clear_all()
-            raise GhStaleGeometryError(_STALE_MSG + " [inside a captured graph: capture again]")
-        if c4[1] & 8:                                  # GH_FLAG_DEPTH24 did not hold for a captured call
-            _depth24[key] = False
-            raise GhOverflowError(_DEPTH24_MSG + " [inside a captured graph: capture again]")
-        if (c4[1] & 0xFFFFFFFF) != 0:                  # the device-side flag decides; reserved[0] of a split call sizes the next capacity
-            need = max(d, (c4[2] & 0xFFFFFFFF) if key[-1] else d)
-            _capacity[key] = max(_capacity.get(key, 0), int(need * 1.5) + 1024)
+            raise GhStaleGeometryError(_STALE_MSG + where)
+        if flags_word & 8:                                  # GH_FLAG_DEPTH24 did not hold for a captured call
             GeometryCache.clear_all()
-            raise GhOverflowError(f"tile instances D={d} exceeded max_instances={cap} inside a captured graph")
-    keep, bad = [], None
-    n_old = len(_pending) - keep_recent if keep_recent > 0 else 0
-    for i, pc in enumerate(_pending):
-        if pc.done:
-            if pc.over and not pc.told:                    # resolved by somebody who did not report it (the geometry-reuse check)
+            raise GhOverflowError(_DEPTH24_MSG + where)
+        if flags_word & _abi.GH_COUNTER_ERROR_MASK:         # the device-side flag decides; reserved[0] of a split call sizes the next capacity
+            need = max(d, reserved0 if key[-1] else d)
+            st.capacity[key] = max(st.capacity.get(key, 0), int(need * 1.5) + 1024)
+            GeometryCache.clear_all()                       # lists truncated by the overflow must not be refreshed again
+            raise GhOverflowError(f"tile instances D={d} exceeded max_instances={cap}" + (where or " inside a captured graph"))
+
+
+def check_overflow(block: bool = True, keep_recent: int = 0, dev=None) -> None:
+    """Verify every outstanding sync-free forward on `dev` (None = the current device) fitted its capacity (raises
+    GhOverflowError). block=False only looks at read-backs that have arrived — except that all but the `keep_recent` latest
+    calls are waited for regardless (they finished long ago), which bounds how late an overflow can surface."""
+    st = _state(dev)
+    with st.lock:
+        for counters, cap, key in list(st.graph_counters.values()):   # graph mode: workspaces are static, read them directly
+            c4 = counters.tolist()
+            report_counter_word(key, c4[1], c4[0] & 0xFFFFFFFF, cap, c4[2] & 0xFFFFFFFF, dev=st.index,
+                                where=" [inside a captured graph: capture again]" if (c4[1] & 10) else "")
+        keep, bad = [], None
+        n_old = len(st.pending) - keep_recent if keep_recent > 0 else 0
+        for i, pc in enumerate(st.pending):
+            if pc.done:
+                if pc.over and not pc.told:                    # resolved by somebody who did not report it (the geometry-reuse check)
+                    bad = pc
+                continue
+            if not block and i >= n_old and not pc.ev.query():
+                keep.append(pc)
+                continue
+            if pc.resolve():
                 bad = pc
-            continue
-        if not block and i >= n_old and not pc.ev.query():
-            keep.append(pc)
-            continue
-        if pc.resolve():
-            bad = pc
-    _pending = keep
-    if bad is not None:
-        raise bad.error()
+        st.pending = keep
+        if bad is not None:
+            raise bad.error()
 
 
 # Workspace pool: a forward takes its workspace from here and the context gives it back when it dies (after its backward,
-# or when a no-grad caller drops it), so steady-state calls allocate nothing. Keyed by (device, stream, bytes): a workspace
+# or when a no-grad caller drops it), so steady-state calls allocate nothing. Per device, keyed by (stream, bytes): a workspace
 # only ever returns to the stream that used it last, and that stream orders its next use behind the previous one (callers
 # that render on several streams at once — e.g. two half-batches overlapped in one captured graph — get one set per stream).
-_ws_pool: Dict[Tuple[int, int, int], list] = {}
 _WS_POOL_DEPTH = 4
 
 
-def _ws_acquire(dev: torch.device, nbytes: int, stream: int) -> torch.Tensor:
-    free = _ws_pool.get((dev.index or 0, stream, nbytes))
-    if free:
-        return free.pop()
+def _ws_acquire(st: _DeviceState, dev: torch.device, nbytes: int, stream: int) -> torch.Tensor:
+    with st.lock:
+        free = st.ws_pool.get((stream, nbytes))
+        if free:
+            return free.pop()
     return torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
 
 def _ws_release(ws: Optional[torch.Tensor], stream: int) -> None:
     if ws is None:
         return
-    free = _ws_pool.setdefault((ws.device.index or 0, stream, ws.numel()), [])
-    if len(free) < _WS_POOL_DEPTH:
-        free.append(ws)
+    st = _state(ws.device)
+    with st.lock:
+        free = st.ws_pool.setdefault((stream, ws.numel()), [])
+        if len(free) < _WS_POOL_DEPTH:
+            free.append(ws)
 
 
 def clear_workspace_pool() -> None:
-    _ws_pool.clear()
+    for st in list(_states.values()):
+        with st.lock:
+            st.ws_pool.clear()
 
 
 def _raw_stream(dev: torch.device) -> int:
@@ -416,6 +506,263 @@ class _Ctx:
             pass
 
 
+class _Call(NamedTuple):
+    """One call's arguments after validation: prepared tensors and the shape / flag words derived from them."""
+    t: dict
+    rows: int
+    NV: int
+    P: int
+    M: int
+    flags: int
+    wpg: bool
+    b_rgb: bool
+    split: bool
+    H: int
+    W: int
+    sh_degree: int
+    scale_modifier: float
+    cams_obj: object          # the caller's camera tensor as passed (identity: DepthBoundCache)
+
+
+def _prepare_call(dev, cams, means3D, opacities, scales, rotations, H, W, shs, colors_precomp, sh_degree, scale_modifier, xyz_b,
+                  opacity_b, color_w, color_b, per_view_gaussians, split_streams, plain: bool) -> _Call:
+    """Validate the arguments of raster_forward and derive rows / P / flags. plain: a full forward without static lists (the only
+    kind that may be split over two streams)."""
+    if (shs is None) == (colors_precomp is None):
+        raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
+    t = dict(cams=_prep(cams, dev).reshape(-1, _abi.GH_CAM_FLOATS), means3D=_prep(means3D, dev),
+             opacities=_prep(opacities, dev).reshape(-1), scales=_prep(scales, dev), rotations=_prep(rotations, dev),
+             shs=_prep(shs, dev), colors_precomp=_prep(colors_precomp, dev), xyz_b=_prep(xyz_b, dev),
+             opacity_b=None if opacity_b is None else _prep(opacity_b, dev).reshape(-1),
+             color_w=_prep(color_w, dev), color_b=_prep(color_b, dev))
+    rows, NV = t["means3D"].shape[0], t["cams"].shape[0]
+    M = 0 if shs is None else t["shs"].shape[1]
+    flags = 0
+    if per_view_gaussians:
+        if NV == 0 or rows % NV:
+            raise ValueError("per_view_gaussians: the Gaussian tensors must hold n_views * P rows")
+        flags |= _abi.GH_FLAG_PER_VIEW_GAUSSIANS
+    P = rows // NV if per_view_gaussians else rows
+    if split_streams is None:
+        split_streams = _policy.split is True or (_policy.split == "auto" and NV >= 4 and H * W > _SPLIT_AUTO_MIN_PIXELS)
+    split = bool(split_streams) and NV >= 2 and P > 0 and plain and not _policy.stage_timing
+    if split:
+        flags |= _abi.GH_FLAG_SPLIT_STREAMS
+    wpg = False
+    if t["color_w"] is not None:
+        if t["color_w"].numel() == 48:
+            pass
+        elif t["color_w"].numel() == rows * 48:
+            flags |= _abi.GH_FLAG_BLEND_W_PER_GAUSSIAN
+            wpg = True
+        else:
+            raise ValueError("color_w must have 48 or P*48 elements")
+    b_rgb = False
+    if t["color_b"] is not None:
+        if t["color_b"].numel() == rows * 3 and colors_precomp is not None:  # the 3 columns RGB mode reads (renderer_one_shot.py:328)
+            flags |= _abi.GH_FLAG_BLEND_COLOR_B_RGB
+            b_rgb = True
+        elif t["color_b"].numel() != rows * 48:
+            raise ValueError("color_b must have P*48 elements (or P*3 with colors_precomp)")
+    return _Call(t, rows, NV, P, M, flags, wpg, b_rgb, split, int(H), int(W), int(sh_degree), float(scale_modifier), cams)
+
+
+def _inputs_struct(c: _Call, with_shs: bool = True, bound=None):
+    t = c.t
+    return _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]), _ptr(t["rotations"]),
+                         _ptr(t["shs"]) if with_shs else None, _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]), _ptr(t["opacity_b"]),
+                         _ptr(t["color_w"]), _ptr(t["color_b"]), _ptr(bound))
+
+
+def _make_ctx(c: _Call, dims, inp, ws, stream, alpha, parent, radii, pending, verdict, refresh) -> _Ctx:
+    ctx = _Ctx()
+    ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, c.t, ws, c.H, c.W, c.P, c.NV, c.M, c.wpg
+    ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = c.b_rgb, c.rows, alpha, parent, radii, stream
+    ctx.pending, ctx.verdict, ctx.refresh = pending, verdict, refresh
+    return ctx
+
+
+def _queue_readback(st: _DeviceState, counters, cap, key, dbound=None, learn24=True) -> _Pending:
+    """Asynchronous copy of a call's GhCounters into a pinned buffer + an event: the record of a sync-free call."""
+    host, ev = st.free_slots.pop() if st.free_slots else (torch.empty(4, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+    host.copy_(counters, non_blocking=True)
+    ev.record()
+    pc = _Pending(st, ev, host, cap, key, dbound, learn24)
+    st.pending.append(pc)
+    return pc
+
+
+def _forward_shared(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool):
+    """gh_forward_shared: a second call over the lists of `g0` (the reference's mask pass after the RGB pass of a view)."""
+    if c.t["shs"] is not None or (g0.dims.flags & _abi.GH_FLAG_SPLIT_STREAMS) or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (c.P, c.NV, c.H, c.W, c.rows) or \
+            (g0.dims.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) != (c.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS):
+        raise ValueError("geometry_of: the second call must have the first one's shapes and precomputed colours")
+    cap = int(g0.dims.max_instances)
+    dims = _abi.GhDims(c.P, c.NV, c.H, c.W, c.sh_degree, c.M, c.scale_modifier, c.flags, cap)
+    nbytes = L.gh_workspace_bytes(C.byref(dims))
+    stream = _raw_stream(dev)
+    ws = _ws_acquire(st, dev, nbytes, stream)
+    image = torch.empty(c.NV, 3, c.H, c.W, dtype=torch.float32, device=dev)
+    alpha = torch.empty(c.NV, c.H, c.W, dtype=torch.float32, device=dev) if return_alpha else None
+    inp = _inputs_struct(c, with_shs=False)
+    out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha))
+    with _OnDevice(dev):
+        rc = L.gh_forward_shared(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(g0.ws.data_ptr()),
+                                 C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"gh_forward_shared failed: {_abi.status_name(rc)}")
+    st.last_ws = ws
+    # the overflow flag is the geometry owner's; same geometry, same radii; an overflow is the first call's (NaN image here too)
+    ctx = _make_ctx(c, dims, inp, ws, stream, alpha, g0, g0.radii, g0.pending, g0.verdict, False)
+    return image, g0.radii, ctx
+
+
+def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, expect_backward: bool):
+    """gh_forward_refresh: this call's opacities / colours over the static lists of `g0`."""
+    if not (g0.dims.flags & _abi.GH_FLAG_STATIC_LISTS) or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (c.P, c.NV, c.H, c.W, c.rows) or \
+            (g0.dims.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) != (c.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) or g0.parent is not None:
+        raise ValueError("refresh_of: needs the context of a static_lists forward with this call's shapes")
+    cap = int(g0.dims.max_instances)
+    dims = _abi.GhDims(c.P, c.NV, c.H, c.W, c.sh_degree, c.M, c.scale_modifier, c.flags, cap)
+    nbytes = L.gh_workspace_bytes(C.byref(dims))
+    # the library applies THIS call's layout to the owner's workspace, and the arrays a refresh reads of it (cull_bound,
+    # inst_c) lie behind the ones sized by the colour mode (sh_rgb, dmean_sh, sh_scratch: M != 0): the two calls must agree
+    # on it (ADVICE r3) — and the owner's workspace must span this call's layout
+    if (g0.M != 0) != (c.M != 0) or g0.ws.numel() < nbytes:
+        raise ValueError("refresh_of: the static lists were built in the other colour mode (shs vs colors_precomp); "
+                         "build them again with this call's colour inputs")
+    stream = _raw_stream(dev)
+    ws = _ws_acquire(st, dev, nbytes, stream)
+    image = torch.empty(c.NV, 3, c.H, c.W, dtype=torch.float32, device=dev)
+    alpha = torch.empty(c.NV, c.H, c.W, dtype=torch.float32, device=dev) if return_alpha else None
+    inp = _inputs_struct(c)
+    out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha))
+    with _OnDevice(dev):
+        rc = L.gh_forward_refresh(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(g0.ws.data_ptr()),
+                                  C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"gh_forward_refresh failed: {_abi.status_name(rc)}")
+    counters = ws[:16].view(torch.int32)
+    st.last_ws = ws
+    pending, auto = None, sync is None
+    gkey = (c.P, c.NV, c.H, c.W, False)
+    if sync is None:
+        sync = not expect_backward
+    if sync:
+        c4 = counters.tolist()
+        st.last_D = c4[0] & 0xFFFFFFFF
+        if c4[1] & 2:
+            GeometryCache.clear_all()
+            raise GhStaleGeometryError(_STALE_MSG)
+        if c4[1] & 1:
+            GeometryCache.clear_all()
+            raise GhOverflowError("the static tile lists were built by a call that overflowed its capacity; caches cleared")
+    elif _policy.graph_mode:
+        st.graph_counters[ws.data_ptr()] = (counters, cap, gkey)
+    else:
+        # a refresh whose opacity guard fired (or whose lists an overflow truncated) poisons every later step too: look at
+        # the read-backs that have arrived, so that a stale loop surfaces within two calls instead of _PENDING_MAX
+        check_overflow(block=False, keep_recent=2, dev=st.index)
+        if len(st.pending) >= _PENDING_MAX:
+            check_overflow(block=True, dev=st.index)
+        pc = _queue_readback(st, counters, cap, gkey, learn24=False)      # (no depth sort in a refresh: nothing to learn about it)
+        if auto:
+            pending = pc
+    ctx = _make_ctx(c, dims, inp, ws, stream, alpha, g0, g0.radii, pending, None, True)
+    return image, g0.radii, ctx
+
+
+def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backward: bool, max_instances, static_lists: bool,
+                  depth_bound):
+    """gh_forward: projection, both sorts, lists, render — with the capacity / GH_FLAG_DEPTH24 / occlusion-bound policies around it
+    (a synced call that the device flags is re-run with what it learned; a sync-free call is recorded for check_overflow)."""
+    P, NV, H, W = c.P, c.NV, c.H, c.W
+    key = (P, NV, H, W, c.split)
+    if depth_bound is not None and (static_lists or _policy.graph_mode or P == 0 or NV * H * W < depth_bound.min_pixels):
+        depth_bound = None                       # lists that outlive the call / a captured call / a small call: no per-call speculation
+    base_flags = c.flags | (_abi.GH_FLAG_STATIC_LISTS if static_lists else 0)
+    while True:
+        cap = int(max_instances) if max_instances is not None else st.capacity.get(key, _initial_capacity(P, NV))
+        # three depth-sort passes only for a shape a read-back has shown them to suffice for (_DeviceState.depth24)
+        flags = base_flags | (_abi.GH_FLAG_DEPTH24 if st.depth24.get(key) is True else 0)
+        dims = _abi.GhDims(P, NV, H, W, c.sh_degree, c.M, c.scale_modifier, flags, cap)
+        nbytes = L.gh_workspace_bytes(C.byref(dims))
+        if nbytes == 0:
+            raise RuntimeError("gh_workspace_bytes rejected the dimensions")
+        stream = _raw_stream(dev)
+        ws = _ws_acquire(st, dev, nbytes, stream)
+        image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
+        radii = torch.empty(NV, P, dtype=torch.int32, device=dev)
+        alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
+        bound, seen = depth_bound._buffers(dev, NV, H, W, key=(P, bool(c.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS), c.cams_obj)) \
+            if depth_bound is not None else (None, None)
+        inp = _inputs_struct(c, bound=bound)
+        out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha), _ptr(seen), 1.0 + (depth_bound.margin if depth_bound is not None else 0.0),
+                             depth_bound.slack if depth_bound is not None else 0)
+        with _OnDevice(dev):
+            fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
+            if _policy.stage_timing:
+                rc = _run_stages(st, L.gh_forward_stages, fargs, (("preprocess_fwd", _abi.GH_FWD_PREPROCESS),
+                                                                   ("binning", _abi.GH_FWD_BINNING),
+                                                                   ("render_fwd", _abi.GH_FWD_RENDER)))
+            else:
+                rc = L.gh_forward(*fargs)
+        if rc != 0:
+            raise RuntimeError(f"gh_forward failed: {_abi.status_name(rc)}")
+        counters = ws[:16].view(torch.int32)
+        st.last_ws = ws
+        pending, auto, verdict = None, sync is None, None
+        do_sync = sync
+        if do_sync is None:
+            # auto: read D back once per shape to size the capacity, then sync-free — but only for calls whose backward will
+            # come (it checks this call's counters before it produces a gradient, see raster_backward). A call outside
+            # autograd (inference) has no such second chance and reads D back like the reference wrapper does.
+            do_sync = (max_instances is None and key not in st.capacity) or not expect_backward
+            if not do_sync:
+                check_overflow(block=False, keep_recent=2, dev=st.index)  # an overflow of an earlier sync-free call surfaces at most two calls late
+        if do_sync:
+            c4 = counters.tolist()                        # the one host read-back, as in the reference wrapper
+            d = c4[0] & 0xFFFFFFFF
+            st.last_D = d
+            _learn_depth24(st, key, c4[1])
+            if c4[1] & 8:                                      # the three-pass depth sort does not cover this call's depths
+                if depth_bound is not None:
+                    depth_bound.clear()
+                continue
+            over = (c4[1] & 1) != 0
+            need = max(d, c4[2] & 0xFFFFFFFF) if c.split else d   # split: the capacity that gives each half a large enough share
+            if over:
+                if max_instances is not None:
+                    raise GhOverflowError(f"tile instances D={d} exceed max_instances={cap}")
+                st.capacity[key] = int(need * 1.5) + 1024
+                if depth_bound is not None:
+                    depth_bound.clear()                        # (the truncated lists' report is not a bound)
+                continue                                       # (the too-small workspace is simply dropped)
+            if c4[1] & 4:                                      # the occlusion bound missed: the same call again, unbounded
+                depth_bound.clear()
+                depth_bound.misses += 1
+                continue
+            if max_instances is None and key not in st.capacity:
+                st.capacity[key] = max(int(need * 1.5) + 1024, 1 << 16)
+        elif _policy.graph_mode:
+            # every captured workspace is registered (keyed by its address, so a workspace re-used by later captures is
+            # listed once); check_overflow() reads each of them
+            st.graph_counters[ws.data_ptr()] = (counters, cap, key)
+        else:
+            if len(st.pending) >= _PENDING_MAX:
+                check_overflow(block=False, dev=st.index)
+                if len(st.pending) >= _PENDING_MAX:
+                    check_overflow(block=True, dev=st.index)
+            pc = _queue_readback(st, counters, cap, key, depth_bound)
+            verdict = pc
+            if auto:                                       # an explicit sync=False never blocks: check_overflow() is the caller's job
+                pending = pc
+        break
+    # verdict: the counter read-back of a sync-free call, whoever is to ask for it
+    ctx = _make_ctx(c._replace(flags=flags), dims, inp, ws, stream, alpha, None, radii, pending, verdict, False)
+    return image, radii, ctx
+
+
 def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None, colors_precomp=None,
                    sh_degree: int = 0, scale_modifier: float = 1.0, xyz_b=None, opacity_b=None, color_w=None,
                    color_b=None, max_instances: Optional[int] = None, sync: Optional[bool] = True, return_alpha: bool = False,
@@ -442,233 +789,24 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     not listed; verified by the forward, re-run without the bound on a miss.
     sync: True = read D back (and re-run with a larger capacity if needed); False = never block (check_overflow() is the
     caller's job); None = auto: read D back for the first call of a shape and for calls whose backward will not come
-    (expect_backward False), otherwise sync-free with the check at the start of raster_backward."""
-    global _last_D, _last_ws
+    (expect_backward False), otherwise sync-free with the check at the start of raster_backward.
+    The three-pass depth sort (GH_FLAG_DEPTH24) is used only for call shapes a read-back has shown it to hold for: the first
+    call of a shape, and every call of a loop that never reads its counters back, run the four-pass sort."""
     L = _lib.lib()
     dev = means3D.device
     if dev.type != "cuda":
         raise RuntimeError("guassianhand_amd rasteriser needs tensors on a ROCm device (no CPU fallback)")
-    if (shs is None) == (colors_precomp is None):
-        raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
-    t = dict(cams=_prep(cams, dev).reshape(-1, _abi.GH_CAM_FLOATS), means3D=_prep(means3D, dev),
-             opacities=_prep(opacities, dev).reshape(-1), scales=_prep(scales, dev), rotations=_prep(rotations, dev),
-             shs=_prep(shs, dev), colors_precomp=_prep(colors_precomp, dev), xyz_b=_prep(xyz_b, dev),
-             opacity_b=None if opacity_b is None else _prep(opacity_b, dev).reshape(-1),
-             color_w=_prep(color_w, dev), color_b=_prep(color_b, dev))
-    rows, NV = t["means3D"].shape[0], t["cams"].shape[0]
-    M = 0 if shs is None else t["shs"].shape[1]
-    flags = 0
-    if per_view_gaussians:
-        if NV == 0 or rows % NV:
-            raise ValueError("per_view_gaussians: the Gaussian tensors must hold n_views * P rows")
-        flags |= _abi.GH_FLAG_PER_VIEW_GAUSSIANS
-    P = rows // NV if per_view_gaussians else rows
-    if split_streams is None:
-        split_streams = _split_policy is True or (_split_policy == "auto" and NV >= 4 and H * W > _SPLIT_AUTO_MIN_PIXELS)
-    split = bool(split_streams) and NV >= 2 and P > 0 and geometry_of is None and refresh_of is None and not static_lists \
-        and not _stage_timing
-    if split:
-        flags |= _abi.GH_FLAG_SPLIT_STREAMS
-    if static_lists or refresh_of is not None:
-        flags |= _abi.GH_FLAG_STATIC_LISTS
-    wpg = False
-    if t["color_w"] is not None:
-        if t["color_w"].numel() == 48:
-            pass
-        elif t["color_w"].numel() == rows * 48:
-            flags |= _abi.GH_FLAG_BLEND_W_PER_GAUSSIAN
-            wpg = True
-        else:
-            raise ValueError("color_w must have 48 or P*48 elements")
-    b_rgb = False
-    if t["color_b"] is not None:
-        if t["color_b"].numel() == rows * 3 and colors_precomp is not None:  # the 3 columns RGB mode reads (renderer_one_shot.py:328)
-            flags |= _abi.GH_FLAG_BLEND_COLOR_B_RGB
-            b_rgb = True
-        elif t["color_b"].numel() != rows * 48:
-            raise ValueError("color_b must have P*48 elements (or P*3 with colors_precomp)")
-    key = (P, NV, H, W, split)
-    if geometry_of is not None:
-        g0 = geometry_of
-        if shs is not None or (g0.dims.flags & _abi.GH_FLAG_SPLIT_STREAMS) or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (P, NV, H, W, rows) or \
-                (g0.dims.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) != (flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS):
-            raise ValueError("geometry_of: the second call must have the first one's shapes and precomputed colours")
-        cap = int(g0.dims.max_instances)
-        dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
-        nbytes = L.gh_workspace_bytes(C.byref(dims))
-        stream = _raw_stream(dev)
-        ws = _ws_acquire(dev, nbytes, stream)
-        image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
-        alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
-        inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
-                            _ptr(t["rotations"]), None, _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
-                            _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
-        out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha))
-        with _OnDevice(dev):
-            rc = L.gh_forward_shared(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(g0.ws.data_ptr()),
-                                     C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
-        if rc != 0:
-            raise RuntimeError(f"gh_forward_shared failed: {_abi.status_name(rc)}")
-        _last_ws = ws
-        ctx = _Ctx()
-        ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
-        ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
-        ctx.pending = g0.pending                 # the overflow flag is the geometry owner's
-        ctx.verdict = g0.verdict
-        ctx.refresh = False
-        return image, g0.radii, ctx           # same geometry, same radii; an overflow is the first call's (NaN image here too)
-    if refresh_of is not None:
-        g0 = refresh_of
-        if not (g0.dims.flags & _abi.GH_FLAG_STATIC_LISTS) or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (P, NV, H, W, rows) or \
-                (g0.dims.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) != (flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) or g0.parent is not None:
-            raise ValueError("refresh_of: needs the context of a static_lists forward with this call's shapes")
-        cap = int(g0.dims.max_instances)
-        dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
-        nbytes = L.gh_workspace_bytes(C.byref(dims))
-        # the library applies THIS call's layout to the owner's workspace, and the arrays a refresh reads of it (cull_bound,
-        # inst_c) lie behind the ones sized by the colour mode (sh_rgb, dmean_sh, sh_scratch: M != 0): the two calls must agree
-        # on it (ADVICE r3) — and the owner's workspace must span this call's layout
-        if (g0.M != 0) != (M != 0) or g0.ws.numel() < nbytes:
-            raise ValueError("refresh_of: the static lists were built in the other colour mode (shs vs colors_precomp); "
-                             "build them again with this call's colour inputs")
-        stream = _raw_stream(dev)
-        ws = _ws_acquire(dev, nbytes, stream)
-        image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
-        alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
-        inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
-                            _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
-                            _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
-        out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha))
-        with _OnDevice(dev):
-            rc = L.gh_forward_refresh(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(g0.ws.data_ptr()),
-                                      C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
-        if rc != 0:
-            raise RuntimeError(f"gh_forward_refresh failed: {_abi.status_name(rc)}")
-        counters = ws[:16].view(torch.int32)
-        _last_ws = ws
-        pending, auto = None, sync is None
-        gkey = (P, NV, H, W, False)
-        if sync is None:
-            sync = not expect_backward
-        if sync:
-            c4 = counters.tolist()
-            _last_D = c4[0] & 0xFFFFFFFF
-            if c4[1] & 2:
-                GeometryCache.clear_all()
-                raise GhStaleGeometryError(_STALE_MSG)
-            if c4[1] & 1:
-                GeometryCache.clear_all()
-                raise GhOverflowError("the static tile lists were built by a call that overflowed its capacity; caches cleared")
-        elif _graph_mode:
-            _graph_counters[ws.data_ptr()] = (counters, cap, gkey)
-        else:
-            # a refresh whose opacity guard fired (or whose lists an overflow truncated) poisons every later step too: look at
-            # the read-backs that have arrived, so that a stale loop surfaces within two calls instead of _PENDING_MAX
-            check_overflow(block=False, keep_recent=2)
-            if len(_pending) >= _PENDING_MAX:
-                check_overflow(block=True)
-            host, ev = _free_slots.pop() if _free_slots else (torch.empty(4, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
-            host.copy_(counters, non_blocking=True)
-            ev.record()
-            pc = _Pending(ev, host, cap, gkey)
-            _pending.append(pc)
-            if auto:
-                pending = pc
-        ctx = _Ctx()
-        ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
-        ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = b_rgb, rows, alpha, g0, g0.radii, stream
-        ctx.pending, ctx.refresh, ctx.verdict = pending, True, None
-        return image, g0.radii, ctx
-    if depth_bound is not None and (static_lists or _graph_mode or P == 0 or NV * H * W < depth_bound.min_pixels):
-        depth_bound = None                       # lists that outlive the call / a captured call / a small call: no per-call speculation
-    base_flags = flags
-    while True:
-        cap = int(max_instances) if max_instances is not None else _capacity.get(key, _initial_capacity(P, NV))
-        flags = base_flags | (_abi.GH_FLAG_DEPTH24 if _depth24.get(key, True) else 0)
-        dims = _abi.GhDims(P, NV, H, W, sh_degree, M, float(scale_modifier), flags, cap)
-        nbytes = L.gh_workspace_bytes(C.byref(dims))
-        if nbytes == 0:
-            raise RuntimeError("gh_workspace_bytes rejected the dimensions")
-        stream = _raw_stream(dev)
-        ws = _ws_acquire(dev, nbytes, stream)
-        image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
-        radii = torch.empty(NV, P, dtype=torch.int32, device=dev)
-        alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None
-        bound, seen = depth_bound._buffers(dev, NV, H, W) if depth_bound is not None else (None, None)
-        inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
-                            _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]),
-                            _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]), _ptr(bound))
-        out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha), _ptr(seen), 1.0 + (depth_bound.margin if depth_bound is not None else 0.0),
-                             depth_bound.slack if depth_bound is not None else 0)
-
-        with _OnDevice(dev):
-            fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
-            if _stage_timing:
-                rc = _run_stages(L.gh_forward_stages, fargs, (("preprocess_fwd", _abi.GH_FWD_PREPROCESS),
-                                                               ("binning", _abi.GH_FWD_BINNING),
-                                                               ("render_fwd", _abi.GH_FWD_RENDER)))
-            else:
-                rc = L.gh_forward(*fargs)
-        if rc != 0:
-            raise RuntimeError(f"gh_forward failed: {_abi.status_name(rc)}")
-        counters = ws[:16].view(torch.int32)
-        _last_ws = ws
-        pending, auto, verdict = None, sync is None, None
-        if sync is None:
-            # auto: read D back once per shape to size the capacity, then sync-free — but only for calls whose backward will
-            # come (it checks this call's counters before it produces a gradient, see raster_backward). A call outside
-            # autograd (inference) has no such second chance and reads D back like the reference wrapper does.
-            sync = (max_instances is None and key not in _capacity) or not expect_backward
-            if not sync:
-                check_overflow(block=False, keep_recent=2)  # an overflow of an earlier sync-free call surfaces at most two calls late
-        if sync:
-            c4 = counters.tolist()                        # the one host read-back, as in the reference wrapper
-            d = c4[0] & 0xFFFFFFFF
-            _last_D = d
-            if c4[1] & 8:                                      # the three-pass depth sort does not cover this call's depths
-                _depth24[key] = False
-                if depth_bound is not None:
-                    depth_bound.clear()
-                continue
-            over = (c4[1] & 1) != 0
-            need = max(d, c4[2] & 0xFFFFFFFF) if split else d   # split: the capacity that gives each half a large enough share
-            if over:
-                if max_instances is not None:
-                    raise GhOverflowError(f"tile instances D={d} exceed max_instances={cap}")
-                _capacity[key] = int(need * 1.5) + 1024
-                if depth_bound is not None:
-                    depth_bound.clear()                        # (the truncated lists' report is not a bound)
-                continue                                       # (the too-small workspace is simply dropped)
-            if c4[1] & 4:                                      # the occlusion bound missed: the same call again, unbounded
-                depth_bound.clear()
-                depth_bound.misses += 1
-                continue
-            if max_instances is None and key not in _capacity:
-                _capacity[key] = max(int(need * 1.5) + 1024, 1 << 16)
-        elif _graph_mode:
-            # every captured workspace is registered (keyed by its address, so a workspace re-used by later captures is
-            # listed once); check_overflow() reads each of them
-            _graph_counters[ws.data_ptr()] = (counters, cap, key)
-        else:
-            if len(_pending) >= _PENDING_MAX:
-                check_overflow(block=False)
-                if len(_pending) >= _PENDING_MAX:
-                    check_overflow(block=True)
-            host, ev = _free_slots.pop() if _free_slots else (torch.empty(4, dtype=torch.int32, pin_memory=True), torch.cuda.Event())
-            host.copy_(counters, non_blocking=True)
-            ev.record()
-            pc = _Pending(ev, host, cap, key, depth_bound)
-            _pending.append(pc)
-            verdict = pc
-            if auto:                                       # an explicit sync=False never blocks: check_overflow() is the caller's job
-                pending = pc
-        break
-    ctx = _Ctx()
-    ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, t, ws, H, W, P, NV, M, wpg
-    ctx.b_rgb, ctx.rows = b_rgb, rows
-    ctx.alpha, ctx.parent, ctx.radii, ctx.stream, ctx.pending, ctx.refresh = alpha, None, radii, stream, pending, False
-    ctx.verdict = verdict                                  # the counter read-back of a sync-free call, whoever is to ask for it
-    return image, radii, ctx
+    plain = geometry_of is None and refresh_of is None and not static_lists
+    c = _prepare_call(dev, cams, means3D, opacities, scales, rotations, H, W, shs, colors_precomp, sh_degree, scale_modifier, xyz_b,
+                      opacity_b, color_w, color_b, per_view_gaussians, split_streams, plain)
+    st = _state(dev)
+    with st.lock:
+        if geometry_of is not None:
+            return _forward_shared(st, L, dev, c, geometry_of, return_alpha)
+        if refresh_of is not None:
+            return _forward_refresh(st, L, dev, c._replace(flags=c.flags | _abi.GH_FLAG_STATIC_LISTS), refresh_of, return_alpha, sync,
+                                    expect_backward)
+        return _forward_full(st, L, dev, c, return_alpha, sync, expect_backward, max_instances, static_lists, depth_bound)
 
 
 def cached_raster_forward(cache: Optional[GeometryCache], cams, means3D, opacities, scales, rotations, **kw):
@@ -713,15 +851,16 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
     color_w, color_b} (None = all): the others get a NULL pointer in GhGrads — with no geometry gradient asked for the
     per-Gaussian chain rule is skipped altogether (the one-shot fit trains colour / opacity biases only)."""
     L = _lib.lib()
+    t = ctx.tensors
+    dev = t["means3D"].device
+    st = _state(dev)
     if ctx.pending is not None and ctx.pending.resolve():
         # auto-sync forward (the drop-in's default): its counters are checked HERE, before any gradient exists — an overflowed
         # call returned a NaN image, and a NaN loss must not reach the caller's optimiser step. The forward finished long ago
         # on any host-bound loop, so this wait is normally free.
-        global _geom_last
-        _geom_last = None                          # the re-run of the step must not be taken for this call's mask pass
+        with st.lock:
+            st.geom_last = None                    # the re-run of the step must not be taken for this call's mask pass
         raise ctx.pending.error()
-    t = ctx.tensors
-    dev = t["means3D"].device
     P, NV, M = ctx.P, ctx.NV, ctx.M
     if dL_dimage is None:
         dL_dimage = torch.zeros(NV, 3, ctx.H, ctx.W, dtype=torch.float32, device=dev)
@@ -774,27 +913,23 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
             fn = L.gh_backward_refresh if ctx.refresh else L.gh_backward_shared
             rc = fn(C.byref(ctx.dims), C.byref(ctx.inp), C.byref(gr), C.c_void_p(ctx.parent.ws.data_ptr()),
                     C.c_void_p(ctx.ws.data_ptr()), ctx.ws.numel(), C.c_void_p(stream))
-        elif _stage_timing:
-            rc = _run_stages(L.gh_backward_stages, bargs, (("render_bwd", _abi.GH_BWD_RENDER),
+        elif _policy.stage_timing:
+            rc = _run_stages(st, L.gh_backward_stages, bargs, (("render_bwd", _abi.GH_BWD_RENDER),
                                                             ("preprocess_bwd", _abi.GH_BWD_PREPROCESS)))
         else:
             rc = L.gh_backward(*bargs)
     if rc != 0:
         raise RuntimeError(f"gh_backward failed: {_abi.status_name(rc)}")
-    global _last_grad_block
-    _last_grad_block = ctx_block
+    st.last_grad_block = ctx_block
     return {k: v for k, v in o.items() if v is not None}
 
 
-_last_grad_block = None
-
-
-def last_grad_block():
+def last_grad_block(dev=None):
     """(block, n_reducible, spans, blend_end) of the most recent raster_backward: `block[:n_reducible]` is the contiguous fp32
     buffer [4 caller floats | every view-summed gradient] the kernels wrote in place, spans = [(name, shape, offset, numel)],
     block[:blend_end] = [4 caller floats | gradients of the blend parameters] (the prefix the one-shot fit reduces).
     The sharded fit all-reduces it directly (dist.allreduce_block): no torch.cat of the parts."""
-    return _last_grad_block
+    return _state(dev).last_grad_block
 
 
 def workspace_counters(ctx: _Ctx):
@@ -830,18 +965,15 @@ def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
 
 
 # ---------------------------------------------------------------------------------------------------
-_reuse_geometry = True
-_geom_last = None        # (identity objects, values, weakref to the context) of the latest full drop-in forward
-
-
 def set_geometry_reuse(on: bool) -> None:
     """The reference renders every view twice over identical geometry (RGB pass, then mask pass with colour 1 / bg 0,
     renderer_one_shot.py:338-346, :372-379). With reuse on (default) a drop-in call that receives the very same tensor
     objects (unmodified) for means3D / opacities / scales / rotations and the same camera as the previous call, with
     precomputed colours, shares the previous call's projection and tile lists (bit-identical results)."""
-    global _reuse_geometry, _geom_last
-    _reuse_geometry = bool(on)
-    _geom_last = None
+    _policy.reuse_geometry = bool(on)
+    for st in list(_states.values()):
+        with st.lock:
+            st.geom_last = None
 
 
 def _geometry_key(means3D, opacities, scales, rotations, rs):
@@ -854,18 +986,19 @@ def _geometry_key(means3D, opacities, scales, rotations, rs):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, raster_settings, sync, expect_backward):
-        global _geom_last
         rs = raster_settings
         cams = pack_camera(rs.viewmatrix, rs.projmatrix, rs.campos, rs.tanfovx, rs.tanfovy, rs.bg)
         parent = None
-        if _reuse_geometry:
+        st = _state(means3D.device)
+        if _policy.reuse_geometry:
             # Only the documented pair is shared: the call DIRECTLY after a full call, with the very same (unmodified, `is` +
             # `_version`) geometry tensors and camera on the same stream, precomputed colours, while the first call's context is
             # still alive (its backward has not run). The record holds weak references and is dropped after one reuse, so
             # nothing of an earlier step can be picked up. (An in-place update through `.data` does not move `_version`:
             # between an RGB call and its mask call nothing updates parameters.)
             objs, vals = _geometry_key(means3D, opacities, scales, rotations, rs)
-            g, _geom_last = _geom_last, None
+            with st.lock:
+                g, st.geom_last = st.geom_last, None
             if g is not None and sh is None and g[1] == vals and all(a() is b for a, b in zip(g[0], objs)):
                 parent = g[2]()                    # alive until its backward has run
                 # never the lists of a call that overflowed: its verdict is known when its counters were read already (the caller
@@ -879,8 +1012,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             shs=sh, colors_precomp=colors_precomp, sh_degree=int(rs.sh_degree),
             scale_modifier=float(rs.scale_modifier), sync=sync, geometry_of=parent,
             expect_backward=expect_backward)
-        if _reuse_geometry and parent is None:
-            _geom_last = (tuple(weakref.ref(o) for o in objs), vals, weakref.ref(rctx))
+        if _policy.reuse_geometry and parent is None:
+            with st.lock:
+                st.geom_last = (tuple(weakref.ref(o) for o in objs), vals, weakref.ref(rctx))
         ctx.rctx = rctx
         # the backward kernels read these tensors again, through the pointers the context holds: registering them makes autograd
         # raise its usual "modified by an inplace operation" error when one of them was written between forward and backward,
@@ -1048,3 +1182,20 @@ def rasterize_views(cams: torch.Tensor, xyz, opacity, scaling, rotation, shs, *,
                                  scaling,
                                  rotation, shs, xyz_b, opacity_b, color_w, color_b)
     return (image, alpha, radii) if return_alpha else (image, radii)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Names of the module-level state of rounds 1-4, kept readable for tests and tools: they resolve to the CURRENT device's state /
+# the policy object (PEP 562). Code in this package uses _state(dev) / _policy directly.
+_LEGACY_STATE = {"_capacity": "capacity", "_depth24": "depth24", "_pending": "pending", "_free_slots": "free_slots", "_last_D": "last_D",
+                 "_last_ws": "last_ws", "_graph_counters": "graph_counters", "_ws_pool": "ws_pool", "_geom_last": "geom_last",
+                 "_last_grad_block": "last_grad_block", "_stage_events": "stage_events"}
+_LEGACY_POLICY = {"_graph_mode": "graph_mode", "_split_policy": "split", "_reuse_geometry": "reuse_geometry", "_stage_timing": "stage_timing"}
+
+
+def __getattr__(name):
+    if name in _LEGACY_STATE:
+        return getattr(_state(), _LEGACY_STATE[name])
+    if name in _LEGACY_POLICY:
+        return getattr(_policy, _LEGACY_POLICY[name])
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

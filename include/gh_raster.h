@@ -157,9 +157,17 @@ typedef struct GhCounters {
                             bit 1: gh_forward_refresh met an opacity above the bound its lists were built for;
                             bit 2: a pixel of a tile with a GhInputs.tile_depth_bound ran off the end of its truncated list
                                    (that pixel is NaN): re-run without the bound;
-                            bit 3: GH_FLAG_DEPTH24 did not hold (NaN image): re-run without the flag */
+                            bit 3: GH_FLAG_DEPTH24 did not hold (NaN image): re-run without the flag
+                            bits 0-3 (GH_COUNTER_ERROR_MASK) are errors — the device-side guards of the loss / optimiser entry points
+                            test exactly these;
+                            bit 4: INFORMATION, set by every full forward: the depth keys of the Gaussians that emit instances did
+                                   not differ in their top byte, i.e. GH_FLAG_DEPTH24 would have held (or did hold) for this call —
+                                   how a caller learns, from a call made WITHOUT the flag, that the flag is safe for a call shape */
   uint32_t reserved[2];  /* [0] after a GH_FLAG_SPLIT_STREAMS forward: the max_instances that would have sufficed */
 } GhCounters;
+
+#define GH_COUNTER_ERROR_MASK 15u
+#define GH_COUNTER_DEPTH24_OK 16u
 
 /* Upstream gradient + outputs of gh_backward. Any output pointer may be NULL (that gradient is skipped). */
 typedef struct GhGrads {
@@ -242,6 +250,9 @@ typedef struct GhLayout {
   size_t tile_bound;     /* float[n_views*tiles] the effective occlusion bound of this call (GhInputs.tile_depth_bound after the
                             neighbourhood test; +inf = unbounded), read by every kernel that decides list membership */
   size_t block_tiles;    /* uint32[projection blocks] instances counted by each block of the projection kernel (record-slot scan) */
+  size_t render_guard;   /* uint32: the error bits of GhCounters.overflow as they stood BEFORE the render kernel of this call — written by
+                            the kernel in front of it, read by every render wave through the scalar cache (the counters' own line
+                            takes the render kernel's atomics) */
 } GhLayout;
 
 /* Library version: major<<16 | minor. */

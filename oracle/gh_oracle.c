@@ -370,7 +370,6 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
     const long NG = (long)NV * P;
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);
-    extern int omp_get_thread_num(void);
     const int nth = omp_get_max_threads();
 #else
     const int nth = 1;
@@ -380,13 +379,10 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
     uint32_t* cnt = (uint32_t*)calloc((size_t)NT + 1, sizeof(uint32_t));
     uint32_t* cur = (uint32_t*)malloc(((size_t)NT + 1) * sizeof(uint32_t));
     uint32_t* lc = (uint32_t*)calloc((size_t)nth * (size_t)NT + 1, sizeof(uint32_t));
-#pragma omp parallel num_threads(nth)
-    {
-#ifdef _OPENMP
-      const int k = omp_get_thread_num();
-#else
-      const int k = 0;
-#endif
+    /* nth LOGICAL slices, one per loop iteration: every slice is processed whatever team the runtime delivers (a smaller
+     * team under OMP_THREAD_LIMIT / OMP_DYNAMIC / a cgroup quota just takes several slices per thread) — ADVICE r4 */
+#pragma omp parallel for schedule(static, 1)
+    for (int k = 0; k < nth; ++k) {
       uint32_t* mine = lc + (size_t)k * NT;
       for (long n = NG * k / nth; n < NG * (k + 1) / nth; ++n) {
         const GView* g = &c->g[n];
@@ -403,13 +399,8 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
       for (int k = 0; k < nth; ++k) { uint32_t x = lc[(size_t)k * NT + t]; lc[(size_t)k * NT + t] = acc; acc += x; cnt[t] += x; }
     }
     t_ser += gho_now() - t_mark;
-#pragma omp parallel num_threads(nth)
-    {
-#ifdef _OPENMP
-      const int k = omp_get_thread_num();
-#else
-      const int k = 0;
-#endif
+#pragma omp parallel for schedule(static, 1)
+    for (int k = 0; k < nth; ++k) {
       uint32_t* mine = lc + (size_t)k * NT;
       for (long n = NG * k / nth; n < NG * (k + 1) / nth; ++n) {
         const GView* g = &c->g[n];

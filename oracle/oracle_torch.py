@@ -62,7 +62,7 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
                     colors_precomp: Optional[torch.Tensor] = None, shs: Optional[torch.Tensor] = None,
                     sh_degree: int = 0, scale_modifier: float = 1.0, pixel_chunk: int = 2048,
                     return_aux: bool = False, pixel_window=None, checkpoint_chunks: bool = False,
-                    ambiguity_eps: Optional[float] = None):
+                    ambiguity_eps: Optional[float] = None, per_gaussian_only: bool = False):
     """Returns (image (3,H,W), radii (P,) int32[, aux dict]).
     pixel_window = (x0, y0, x1, y1): evaluate only the pixels x0 <= x < x1, y0 <= y < y1 of the H x W image (the image
     returned is (3, y1-y0, x1-x0)); everything else — projection, tile rects, tile membership of a pixel — is that of the
@@ -72,7 +72,10 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
     ambiguity_eps (with checkpoint_chunks): also return a bool mask (h, w) of the pixels at which some discrete decision of
     App. A.3 sits within that RELATIVE margin of its threshold — alpha against 1/255, power against 0 (|power| <= eps),
     T (1 - alpha) against 1e-4 (margin 5 eps: a product of up to a thousand factors) — i.e. the pixels where an evaluation in
-    another precision may legitimately decide differently: returns (image, radii, ambiguous)."""
+    another precision may legitimately decide differently: returns (image, radii, ambiguous).
+    per_gaussian_only: stop after the per-Gaussian stage (App. A.1) — O(P), no pixel is evaluated — and return (None, radii, aux)
+    with the projected centre, depth, conic, colour, validity, tile rect and the quantities the discrete decisions are taken on
+    (3 sqrt(lambda_max) before the ceil, the rect bounds before the truncation, the SH colour before the clamp)."""
     if (shs is None) == (colors_precomp is None):
         raise ValueError("provide exactly one of shs / colors_precomp")
     dt, dev = means3D.dtype, means3D.device
@@ -128,12 +131,23 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
         valid = (tz > 0.2) & (det != 0) & (tiles > 0) & finite
         radii = torch.where(valid, radius, torch.zeros_like(radius)).to(torch.int32)
 
+    rgb_raw = None
     if colors_precomp is not None:
         rgb = colors_precomp.to(dt)
     else:
         d = means3D - campos.to(dt)[None, :]
         d = d / d.norm(dim=1, keepdim=True)
-        rgb = torch.clamp_min(eval_sh(sh_degree, shs.to(dt), d) + 0.5, 0.0)
+        rgb_raw = eval_sh(sh_degree, shs.to(dt), d) + 0.5
+        rgb = torch.clamp_min(rgb_raw, 0.0)
+    if per_gaussian_only:
+        with torch.no_grad():
+            r_f = 3.0 * torch.sqrt(torch.maximum(mid + sq, mid - sq))
+            edges = torch.stack([(pxs - rs) / TILE, (pys - rs) / TILE, (pxs + rs + (TILE - 1)) / TILE, (pys + rs + (TILE - 1)) / TILE], -1)
+            aux = dict(px=px.detach(), py=py.detach(), depth=tz.detach(), conic=torch.stack([cA, cB, cC], -1).detach(), det=det.detach(),
+                       cov=torch.stack([a, b, c], -1).detach(), rgb=rgb.detach(), rgb_raw=None if rgb_raw is None else rgb_raw.detach(),
+                       valid=valid, rect=torch.stack([minx, miny, maxx, maxy], -1), radius_f=r_f, rect_edges=edges,
+                       opacity=opacities.reshape(-1).to(dt).detach())
+        return None, radii, aux
 
     # depth order, stable, ties by index (App. A.2); invalid Gaussians pushed to the end
     # The sort key of App. A.2 is the FLOAT32 bit pattern of the depth, whatever precision the rest is evaluated in: a float64

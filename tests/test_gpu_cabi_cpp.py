@@ -65,7 +65,7 @@ def test_cpp_driver_matches_python_host_and_oracle(tmp_path, gh_lib_path):
     assert off == raw.size
     # v0.5 from plain C++: a forward that applies the occlusion bound another forward reported, with the three-pass depth sort —
     # verified on the device (no flag set), never more instances, the same image bit for bit
-    assert overflow_bits == 0 and 0 < D_bounded <= D and torch.equal(bounded_image, image)
+    assert overflow_bits & 15 == 0 and overflow_bits & 16 and 0 < D_bounded <= D and torch.equal(bounded_image, image)   # (bit 4: information)
 
     # the same call through the Python host (ctypes + torch memory): identical bits
     dev = torch.device("cuda:0")

@@ -303,10 +303,13 @@ def test_two_hands_at_the_reference_render_size_256(dev):
 
 
 def test_depth_ranges_wider_than_the_three_pass_sort(dev):
-    """GH_FLAG_DEPTH24 (three depth-sort passes, tried first for every call shape) covers visible depths whose float bit patterns
-    share their top byte, e.g. everything in [0.5, 2) m. A scene that straddles 0.5 m and 2 m must still come out bit-exact: the
-    device flags the call (overflow bit 3), a sync call re-runs with four passes transparently, the shape remembers; a sync-free
-    call returns NaN and raises at the check."""
+    """GH_FLAG_DEPTH24 (three depth-sort passes) covers visible depths whose float bit patterns share their top byte, e.g.
+    everything in [0.5, 2) m. The flag is a speculation the device can only answer with a NaN image, so it is used
+    only for a call shape a read-back has shown it to hold for: every full forward reports whether the top byte varied
+    (GhCounters.overflow bit 4), with or without the flag. A scene that straddles 0.5 m and 2 m comes out bit-exact through four
+    passes and the shape learns False; a shape that was LEARNED to hold and whose scene then moves across a boundary is flagged
+    (bit 3): a sync call re-runs with four passes transparently, a sync-free call returns NaN and raises at the check."""
+    from guassianhand_amd import _abi
     from guassianhand_amd import rasterizer as R
     from guassianhand_amd.scenes import make_scene
     sc = make_scene("random1k", n_views=2, P=1500)
@@ -314,21 +317,41 @@ def test_depth_ranges_wider_than_the_three_pass_sort(dev):
     sc.scaling = sc.scaling * 2.0
     key = R.capacity_key(sc.P, 2, sc.H, sc.W)
     R._depth24.pop(key, None)
-    compare(sc, dev)                                          # sync=True: flagged, re-run, bit-exact against the oracle
+    compare(sc, dev)                                          # unknown shape: four passes, bit-exact against the oracle
+    assert R._depth24.get(key) is False                       # ... and the call reported that its top byte varies
+    # the verdict forced to "holds" (as if learned on an earlier, narrower scene of this shape): sync=True re-runs transparently
+    R._depth24[key] = True
+    compare(sc, dev)
     assert R._depth24.get(key) is False
-    # sync-free with the flag forced back on: NaN image + an error at the check, and the shape is demoted again
-    R._depth24.pop(key, None)
+    # ... and sync-free: NaN image + an error at the check, and the shape is demoted again
+    R._depth24[key] = True
     s = sc.to(dev)
-    img, _, _ = R.raster_forward(sc.cams().to(dev), s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W, sync=False,
-                                 colors_precomp=s.shs.squeeze(1))
+    img, _, ctx = R.raster_forward(sc.cams().to(dev), s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W, sync=False,
+                                   colors_precomp=s.shs.squeeze(1))
+    assert ctx.dims.flags & _abi.GH_FLAG_DEPTH24
     with pytest.raises(R.GhOverflowError, match="24 key bits"):
         R.check_overflow()
     assert bool(torch.isnan(img).all()) and R._depth24.get(key) is False
-    # a scene inside one factor-4 range keeps the three-pass sort
+    # a scene inside one factor-4 range: the first call (four passes) learns that three suffice, the second uses them — both bit-exact
     sc2 = make_scene("random1k", n_views=2, P=1500, seed=5)
     sc2.H, sc2.W = 96, 80
+    key2 = R.capacity_key(sc2.P, 2, 96, 80)
+    R._depth24.pop(key2, None)
     compare(sc2, dev)
-    assert R._depth24.get(R.capacity_key(sc2.P, 2, 96, 80), True) is True
+    assert R._depth24.get(key2) is True
+    s2 = sc2.to(dev)
+    _, _, ctx2 = R.raster_forward(sc2.cams().to(dev), s2.xyz, s2.opacity, s2.scaling, s2.rotation, H=96, W=80, sync=False,
+                                  colors_precomp=s2.shs.squeeze(1))
+    assert ctx2.dims.flags & _abi.GH_FLAG_DEPTH24             # (also for an explicit sync=False call: the knowledge is there now)
+    R.check_overflow()
+    compare(sc2, dev)
+    # a sync-free loop that never read anything back knows nothing: four passes
+    R._depth24.pop(key2, None)
+    _, _, ctx3 = R.raster_forward(sc2.cams().to(dev), s2.xyz, s2.opacity, s2.scaling, s2.rotation, H=96, W=80, sync=False,
+                                  colors_precomp=s2.shs.squeeze(1))
+    assert not (ctx3.dims.flags & _abi.GH_FLAG_DEPTH24)
+    R.check_overflow()                                        # ... until a read-back arrives: the verdict is learned from it
+    assert R._depth24.get(key2) is True
 
 
 def test_reference_init_scale(dev):

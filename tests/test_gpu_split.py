@@ -108,7 +108,7 @@ def test_split_call_that_fits_is_not_reported_as_overflowed(dev):
     img, _, ctx = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, colors_precomp=cols, sync=True,
                                    split_streams=True, max_instances=cap)
     c = R.workspace_counters(ctx)
-    assert c[1] == 0 and c[2] > cap                   # fits, yet the comfortable capacity is larger than the one given
+    assert c[1] & 15 == 0 and c[2] > cap              # fits (no error bit), yet the comfortable capacity is larger than the one given
     assert torch.equal(img, ref)
     R.check_overflow()
     img2, _, _ = R.raster_forward(cams, s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, colors_precomp=cols, sync=False,

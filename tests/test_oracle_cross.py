@@ -118,6 +118,33 @@ def test_baseline_mode_equals_the_checker(use_rgb, blend):
     assert f1 <= f0                                   # the baseline mode has less single-threaded time, never more
 
 
+def test_baseline_mode_with_a_smaller_team_than_asked_for():
+    """the baseline mode partitions the Gaussians into omp_get_max_threads() slices; a runtime that delivers FEWER
+    threads (OMP_THREAD_LIMIT, OMP_DYNAMIC, a cgroup quota) must still process every slice — the published cpu_baseline rests on
+    this path. A child process with OMP_NUM_THREADS=8 and OMP_THREAD_LIMIT=3: parallel mode == serial mode bit for bit."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import torch\n"
+        "from guassianhand_amd.scenes import make_scene\n"
+        "from oracle import oracle_c\n"
+        "from oracle.oracle_c import OracleRender\n"
+        "sc = make_scene('random1k', n_views=2, P=900)\n"
+        "res = []\n"
+        "for par in (False, True):\n"
+        "    oracle_c.set_parallel(par)\n"
+        "    o = OracleRender(sc.cams(), sc.xyz, sc.opacity, sc.scaling, sc.rotation, H=sc.H, W=sc.W, debug=True, colors_precomp=sc.shs.squeeze(1))\n"
+        "    res.append((o.image.clone(), o.debug['sorted_keys'].clone(), o.debug['sorted_gid'].clone(), int(o.num_rendered)))\n"
+        "    o.close()\n"
+        "oracle_c.set_parallel(False)\n"
+        "assert res[0][3] == res[1][3] and res[0][3] > 1000\n"
+        "assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])\n"
+        "print('ok', oracle_c.num_threads())\n")
+    env = dict(os.environ, OMP_NUM_THREADS="8", OMP_THREAD_LIMIT="3", OMP_DYNAMIC="false", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_c_oracle_against_the_float64_dense_oracle_over_the_feature_matrix():
     """tools/fuzz_oracles_cpu.py, 250 fixed-seed draws: the C oracle (what the HIP path is bit-equal to) against Oracle A (dense float64
     autograd from the behavioural spec) over RGB / SH degree 0-3 x M x every blend subset and form x off-grid sizes — the checker's

@@ -130,7 +130,13 @@ def one(it):
         img, radii, ctx = R.raster_forward(*geo, H=H, W=W, sync=True, split_streams=(variant == "split"), **todev(kw), **todev(bl))
     D = R.last_num_rendered()
     key = (P, NV, H, W, variant == "split")
-    d24 = R._depth24.get(key, True)
+    d24 = R._depth24.get(key) is True
+    if d24 and variant != "static_refresh":
+        # the first call of a shape runs four depth-sort passes and learns that three suffice: the three-pass path is the SECOND call
+        img2, radii2, ctx2 = R.raster_forward(*geo, H=H, W=W, sync=True, split_streams=(variant == "split"), **todev(kw), **todev(bl))
+        assert ctx2.dims.flags & 32, tag + " (GH_FLAG_DEPTH24 not used by the second call)"
+        assert torch.equal(img2, img) and torch.equal(radii2, radii), tag + " (three-pass depth sort differs from four-pass)"
+        del img2, radii2, ctx2
     tiles = NV * ((W + 15) // 16) * ((H + 15) // 16)
     tb = max(1, (tiles - 1).bit_length())
     cap = int(ctx.dims.max_instances)
