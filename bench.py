@@ -64,7 +64,7 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-PROFILE_TAG = "r4"        # profiles/<tag>_pmc_*.json: the committed counter passes this build's bench lines quote
+PROFILE_TAG = "r5"        # profiles/<tag>_pmc_*.json: the committed counter passes this build's bench lines quote
 
 
 def workload_key(args, V: int):
@@ -277,8 +277,8 @@ def self_launch(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--views-per-step", type=int, default=8)
     ap.add_argument("--dist-backend", default=None, choices=[None, "nccl", "gloo"],
                     help="torch.distributed backend for N>1 (default: nccl = RCCL); gloo only to exercise the path without N GPUs")

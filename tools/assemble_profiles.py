@@ -96,6 +96,7 @@ for w, (desc, args) in WORKLOADS.items():
 for n in ("bench_default", "bench_1view", "bench_2view", "bench_4view", "bench_16view", "bench_split", "bench_hd_sh3", "bench_hd_sh3_split", "bench_hd_sh3_pose32", "bench_hd_sh3_pose32_split", "bench_random1k"):
     if os.path.exists(f"{O}/{n}.json") and os.path.getsize(f"{O}/{n}.json") > 0:
         shutil.copy(f"{O}/{n}.json", f"profiles/{tag}_{n}.json")
-for n in ("two_call_cost.txt", "valu_rate_wallclock.txt", "valu_cycles_pmc.txt", "dropin_host_breakdown.txt", "fit_step_profile.txt", "fit_step_views.txt"):
+for n in ("two_call_cost.txt", "valu_rate_wallclock.txt", "valu_cycles_pmc.txt", "dropin_host_breakdown.txt", "fit_step_profile.txt", "fit_step_views.txt",
+          "kernel_floor.txt", "fetch_calib.txt", "timeline_8view.txt", "timeline_1view.txt"):
     if os.path.exists(f"{O}/{n}") and os.path.getsize(f"{O}/{n}") > 0:
         shutil.copy(f"{O}/{n}", f"profiles/{tag}_{n}")

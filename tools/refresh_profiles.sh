@@ -1,6 +1,6 @@
 # One GPU call that regenerates everything under profiles/ for the current build (usage: bash tools/refresh_profiles.sh <tag>)
 # Per workload: the bench line, rocprofv3 kernel stats, HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and the SQ passes.
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
@@ -34,6 +34,11 @@ profile_workload hd_sh3_pose32 --config two_hands_hd --pose-batch --views-per-st
 echo "== valu issue costs (s_memtime / wall clock, then GRBM cycles under the profiler)"
 (hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_cycles tools/micro/valu_cycles.hip && timeout 200 /tmp/valu_cycles > $O/valu_rate_wallclock.txt) 2> $O/valu_rate.err
 bash tools/micro/valu_cycles_pmc.sh $O > $O/valu_cycles_pmc.log 2>&1
+echo "== kernel boundary floor, FETCH_SIZE calibration, one-step timelines"
+bash tools/micro/kernel_floor.sh $O > /dev/null 2>&1
+bash tools/micro/fetch_calib.sh $O > /dev/null 2>&1
+bash tools/kernel_timeline.sh > $O/timeline_8view.txt 2>&1
+bash tools/kernel_timeline.sh --views-per-step 1 > $O/timeline_1view.txt 2>&1
 echo "== two-call protocol, host breakdown of the drop-in, fit step"
 timeout 300 python3 tools/two_call_cost.py > $O/two_call_cost.txt 2> $O/two_call_cost.err
 timeout 300 python3 tools/dropin_time.py 2> /dev/null | grep -v amdgpu.ids > $O/dropin_host_breakdown.txt
