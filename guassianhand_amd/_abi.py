@@ -34,7 +34,7 @@ class GhDims(C.Structure):
 class GhInputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "cams", "means3D", "opacities", "scales", "rotations", "shs", "colors_precomp",
-        "blend_xyz_b", "blend_opacity_b", "blend_color_w", "blend_color_b", "tile_depth_bound")]
+        "blend_xyz_b", "blend_opacity_b", "blend_color_w", "blend_color_b", "tile_depth_bound", "cov3D_precomp")]
 
 
 class GhOutputs(C.Structure):
@@ -50,7 +50,7 @@ class GhGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "dL_dimage", "dL_dalpha", "dL_dmeans3D", "dL_dmeans2D", "dL_dopacities", "dL_dscales", "dL_drotations",
         "dL_dshs", "dL_dcolors", "dL_dblend_xyz_b", "dL_dblend_opacity_b", "dL_dblend_color_w",
-        "dL_dblend_color_b", "upstream_scale")]
+        "dL_dblend_color_b", "upstream_scale", "dL_dcov3D")]
 
 
 class GhAdamTensor(C.Structure):

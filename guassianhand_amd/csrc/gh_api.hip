@@ -126,7 +126,10 @@ extern "C" size_t gh_workspace_bytes(const GhDims* d) {
 static int check_inputs(const GhDims* d, const GhInputs* in) {
   if (!in || !in->cams) return GH_ERR_INVALID_ARG;
   if (d->P == 0) return GH_OK;                      // nothing to read: only the background is composited
-  if (d->P > 0 && (!in->means3D || !in->opacities || !in->scales || !in->rotations)) return GH_ERR_INVALID_ARG;
+  if (d->P > 0 && (!in->means3D || !in->opacities)) return GH_ERR_INVALID_ARG;
+  // exactly one of {scales AND rotations, cov3D_precomp} (the published wrapper's second validation, App. A.0)
+  if ((in->scales != nullptr) != (in->rotations != nullptr)) return GH_ERR_INVALID_ARG;
+  if ((in->scales != nullptr) == (in->cov3D_precomp != nullptr)) return GH_ERR_INVALID_ARG;
   if ((in->shs != nullptr) == (in->colors_precomp != nullptr)) return GH_ERR_INVALID_ARG;  // exactly one
   if (in->shs && d->M == 0) return GH_ERR_INVALID_ARG;
   if (in->colors_precomp && d->M != 0) return GH_ERR_INVALID_ARG;
@@ -186,7 +189,8 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     if (per_view) {                                       // pose batch: the half's own rows of every per-Gaussian array
       const size_t r0 = n0;
       H.in.means3D = in->means3D + r0 * 3; H.in.opacities = in->opacities + r0;
-      H.in.scales = in->scales + r0 * 3; H.in.rotations = in->rotations + r0 * 4;
+      if (in->scales) { H.in.scales = in->scales + r0 * 3; H.in.rotations = in->rotations + r0 * 4; }
+      if (in->cov3D_precomp) H.in.cov3D_precomp = in->cov3D_precomp + r0 * 6;
       if (in->shs) H.in.shs = in->shs + r0 * (size_t)d->M * 3;
       if (in->colors_precomp) H.in.colors_precomp = in->colors_precomp + r0 * 3;
       if (in->blend_opacity_b) H.in.blend_opacity_b = in->blend_opacity_b + r0;

@@ -66,7 +66,8 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                           bool geom);
 // Is a gradient that flows through the projection wanted (means, scales, rotations, means2D, xyz_b)?
 static inline bool gh_wants_geometry(const GhInputs* in, const GhGrads* gr) {
-  return gr->dL_dmeans3D || gr->dL_dmeans2D || gr->dL_dscales || gr->dL_drotations || (in->blend_xyz_b && gr->dL_dblend_xyz_b);
+  return gr->dL_dmeans3D || gr->dL_dmeans2D || gr->dL_dscales || gr->dL_drotations || gr->dL_dcov3D ||
+         (in->blend_xyz_b && gr->dL_dblend_xyz_b);
 }
 // Do the render backward's sub-records need their five position / conic moments? Not when no geometry gradient is wanted and
 // the colours are precomputed (with SH colours gh_record_sum_kernel reads whole records).
@@ -139,6 +140,9 @@ struct GhGeo {
 };
 
 // View transform, Sigma3D, EWA projection — one Gaussian, one camera. cam = GH_CAM_FLOATS record.
+// COV: Sigma3D is given (GhInputs.cov3D_precomp) — a template parameter, so that the common kernels carry neither the branch nor
+// its registers (as a run-time branch it cost the projection kernel 2 us and the chain rule 2 us of 39 / 70).
+template <bool COV = false>
 __device__ __forceinline__ void gh_geo_forward(const GhInputs& in, const float* __restrict__ cam, int i,
                                                float mod, int H, int W, GhGeo& o) {
   const float* V = cam; const float* PM = cam + 16;
@@ -152,23 +156,31 @@ __device__ __forceinline__ void gh_geo_forward(const GhInputs& in, const float* 
   o.hy = fmaf(PM[1], mx, fmaf(PM[5], my, fmaf(PM[9], mz, PM[13])));
   o.hw = fmaf(PM[3], mx, fmaf(PM[7], my, fmaf(PM[11], mz, PM[15])));
   o.winv = 1.0f / (o.hw + 1e-7f);
-  o.s[0] = mod * in.scales[3 * i]; o.s[1] = mod * in.scales[3 * i + 1]; o.s[2] = mod * in.scales[3 * i + 2];
-  float r = in.rotations[4 * i], x = in.rotations[4 * i + 1], y = in.rotations[4 * i + 2], z = in.rotations[4 * i + 3];
-  float* R = o.R;
-  R[0] = 1.0f - 2.0f * fmaf(y, y, z * z); R[1] = 2.0f * fmaf(x, y, -(r * z)); R[2] = 2.0f * fmaf(x, z, r * y);
-  R[3] = 2.0f * fmaf(x, y, r * z); R[4] = 1.0f - 2.0f * fmaf(x, x, z * z); R[5] = 2.0f * fmaf(y, z, -(r * x));
-  R[6] = 2.0f * fmaf(x, z, -(r * y)); R[7] = 2.0f * fmaf(y, z, r * x); R[8] = 1.0f - 2.0f * fmaf(x, x, y * y);
-  float M[9];
+  if (COV) {                                         // the published module's cov3D_precomp: Sigma as given (no scale_modifier)
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+    for (int k = 0; k < 6; ++k) o.S[k] = in.cov3D_precomp[6 * i + k];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) M[3 * a + j] = R[3 * a + j] * o.s[j];
-  o.S[0] = fmaf(M[0], M[0], fmaf(M[1], M[1], M[2] * M[2]));
-  o.S[1] = fmaf(M[0], M[3], fmaf(M[1], M[4], M[2] * M[5]));
-  o.S[2] = fmaf(M[0], M[6], fmaf(M[1], M[7], M[2] * M[8]));
-  o.S[3] = fmaf(M[3], M[3], fmaf(M[4], M[4], M[5] * M[5]));
-  o.S[4] = fmaf(M[3], M[6], fmaf(M[4], M[7], M[5] * M[8]));
-  o.S[5] = fmaf(M[6], M[6], fmaf(M[7], M[7], M[8] * M[8]));
+    for (int k = 0; k < 9; ++k) o.R[k] = 0.0f;
+    o.s[0] = o.s[1] = o.s[2] = 0.0f;
+  } else {
+    o.s[0] = mod * in.scales[3 * i]; o.s[1] = mod * in.scales[3 * i + 1]; o.s[2] = mod * in.scales[3 * i + 2];
+    float r = in.rotations[4 * i], x = in.rotations[4 * i + 1], y = in.rotations[4 * i + 2], z = in.rotations[4 * i + 3];
+    float* R = o.R;
+    R[0] = 1.0f - 2.0f * fmaf(y, y, z * z); R[1] = 2.0f * fmaf(x, y, -(r * z)); R[2] = 2.0f * fmaf(x, z, r * y);
+    R[3] = 2.0f * fmaf(x, y, r * z); R[4] = 1.0f - 2.0f * fmaf(x, x, z * z); R[5] = 2.0f * fmaf(y, z, -(r * x));
+    R[6] = 2.0f * fmaf(x, z, -(r * y)); R[7] = 2.0f * fmaf(y, z, r * x); R[8] = 1.0f - 2.0f * fmaf(x, x, y * y);
+    float M[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) M[3 * a + j] = R[3 * a + j] * o.s[j];
+    o.S[0] = fmaf(M[0], M[0], fmaf(M[1], M[1], M[2] * M[2]));
+    o.S[1] = fmaf(M[0], M[3], fmaf(M[1], M[4], M[2] * M[5]));
+    o.S[2] = fmaf(M[0], M[6], fmaf(M[1], M[7], M[2] * M[8]));
+    o.S[3] = fmaf(M[3], M[3], fmaf(M[4], M[4], M[5] * M[5]));
+    o.S[4] = fmaf(M[3], M[6], fmaf(M[4], M[7], M[5] * M[8]));
+    o.S[5] = fmaf(M[6], M[6], fmaf(M[7], M[7], M[8] * M[8]));
+  }
   float tanx = cam[35], tany = cam[36];
   float limx = 1.3f * tanx, limy = 1.3f * tany;
   float txtz = o.tx / o.tz, tytz = o.ty / o.tz;

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_tile_bound_kernel(const float2* _
   bound[t] = ok ? d : __uint_as_float(0x7F800000u);
 }
 
+template <bool COV>
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     GhInputs in, int P, int NV, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
     const float4* __restrict__ sh_rgb, float4* __restrict__ geom, float* __restrict__ depth,
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     n = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : v * P + i;
     const float* cam = in.cams + (size_t)v * GH_CAM_FLOATS;
     GhGeo e;
-    gh_geo_forward(in, cam, i, mod, H, W, e);
+    gh_geo_forward<COV>(in, cam, i, mod, H, W, e);
     const bool ok = (e.tz > 0.2f) && (e.det != 0.0f);
     if (ok) {
       float dinv = 1.0f / e.det;
@@ -196,7 +197,8 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
                        g.NV, g.gx, g.gy, (float*)(ws + L.tile_bound));
     tile_bound = (const float*)(ws + L.tile_bound);
   }
-  hipLaunchKernelGGL(gh_preprocess_fwd_kernel, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.NV, g.N, g.H, g.W, g.gx, g.gy,
+  auto kern = in->cov3D_precomp ? gh_preprocess_fwd_kernel<true> : gh_preprocess_fwd_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.NV, g.N, g.H, g.W, g.gx, g.gy,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (const float4*)(ws + L.sh_rgb), (float4*)(ws + L.geom),
                      (float*)(ws + L.depth),
                      (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
@@ -389,7 +391,9 @@ __device__ __forceinline__ void gh_sum_records_colour(uint32_t o0, uint32_t o1, 
 
 // FUSED (RGB_MODE only): the sums come straight from the render backward's sub-records (gh_sum_records). A split call's second
 // half keeps its per-instance arrays cap_a entries further on (views >= v_split; unsplit: v_split = NV).
-template <bool RGB_MODE, bool GEOM, bool FUSED>
+// COV (GEOM only): Sigma3D was given (GhInputs.cov3D_precomp): the chain ends at dL/dSigma (GhGrads.dL_dcov3D) instead of running on
+// to scales and rotations — an instantiation of its own, so that the six extra accumulators never cost the common kernels a register.
+template <bool RGB_MODE, bool GEOM, bool FUSED, bool COV = false>
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     GhInputs in, GhGrads gr, int P, int NV, int H, int W, int sh_degree, int M, float mod, uint32_t flags, int lg,
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ dmean_sh, const float4* __restrict__ gsum,
@@ -413,6 +417,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
   __syncthreads();
 
   float am[3] = {0, 0, 0}, as[3] = {0, 0, 0}, aq[4] = {0, 0, 0, 0}, araw[3] = {0, 0, 0}, ao = 0.0f;
+  float acov[6] = {0, 0, 0, 0, 0, 0};                   // COV only
   for (int k = 0; k < n_rounds; ++k) {
     const int v_raw = per_view ? (live ? i / P : 0) : vv + k * G;
     const bool vok = per_view || v_raw < NV;
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
       }
     } else if (vis) {
       GhGeo e;
-      gh_geo_forward(in, cam, i, mod, H, W, e);
+      gh_geo_forward<COV>(in, cam, i, mod, H, W, e);
       // The render backward sums the raw pixel moments of h = G * dL/dalpha per instance:
       //   s9[0..5] = sum h dx, sum h dy, sum h dx^2, sum h dx dy, sum h dy^2, sum h     (dx = px_gaussian - px_pixel)
       // the factors that are constant per (view, Gaussian) — opacity and the conic — are applied here, once, instead of
@@ -491,6 +496,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
 #pragma unroll
         for (int q = 0; q < 3; ++q)
           dT[3 * r2 + q] = 2.0f * (GT[3 * r2] * Sf[q] + GT[3 * r2 + 1] * Sf[3 + q] + GT[3 * r2 + 2] * Sf[6 + q]);
+      if (COV) {
+        // Sigma itself is the input: its symmetric storage (xx xy xz yy yz zz) receives both matrix positions of an off-diagonal entry
+        acov[0] += dS[0]; acov[1] += dS[1] + dS[3]; acov[2] += dS[2] + dS[6]; acov[3] += dS[4]; acov[4] += dS[5] + dS[7]; acov[5] += dS[8];
+      } else {
       // Sigma = M M^T, M = R diag(s): dM = 2 dSigma M
       float Mm[9];
 #pragma unroll
@@ -517,6 +526,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
         aq[1] += 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
         aq[2] += 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
         aq[3] += 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+      }
       }
       // ---- T = J W (the 1.3*tanfov clamp freezes the clamped view-space x / y, App. A.4-3) ----
       float dJ00 = dT[0] * V[0] + dT[1] * V[4] + dT[2] * V[8];
@@ -552,6 +562,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     for (int c3 = 0; c3 < 3; ++c3) { am[c3] = gh_group_sum(am[c3], lg); as[c3] = gh_group_sum(as[c3], lg); }
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) aq[c4] = gh_group_sum(aq[c4], lg);
+    if (COV) {
+#pragma unroll
+      for (int c6 = 0; c6 < 6; ++c6) acov[c6] = gh_group_sum(acov[c6], lg);
+    }
   }
   ao = gh_group_sum(ao, lg);
   if (rgb_mode) {
@@ -563,8 +577,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     if (GEOM && gr.dL_dmeans3D) { gr.dL_dmeans3D[3 * i] = am[0]; gr.dL_dmeans3D[3 * i + 1] = am[1]; gr.dL_dmeans3D[3 * i + 2] = am[2]; }
     if (gr.dL_dopacities) gr.dL_dopacities[i] = ao;
     if (gr.dL_dblend_opacity_b && in.blend_opacity_b) gr.dL_dblend_opacity_b[i] = ao;
-    if (GEOM && gr.dL_dscales) { gr.dL_dscales[3 * i] = as[0]; gr.dL_dscales[3 * i + 1] = as[1]; gr.dL_dscales[3 * i + 2] = as[2]; }
-    if (GEOM && gr.dL_drotations) { gr.dL_drotations[4 * i] = aq[0]; gr.dL_drotations[4 * i + 1] = aq[1]; gr.dL_drotations[4 * i + 2] = aq[2]; gr.dL_drotations[4 * i + 3] = aq[3]; }
+    if (GEOM && !COV && gr.dL_dscales) { gr.dL_dscales[3 * i] = as[0]; gr.dL_dscales[3 * i + 1] = as[1]; gr.dL_dscales[3 * i + 2] = as[2]; }
+    if (GEOM && !COV && gr.dL_drotations) { gr.dL_drotations[4 * i] = aq[0]; gr.dL_drotations[4 * i + 1] = aq[1]; gr.dL_drotations[4 * i + 2] = aq[2]; gr.dL_drotations[4 * i + 3] = aq[3]; }
+    if (GEOM && COV && gr.dL_dcov3D) {
+#pragma unroll
+      for (int c6 = 0; c6 < 6; ++c6) gr.dL_dcov3D[6 * i + c6] = acov[c6];
+    }
   }
   if (rgb_mode) {
     // c' = ((c*w0 + w1) - 1) + b0  (renderer_one_shot.py:324,328): araw = sum over views of dL/dc'
@@ -647,6 +665,9 @@ void gh_launch_preprocess_bwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   auto kern = rgb ? (fused ? (geom ? gh_preprocess_bwd_kernel<true, true, true> : gh_preprocess_bwd_kernel<true, false, true>)
                            : (geom ? gh_preprocess_bwd_kernel<true, true, false> : gh_preprocess_bwd_kernel<true, false, false>))
                   : (geom ? gh_preprocess_bwd_kernel<false, true, false> : gh_preprocess_bwd_kernel<false, false, false>);
+  if (in->cov3D_precomp && geom)                         // Sigma3D given: the chain ends at dL/dSigma
+    kern = rgb ? (fused ? gh_preprocess_bwd_kernel<true, true, true, true> : gh_preprocess_bwd_kernel<true, true, false, true>)
+               : gh_preprocess_bwd_kernel<false, true, false, true>;
   const int nblk_n = (int)(((size_t)g.N * 4 + GH_BLOCK - 1) / GH_BLOCK);
   if ((parts & GH_PBWD_RECORD_SUM) && !fused)
     hipLaunchKernelGGL(gh_record_sum_kernel, dim3(nblk_n), dim3(GH_BLOCK), 0, s, g.N, g.P, per_view ? 0 : g.NV,

@@ -525,12 +525,15 @@ class _Call(NamedTuple):
 
 
 def _prepare_call(dev, cams, means3D, opacities, scales, rotations, H, W, shs, colors_precomp, sh_degree, scale_modifier, xyz_b,
-                  opacity_b, color_w, color_b, per_view_gaussians, split_streams, plain: bool) -> _Call:
+                  opacity_b, color_w, color_b, per_view_gaussians, split_streams, plain: bool, cov3D_precomp=None) -> _Call:
     """Validate the arguments of raster_forward and derive rows / P / flags. plain: a full forward without static lists (the only
     kind that may be split over two streams)."""
     if (shs is None) == (colors_precomp is None):
         raise ValueError("Please provide exactly one of either SHs or precomputed colors!")
-    t = dict(cams=_prep(cams, dev).reshape(-1, _abi.GH_CAM_FLOATS), means3D=_prep(means3D, dev),
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    t = dict(cov3D=_prep(cov3D_precomp, dev), cams=_prep(cams, dev).reshape(-1, _abi.GH_CAM_FLOATS), means3D=_prep(means3D, dev),
              opacities=_prep(opacities, dev).reshape(-1), scales=_prep(scales, dev), rotations=_prep(rotations, dev),
              shs=_prep(shs, dev), colors_precomp=_prep(colors_precomp, dev), xyz_b=_prep(xyz_b, dev),
              opacity_b=None if opacity_b is None else _prep(opacity_b, dev).reshape(-1),
@@ -571,7 +574,7 @@ def _inputs_struct(c: _Call, with_shs: bool = True, bound=None):
     t = c.t
     return _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]), _ptr(t["rotations"]),
                          _ptr(t["shs"]) if with_shs else None, _ptr(t["colors_precomp"]), _ptr(t["xyz_b"]), _ptr(t["opacity_b"]),
-                         _ptr(t["color_w"]), _ptr(t["color_b"]), _ptr(bound))
+                         _ptr(t["color_w"]), _ptr(t["color_b"]), _ptr(bound), _ptr(t["cov3D"]))
 
 
 def _make_ctx(c: _Call, dims, inp, ws, stream, alpha, parent, radii, pending, verdict, refresh) -> _Ctx:
@@ -768,8 +771,10 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                    color_b=None, max_instances: Optional[int] = None, sync: Optional[bool] = True, return_alpha: bool = False,
                    per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None,
                    split_streams: Optional[bool] = None, expect_backward: bool = False, static_lists: bool = False,
-                   refresh_of: Optional["_Ctx"] = None, depth_bound: Optional[DepthBoundCache] = None):
+                   refresh_of: Optional["_Ctx"] = None, depth_bound: Optional[DepthBoundCache] = None, cov3D_precomp=None):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
+    cov3D_precomp (P,6): the published module's precomputed 3-D covariance (xx xy xz yy yz zz, used as given: scale_modifier is
+    not applied) in place of scales + rotations (pass None for both); its gradient comes back as "cov3D_precomp".
     with return_alpha the fused mask channel (NV,H,W) is available as ctx.alpha.
     per_view_gaussians (pose batch, the batch loop of GS3DRenderer.forward): every per-Gaussian tensor holds NV*P rows and
     view v renders rows [v*P, (v+1)*P) — NV different Gaussian sets in one launch sequence.
@@ -798,7 +803,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         raise RuntimeError("guassianhand_amd rasteriser needs tensors on a ROCm device (no CPU fallback)")
     plain = geometry_of is None and refresh_of is None and not static_lists
     c = _prepare_call(dev, cams, means3D, opacities, scales, rotations, H, W, shs, colors_precomp, sh_degree, scale_modifier, xyz_b,
-                      opacity_b, color_w, color_b, per_view_gaussians, split_streams, plain)
+                      opacity_b, color_w, color_b, per_view_gaussians, split_streams, plain, cov3D_precomp)
     st = _state(dev)
     with st.lock:
         if geometry_of is not None:
@@ -877,7 +882,8 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
               ("opacity_b", (R_,) if t["opacity_b"] is not None else None),
               ("color_b", (R_, 3 if ctx.b_rgb else 48) if t["color_b"] is not None else None),
               ("xyz_b", (3,) if t["xyz_b"] is not None else None),
-              ("means3D", (R_, 3)), ("opacities", (R_,)), ("scales", (R_, 3)), ("rotations", (R_, 4)),
+              ("means3D", (R_, 3)), ("opacities", (R_,)), ("scales", (R_, 3) if t["scales"] is not None else None),
+              ("rotations", (R_, 4) if t["rotations"] is not None else None), ("cov3D_precomp", (R_, 6) if t["cov3D"] is not None else None),
               ("shs", (R_, M, 3) if M else None), ("colors_precomp", (R_, 3) if t["colors_precomp"] is not None else None),
               ("means2D", (NV, P, 3) if want_means2D else None)]
     off, spans = 4, []                             # floats 0..3: reserved for the caller (e.g. the loss of the sharded fit)
@@ -903,7 +909,7 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
                       dL_dopacities=_ptr(o["opacities"]), dL_dscales=_ptr(o["scales"]), dL_drotations=_ptr(o["rotations"]),
                       dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]), dL_dblend_xyz_b=_ptr(o["xyz_b"]),
                       dL_dblend_opacity_b=_ptr(o["opacity_b"]), dL_dblend_color_w=_ptr(o["color_w"]),
-                      dL_dblend_color_b=_ptr(o["color_b"]), upstream_scale=_ptr(gs))
+                      dL_dblend_color_b=_ptr(o["color_b"]), upstream_scale=_ptr(gs), dL_dcov3D=_ptr(o["cov3D_precomp"]))
     stream = _raw_stream(dev)
     ctx.stream = stream                            # the workspace goes back to the pool of the stream that used it last
     with _OnDevice(dev):
@@ -985,7 +991,8 @@ def _geometry_key(means3D, opacities, scales, rotations, rs):
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, raster_settings, sync, expect_backward):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, raster_settings, sync, expect_backward,
+                cov3D_precomp=None):
         rs = raster_settings
         cams = pack_camera(rs.viewmatrix, rs.projmatrix, rs.campos, rs.tanfovx, rs.tanfovy, rs.bg)
         parent = None
@@ -996,7 +1003,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             # still alive (its backward has not run). The record holds weak references and is dropped after one reuse, so
             # nothing of an earlier step can be picked up. (An in-place update through `.data` does not move `_version`:
             # between an RGB call and its mask call nothing updates parameters.)
-            objs, vals = _geometry_key(means3D, opacities, scales, rotations, rs)
+            # (shape of the Gaussians: scales + rotations, or the precomputed covariance in both places)
+            objs, vals = _geometry_key(means3D, opacities, scales if cov3D_precomp is None else cov3D_precomp,
+                                       rotations if cov3D_precomp is None else cov3D_precomp, rs)
             with st.lock:
                 g, st.geom_last = st.geom_last, None
             if g is not None and sh is None and g[1] == vals and all(a() is b for a, b in zip(g[0], objs)):
@@ -1011,7 +1020,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             cams, means3D, opacities, scales, rotations, H=int(rs.image_height), W=int(rs.image_width),
             shs=sh, colors_precomp=colors_precomp, sh_degree=int(rs.sh_degree),
             scale_modifier=float(rs.scale_modifier), sync=sync, geometry_of=parent,
-            expect_backward=expect_backward)
+            expect_backward=expect_backward, cov3D_precomp=cov3D_precomp)
         if _policy.reuse_geometry and parent is None:
             with st.lock:
                 st.geom_last = (tuple(weakref.ref(o) for o in objs), vals, weakref.ref(rctx))
@@ -1019,10 +1028,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         # the backward kernels read these tensors again, through the pointers the context holds: registering them makes autograd
         # raise its usual "modified by an inplace operation" error when one of them was written between forward and backward,
         # as it does for the reference extension (which saves them) — instead of gradients of a scene that never existed
-        ctx.save_for_backward(*[t for t in (means3D, sh, colors_precomp, opacities, scales, rotations) if t is not None])
+        ctx.save_for_backward(*[t for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp) if t is not None])
         ctx.shapes = (means3D.shape, means2D.shape, None if sh is None else sh.shape,
-                      None if colors_precomp is None else colors_precomp.shape, opacities.shape, scales.shape,
-                      rotations.shape)
+                      None if colors_precomp is None else colors_precomp.shape, opacities.shape,
+                      None if scales is None else scales.shape, None if rotations is None else rotations.shape,
+                      None if cov3D_precomp is None else cov3D_precomp.shape)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)
         return image[0], radii[0]
@@ -1036,7 +1046,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         return (g["means3D"].reshape(s[0]), g["means2D"][0].reshape(s[1]),
                 g["shs"].reshape(s[2]) if s[2] is not None else None,
                 g["colors_precomp"].reshape(s[3]) if s[3] is not None else None,
-                g["opacities"].reshape(s[4]), g["scales"].reshape(s[5]), g["rotations"].reshape(s[6]), None, None, None)
+                g["opacities"].reshape(s[4]), g["scales"].reshape(s[5]) if s[5] is not None else None,
+                g["rotations"].reshape(s[6]) if s[6] is not None else None, None, None, None,
+                g["cov3D_precomp"].reshape(s[7]) if s[7] is not None else None)
 
 
 def _any_global_hook() -> bool:
@@ -1071,9 +1083,8 @@ class GaussianRasterizer(nn.Module):
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
-        if cov3D_precomp is not None:
-            raise NotImplementedError("cov3D_precomp is never passed by the reference "
-                                      "(renderer_one_shot.py:313, :346) and is not supported")
+        # (cov3D_precomp: the reference never passes it, renderer_one_shot.py:313, :346; supported since round 5 — the covariance is
+        # used as given, scale_modifier is not applied, and its gradient flows back like the published module's)
         if means3D.shape[0] == 0:
             # No Gaussians. The published wrapper skips the kernels then (`if(P != 0)` around the rasteriser call in the extension's
             # RasterizeGaussiansCUDA — third-party source, not in the reference tree) and returns the image it allocated: ZEROS, not the
@@ -1085,12 +1096,12 @@ class GaussianRasterizer(nn.Module):
         # will a backward come? (decided here: inside an autograd Function's forward the grad mode is always off, and
         # needs_input_grad ignores torch.no_grad())
         expect_backward = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (means3D, means2D, shs, colors_precomp, opacities, scales, rotations))
+            t is not None and t.requires_grad for t in (means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp))
         # (The reference wraps the call in torch.autocast(dtype=float32), renderer_one_shot.py:337. Nothing below is an autocast-
         # eligible torch op — tensors go to the C-ABI as raw pointers after an explicit float32 check in _prep — so no
         # autocast(enabled=False) context is entered here: it cost 6 us per call for nothing.)
         return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                         self.raster_settings, self.sync, expect_backward)
+                                         self.raster_settings, self.sync, expect_backward, cov3D_precomp)
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         """The published module's frustum test (its `mark_visible`: a point is visible when its view-space depth exceeds 0.2 — the

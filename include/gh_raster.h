@@ -108,8 +108,8 @@ typedef struct GhInputs {
   const float* cams;            /* (n_views, GH_CAM_FLOATS) */
   const float* means3D;         /* (P,3) */
   const float* opacities;       /* (P,)  — reference passes (P,1) */
-  const float* scales;          /* (P,3) */
-  const float* rotations;       /* (P,4) quaternion (w,x,y,z), used as given */
+  const float* scales;          /* (P,3)                                           (NULL with cov3D_precomp) */
+  const float* rotations;       /* (P,4) quaternion (w,x,y,z), used as given       (NULL with cov3D_precomp) */
   const float* shs;             /* (P,M,3) or NULL */
   const float* colors_precomp;  /* (P,3)   or NULL — exactly one of shs / colors_precomp */
   /* Optional fused attribute blend (renderer_one_shot.py:298-334). NULL => that term is absent. */
@@ -127,6 +127,10 @@ typedef struct GhInputs {
      truncated list — then nothing behind the bound could have been looked at and the result is the unbounded call's bit for
      bit; a pixel that runs off the end of a truncated list gets NaN and GhCounters.overflow |= 4: re-run without the bound. */
   const float* tile_depth_bound;
+  /* Precomputed 3-D covariance, the published module's `cov3D_precomp` (the reference never passes it, renderer_one_shot.py:313,
+     :346): (P,6) = the upper triangle (xx, xy, xz, yy, yz, zz) of Sigma, used AS GIVEN — scale_modifier is not applied — in place
+     of scales + rotations: exactly one of {scales AND rotations, cov3D_precomp} (App. A.1-3). NULL = scales + rotations. */
+  const float* cov3D_precomp;
 } GhInputs;
 
 typedef struct GhOutputs {
@@ -189,6 +193,8 @@ typedef struct GhGrads {
      a scalar loss whose image gradient was produced unscaled by the loss kernel (gh_l1_loss / gh_fit_loss), so that the
      autograd product `dL/dimage * dL/dloss` needs no pass over the images of its own. */
   const float* upstream_scale;
+  float* dL_dcov3D;           /* (P,6) with GhInputs.cov3D_precomp: d(loss)/d(xx, xy, xz, yy, yz, zz) of the symmetric storage (an
+                                 off-diagonal entry carries both of its matrix positions), summed over views */
 } GhGrads;
 
 /* Byte offsets of the internal arrays inside the workspace (public so tests can inspect every stage). */

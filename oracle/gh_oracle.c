@@ -224,7 +224,12 @@ static void geo_forward(const GhDims* d, const GhInputs* in, const float* cam, i
   o->hy = fmaf(PM[1], mx, fmaf(PM[5], my, fmaf(PM[9], mz, PM[13])));
   o->hw = fmaf(PM[3], mx, fmaf(PM[7], my, fmaf(PM[11], mz, PM[15])));
   o->winv = 1.0f / (o->hw + 1e-7f);
-  /* Sigma3D = R S S^T R^T */
+  /* Sigma3D = R S S^T R^T — or given (the published module's cov3D_precomp: used as it stands, scale_modifier not applied) */
+  if (in->cov3D_precomp) {
+    for (int k = 0; k < 6; ++k) o->S[k] = in->cov3D_precomp[6 * i + k];
+    for (int k = 0; k < 9; ++k) o->R[k] = 0.0f;
+    o->s[0] = o->s[1] = o->s[2] = 0.0f;
+  } else {
   float mod = d->scale_modifier;
   o->s[0] = mod * in->scales[3 * i]; o->s[1] = mod * in->scales[3 * i + 1]; o->s[2] = mod * in->scales[3 * i + 2];
   float r = in->rotations[4 * i], x = in->rotations[4 * i + 1], y = in->rotations[4 * i + 2], z = in->rotations[4 * i + 3];
@@ -240,6 +245,7 @@ static void geo_forward(const GhDims* d, const GhInputs* in, const float* cam, i
   o->S[3] = fmaf(M[3], M[3], fmaf(M[4], M[4], M[5] * M[5]));
   o->S[4] = fmaf(M[3], M[6], fmaf(M[4], M[7], M[5] * M[8]));
   o->S[5] = fmaf(M[6], M[6], fmaf(M[7], M[7], M[8] * M[8]));
+  }
   /* EWA projection */
   float tanx = cam[35], tany = cam[36];
   float limx = 1.3f * tanx, limy = 1.3f * tany;
@@ -279,6 +285,8 @@ static inline int f2i(float x) {
 int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCtx** ctx_out, GhoDebug* dbg) {
   if (!d || !in || !out || !ctx_out) return GH_ERR_INVALID_ARG;
   if (d->P != 0 && (in->shs != NULL) == (in->colors_precomp != NULL)) return GH_ERR_INVALID_ARG;   /* (P = 0: nothing is read, the background only) */
+  /* exactly one of {scales AND rotations, cov3D_precomp} (the published wrapper's second validation, App. A.0) */
+  if (d->P != 0 && (((in->scales != NULL) != (in->rotations != NULL)) || ((in->scales != NULL) == (in->cov3D_precomp != NULL)))) return GH_ERR_INVALID_ARG;
   const int P = d->P, NV = d->n_views, H = d->H, W = d->W;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, tiles = gx * gy;
   if (gx > 255 || gy > 255 || d->sh_degree > 3) return GH_ERR_UNSUPPORTED;
@@ -510,12 +518,12 @@ int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCt
 
 /* A.5 for one (view, Gaussian) n = v*P + i: sums its instance records, chain rule, adds into the per-Gaussian accumulators.
  * acc_cw: where the color_w gradient goes (the global array, or a thread's private 48 doubles in baseline mode). */
-typedef struct A5Acc { double *m, *o, *s, *q, *c, *sh, *cb; } A5Acc;
+typedef struct A5Acc { double *m, *o, *s, *q, *c, *sh, *cb, *cov; } A5Acc;
 static void a5_one(const GhoCtx* c, const GhInputs* in, const GhGrads* gr, long n, const double* rec, const A5Acc* A, double* acc_cw) {
   const GhDims* d = &c->dims;
   const int P = d->P, H = d->H, W = d->W, M = d->M;
   const int wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? 1 : 0;
-  double *acc_m = A->m, *acc_o = A->o, *acc_s = A->s, *acc_q = A->q, *acc_c = A->c, *acc_sh = A->sh, *acc_cb = A->cb;
+  double *acc_m = A->m, *acc_o = A->o, *acc_s = A->s, *acc_q = A->q, *acc_c = A->c, *acc_sh = A->sh, *acc_cb = A->cb, *acc_cov = A->cov;
   {
     int v = (int)(n / P), i = (int)(n % P);
     const GView* g = &c->g[n];
@@ -595,6 +603,11 @@ static void a5_one(const GhoCtx* c, const GhInputs* in, const GhGrads* gr, long 
     float dT[6];
     for (int r2 = 0; r2 < 2; ++r2) for (int q = 0; q < 3; ++q)
       dT[3 * r2 + q] = 2.0f * (GT[3 * r2] * Sf[q] + GT[3 * r2 + 1] * Sf[3 + q] + GT[3 * r2 + 2] * Sf[6 + q]);
+    if (in->cov3D_precomp) {
+      /* Sigma itself is the input: symmetric storage (xx xy xz yy yz zz), an off-diagonal entry carries both matrix positions */
+      acc_cov[6 * i + 0] += (double)dS[0]; acc_cov[6 * i + 1] += (double)(dS[1] + dS[3]); acc_cov[6 * i + 2] += (double)(dS[2] + dS[6]);
+      acc_cov[6 * i + 3] += (double)dS[4]; acc_cov[6 * i + 4] += (double)(dS[5] + dS[7]); acc_cov[6 * i + 5] += (double)dS[8];
+    } else {
     /* Sigma = M M^T, M = R diag(s): dM = 2 dS M */
     float Mm[9]; for (int p = 0; p < 3; ++p) for (int j = 0; j < 3; ++j) Mm[3 * p + j] = e.R[3 * p + j] * e.s[j];
     float dM[9];
@@ -613,6 +626,7 @@ static void a5_one(const GhoCtx* c, const GhInputs* in, const GhGrads* gr, long 
       float dyq = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
       float dzq = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
       acc_q[4 * i] += dr; acc_q[4 * i + 1] += dxq; acc_q[4 * i + 2] += dyq; acc_q[4 * i + 3] += dzq;
+    }
     }
     /* T = J W : dJ_ab = sum_c dT_ac W_bc, W_bc = V[4c+b] */
     float dJ00 = dT[0] * V[0] + dT[1] * V[4] + dT[2] * V[8];
@@ -703,13 +717,14 @@ int gho_backward(const GhoCtx* c, const GhInputs* in, const GhGrads* gr) {
   double* acc_o = (double*)calloc((size_t)P + 1, sizeof(double));
   double* acc_s = (double*)calloc((size_t)P * 3 + 3, sizeof(double));
   double* acc_q = (double*)calloc((size_t)P * 4 + 4, sizeof(double));
+  double* acc_cov = (double*)calloc((size_t)P * 6 + 6, sizeof(double));
   double* acc_c = (double*)calloc((size_t)P * 3 + 3, sizeof(double));
   double* acc_sh = (double*)calloc((size_t)P * (M > 0 ? M : 1) * 3 + 3, sizeof(double));
   double* acc_cb = (double*)calloc((size_t)P * 48 + 48, sizeof(double));
   int wpg = (d->flags & GH_FLAG_BLEND_W_PER_GAUSSIAN) ? 1 : 0;
   double* acc_cw = (double*)calloc((wpg ? (size_t)P * 48 : 48) + 48, sizeof(double));
 
-  const A5Acc A5 = {acc_m, acc_o, acc_s, acc_q, acc_c, acc_sh, acc_cb};
+  const A5Acc A5 = {acc_m, acc_o, acc_s, acc_q, acc_c, acc_sh, acc_cb, acc_cov};
   if (g_parallel) {
     /* baseline mode: Gaussians in parallel, the views of a Gaussian in the checker's (ascending) order */
 #pragma omp parallel
@@ -739,6 +754,7 @@ int gho_backward(const GhoCtx* c, const GhInputs* in, const GhGrads* gr) {
     if (gr->dL_dblend_opacity_b) gr->dL_dblend_opacity_b[i] = (float)acc_o[i];
     if (gr->dL_dscales) for (int a = 0; a < 3; ++a) gr->dL_dscales[3 * i + a] = (float)acc_s[3 * i + a];
     if (gr->dL_drotations) for (int a = 0; a < 4; ++a) gr->dL_drotations[4 * i + a] = (float)acc_q[4 * i + a];
+    if (gr->dL_dcov3D) for (int a = 0; a < 6; ++a) gr->dL_dcov3D[6 * i + a] = (float)acc_cov[6 * i + a];
     if (gr->dL_dcolors) for (int a = 0; a < 3; ++a) gr->dL_dcolors[3 * i + a] = (float)acc_c[3 * i + a];
     if (gr->dL_dshs) for (int a = 0; a < M * 3; ++a) gr->dL_dshs[(size_t)i * M * 3 + a] = (float)acc_sh[(size_t)i * M * 3 + a];
     if (gr->dL_dblend_color_b) for (int a = 0; a < 48; ++a) gr->dL_dblend_color_b[(size_t)i * 48 + a] = (float)acc_cb[(size_t)i * 48 + a];
@@ -751,7 +767,7 @@ int gho_backward(const GhoCtx* c, const GhInputs* in, const GhGrads* gr) {
     for (int a = 0; a < 3; ++a) gr->dL_dblend_xyz_b[a] = (float)s[a];
   }
   if (!g_parallel) t_ser += gho_now() - t_mark;
-  free(rec); free(acc_m); free(acc_o); free(acc_s); free(acc_q); free(acc_c); free(acc_sh); free(acc_cb); free(acc_cw);
+  free(rec); free(acc_m); free(acc_o); free(acc_s); free(acc_q); free(acc_cov); free(acc_c); free(acc_sh); free(acc_cb); free(acc_cw);
   g_t_total += gho_now() - t_begin; g_t_serial += t_ser;
   return GH_OK;
 }

@@ -77,13 +77,13 @@ class OracleRender:
     def __init__(self, cams, means3D, opacities, scales, rotations, *, H: int, W: int, shs=None,
                  colors_precomp=None, sh_degree: int = 0, scale_modifier: float = 1.0,
                  xyz_b=None, opacity_b=None, color_w=None, color_b=None, debug: bool = False,
-                 debug_capacity: int = 0):
+                 debug_capacity: int = 0, cov3D_precomp=None):
         L = lib()
         self.t = dict(cams=_f32(cams).reshape(-1, _abi.GH_CAM_FLOATS), means3D=_f32(means3D),
                       opacities=_f32(opacities).reshape(-1), scales=_f32(scales), rotations=_f32(rotations),
                       shs=_f32(shs), colors_precomp=_f32(colors_precomp), xyz_b=_f32(xyz_b),
                       opacity_b=None if opacity_b is None else _f32(opacity_b).reshape(-1),
-                      color_w=_f32(color_w), color_b=_f32(color_b))
+                      color_w=_f32(color_w), color_b=_f32(color_b), cov3D=_f32(cov3D_precomp))
         t = self.t
         self.P = P = t["means3D"].shape[0]
         self.NV = NV = t["cams"].shape[0]
@@ -95,7 +95,7 @@ class OracleRender:
         self.dims = _abi.GhDims(P, NV, H, W, sh_degree, self.M, scale_modifier, flags, 0)
         self.inp = _abi.GhInputs(_ptr(t["cams"]), _ptr(t["means3D"]), _ptr(t["opacities"]), _ptr(t["scales"]),
                                  _ptr(t["rotations"]), _ptr(t["shs"]), _ptr(t["colors_precomp"]),
-                                 _ptr(t["xyz_b"]), _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]))
+                                 _ptr(t["xyz_b"]), _ptr(t["opacity_b"]), _ptr(t["color_w"]), _ptr(t["color_b"]), None, _ptr(t["cov3D"]))
         self.image = torch.zeros(NV, 3, H, W, dtype=torch.float32)
         self.radii = torch.zeros(NV, P, dtype=torch.int32)
         out = _abi.GhOutputs(_ptr(self.image), _ptr(self.radii))
@@ -136,7 +136,9 @@ class OracleRender:
         g = _f32(dL_dimage).reshape(NV, 3, self.H, self.W).contiguous()
         wpg = bool(self.dims.flags & _abi.GH_FLAG_BLEND_W_PER_GAUSSIAN)
         o = dict(means3D=torch.zeros(P, 3), means2D=torch.zeros(NV, P, 3), opacities=torch.zeros(P),
-                 scales=torch.zeros(P, 3), rotations=torch.zeros(P, 4),
+                 scales=torch.zeros(P, 3) if t["scales"] is not None else None,
+                 rotations=torch.zeros(P, 4) if t["rotations"] is not None else None,
+                 cov3D_precomp=torch.zeros(P, 6) if t["cov3D"] is not None else None,
                  shs=torch.zeros(P, M, 3) if M else None,
                  colors_precomp=torch.zeros(P, 3) if t["colors_precomp"] is not None else None,
                  xyz_b=torch.zeros(3) if t["xyz_b"] is not None else None,
@@ -147,7 +149,7 @@ class OracleRender:
                           dL_dopacities=_ptr(o["opacities"]), dL_dscales=_ptr(o["scales"]),
                           dL_drotations=_ptr(o["rotations"]), dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]),
                           dL_dblend_xyz_b=_ptr(o["xyz_b"]), dL_dblend_opacity_b=_ptr(o["opacity_b"]),
-                          dL_dblend_color_w=_ptr(o["color_w"]), dL_dblend_color_b=_ptr(o["color_b"]))
+                          dL_dblend_color_w=_ptr(o["color_w"]), dL_dblend_color_b=_ptr(o["color_b"]), dL_dcov3D=_ptr(o["cov3D_precomp"]))
         rc = lib().gho_backward(self._ctx, C.byref(self.inp), C.byref(gr))
         if rc != 0:
             raise RuntimeError(f"gho_backward failed: {_abi.status_name(rc)}")

@@ -62,7 +62,8 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
                     colors_precomp: Optional[torch.Tensor] = None, shs: Optional[torch.Tensor] = None,
                     sh_degree: int = 0, scale_modifier: float = 1.0, pixel_chunk: int = 2048,
                     return_aux: bool = False, pixel_window=None, checkpoint_chunks: bool = False,
-                    ambiguity_eps: Optional[float] = None, per_gaussian_only: bool = False):
+                    ambiguity_eps: Optional[float] = None, per_gaussian_only: bool = False,
+                    cov3D_precomp: Optional[torch.Tensor] = None):
     """Returns (image (3,H,W), radii (P,) int32[, aux dict]).
     pixel_window = (x0, y0, x1, y1): evaluate only the pixels x0 <= x < x1, y0 <= y < y1 of the H x W image (the image
     returned is (3, y1-y0, x1-x0)); everything else — projection, tile rects, tile membership of a pixel — is that of the
@@ -90,9 +91,16 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
     winv = 1.0 / (hom[:, 3] + 1e-7)
     ndcx, ndcy = hom[:, 0] * winv, hom[:, 1] * winv
 
-    R = quat_to_rot(rotations)
-    Mm = R * (scale_modifier * scales)[:, None, :]
-    Sigma = Mm @ Mm.transpose(1, 2)
+    if cov3D_precomp is not None:
+        # the published module's cov3D_precomp: (P,6) = xx xy xz yy yz zz of Sigma, used as given (no scale_modifier)
+        if scales is not None or rotations is not None:
+            raise ValueError("provide exactly one of scales / rotations or cov3D_precomp")
+        c6 = cov3D_precomp.to(dt)
+        Sigma = torch.stack([c6[:, 0], c6[:, 1], c6[:, 2], c6[:, 1], c6[:, 3], c6[:, 4], c6[:, 2], c6[:, 4], c6[:, 5]], -1).reshape(P, 3, 3)
+    else:
+        R = quat_to_rot(rotations)
+        Mm = R * (scale_modifier * scales)[:, None, :]
+        Sigma = Mm @ Mm.transpose(1, 2)
 
     limx, limy = 1.3 * tanfovx, 1.3 * tanfovy
     tz_safe = torch.where(tz.abs() < 1e-12, torch.full_like(tz, 1e-12), tz)

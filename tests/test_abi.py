@@ -31,8 +31,8 @@ def test_library_exports_every_declared_symbol(gh_lib_path):
 def test_struct_sizes_match_header():
     # GhDims: 6 int32 + float + uint32 + int64
     assert C.sizeof(_abi.GhDims) == 40
-    assert C.sizeof(_abi.GhInputs) == 12 * 8
-    assert C.sizeof(_abi.GhGrads) == 14 * 8
+    assert C.sizeof(_abi.GhInputs) == 13 * 8          # v0.6: + cov3D_precomp
+    assert C.sizeof(_abi.GhGrads) == 15 * 8           # v0.6: + dL_dcov3D
     assert C.sizeof(_abi.GhOutputs) == 5 * 8          # 4 pointers + (float, uint32)
     assert C.sizeof(_abi.GhCounters) == 16
     assert C.sizeof(_abi.GhLayout) == len(_abi.LAYOUT_FIELDS) * 8
