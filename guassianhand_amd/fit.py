@@ -195,6 +195,8 @@ class OneShotFit(nn.Module):
         if not isinstance(self._geom_cache, DepthBoundCache):      # (an occlusion bound survives a small move: that is its purpose)
             self.invalidate_geometry()
 
+    skipped_steps = 0      # sync-free steps a miss of the speculative occlusion bound turned into no-ops (counted by step())
+
     def invalidate_geometry(self) -> None:
         """Forget the static tile lists (after modifying a geometry tensor in place through `.data`)."""
         if self._geom_cache is not None:
@@ -220,6 +222,16 @@ class OneShotFit(nn.Module):
         if not self.active:
             self.opt.zero_grad(set_to_none=True)
 
+        if not sync and self._geom_cache is not None and not hasattr(self._geom_cache, "ctx") and self.color_w.is_cuda:
+            # Moving geometry through a DepthBoundCache, sync-free: a miss of the speculative bound is an EXPECTED event
+            # there — the device-side guard turned that step into a no-op (NaN loss, untouched parameters) and the cache dropped the
+            # bound. Look at the read-backs that have arrived, count the skipped step instead of leaving it unseen until somebody
+            # calls check_overflow(), and go on: this step renders without a bound. Any other verdict (capacity, stale lists) raises.
+            from . import rasterizer as R
+            try:
+                R.check_overflow(block=False)
+            except R.GhDepthBoundMiss:
+                self.skipped_steps += 1
         blend = self.blend_values()                                   # graph A: maps -> per-Gaussian values
         names = ["color_w", "color_b", "opacity_b"] if self.active else \
             [k for k in ("color_w", "color_b", "opacity_b") if blend[k].requires_grad]
