@@ -64,7 +64,7 @@ def gs_activations(raw: Dict[str, torch.Tensor], pts: torch.Tensor, *, use_rgb: 
     shs = raw["shs"]
     if use_rgb:
         shs = torch.sigmoid(shs)
-    shs = torch.reshape(shs, (shs.shape[0], -1, 3))
+    shs = torch.reshape(shs, (shs.shape[0], shs.shape[1] // 3, 3))       # (the reference's `-1` is ambiguous for zero rows)
     return GaussianModel(xyz=xyz, opacity=torch.sigmoid(raw["opacity"]), rotation=F.normalize(raw["rotation"]),
                          scaling=scaling, shs=shs)
 

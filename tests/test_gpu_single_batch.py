@@ -110,3 +110,22 @@ def test_composed_path_equals_the_two_call_protocol_with_gradients(dev, use_rgb)
         assert bool(torch.isfinite(a).all()) and float(b.abs().max()) > 0, k
         rel = ((a - b).norm() / (b.norm() + 1e-20)).item()
         assert rel <= 1e-4, (k, rel)
+
+
+@pytest.mark.parametrize("lo,hi,what", [(0.1, 2.0, "no row is duplicated"), (2.0, 3.0, "no row survives the prune")])
+def test_composed_path_with_empty_selections(dev, lo, hi, what):
+    """The two degenerate outcomes of the selection (renderer_one_shot.py:469-473): nothing above threshold_high (the refinement network
+    sees zero rows) and nothing above threshold_low (zero Gaussians: every view is the background, the mask is zero)."""
+    from guassianhand_amd.renderer import forward_single_batch
+    st, inp = BatchStandIns(dev, use_rgb=True), batch_inputs(N=150)
+    st.threshold_low, st.threshold_high = lo, hi
+    d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    out = forward_single_batch(st.namespace(dev), d["feat"], d["pts"], d["w2cs"], d["Ks"], d["H"], d["W"], 0.71, 1.42, d["bg"],
+                               color_w=d["color_w"], xyz_b=d["xyz_b"], color_b=d["color_b"], opacity_b=d["opacity_b"], vert3d_uv=[None])
+    s = d["feat"][:, 0]
+    n = int((s > lo).sum()) + int((s > hi).sum())
+    assert out["3dgs"].xyz.shape[0] == n and out["comp_rgb"].shape == (2, d["H"], d["W"], 3), what
+    if n == 0:
+        assert torch.equal(out["comp_rgb"], d["bg"].expand(2, d["H"], d["W"], 3)) and float(out["comp_mask"].abs().max()) == 0.0
+    else:
+        assert float(out["comp_mask"].max()) > 0.5
