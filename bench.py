@@ -302,6 +302,9 @@ def main():
     ap.add_argument("--split-streams", default="off", choices=["off", "on", "auto"],
                     help="GH_FLAG_SPLIT_STREAMS: render the step's views as two halves on two HIP streams inside the library "
                          "(bit-identical results); auto = from 4 views of more than half a megapixel per rank up")
+    ap.add_argument("--fused-loss", default="on", choices=["on", "off"],
+                    help="on (default): mean|render - gt| and its gradient come out of the render kernel's own epilogue (GhOutputs.l1_*); "
+                         "off: gh_l1_loss reads the stored image back (rounds 1-4; same gradients bit for bit)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="EXPERIMENT: capture this many copies of the step on as many streams and replay them round-robin, so that "
                          "consecutive (independent) steps overlap on the GPU; 1 = steps strictly one after the other (the contract's default)")
@@ -347,6 +350,7 @@ def main():
     torch.cuda.set_device(dev)
 
     R.set_split_streams({"off": False, "on": True, "auto": "auto"}[args.split_streams])
+    R.set_fused_loss(args.fused_loss == "on")
     V = args.views_per_step
     if args.scaling == "strong":
         assert V % world == 0, "--scaling strong: --views-per-step must be a multiple of the rank count"
@@ -625,7 +629,7 @@ def main():
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
                        "split_streams": bool(V >= 2 and (R._split_policy is True or (
                            R._split_policy == "auto" and V >= 4 and H * W > R._SPLIT_AUTO_MIN_PIXELS))),
-                       "pipelined_steps": args.pipeline,
+                       "pipelined_steps": args.pipeline, "fused_loss": args.fused_loss == "on",
                        "hip_graph": graph is not None, "timed_steps": "HIP graph replay of one captured step" if graph is not None
                        else "eager kernel-by-kernel enqueue" + (f" [{graph_note}]" if graph_note else "")},
             "roofline": roofline, "stages": stages,

@@ -39,7 +39,8 @@ class GhInputs(C.Structure):
 
 class GhOutputs(C.Structure):
     _fields_ = [("image", C.c_void_p), ("radii", C.c_void_p), ("alpha", C.c_void_p), ("tile_depth_seen", C.c_void_p),
-                ("tile_depth_seen_scale", C.c_float), ("tile_depth_seen_slack", C.c_uint32)]
+                ("tile_depth_seen_scale", C.c_float), ("tile_depth_seen_slack", C.c_uint32),
+                ("l1_target", C.c_void_p), ("l1_dL_dimage", C.c_void_p), ("l1_loss", C.c_void_p)]
 
 
 class GhCounters(C.Structure):
@@ -62,7 +63,7 @@ class GhAdamTensor(C.Structure):
 LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "depth", "rect", "clamped",
                  "tiles_touched", "slot_begin", "depth_keys_a", "depth_keys_b", "depth_vals_a", "depth_vals_b",
                  "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "sorted_slot", "inst_r0", "inst_r1", "inst_r2",
-                 "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "cull_bound", "inst_c", "attr", "half_counters", "key_bits", "tile_bound", "block_tiles", "render_guard")
+                 "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "cull_bound", "inst_c", "attr", "half_counters", "key_bits", "tile_bound", "block_tiles", "render_guard", "loss_partials")
 
 
 class GhLayout(C.Structure):

@@ -113,6 +113,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->tile_bound = take((size_t)g.NV * g.tiles * 4);
   L->block_tiles = take((gh_proj_blocks(g) + 4) * 4);     // (two halves: + 1 block of rounding + 1 spare word each)
   L->render_guard = take(512);                            // one word (+ a second, 256 bytes on, for the other half of a split call)
+  L->loss_partials = take((size_t)g.NV * g.tiles * 4 * 4);
   L->total_bytes = off;
   return GH_OK;
 }
@@ -257,6 +258,12 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   if (in->tile_depth_bound && (const float*)out->tile_depth_seen == in->tile_depth_bound) return GH_ERR_INVALID_ARG;
   // lists that must outlive this call's opacities cannot be truncated by a bound that holds for this call only
   if (in->tile_depth_bound && (d->flags & GH_FLAG_STATIC_LISTS)) return GH_ERR_UNSUPPORTED;
+  if (out->l1_target) {                                    // fused image loss
+    if (!out->l1_dL_dimage || !out->l1_loss) return GH_ERR_INVALID_ARG;
+    // one walk, one loss: not with the mask channel, an occlusion bound / report (a miss found late could not take back the
+    // gradients of the waves that finished early), or two halves on two streams
+    if (out->alpha || out->tile_depth_seen || in->tile_depth_bound || gh_split_on(d)) return GH_ERR_UNSUPPORTED;
+  }
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
@@ -301,7 +308,7 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   }
   if (stages & GH_FWD_RENDER)
     gh_launch_render_fwd(d, g, in, out->image, out->alpha, ws, ws, L, s, out->tile_depth_seen, out->tile_depth_seen_scale,
-                         out->tile_depth_seen_slack);
+                         out->tile_depth_seen_slack, out);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 
@@ -370,6 +377,7 @@ extern "C" int gh_forward_shared(const GhDims* d, const GhInputs* in, const GhOu
   int rc = check_shared(d, in);
   if (rc != GH_OK) return rc;
   if (!out || !out->image || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
+  if (out->l1_target) return GH_ERR_UNSUPPORTED;            // the fused image loss is gh_forward's
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
@@ -415,6 +423,7 @@ extern "C" int gh_forward_refresh(const GhDims* d, const GhInputs* in, const GhO
   int rc = check_refresh(d, in);
   if (rc != GH_OK) return rc;
   if (!out || !out->image || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
+  if (out->l1_target) return GH_ERR_UNSUPPORTED;            // the fused image loss is gh_forward's
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;

@@ -59,7 +59,9 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
 // seen / seen_scale: GhOutputs.tile_depth_seen (optional; full forwards only)
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha,
                           const char* wg, char* ws, const GhLayout& L, hipStream_t s, float* seen = nullptr, float seen_scale = 1.0f,
-                          uint32_t seen_slack = 0u);
+                          uint32_t seen_slack = 0u, const GhOutputs* fused = nullptr);   // fused: GhOutputs.l1_* (full forwards only)
+// out[0] = scale * (fixed-order sum of n floats, n a multiple of 4, 16-byte aligned): one workgroup (gh_loss.hip)
+void gh_launch_partials_sum(const float* partials, size_t n, float scale, float* out, hipStream_t s);
 // geom: gh_records_need_geometry(in, gr) — false: the sub-records carry the colour / opacity moments only
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s,

@@ -276,7 +276,19 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
 
 // grid = 4 blocks per tile (one per 8x8 quadrant), 4 waves per block (one per 4x4 pixel block); no LDS, no barriers.
 // ALPHA: also accumulate the mask channel (colour 1, bg 0) — SURVEY §8 f-2.
-template <bool ALPHA, bool SEEN>
+// LOSS: fused image loss (GhOutputs.l1_target): every wave leaves the gradient sign(img - gt) / n of its 16 pixels, every workgroup
+// ONE partial sum of |img - gt| at a place fixed by (tile, quadrant) — plain stores, no hand-off between workgroups inside this
+// kernel (a last-arriver tree over the tiles was costed: every level is a drained store + an RMW + dependent loads on the kernel's
+// tail, as long as the small sum kernel that follows). gh_launch_partials_sum adds the partials up in index order: bitwise
+// reproducible.
+struct GhFusedL1 {
+  const float* target;       // (n_views,3,H,W)
+  float* dL;                 // (n_views,3,H,W)
+  float inv_n;               // 1 / (n_views*3*H*W)
+  float* part;               // [T][4]: one sum per 8x8-pixel quadrant
+};
+
+template <bool ALPHA, bool SEEN, bool LOSS>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
     const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
@@ -284,7 +296,15 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
     float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const uint32_t* __restrict__ render_guard,
     uint32_t guard_mask, const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
-    const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth) {
+    const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth, const GhFusedL1 l1) {
+  // LOSS: the quadrant's four wave sums meet in LDS (the last wave to arrive adds them up in block order); the arrival counter is
+  // cleared behind the one barrier of the kernel, which the four waves reach as they start — before any load is in flight
+  __shared__ float s_l1[GH_BLOCK / GH_WAVE];
+  __shared__ uint32_t s_l1_n;
+  if (LOSS) {
+    if (threadIdx.x == 0) s_l1_n = 0u;
+    __syncthreads();
+  }
   int v, tx, ty;
   uint32_t item_idx, quad_u;
   gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);
@@ -307,6 +327,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
 
   __shared__ float4 s_col_all[GH_BLOCK / GH_WAVE][GH_WAVE];
   float4* s_col = s_col_all[wid];
+  // LOSS: the pixel's target is fetched NOW (three registers through the walk) — at the end of the wave the loads' latency would be
+  // exposed time of a finished wave's slot
+  float tg0 = 0.0f, tg1 = 0.0f, tg2 = 0.0f;
+  if (LOSS && inside && slot == 0) {
+    const size_t o = (size_t)v * 3 * H * W + (size_t)y * W + x, hw = (size_t)H * W;
+    tg0 = l1.target[o]; tg1 = l1.target[o + hw]; tg2 = l1.target[o + 2 * hw];
+  }
   GhPixelFwd p;
   p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.stopq = 0; p.done = inside ? 0 : 1;
   p.vT = 1.0f; p.vdone = p.done;
@@ -345,6 +372,30 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   if (bounded && wave_miss && lane == 0) atomicOr(&ctr->overflow, 4u);
   if (SEEN && total == 0 && tid == 0 && quad == 0) {   // empty list: no bound, no block of it stops anything
     tile_depth_seen[2 * tile] = __uint_as_float(0x7F800000u); tile_depth_seen[2 * tile + 1] = __uint_as_float(0u);
+  }
+  if (LOSS) {
+    // (a fused loss never comes with an occlusion bound — gh_forward rejects the pair — so pixel_miss is false here and the
+    // pixel values below are the ones stored at the end of the kernel)
+    float labs = 0.0f;
+    if (inside && slot == 0) {
+      const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
+      const float poison = (*render_guard & guard_mask) ? __uint_as_float(0x7FC00000u) : 0.0f;
+      const size_t o = (size_t)v * 3 * H * W + (size_t)y * W + x, hw = (size_t)H * W;
+      const float d0 = (fmaf(p.T, bg[0], p.C0) + poison) - tg0;
+      const float d1 = (fmaf(p.T, bg[1], p.C1) + poison) - tg1;
+      const float d2 = (fmaf(p.T, bg[2], p.C2) + poison) - tg2;
+      labs = (fabsf(d0) + fabsf(d1)) + fabsf(d2);
+      // torch.sign: sign(0) = 0; a NaN pixel (poisoned call) leaves no gradient, as gh_l1_loss's guard
+      l1.dL[o] = d0 > 0.0f ? l1.inv_n : (d0 < 0.0f ? -l1.inv_n : 0.0f);
+      l1.dL[o + hw] = d1 > 0.0f ? l1.inv_n : (d1 < 0.0f ? -l1.inv_n : 0.0f);
+      l1.dL[o + 2 * hw] = d2 > 0.0f ? l1.inv_n : (d2 < 0.0f ? -l1.inv_n : 0.0f);
+    }
+    const float wsum = gh_wave_sum_to63(labs);
+    if (lane == 63) {
+      s_l1[wid] = wsum;
+      const uint32_t k = __hip_atomic_fetch_add(&s_l1_n, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (k == GH_BLOCK / GH_WAVE - 1) l1.part[(size_t)tile * 4 + quad] = (s_l1[0] + s_l1[1]) + (s_l1[2] + s_l1[3]);
+    }
   }
   if (total > 0) {                                   // walked length of the tile = max n_contrib over its 16 waves
     uint32_t m = p.last;
@@ -425,7 +476,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
 }
 
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha, const char* wg, char* ws,
-                          const GhLayout& L, hipStream_t s, float* seen, float seen_scale, uint32_t seen_slack) {
+                          const GhLayout& L, hipStream_t s, float* seen, float seen_scale, uint32_t seen_slack, const GhOutputs* fused) {
   const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
   const uint2* ranges = (const uint2*)(wg + L.ranges);
   const uint32_t* order = (const uint32_t*)(wg + L.tile_order);
@@ -439,14 +490,25 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   const float* bound = (wg == ws && in->tile_depth_bound && g.N > 0) ? (const float*)(ws + L.tile_bound) : nullptr;
   if (wg != ws) seen = nullptr;
   const uint32_t* gid = (const uint32_t*)(wg + L.vals_a); const float* depth = (const float*)(wg + L.depth);
+  GhFusedL1 l1 = {};
+  if (fused && fused->l1_target) {                   // GhOutputs.l1_*: the image loss from the kernel's own epilogue
+    l1.target = fused->l1_target; l1.dL = fused->l1_dL_dimage;
+    l1.inv_n = (float)(1.0 / ((double)g.NV * 3.0 * (double)g.H * (double)g.W));
+    l1.part = (float*)(ws + L.loss_partials);
+  }
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
                        g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const uint32_t*)(ws + L.render_guard),
-                       wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, depth);
+                       wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, depth, l1);
   };
+  if (l1.target) {                                   // (the entry point has ruled out alpha / seen / a bound)
+    launch(gh_render_fwd_kernel<false, false, true>);
+    gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, l1.inv_n, fused->l1_loss, s);
+    return;
+  }
   // SEEN (GhOutputs.tile_depth_seen wanted): the variant that walks on virtually behind the stop; the plain kernels are untouched
-  if (seen) { if (alpha) launch(gh_render_fwd_kernel<true, true>); else launch(gh_render_fwd_kernel<false, true>); }
-  else { if (alpha) launch(gh_render_fwd_kernel<true, false>); else launch(gh_render_fwd_kernel<false, false>); }
+  if (seen) { if (alpha) launch(gh_render_fwd_kernel<true, true, false>); else launch(gh_render_fwd_kernel<false, true, false>); }
+  else { if (alpha) launch(gh_render_fwd_kernel<true, false, false>); else launch(gh_render_fwd_kernel<false, false, false>); }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -189,6 +189,7 @@ class _Policy:
     split = False                # False | True | "auto"
     reuse_geometry = True
     stage_timing = False
+    fused_loss = True            # raster_forward(l1_target=...) takes the render kernel's epilogue (GhOutputs.l1_*) where the library offers it
 
 
 _policy = _Policy()
@@ -372,6 +373,13 @@ def set_split_streams(mode) -> None:
     _policy.split = mode
 
 
+def set_fused_loss(on: bool) -> None:
+    """Module policy: let raster_forward(l1_target=...) — i.e. loss.rendered_l1_loss — take the image loss from the render kernel's
+    own epilogue (GhOutputs.l1_*, the default) or always run gh_l1_loss on the stored image (measurement A/B; same gradients bit for
+    bit, the loss up to the order of its float32 sums)."""
+    _policy.fused_loss = bool(on)
+
+
 def capacity_key(P: int, NV: int, H: int, W: int, split: bool = False):
     """Key of the learned instance capacity of a call shape (tests / tools)."""
     return (P, NV, H, W, bool(split))
@@ -497,7 +505,7 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 class _Ctx:
     __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "rows", "stream", "alpha",
-                 "parent", "radii", "pending", "verdict", "refresh", "__weakref__")
+                 "parent", "radii", "pending", "verdict", "refresh", "l1", "__weakref__")
 
     def __del__(self):
         try:
@@ -577,11 +585,12 @@ def _inputs_struct(c: _Call, with_shs: bool = True, bound=None):
                          _ptr(t["color_w"]), _ptr(t["color_b"]), _ptr(bound), _ptr(t["cov3D"]))
 
 
-def _make_ctx(c: _Call, dims, inp, ws, stream, alpha, parent, radii, pending, verdict, refresh) -> _Ctx:
+def _make_ctx(c: _Call, dims, inp, ws, stream, alpha, parent, radii, pending, verdict, refresh, l1=None) -> _Ctx:
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, c.t, ws, c.H, c.W, c.P, c.NV, c.M, c.wpg
     ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = c.b_rgb, c.rows, alpha, parent, radii, stream
     ctx.pending, ctx.verdict, ctx.refresh = pending, verdict, refresh
+    ctx.l1 = l1                                    # (loss, dL/dimage) of a fused image loss (GhOutputs.l1_*), else None
     return ctx
 
 
@@ -676,7 +685,7 @@ def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, e
 
 
 def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backward: bool, max_instances, static_lists: bool,
-                  depth_bound):
+                  depth_bound, l1_target=None):
     """gh_forward: projection, both sorts, lists, render — with the capacity / GH_FLAG_DEPTH24 / occlusion-bound policies around it
     (a synced call that the device flags is re-run with what it learned; a sync-free call is recorded for check_overflow)."""
     P, NV, H, W = c.P, c.NV, c.H, c.W
@@ -700,8 +709,16 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
         bound, seen = depth_bound._buffers(dev, NV, H, W, key=(P, bool(c.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS), c.cams_obj)) \
             if depth_bound is not None else (None, None)
         inp = _inputs_struct(c, bound=bound)
+        l1 = None
+        if l1_target is not None and alpha is None and depth_bound is None and not c.split and _policy.fused_loss:
+            # fused image loss: mean|image - target| and its gradient from the render kernel's epilogue (GhOutputs.l1_*); the
+            # combinations the library does not fuse fall back to gh_l1_loss in loss.py (ctx.l1 is None)
+            if l1_target.shape != image.shape or l1_target.dtype is not torch.float32 or not l1_target.is_contiguous():
+                raise ValueError("l1_target must be a contiguous float32 (n_views, 3, H, W) tensor")
+            l1 = (torch.empty((), dtype=torch.float32, device=dev), torch.empty_like(image))
         out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha), _ptr(seen), 1.0 + (depth_bound.margin if depth_bound is not None else 0.0),
-                             depth_bound.slack if depth_bound is not None else 0)
+                             depth_bound.slack if depth_bound is not None else 0,
+                             *((_ptr(l1_target), _ptr(l1[1]), _ptr(l1[0])) if l1 is not None else (None, None, None)))
         with _OnDevice(dev):
             fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
             if _policy.stage_timing:
@@ -762,7 +779,7 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
                 pending = pc
         break
     # verdict: the counter read-back of a sync-free call, whoever is to ask for it
-    ctx = _make_ctx(c._replace(flags=flags), dims, inp, ws, stream, alpha, None, radii, pending, verdict, False)
+    ctx = _make_ctx(c._replace(flags=flags), dims, inp, ws, stream, alpha, None, radii, pending, verdict, False, l1)
     return image, radii, ctx
 
 
@@ -771,7 +788,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                    color_b=None, max_instances: Optional[int] = None, sync: Optional[bool] = True, return_alpha: bool = False,
                    per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None,
                    split_streams: Optional[bool] = None, expect_backward: bool = False, static_lists: bool = False,
-                   refresh_of: Optional["_Ctx"] = None, depth_bound: Optional[DepthBoundCache] = None, cov3D_precomp=None):
+                   refresh_of: Optional["_Ctx"] = None, depth_bound: Optional[DepthBoundCache] = None, cov3D_precomp=None,
+                   l1_target: Optional[torch.Tensor] = None):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
     cov3D_precomp (P,6): the published module's precomputed 3-D covariance (xx xy xz yy yz zz, used as given: scale_modifier is
     not applied) in place of scales + rotations (pass None for both); its gradient comes back as "cov3D_precomp".
@@ -792,6 +810,9 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     the policy object on top of the two.
     depth_bound: a DepthBoundCache (full forwards only): instances behind the previous call's per-tile occlusion depth are
     not listed; verified by the forward, re-run without the bound on a miss.
+    l1_target (n_views,3,H,W): fused image loss — ctx.l1 = (mean|image - l1_target|, its gradient w.r.t. image) from the render
+    kernel's own epilogue (GhOutputs.l1_*). ctx.l1 is None where the library does not fuse it (alpha, a depth bound, two
+    streams, shared / refresh calls): the caller then runs gh_l1_loss on the image (loss.py does).
     sync: True = read D back (and re-run with a larger capacity if needed); False = never block (check_overflow() is the
     caller's job); None = auto: read D back for the first call of a shape and for calls whose backward will not come
     (expect_backward False), otherwise sync-free with the check at the start of raster_backward.
@@ -811,7 +832,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
         if refresh_of is not None:
             return _forward_refresh(st, L, dev, c._replace(flags=c.flags | _abi.GH_FLAG_STATIC_LISTS), refresh_of, return_alpha, sync,
                                     expect_backward)
-        return _forward_full(st, L, dev, c, return_alpha, sync, expect_backward, max_instances, static_lists, depth_bound)
+        return _forward_full(st, L, dev, c, return_alpha, sync, expect_backward, max_instances, static_lists, depth_bound, l1_target)
 
 
 def cached_raster_forward(cache: Optional[GeometryCache], cams, means3D, opacities, scales, rotations, **kw):

@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define GH_VERSION_MAJOR 0
-#define GH_VERSION_MINOR 6
+#define GH_VERSION_MINOR 7
 
 #define GH_TILE 16           /* tile edge in pixels (binning granularity; fixes which Gaussians a pixel sees) */
 #define GH_CAM_FLOATS 40     /* floats per camera record, see GhCamera */
@@ -152,6 +152,17 @@ typedef struct GhOutputs {
      transmittance ended just below the 1e-4 stop needs a few more entries as soon as anything moves — possibly from the next
      surface centimetres behind; the slack entries are what it then finds. */
   uint32_t tile_depth_seen_slack;
+  /* Fused image loss (v0.7; gh_forward / gh_forward_stages only; NULL = none): the L1 term of utils.py:282-294 as bench.py and the
+     fit loop consume the render — l1_loss[0] = mean|image - l1_target| over all n_views*3*H*W values and l1_dL_dimage =
+     sign(image - l1_target) / (n_views*3*H*W) (sign(0) = 0, as torch.abs' backward), both (n_views,3,H,W) like `image` —
+     produced by the render kernel's own epilogue while the pixel is still in registers: the same values gh_l1_loss computes from
+     the stored image (the gradient bit for bit; the loss up to the order of its fixed-order sums), without the pass over the
+     images. Bitwise reproducible. A call the device flags as invalid (GhCounters.overflow bits 0, 1, 3) yields l1_loss = NaN and
+     l1_dL_dimage = 0, like gh_l1_loss under its guard. Not available together with `alpha`, `tile_depth_seen`,
+     GhInputs.tile_depth_bound or GH_FLAG_SPLIT_STREAMS (GH_ERR_UNSUPPORTED). All three pointers or none. */
+  const float* l1_target;
+  float* l1_dL_dimage;
+  float* l1_loss;
 } GhOutputs;
 
 /* Device-side counters written by gh_forward (first bytes of the workspace, see GhLayout.counters). */
@@ -259,6 +270,8 @@ typedef struct GhLayout {
   size_t render_guard;   /* uint32: the error bits of GhCounters.overflow as they stood BEFORE the render kernel of this call — written by
                             the kernel in front of it, read by every render wave through the scalar cache (the counters' own line
                             takes the render kernel's atomics) */
+  size_t loss_partials;  /* float[n_views*tiles][4]: the fused image loss's sums of |image - target| per 8x8-pixel quadrant
+                            (GhOutputs.l1_target), added up in index order by a one-workgroup kernel behind the render */
 } GhLayout;
 
 /* Library version: major<<16 | minor. */

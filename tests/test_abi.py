@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(gh_lib_path):
     for sym in header_symbols():
         assert hasattr(L, sym), sym
     _abi.declare(L)
-    assert L.gh_version() == (0 << 16) | 6
+    assert L.gh_version() == (0 << 16) | 7
 
 
 def test_struct_sizes_match_header():
@@ -33,7 +33,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_abi.GhDims) == 40
     assert C.sizeof(_abi.GhInputs) == 13 * 8          # v0.6: + cov3D_precomp
     assert C.sizeof(_abi.GhGrads) == 15 * 8           # v0.6: + dL_dcov3D
-    assert C.sizeof(_abi.GhOutputs) == 5 * 8          # 4 pointers + (float, uint32)
+    assert C.sizeof(_abi.GhOutputs) == 8 * 8          # 4 pointers + (float, uint32) + v0.7: the fused loss's 3 pointers
     assert C.sizeof(_abi.GhCounters) == 16
     assert C.sizeof(_abi.GhLayout) == len(_abi.LAYOUT_FIELDS) * 8
 
@@ -104,6 +104,30 @@ def test_occlusion_bound_arguments_are_validated_before_any_launch(gh_lib_path):
     out2 = _abi.GhOutputs(one, one, None, None, 1.0, 0)
     assert L.gh_forward(C.byref(ds), C.byref(inp), C.byref(out2), one, 1 << 30, None) == _abi.GH_ERR_UNSUPPORTED
     assert _abi.GH_FLAG_DEPTH24 == 32
+
+
+def test_fused_loss_arguments_are_validated_before_any_launch(gh_lib_path):
+    """GhOutputs.l1_* (v0.7): all three pointers or none; not with the mask channel, an occlusion report / bound or two streams;
+    gh_forward only."""
+    L = C.CDLL(gh_lib_path)
+    _abi.declare(L)
+    one, two = C.c_void_p(256), C.c_void_p(512)
+    d = _abi.GhDims(10, 2, 32, 32, 0, 0, 1.0, 0, 1000)
+    inp = _abi.GhInputs(one, one, one, one, one, None, one)
+    call = lambda out, dims=d, i=inp: L.gh_forward(C.byref(dims), C.byref(i), C.byref(out), one, 16, None)
+    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, one, one)) == _abi.GH_ERR_WORKSPACE_SMALL     # accepted this far
+    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, None, one)) == _abi.GH_ERR_INVALID_ARG
+    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, one, None)) == _abi.GH_ERR_INVALID_ARG
+    assert call(_abi.GhOutputs(one, one, one, None, 1.0, 0, one, one, one)) == _abi.GH_ERR_UNSUPPORTED
+    assert call(_abi.GhOutputs(one, one, None, two, 1.0, 0, one, one, one)) == _abi.GH_ERR_UNSUPPORTED
+    inp_b = _abi.GhInputs(one, one, one, one, one, None, one, None, None, None, None, two)
+    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, one, one), i=inp_b) == _abi.GH_ERR_UNSUPPORTED
+    d2 = _abi.GhDims(10, 2, 32, 32, 0, 0, 1.0, _abi.GH_FLAG_SPLIT_STREAMS, 1000)
+    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, one, one), d2) == _abi.GH_ERR_UNSUPPORTED
+    out = _abi.GhOutputs(one, None, None, None, 1.0, 0, one, one, one)
+    assert L.gh_forward_shared(C.byref(d), C.byref(inp), C.byref(out), two, one, 16, None) == _abi.GH_ERR_UNSUPPORTED
+    d3 = _abi.GhDims(10, 2, 32, 32, 0, 0, 1.0, _abi.GH_FLAG_STATIC_LISTS, 1000)
+    assert L.gh_forward_refresh(C.byref(d3), C.byref(inp), C.byref(out), two, one, 16, None) == _abi.GH_ERR_UNSUPPORTED
 
 
 def test_product_has_no_cpu_fallback():

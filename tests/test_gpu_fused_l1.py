@@ -1,0 +1,114 @@
+"""Fused image loss (GhOutputs.l1_target, include/gh_raster.h v0.7): mean|image - target| and its gradient from the render
+kernel's own epilogue must be what gh_l1_loss computes from the stored image — the gradient bit for bit, the loss up to the
+order of its fixed-order float32 sums — and what the L1 term of the reference's loss (utils.py:282-294) is in float64."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from guassianhand_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def _fwd(s, target, **kw):
+    from guassianhand_amd.rasterizer import raster_forward
+    return raster_forward(s.cams().contiguous(), s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W,
+                          colors_precomp=s.shs.squeeze(1), l1_target=target, **kw)
+
+
+# (512 x 334 is ragged: the last tile column holds 14 pixels, its last 4x4 blocks 2)
+@pytest.mark.parametrize("scene,nv,P", [("random1k", 1, 1000), ("random1k", 3, 2500), ("one_hand", 2, 6000), ("two_hands", 8, None)])
+def test_fused_l1_is_gh_l1_loss_of_the_stored_image(dev, scene, nv, P):
+    from guassianhand_amd.loss import _l1_kernel
+    from guassianhand_amd.scenes import make_scene
+    kw = {} if P is None else dict(P=P)
+    sc = make_scene(scene, n_views=nv, use_rgb=True, **kw)
+    s = sc.to(dev)
+    g = torch.Generator().manual_seed(11)
+    target = torch.rand(nv, 3, sc.H, sc.W, generator=g).to(dev)
+    img, _, ctx = _fwd(s, target)
+    assert ctx.l1 is not None
+    loss, dimg = ctx.l1
+    img0, _, ctx0 = _fwd(s, None)                       # the plain kernel: same image
+    assert ctx0.l1 is None and torch.equal(img, img0)
+    loss_k, dimg_k = _l1_kernel(img0, target)
+    assert torch.equal(dimg, dimg_k)                    # sign(img - gt) / n, bit for bit
+    ref = (img0.double() - target.double()).abs().mean().item()
+    assert abs(loss.item() - ref) <= 2e-6 * ref and abs(loss_k.item() - ref) <= 2e-6 * ref
+    # an exact zero difference has no gradient (torch.abs' backward): make the target equal the render in a patch
+    t2 = target.clone()
+    t2[:, :, : sc.H // 2, : sc.W // 2] = img0[:, :, : sc.H // 2, : sc.W // 2]
+    _, _, ctx2 = _fwd(s, t2)
+    assert float(ctx2.l1[1][:, :, : sc.H // 2, : sc.W // 2].abs().max()) == 0.0
+    assert torch.equal(ctx2.l1[1], _l1_kernel(img0, t2)[1])
+    # bitwise reproducible
+    _, _, ctx3 = _fwd(s, target)
+    assert torch.equal(ctx3.l1[0], loss) and torch.equal(ctx3.l1[1], dimg)
+
+
+def test_fused_l1_through_the_one_node_loss_equals_the_two_node_form(dev):
+    """loss.rendered_l1_loss takes the fused epilogue; values and every gradient against rasterize_views + l1_mean_loss."""
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.loss import l1_mean_loss, rendered_l1_loss
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("one_hand", n_views=4, P=8000, use_rgb=True, blend=True)
+    s = sc.to(dev)
+    cams = s.cams().contiguous()
+    names = ("xyz", "opacity", "scaling", "rotation", "shs", "xyz_b", "opacity_b", "color_w", "color_b")
+    target = torch.rand(4, 3, sc.H, sc.W, generator=torch.Generator().manual_seed(2)).to(dev)
+    pa = {k: getattr(s, k).clone().requires_grad_(True) for k in names}
+    pb = {k: getattr(s, k).clone().requires_grad_(True) for k in names}
+    kw = lambda p: dict(H=sc.H, W=sc.W, use_rgb=True, xyz_b=p["xyz_b"], opacity_b=p["opacity_b"], color_w=p["color_w"], color_b=p["color_b"])
+    img, _ = R.rasterize_views(cams, pa["xyz"], pa["opacity"], pa["scaling"], pa["rotation"], pa["shs"], **kw(pa))
+    la = l1_mean_loss(img, target)
+    lb, img_b, _ = rendered_l1_loss(cams, pb["xyz"], pb["opacity"], pb["scaling"], pb["rotation"], pb["shs"], target, **kw(pb))
+    assert torch.equal(img_b, img.detach())
+    assert abs(la.item() - lb.item()) <= 4e-6 * abs(la.item())
+    (2.5 * la).backward()
+    (2.5 * lb).backward()
+    for k in names:
+        assert torch.equal(pa[k].grad, pb[k].grad), k
+
+
+def test_fused_l1_of_an_invalid_call_is_nan_with_no_gradient(dev):
+    """An instance overflow poisons the image; the fused loss is then NaN and its gradient zero — gh_l1_loss under its guard."""
+    from guassianhand_amd.scenes import make_scene
+    s = make_scene("random1k", n_views=2).to(dev)
+    target = torch.rand(2, 3, s.H, s.W, generator=torch.Generator().manual_seed(3)).to(dev)
+    img, _, ctx = _fwd(s, target, max_instances=128, sync=False)
+    torch.cuda.synchronize()
+    assert torch.isnan(img).all() and torch.isnan(ctx.l1[0]) and float(ctx.l1[1].abs().max()) == 0.0
+    from guassianhand_amd.rasterizer import GhOverflowError, check_overflow
+    with pytest.raises(GhOverflowError):
+        check_overflow()
+
+
+def test_fused_l1_of_an_empty_scene_is_the_background(dev):
+    from guassianhand_amd.scenes import make_scene
+    s = make_scene("random1k", n_views=2, P=1000).to(dev)
+    target = torch.rand(2, 3, s.H, s.W, generator=torch.Generator().manual_seed(4)).to(dev)
+    from guassianhand_amd.rasterizer import raster_forward
+    e = lambda *shape: torch.empty(*shape, device=dev)
+    img, _, ctx = raster_forward(s.cams().contiguous(), e(0, 3), e(0, 1), e(0, 3), e(0, 4), H=s.H, W=s.W, colors_precomp=e(0, 3),
+                                 l1_target=target)
+    ref = (img.double() - target.double()).abs().mean().item()
+    assert abs(ctx.l1[0].item() - ref) <= 2e-6 * ref
+    assert torch.equal(ctx.l1[1], torch.sign(img - target) / img.numel())
+
+
+def test_fused_l1_combinations_the_library_does_not_fuse(dev):
+    """alpha / two streams: ctx.l1 is None on the host side and loss.py runs gh_l1_loss on the image (the C-ABI's own answer,
+    GH_ERR_UNSUPPORTED, is tested without a GPU in tests/test_abi.py)."""
+    from guassianhand_amd.scenes import make_scene
+    s = make_scene("random1k", n_views=2).to(dev)
+    target = torch.rand(2, 3, s.H, s.W).to(dev)
+    _, _, ctx = _fwd(s, target, return_alpha=True)
+    assert ctx.l1 is None
+    _, _, ctx = _fwd(s, target, split_streams=True)
+    assert ctx.l1 is None
