@@ -205,7 +205,7 @@ def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
                       "value = renders per second of library time; serial_fraction = library time on one thread / library time"}
 
 
-def two_call_cost(s, cams_w2c_K, n_iter: int = 12):
+def two_call_cost(s, cams_w2c_K, n_iter: int = 30):
     """per-view cost of the REFERENCE's protocol through the drop-in — blend in torch, then the RGB call and the
     mask call of renderer_one_shot.py:338-346 / :372-379 through GaussianRasterizer (autograd, L1 + mask loss), forward +
     backward — as a maintainer who changes nothing gets it. Milliseconds per view; host-bound."""
@@ -248,9 +248,12 @@ def two_call_cost(s, cams_w2c_K, n_iter: int = 12):
         msk, _ = GaussianRasterizer(mk(zero, 0))(colors_precomp=torch.ones_like(means), **kw)
         ((img - gt).abs().mean() + ((msk.mean(0) - gt[0]) ** 2).mean()).backward()
 
-    for _ in range(3):
+    import gc
+    for _ in range(5):
         one()
     torch.cuda.synchronize()
+    gc.collect()          # (a full collection of the interpreter's ~1e6 objects is 40-60 ms: pending at the start of a 12-call window it
+                          # was a third of the figure — measured with tools/ptr_probe2.py; collected here, never disabled)
     t0 = time.perf_counter()
     for _ in range(n_iter):
         one()

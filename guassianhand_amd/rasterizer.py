@@ -490,7 +490,9 @@ class _OnDevice:
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    # (a plain int: a ctypes pointer FIELD takes it as it stands — thirty c_void_p objects per call were thirty GC-tracked
+    # allocations per call for nothing)
+    return None if t is None else t.data_ptr()
 
 
 def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:

@@ -27,7 +27,9 @@ def fused():
                        opacity_b=sc.opacity_b, use_rgb=True, sync=False)
     (out["comp_rgb"].mean() + out["comp_mask"].mean()).backward()
 def t(fn, n=30):
+    import gc
     for _ in range(4): fn()
+    gc.collect()          # a pending full collection (40-60 ms for the interpreter's ~1e6 objects) is not part of a 30-call figure
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     global enq
