@@ -99,7 +99,8 @@ def test_fused_l1_of_an_empty_scene_is_the_background(dev):
                                  l1_target=target)
     ref = (img.double() - target.double()).abs().mean().item()
     assert abs(ctx.l1[0].item() - ref) <= 2e-6 * ref
-    assert torch.equal(ctx.l1[1], torch.sign(img - target) / img.numel())
+    inv_n = torch.tensor(1.0 / img.numel(), dtype=torch.float64).to(torch.float32).to(dev)           # (float)(1.0 / n), as the library rounds it
+    assert torch.equal(ctx.l1[1], torch.sign(img - target) * inv_n)
 
 
 def test_fused_l1_combinations_the_library_does_not_fuse(dev):

@@ -173,6 +173,18 @@ def one(it):
         part = R.raster_backward(ctx, dimg.to(dev), want_means2D=False, want=sub)
         for k in sub:
             assert torch.equal(part[k], full[k]), tag + f" (want subset: {k})"
+        if variant == "plain":
+            # the fused image loss (GhOutputs.l1_*): same image, the gradient of mean|image - target| bit for bit, the loss against float64
+            tgt = torch.rand(NV, 3, H, W, generator=torch.Generator().manual_seed(it + 7)).to(dev)
+            if rnd.random() < 0.3:
+                tgt[:, :, : H // 2] = img[:, :, : H // 2]             # exact zeros: no gradient there (torch.abs' backward)
+            img1, radii1, ctx1 = R.raster_forward(cg, s.xyz, s.opacity, s.scaling, s.rotation, H=H, W=W, l1_target=tgt,
+                                                  **colour_kw(s), **blend_kw(s, b3=b3))
+            assert ctx1.l1 is not None and torch.equal(img1, img) and torch.equal(radii1, radii), tag + " (fused loss: image)"
+            inv_n = torch.tensor(1.0 / img.numel(), dtype=torch.float64).to(torch.float32).to(dev)       # (float)(1.0 / n), as the library rounds it
+            assert torch.equal(ctx1.l1[1], torch.sign(img - tgt) * inv_n), tag + " (fused loss: gradient)"
+            ref = float((img.double() - tgt.double()).abs().mean())
+            assert abs(float(ctx1.l1[0]) - ref) <= 3e-6 * ref + 1e-12, tag + f" (fused loss: {float(ctx1.l1[0])} vs {ref})"
         om.close(); o.close()
     elif variant == "static_refresh":
         img0, radii0, ctx0 = R.raster_forward(cg, s.xyz, s.opacity, s.scaling, s.rotation, H=H, W=W, static_lists=True,
