@@ -260,6 +260,9 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   if (in->tile_depth_bound && (d->flags & GH_FLAG_STATIC_LISTS)) return GH_ERR_UNSUPPORTED;
   if (out->l1_target) {                                    // fused image loss
     if (!out->l1_dL_dimage || !out->l1_loss) return GH_ERR_INVALID_ARG;
+    // the gradient is stored while other waves still read the target and store the image
+    if (out->l1_dL_dimage == out->image || (const float*)out->l1_dL_dimage == out->l1_target || (const float*)out->image == out->l1_target)
+      return GH_ERR_INVALID_ARG;
     // one walk, one loss: not with the mask channel, an occlusion bound / report (a miss found late could not take back the
     // gradients of the waves that finished early), or two halves on two streams
     if (out->alpha || out->tile_depth_seen || in->tile_depth_bound || gh_split_on(d)) return GH_ERR_UNSUPPORTED;

@@ -159,7 +159,8 @@ typedef struct GhOutputs {
      the stored image (the gradient bit for bit; the loss up to the order of its fixed-order sums), without the pass over the
      images. Bitwise reproducible. A call the device flags as invalid (GhCounters.overflow bits 0, 1, 3) yields l1_loss = NaN and
      l1_dL_dimage = 0, like gh_l1_loss under its guard. Not available together with `alpha`, `tile_depth_seen`,
-     GhInputs.tile_depth_bound or GH_FLAG_SPLIT_STREAMS (GH_ERR_UNSUPPORTED). All three pointers or none. */
+     GhInputs.tile_depth_bound or GH_FLAG_SPLIT_STREAMS (GH_ERR_UNSUPPORTED). All three pointers or none; image, l1_target and
+     l1_dL_dimage are three different arrays (GH_ERR_INVALID_ARG). */
   const float* l1_target;
   float* l1_dL_dimage;
   float* l1_loss;

@@ -115,15 +115,18 @@ def test_fused_loss_arguments_are_validated_before_any_launch(gh_lib_path):
     d = _abi.GhDims(10, 2, 32, 32, 0, 0, 1.0, 0, 1000)
     inp = _abi.GhInputs(one, one, one, one, one, None, one)
     call = lambda out, dims=d, i=inp: L.gh_forward(C.byref(dims), C.byref(i), C.byref(out), one, 16, None)
-    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, one, one)) == _abi.GH_ERR_WORKSPACE_SMALL     # accepted this far
     assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, None, one)) == _abi.GH_ERR_INVALID_ARG
     assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, one, None)) == _abi.GH_ERR_INVALID_ARG
-    assert call(_abi.GhOutputs(one, one, one, None, 1.0, 0, one, one, one)) == _abi.GH_ERR_UNSUPPORTED
-    assert call(_abi.GhOutputs(one, one, None, two, 1.0, 0, one, one, one)) == _abi.GH_ERR_UNSUPPORTED
+    three = C.c_void_p(768)
+    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, two, three, one)) == _abi.GH_ERR_WORKSPACE_SMALL   # three distinct arrays
+    for img, tgt, dl in ((one, one, two), (one, two, one), (one, two, two)):                                     # any two the same
+        assert call(_abi.GhOutputs(img, one, None, None, 1.0, 0, tgt, dl, three)) == _abi.GH_ERR_INVALID_ARG
+    assert call(_abi.GhOutputs(one, one, one, None, 1.0, 0, two, three, one)) == _abi.GH_ERR_UNSUPPORTED
+    assert call(_abi.GhOutputs(one, one, None, two, 1.0, 0, two, three, one)) == _abi.GH_ERR_UNSUPPORTED
     inp_b = _abi.GhInputs(one, one, one, one, one, None, one, None, None, None, None, two)
-    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, one, one), i=inp_b) == _abi.GH_ERR_UNSUPPORTED
+    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, two, three, one), i=inp_b) == _abi.GH_ERR_UNSUPPORTED
     d2 = _abi.GhDims(10, 2, 32, 32, 0, 0, 1.0, _abi.GH_FLAG_SPLIT_STREAMS, 1000)
-    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, one, one, one), d2) == _abi.GH_ERR_UNSUPPORTED
+    assert call(_abi.GhOutputs(one, one, None, None, 1.0, 0, two, three, one), d2) == _abi.GH_ERR_UNSUPPORTED
     out = _abi.GhOutputs(one, None, None, None, 1.0, 0, one, one, one)
     assert L.gh_forward_shared(C.byref(d), C.byref(inp), C.byref(out), two, one, 16, None) == _abi.GH_ERR_UNSUPPORTED
     d3 = _abi.GhDims(10, 2, 32, 32, 0, 0, 1.0, _abi.GH_FLAG_STATIC_LISTS, 1000)
