@@ -37,10 +37,17 @@ class GhInputs(C.Structure):
         "blend_xyz_b", "blend_opacity_b", "blend_color_w", "blend_color_b", "tile_depth_bound", "cov3D_precomp")]
 
 
+class GhFitLoss(C.Structure):
+    _fields_ = [("gt_rgb", C.c_void_p), ("gt_mask", C.c_void_p), ("bbox", C.c_void_p), ("lambda_l1", C.c_float),
+                ("lambda_mask", C.c_float), ("scale", C.c_float), ("dL_dimage", C.c_void_p), ("dL_dalpha", C.c_void_p),
+                ("loss", C.c_void_p)]
+
+
 class GhOutputs(C.Structure):
     _fields_ = [("image", C.c_void_p), ("radii", C.c_void_p), ("alpha", C.c_void_p), ("tile_depth_seen", C.c_void_p),
                 ("tile_depth_seen_scale", C.c_float), ("tile_depth_seen_slack", C.c_uint32),
-                ("l1_target", C.c_void_p), ("l1_dL_dimage", C.c_void_p), ("l1_loss", C.c_void_p)]
+                ("l1_target", C.c_void_p), ("l1_dL_dimage", C.c_void_p), ("l1_loss", C.c_void_p),
+                ("fit_loss", C.POINTER(GhFitLoss))]
 
 
 class GhCounters(C.Structure):

@@ -243,6 +243,28 @@ __global__ void gh_merge_counters_kernel(const GhCounters* __restrict__ a, const
   out->reserved[1] = 0u;
 }
 
+// GhOutputs.l1_* / fit_loss: the image loss from the render kernel's epilogue
+static int check_fused_loss(const GhDims* d, const GhInputs* in, const GhOutputs* out) {
+  if (!out->l1_target && !out->fit_loss) return GH_OK;
+  if (out->l1_target && out->fit_loss) return GH_ERR_INVALID_ARG;
+  // one walk, one loss: not with an occlusion bound / report (a miss found late could not take back the gradients of the waves
+  // that finished early) or two halves on two streams
+  if (out->tile_depth_seen || in->tile_depth_bound || gh_split_on(d)) return GH_ERR_UNSUPPORTED;
+  if (out->l1_target) {
+    if (!out->l1_dL_dimage || !out->l1_loss) return GH_ERR_INVALID_ARG;
+    // the gradient is stored while other waves still read the target and store the image
+    if (out->l1_dL_dimage == out->image || (const float*)out->l1_dL_dimage == out->l1_target || (const float*)out->image == out->l1_target)
+      return GH_ERR_INVALID_ARG;
+    if (out->alpha) return GH_ERR_UNSUPPORTED;             // (the L1 form has no mask channel)
+    return GH_OK;
+  }
+  const GhFitLoss* f = out->fit_loss;
+  if (!f->gt_rgb || !f->gt_mask || !f->dL_dimage || !f->dL_dalpha || !f->loss) return GH_ERR_INVALID_ARG;
+  if (!out->alpha) return GH_ERR_INVALID_ARG;              // the mask term reads the fused mask channel
+  if (f->dL_dimage == out->image || f->dL_dalpha == out->alpha || f->dL_dalpha == f->dL_dimage) return GH_ERR_INVALID_ARG;
+  return GH_OK;
+}
+
 extern "C" int gh_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, void* workspace,
                           size_t ws_bytes, void* hip_stream) {
   return gh_forward_stages(d, in, out, workspace, ws_bytes, hip_stream, GH_FWD_ALL);
@@ -258,15 +280,8 @@ extern "C" int gh_forward_stages(const GhDims* d, const GhInputs* in, const GhOu
   if (in->tile_depth_bound && (const float*)out->tile_depth_seen == in->tile_depth_bound) return GH_ERR_INVALID_ARG;
   // lists that must outlive this call's opacities cannot be truncated by a bound that holds for this call only
   if (in->tile_depth_bound && (d->flags & GH_FLAG_STATIC_LISTS)) return GH_ERR_UNSUPPORTED;
-  if (out->l1_target) {                                    // fused image loss
-    if (!out->l1_dL_dimage || !out->l1_loss) return GH_ERR_INVALID_ARG;
-    // the gradient is stored while other waves still read the target and store the image
-    if (out->l1_dL_dimage == out->image || (const float*)out->l1_dL_dimage == out->l1_target || (const float*)out->image == out->l1_target)
-      return GH_ERR_INVALID_ARG;
-    // one walk, one loss: not with the mask channel, an occlusion bound / report (a miss found late could not take back the
-    // gradients of the waves that finished early), or two halves on two streams
-    if (out->alpha || out->tile_depth_seen || in->tile_depth_bound || gh_split_on(d)) return GH_ERR_UNSUPPORTED;
-  }
+  rc = check_fused_loss(d, in, out);
+  if (rc != GH_OK) return rc;
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
@@ -380,7 +395,7 @@ extern "C" int gh_forward_shared(const GhDims* d, const GhInputs* in, const GhOu
   int rc = check_shared(d, in);
   if (rc != GH_OK) return rc;
   if (!out || !out->image || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
-  if (out->l1_target) return GH_ERR_UNSUPPORTED;            // the fused image loss is gh_forward's
+  if (out->l1_target || out->fit_loss) return GH_ERR_UNSUPPORTED;            // the fused image losses are gh_forward's / gh_forward_refresh's
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
@@ -426,7 +441,8 @@ extern "C" int gh_forward_refresh(const GhDims* d, const GhInputs* in, const GhO
   int rc = check_refresh(d, in);
   if (rc != GH_OK) return rc;
   if (!out || !out->image || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
-  if (out->l1_target) return GH_ERR_UNSUPPORTED;            // the fused image loss is gh_forward's
+  rc = check_fused_loss(d, in, out);
+  if (rc != GH_OK) return rc;
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
@@ -435,12 +451,12 @@ extern "C" int gh_forward_refresh(const GhDims* d, const GhInputs* in, const GhO
   (void)hipGetLastError();
   if (g.N == 0) {                                        // nothing to draw: the background, through the plain path's state
     gh_launch_preprocess_fwd(d, g, in, nullptr, (char*)workspace, L, s);
-    gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s);
+    gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s, nullptr, 1.0f, 0u, out);
     return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
   }
   gh_launch_sh_colour_fwd(d, g, in, (char*)workspace, L, s);           // SH mode only
   gh_launch_refresh(d, g, in, (const char*)geometry_ws, (char*)workspace, L, s);
-  gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s);
+  gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s, nullptr, 1.0f, 0u, out);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 

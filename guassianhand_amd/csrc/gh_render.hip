@@ -276,19 +276,24 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
 
 // grid = 4 blocks per tile (one per 8x8 quadrant), 4 waves per block (one per 4x4 pixel block); no LDS, no barriers.
 // ALPHA: also accumulate the mask channel (colour 1, bg 0) — SURVEY §8 f-2.
-// LOSS: fused image loss (GhOutputs.l1_target): every wave leaves the gradient sign(img - gt) / n of its 16 pixels, every workgroup
+// LOSS: fused image loss. 1 = GhOutputs.l1_target: every wave leaves the gradient sign(img - gt) / n of its 16 pixels, every workgroup
 // ONE partial sum of |img - gt| at a place fixed by (tile, quadrant) — plain stores, no hand-off between workgroups inside this
 // kernel (a last-arriver tree over the tiles was costed: every level is a drained store + an RMW + dependent loads on the kernel's
 // tail, as long as the small sum kernel that follows). gh_launch_partials_sum adds the partials up in index order: bitwise
-// reproducible.
-struct GhFusedL1 {
-  const float* target;       // (n_views,3,H,W)
+// reproducible. 2 = GhOutputs.fit_loss (with ALPHA): the fit's image loss k_l1 |bbox * rgb - gt_rgb| + k_m (clip(alpha) - gt_mask)^2
+// and its gradients w.r.t. image and alpha — gh_fit_loss_kernel's expressions, pixel for pixel.
+struct GhFusedLoss {
+  const float* target;       // LOSS 1: (n_views,3,H,W); LOSS 2: gt_rgb (n_views,H,W,3)
   float* dL;                 // (n_views,3,H,W)
-  float inv_n;               // 1 / (n_views*3*H*W)
+  float inv_n;               // LOSS 1: 1 / (n_views*3*H*W)
   float* part;               // [T][4]: one sum per 8x8-pixel quadrant
+  const float* gt_mask;      // LOSS 2: (n_views,H,W)
+  const float* bbox;         // LOSS 2: (n_views,H,W) or NULL
+  float* dalpha;             // LOSS 2: (n_views,H,W)
+  float k_l1, k_m;           // LOSS 2: scale * lambda_l1 / (3 HW), scale * lambda_mask / HW
 };
 
-template <bool ALPHA, bool SEEN, bool LOSS>
+template <bool ALPHA, bool SEEN, int LOSS>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
     const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
     float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const uint32_t* __restrict__ render_guard,
     uint32_t guard_mask, const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
-    const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth, const GhFusedL1 l1) {
+    const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth, const GhFusedLoss l1) {
   // LOSS: the quadrant's four wave sums meet in LDS (the last wave to arrive adds them up in block order); the arrival counter is
   // cleared behind the one barrier of the kernel, which the four waves reach as they start — before any load is in flight
   __shared__ float s_l1[GH_BLOCK / GH_WAVE];
@@ -329,10 +334,17 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   float4* s_col = s_col_all[wid];
   // LOSS: the pixel's target is fetched NOW (three registers through the walk) — at the end of the wave the loads' latency would be
   // exposed time of a finished wave's slot
-  float tg0 = 0.0f, tg1 = 0.0f, tg2 = 0.0f;
-  if (LOSS && inside && slot == 0) {
+  float tg0 = 0.0f, tg1 = 0.0f, tg2 = 0.0f, tgm = 0.0f;
+  bool in_box = true;
+  if (LOSS == 1 && inside && slot == 0) {
     const size_t o = (size_t)v * 3 * H * W + (size_t)y * W + x, hw = (size_t)H * W;
     tg0 = l1.target[o]; tg1 = l1.target[o + hw]; tg2 = l1.target[o + 2 * hw];
+  }
+  if (LOSS == 2 && inside && slot == 0) {
+    const size_t pix = ((size_t)v * H + y) * W + x;
+    tg0 = l1.target[pix * 3]; tg1 = l1.target[pix * 3 + 1]; tg2 = l1.target[pix * 3 + 2];     // channel-last, as the reference holds it
+    tgm = l1.gt_mask[pix];
+    if (l1.bbox) in_box = l1.bbox[pix] != 0.0f;
   }
   GhPixelFwd p;
   p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.stopq = 0; p.done = inside ? 0 : 1;
@@ -381,14 +393,27 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
       const float poison = (*render_guard & guard_mask) ? __uint_as_float(0x7FC00000u) : 0.0f;
       const size_t o = (size_t)v * 3 * H * W + (size_t)y * W + x, hw = (size_t)H * W;
-      const float d0 = (fmaf(p.T, bg[0], p.C0) + poison) - tg0;
-      const float d1 = (fmaf(p.T, bg[1], p.C1) + poison) - tg1;
-      const float d2 = (fmaf(p.T, bg[2], p.C2) + poison) - tg2;
-      labs = (fabsf(d0) + fabsf(d1)) + fabsf(d2);
-      // torch.sign: sign(0) = 0; a NaN pixel (poisoned call) leaves no gradient, as gh_l1_loss's guard
-      l1.dL[o] = d0 > 0.0f ? l1.inv_n : (d0 < 0.0f ? -l1.inv_n : 0.0f);
-      l1.dL[o + hw] = d1 > 0.0f ? l1.inv_n : (d1 < 0.0f ? -l1.inv_n : 0.0f);
-      l1.dL[o + 2 * hw] = d2 > 0.0f ? l1.inv_n : (d2 < 0.0f ? -l1.inv_n : 0.0f);
+      const float c0 = fmaf(p.T, bg[0], p.C0) + poison, c1 = fmaf(p.T, bg[1], p.C1) + poison, c2 = fmaf(p.T, bg[2], p.C2) + poison;
+      if (LOSS == 1) {
+        const float d0 = c0 - tg0, d1 = c1 - tg1, d2 = c2 - tg2;
+        labs = (fabsf(d0) + fabsf(d1)) + fabsf(d2);
+        // torch.sign: sign(0) = 0; a NaN pixel (poisoned call) leaves no gradient, as gh_l1_loss's guard
+        l1.dL[o] = d0 > 0.0f ? l1.inv_n : (d0 < 0.0f ? -l1.inv_n : 0.0f);
+        l1.dL[o + hw] = d1 > 0.0f ? l1.inv_n : (d1 < 0.0f ? -l1.inv_n : 0.0f);
+        l1.dL[o + 2 * hw] = d2 > 0.0f ? l1.inv_n : (d2 < 0.0f ? -l1.inv_n : 0.0f);
+      } else {
+        // gh_fit_loss_kernel's expressions: colour zeroed outside the box, clip(alpha, -0.001, 1) passes the gradient on [min, max]
+        const float d0 = (in_box ? c0 : 0.0f) - tg0, d1 = (in_box ? c1 : 0.0f) - tg1, d2 = (in_box ? c2 : 0.0f) - tg2;
+        labs = l1.k_l1 * fabsf(d0); labs += l1.k_l1 * fabsf(d1); labs += l1.k_l1 * fabsf(d2);
+        l1.dL[o] = in_box ? (d0 > 0.0f ? l1.k_l1 : (d0 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
+        l1.dL[o + hw] = in_box ? (d1 > 0.0f ? l1.k_l1 : (d1 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
+        l1.dL[o + 2 * hw] = in_box ? (d2 > 0.0f ? l1.k_l1 : (d2 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
+        const float a = fmaf(p.T, 0.0f, p.A) + poison;                 // the mask channel as it is stored below
+        const float ac = fminf(fmaxf(a, -0.001f), 1.0f);
+        const float e = ac - tgm;
+        labs += l1.k_m * e * e;
+        l1.dalpha[((size_t)v * H + y) * W + x] = (a >= -0.001f && a <= 1.0f) ? 2.0f * l1.k_m * e : 0.0f;
+      }
     }
     const float wsum = gh_wave_sum_to63(labs);
     if (lane == 63) {
@@ -490,25 +515,38 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   const float* bound = (wg == ws && in->tile_depth_bound && g.N > 0) ? (const float*)(ws + L.tile_bound) : nullptr;
   if (wg != ws) seen = nullptr;
   const uint32_t* gid = (const uint32_t*)(wg + L.vals_a); const float* depth = (const float*)(wg + L.depth);
-  GhFusedL1 l1 = {};
+  GhFusedLoss l1 = {};
+  int loss_kind = 0;
   if (fused && fused->l1_target) {                   // GhOutputs.l1_*: the image loss from the kernel's own epilogue
+    loss_kind = 1;
     l1.target = fused->l1_target; l1.dL = fused->l1_dL_dimage;
     l1.inv_n = (float)(1.0 / ((double)g.NV * 3.0 * (double)g.H * (double)g.W));
-    l1.part = (float*)(ws + L.loss_partials);
+  } else if (fused && fused->fit_loss) {             // GhOutputs.fit_loss: the fit's image loss (needs the mask channel)
+    const GhFitLoss* f = fused->fit_loss;
+    loss_kind = 2;
+    l1.target = f->gt_rgb; l1.gt_mask = f->gt_mask; l1.bbox = f->bbox; l1.dL = f->dL_dimage; l1.dalpha = f->dL_dalpha;
+    const float HW = (float)(g.H * g.W);
+    l1.k_l1 = f->scale * f->lambda_l1 / (3.0f * HW); l1.k_m = f->scale * f->lambda_mask / HW;     // as gh_fit_loss
   }
+  l1.part = (float*)(ws + L.loss_partials);
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
                        g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const uint32_t*)(ws + L.render_guard),
                        wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, depth, l1);
   };
-  if (l1.target) {                                   // (the entry point has ruled out alpha / seen / a bound)
-    launch(gh_render_fwd_kernel<false, false, true>);
+  if (loss_kind == 1) {                              // (the entry point has ruled out alpha / seen / a bound)
+    launch(gh_render_fwd_kernel<false, false, 1>);
     gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, l1.inv_n, fused->l1_loss, s);
     return;
   }
+  if (loss_kind == 2) {                              // (... seen / a bound, and required alpha)
+    launch(gh_render_fwd_kernel<true, false, 2>);
+    gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, 1.0f, fused->fit_loss->loss, s);
+    return;
+  }
   // SEEN (GhOutputs.tile_depth_seen wanted): the variant that walks on virtually behind the stop; the plain kernels are untouched
-  if (seen) { if (alpha) launch(gh_render_fwd_kernel<true, true, false>); else launch(gh_render_fwd_kernel<false, true, false>); }
-  else { if (alpha) launch(gh_render_fwd_kernel<true, false, false>); else launch(gh_render_fwd_kernel<false, false, false>); }
+  if (seen) { if (alpha) launch(gh_render_fwd_kernel<true, true, 0>); else launch(gh_render_fwd_kernel<false, true, 0>); }
+  else { if (alpha) launch(gh_render_fwd_kernel<true, false, 0>); else launch(gh_render_fwd_kernel<false, false, 0>); }
 }
 
 // ------------------------------------------------------------------------------------------------

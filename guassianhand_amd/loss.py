@@ -119,18 +119,22 @@ class _RenderedLoss(torch.autograd.Function):
             if tuple(tgt.shape) != (cams.reshape(-1, 40).shape[0], 3, H, W):
                 raise ValueError("image and target must have the same shape")
             spec = ("l1", tgt)
+        elif kind == "fit":
+            f32 = lambda t: None if t is None else t.detach().float().contiguous()
+            spec = ("fit", f32(spec[1]), f32(spec[2]), f32(spec[3])) + tuple(spec[4:])
         image, radii, rctx = R.cached_raster_forward(cache, cams, xyz, opacity, scaling, rotation, H=H, W=W, sh_degree=sh_degree,
                                                      scale_modifier=scale_modifier, xyz_b=xyz_b, opacity_b=opacity_b,
                                                      color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances,
                                                      return_alpha=(kind == "fit"), per_view_gaussians=per_view,
-                                                     l1_target=spec[1] if kind == "l1" else None, **kw)
+                                                     l1_target=spec[1] if kind == "l1" else None,
+                                                     fit_loss=spec[1:] if kind == "fit" else None, **kw)
         guard = rctx.ws[:16]                          # device-side overflow guard: an overflowed render yields loss NaN, zero gradients
         if kind == "l1":
             # the render kernel's epilogue has produced both (GhOutputs.l1_*) wherever the library fuses them; else one pass over the image
             loss, dimg = rctx.l1 if rctx.l1 is not None else _l1_kernel(image, spec[1], guard)
             dal = None
         elif kind == "fit":
-            loss, dimg, dal = _fit_kernel(image, rctx.alpha, *spec[1:], guard=guard)
+            loss, dimg, dal = rctx.fit if rctx.fit is not None else _fit_kernel(image, rctx.alpha, *spec[1:], guard=guard)
         else:
             raise ValueError(kind)
         ctx.rctx, ctx.dimg, ctx.dal, ctx.use_rgb = rctx, dimg, dal, use_rgb

@@ -16,6 +16,7 @@ there is no PyTorch/CPU fallback — a missing library or a CPU tensor raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 import weakref
 from typing import Dict, NamedTuple, Optional, Tuple
@@ -189,7 +190,9 @@ class _Policy:
     split = False                # False | True | "auto"
     reuse_geometry = True
     stage_timing = False
-    fused_loss = True            # raster_forward(l1_target=...) takes the render kernel's epilogue (GhOutputs.l1_*) where the library offers it
+    # raster_forward(l1_target=... / fit_loss=...) takes the render kernel's epilogue (GhOutputs.l1_* / fit_loss) where the library
+    # offers it; GH_FUSED_LOSS=0 in the environment: measurement A/B (set_fused_loss)
+    fused_loss = os.environ.get("GH_FUSED_LOSS", "1") != "0"
 
 
 _policy = _Policy()
@@ -507,7 +510,7 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 class _Ctx:
     __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "rows", "stream", "alpha",
-                 "parent", "radii", "pending", "verdict", "refresh", "l1", "__weakref__")
+                 "parent", "radii", "pending", "verdict", "refresh", "l1", "fit", "__weakref__")
 
     def __del__(self):
         try:
@@ -587,12 +590,13 @@ def _inputs_struct(c: _Call, with_shs: bool = True, bound=None):
                          _ptr(t["color_w"]), _ptr(t["color_b"]), _ptr(bound), _ptr(t["cov3D"]))
 
 
-def _make_ctx(c: _Call, dims, inp, ws, stream, alpha, parent, radii, pending, verdict, refresh, l1=None) -> _Ctx:
+def _make_ctx(c: _Call, dims, inp, ws, stream, alpha, parent, radii, pending, verdict, refresh, l1=None, fit=None) -> _Ctx:
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, c.t, ws, c.H, c.W, c.P, c.NV, c.M, c.wpg
     ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = c.b_rgb, c.rows, alpha, parent, radii, stream
     ctx.pending, ctx.verdict, ctx.refresh = pending, verdict, refresh
     ctx.l1 = l1                                    # (loss, dL/dimage) of a fused image loss (GhOutputs.l1_*), else None
+    ctx.fit = fit                                  # (loss, dL/dimage, dL/dalpha) of a fused fit loss (GhOutputs.fit_loss), else None
     return ctx
 
 
@@ -604,6 +608,32 @@ def _queue_readback(st: _DeviceState, counters, cap, key, dbound=None, learn24=T
     pc = _Pending(st, ev, host, cap, key, dbound, learn24)
     st.pending.append(pc)
     return pc
+
+
+def _fused_loss(dev, image, alpha, l1_target, fit_loss, allowed: bool):
+    """GhOutputs' trailing fields for a fused image loss (l1_target / l1_dL_dimage / l1_loss / fit_loss) + what the context keeps:
+    ((loss, dL/dimage) or None, (loss, dL/dimage, dL/dalpha) or None, the four GhOutputs fields). The combinations the library does
+    not fuse (allowed False, or the L1 form with a mask channel, or the fit form without one) yield (None, None, no fields): the caller
+    runs gh_l1_loss / gh_fit_loss on the stored images (loss.py does)."""
+    none = (None, None, (None, None, None, None))
+    if not allowed or not _policy.fused_loss:
+        return none
+    if l1_target is not None and alpha is None:
+        if l1_target.shape != image.shape or l1_target.dtype is not torch.float32 or not l1_target.is_contiguous():
+            raise ValueError("l1_target must be a contiguous float32 (n_views, 3, H, W) tensor")
+        l1 = (torch.empty((), dtype=torch.float32, device=dev), torch.empty_like(image))
+        return l1, None, (_ptr(l1_target), _ptr(l1[1]), _ptr(l1[0]), None)
+    if fit_loss is not None and alpha is not None:
+        gt_rgb, gt_mask, bbox, lam_l1, lam_m, scale = fit_loss
+        NV, _, H, W = image.shape
+        for t, shape in ((gt_rgb, (NV, H, W, 3)), (gt_mask, (NV, H, W)), (bbox, (NV, H, W))):
+            if t is not None and (tuple(t.shape) != shape or t.dtype is not torch.float32 or not t.is_contiguous()):
+                raise ValueError("fit_loss: gt_rgb (n_views,H,W,3), gt_mask and bbox (n_views,H,W) must be contiguous float32 tensors")
+        fit = (torch.empty((), dtype=torch.float32, device=dev), torch.empty_like(image), torch.empty_like(alpha))
+        rec = _abi.GhFitLoss(_ptr(gt_rgb), _ptr(gt_mask), _ptr(bbox), float(lam_l1), float(lam_m), float(scale), _ptr(fit[1]), _ptr(fit[2]),
+                             _ptr(fit[0]))
+        return None, fit, (None, None, None, C.pointer(rec))          # (the pointer object keeps `rec` alive through the call)
+    return none
 
 
 def _forward_shared(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool):
@@ -631,7 +661,7 @@ def _forward_shared(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool):
     return image, g0.radii, ctx
 
 
-def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, expect_backward: bool):
+def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, expect_backward: bool, l1_target=None, fit_loss=None):
     """gh_forward_refresh: this call's opacities / colours over the static lists of `g0`."""
     if not (g0.dims.flags & _abi.GH_FLAG_STATIC_LISTS) or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (c.P, c.NV, c.H, c.W, c.rows) or \
             (g0.dims.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) != (c.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) or g0.parent is not None:
@@ -650,7 +680,8 @@ def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, e
     image = torch.empty(c.NV, 3, c.H, c.W, dtype=torch.float32, device=dev)
     alpha = torch.empty(c.NV, c.H, c.W, dtype=torch.float32, device=dev) if return_alpha else None
     inp = _inputs_struct(c)
-    out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha))
+    l1, fit, loss_fields = _fused_loss(dev, image, alpha, l1_target, fit_loss, True)
+    out = _abi.GhOutputs(_ptr(image), None, _ptr(alpha), None, 1.0, 0, *loss_fields)
     with _OnDevice(dev):
         rc = L.gh_forward_refresh(C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(g0.ws.data_ptr()),
                                   C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
@@ -682,12 +713,12 @@ def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, e
         pc = _queue_readback(st, counters, cap, gkey, learn24=False)      # (no depth sort in a refresh: nothing to learn about it)
         if auto:
             pending = pc
-    ctx = _make_ctx(c, dims, inp, ws, stream, alpha, g0, g0.radii, pending, None, True)
+    ctx = _make_ctx(c, dims, inp, ws, stream, alpha, g0, g0.radii, pending, None, True, l1, fit)
     return image, g0.radii, ctx
 
 
 def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backward: bool, max_instances, static_lists: bool,
-                  depth_bound, l1_target=None):
+                  depth_bound, l1_target=None, fit_loss=None):
     """gh_forward: projection, both sorts, lists, render — with the capacity / GH_FLAG_DEPTH24 / occlusion-bound policies around it
     (a synced call that the device flags is re-run with what it learned; a sync-free call is recorded for check_overflow)."""
     P, NV, H, W = c.P, c.NV, c.H, c.W
@@ -711,16 +742,11 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
         bound, seen = depth_bound._buffers(dev, NV, H, W, key=(P, bool(c.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS), c.cams_obj)) \
             if depth_bound is not None else (None, None)
         inp = _inputs_struct(c, bound=bound)
-        l1 = None
-        if l1_target is not None and alpha is None and depth_bound is None and not c.split and _policy.fused_loss:
-            # fused image loss: mean|image - target| and its gradient from the render kernel's epilogue (GhOutputs.l1_*); the
-            # combinations the library does not fuse fall back to gh_l1_loss in loss.py (ctx.l1 is None)
-            if l1_target.shape != image.shape or l1_target.dtype is not torch.float32 or not l1_target.is_contiguous():
-                raise ValueError("l1_target must be a contiguous float32 (n_views, 3, H, W) tensor")
-            l1 = (torch.empty((), dtype=torch.float32, device=dev), torch.empty_like(image))
+        # fused image loss: the loss and its gradient(s) from the render kernel's epilogue (GhOutputs.l1_* / fit_loss); the
+        # combinations the library does not fuse fall back to gh_l1_loss / gh_fit_loss in loss.py (ctx.l1 / ctx.fit are None)
+        l1, fit, loss_fields = _fused_loss(dev, image, alpha, l1_target, fit_loss, depth_bound is None and not c.split)
         out = _abi.GhOutputs(_ptr(image), _ptr(radii), _ptr(alpha), _ptr(seen), 1.0 + (depth_bound.margin if depth_bound is not None else 0.0),
-                             depth_bound.slack if depth_bound is not None else 0,
-                             *((_ptr(l1_target), _ptr(l1[1]), _ptr(l1[0])) if l1 is not None else (None, None, None)))
+                             depth_bound.slack if depth_bound is not None else 0, *loss_fields)
         with _OnDevice(dev):
             fargs = (C.byref(dims), C.byref(inp), C.byref(out), C.c_void_p(ws.data_ptr()), nbytes, C.c_void_p(stream))
             if _policy.stage_timing:
@@ -781,7 +807,7 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
                 pending = pc
         break
     # verdict: the counter read-back of a sync-free call, whoever is to ask for it
-    ctx = _make_ctx(c._replace(flags=flags), dims, inp, ws, stream, alpha, None, radii, pending, verdict, False, l1)
+    ctx = _make_ctx(c._replace(flags=flags), dims, inp, ws, stream, alpha, None, radii, pending, verdict, False, l1, fit)
     return image, radii, ctx
 
 
@@ -791,7 +817,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                    per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None,
                    split_streams: Optional[bool] = None, expect_backward: bool = False, static_lists: bool = False,
                    refresh_of: Optional["_Ctx"] = None, depth_bound: Optional[DepthBoundCache] = None, cov3D_precomp=None,
-                   l1_target: Optional[torch.Tensor] = None):
+                   l1_target: Optional[torch.Tensor] = None, fit_loss=None):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
     cov3D_precomp (P,6): the published module's precomputed 3-D covariance (xx xy xz yy yz zz, used as given: scale_modifier is
     not applied) in place of scales + rotations (pass None for both); its gradient comes back as "cov3D_precomp".
@@ -814,7 +840,10 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     not listed; verified by the forward, re-run without the bound on a miss.
     l1_target (n_views,3,H,W): fused image loss — ctx.l1 = (mean|image - l1_target|, its gradient w.r.t. image) from the render
     kernel's own epilogue (GhOutputs.l1_*). ctx.l1 is None where the library does not fuse it (alpha, a depth bound, two
-    streams, shared / refresh calls): the caller then runs gh_l1_loss on the image (loss.py does).
+    streams, shared calls): the caller then runs gh_l1_loss on the image (loss.py does).
+    fit_loss (gt_rgb (n_views,H,W,3), gt_mask (n_views,H,W), bbox (n_views,H,W) or None, lambda_l1, lambda_mask, scale), with
+    return_alpha: the fit's image loss the same way — ctx.fit = (loss, dL/dimage, dL/dalpha) (GhOutputs.fit_loss), None where
+    it is not fused (loss.py then runs gh_fit_loss).
     sync: True = read D back (and re-run with a larger capacity if needed); False = never block (check_overflow() is the
     caller's job); None = auto: read D back for the first call of a shape and for calls whose backward will not come
     (expect_backward False), otherwise sync-free with the check at the start of raster_backward.
@@ -833,8 +862,9 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             return _forward_shared(st, L, dev, c, geometry_of, return_alpha)
         if refresh_of is not None:
             return _forward_refresh(st, L, dev, c._replace(flags=c.flags | _abi.GH_FLAG_STATIC_LISTS), refresh_of, return_alpha, sync,
-                                    expect_backward)
-        return _forward_full(st, L, dev, c, return_alpha, sync, expect_backward, max_instances, static_lists, depth_bound, l1_target)
+                                    expect_backward, l1_target, fit_loss)
+        return _forward_full(st, L, dev, c, return_alpha, sync, expect_backward, max_instances, static_lists, depth_bound, l1_target,
+                             fit_loss)
 
 
 def cached_raster_forward(cache: Optional[GeometryCache], cams, means3D, opacities, scales, rotations, **kw):

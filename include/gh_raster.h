@@ -133,6 +133,21 @@ typedef struct GhInputs {
   const float* cov3D_precomp;
 } GhInputs;
 
+/* The image part of the one-shot fit loss (gh_fit_loss below: utils.py:180-252, :282-294; infer_one_shot.py:497, :507-510), evaluated
+   by the render kernel's epilogue (GhOutputs.fit_loss):
+     loss[0] = scale * sum_v [ lambda_l1 * mean|bbox * rgb - gt_rgb| + lambda_mask * mean((clip(alpha, -0.001, 1) - gt_mask)^2) ]
+   with dL_dimage / dL_dalpha as GhGrads takes them — gh_fit_loss's values: the gradients bit for bit, the loss up to the order of
+   its fixed-order float32 sums. An invalid call (GhCounters.overflow bits 0, 1, 3) yields loss NaN and zero gradients. */
+typedef struct GhFitLoss {
+  const float* gt_rgb;     /* (n_views,H,W,3) */
+  const float* gt_mask;    /* (n_views,H,W) */
+  const float* bbox;       /* (n_views,H,W) or NULL: colour is zeroed where bbox == 0 */
+  float lambda_l1, lambda_mask, scale;
+  float* dL_dimage;        /* (n_views,3,H,W) */
+  float* dL_dalpha;        /* (n_views,H,W) */
+  float* loss;             /* 1 float */
+} GhFitLoss;
+
 typedef struct GhOutputs {
   float* image;    /* (n_views,3,H,W) */
   int32_t* radii;  /* (n_views,P)   0 for culled Gaussians */
@@ -164,6 +179,9 @@ typedef struct GhOutputs {
   const float* l1_target;
   float* l1_dL_dimage;
   float* l1_loss;
+  /* The fit's image loss fused the same way (v0.7; gh_forward / gh_forward_stages / gh_forward_refresh; NULL = none; needs `alpha`):
+     a HOST struct, read during the call. Same exclusions as l1_target, and not both. */
+  const struct GhFitLoss* fit_loss;
 } GhOutputs;
 
 /* Device-side counters written by gh_forward (first bytes of the workspace, see GhLayout.counters). */

@@ -33,7 +33,8 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_abi.GhDims) == 40
     assert C.sizeof(_abi.GhInputs) == 13 * 8          # v0.6: + cov3D_precomp
     assert C.sizeof(_abi.GhGrads) == 15 * 8           # v0.6: + dL_dcov3D
-    assert C.sizeof(_abi.GhOutputs) == 8 * 8          # 4 pointers + (float, uint32) + v0.7: the fused loss's 3 pointers
+    assert C.sizeof(_abi.GhOutputs) == 9 * 8          # 4 pointers + (float, uint32) + v0.7: the fused L1's 3 pointers + fit_loss
+    assert C.sizeof(_abi.GhFitLoss) == 8 * 8          # 3 pointers, 3 floats (+ padding), 3 pointers
     assert C.sizeof(_abi.GhCounters) == 16
     assert C.sizeof(_abi.GhLayout) == len(_abi.LAYOUT_FIELDS) * 8
 
@@ -130,7 +131,20 @@ def test_fused_loss_arguments_are_validated_before_any_launch(gh_lib_path):
     out = _abi.GhOutputs(one, None, None, None, 1.0, 0, one, one, one)
     assert L.gh_forward_shared(C.byref(d), C.byref(inp), C.byref(out), two, one, 16, None) == _abi.GH_ERR_UNSUPPORTED
     d3 = _abi.GhDims(10, 2, 32, 32, 0, 0, 1.0, _abi.GH_FLAG_STATIC_LISTS, 1000)
-    assert L.gh_forward_refresh(C.byref(d3), C.byref(inp), C.byref(out), two, one, 16, None) == _abi.GH_ERR_UNSUPPORTED
+    out3 = _abi.GhOutputs(one, None, None, None, 1.0, 0, two, three, one)
+    assert L.gh_forward_refresh(C.byref(d3), C.byref(inp), C.byref(out3), two, one, 16, None) == _abi.GH_ERR_WORKSPACE_SMALL   # a refresh fuses it too
+    # the fit's image loss (GhOutputs.fit_loss): needs the mask channel; every pointer but bbox; not together with l1_target
+    four, five = C.c_void_p(1024), C.c_void_p(1280)
+    fit = _abi.GhFitLoss(two, three, None, 10.0, 1.0, 1.0, four, five, one)
+    mk = lambda alpha, f, l1=(None, None, None): _abi.GhOutputs(one, one, alpha, None, 1.0, 0, *l1, C.pointer(f))
+    assert call(mk(C.c_void_p(1536), fit)) == _abi.GH_ERR_WORKSPACE_SMALL
+    assert L.gh_forward_refresh(C.byref(d3), C.byref(inp), C.byref(mk(C.c_void_p(1536), fit)), two, one, 16, None) == _abi.GH_ERR_WORKSPACE_SMALL
+    assert call(mk(None, fit)) == _abi.GH_ERR_INVALID_ARG                                       # no mask channel
+    assert call(mk(C.c_void_p(1536), fit, (two, three, one))) == _abi.GH_ERR_INVALID_ARG          # both losses
+    assert call(mk(C.c_void_p(1536), _abi.GhFitLoss(two, None, None, 10.0, 1.0, 1.0, four, five, one))) == _abi.GH_ERR_INVALID_ARG
+    assert call(mk(C.c_void_p(1536), _abi.GhFitLoss(two, three, None, 10.0, 1.0, 1.0, one, five, one))) == _abi.GH_ERR_INVALID_ARG   # dL aliases the image
+    assert call(mk(C.c_void_p(1536), fit), d2) == _abi.GH_ERR_UNSUPPORTED                        # two streams
+    assert L.gh_forward_shared(C.byref(d), C.byref(inp), C.byref(mk(C.c_void_p(1536), fit)), two, one, 16, None) == _abi.GH_ERR_UNSUPPORTED
 
 
 def test_product_has_no_cpu_fallback():

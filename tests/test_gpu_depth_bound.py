@@ -151,7 +151,9 @@ def test_fit_whose_gaussians_move_every_step_with_the_occlusion_bound(dev):
         a.update_gaussians(moved)
         b.update_gaussians(moved)
         la, lb = a.step(*args, sync=True), b.step(*args, sync=True)
-        assert float(la) == float(lb), step
+        # (the parameters below are bit-equal; the loss VALUE is a float32 sum whose order differs: the plain path takes it from the
+        # render kernel's epilogue, GhOutputs.fit_loss, the bounded path — not fused — from gh_fit_loss)
+        assert float(la) == pytest.approx(float(lb), rel=4e-6), step
         for k in a._adam:
             assert torch.equal(a._adam[k].param, b._adam[k].param), (step, k)
     assert b._geom_cache.bounded_calls >= 5

@@ -113,3 +113,92 @@ def test_fused_l1_combinations_the_library_does_not_fuse(dev):
     assert ctx.l1 is None
     _, _, ctx = _fwd(s, target, split_streams=True)
     assert ctx.l1 is None
+
+
+# ---- the fit's image loss (GhOutputs.fit_loss) ----------------------------------------------------------------------------------
+def _fit_inputs(sc, nv, dev, seed, with_bbox):
+    g = torch.Generator().manual_seed(seed)
+    gt_rgb = torch.rand(nv, sc.H, sc.W, 3, generator=g).to(dev)
+    gt_mask = (torch.rand(nv, sc.H, sc.W, generator=g) > 0.5).float().to(dev)
+    bbox = (torch.rand(nv, sc.H, sc.W, generator=g) > 0.3).float().to(dev) if with_bbox else None
+    return gt_rgb, gt_mask, bbox
+
+
+@pytest.mark.parametrize("scene,nv,P,with_bbox", [("random1k", 2, 2000, False), ("one_hand", 2, 6000, True), ("two_hands", 8, None, True)])
+def test_fused_fit_loss_is_gh_fit_loss_of_the_stored_images(dev, scene, nv, P, with_bbox):
+    """Full forward and refresh over static lists: gradients w.r.t. image and alpha bit for bit gh_fit_loss's, the loss to the order of
+    the float32 sums and against the float64 statement of utils.py:180-252 / :282-294."""
+    from guassianhand_amd.loss import _fit_kernel
+    from guassianhand_amd.rasterizer import raster_forward
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene(scene, n_views=nv, use_rgb=True, **({} if P is None else dict(P=P)))
+    s = sc.to(dev)
+    gt_rgb, gt_mask, bbox = _fit_inputs(sc, nv, dev, 21, with_bbox)
+    spec = (gt_rgb, gt_mask, bbox, 10.0, 1.0, 0.5)
+    args = (s.cams().contiguous(), s.xyz, s.opacity, s.scaling, s.rotation)
+    kw = dict(H=s.H, W=s.W, colors_precomp=s.shs.squeeze(1), return_alpha=True)
+    img, _, ctx = raster_forward(*args, fit_loss=spec, **kw)
+    assert ctx.fit is not None and ctx.l1 is None
+    loss, dimg, dal = ctx.fit
+    img0, _, ctx0 = raster_forward(*args, **kw)
+    assert ctx0.fit is None and torch.equal(img, img0) and torch.equal(ctx.alpha, ctx0.alpha)
+    loss_k, dimg_k, dal_k = _fit_kernel(img0, ctx0.alpha, *spec)
+    assert torch.equal(dimg, dimg_k) and torch.equal(dal, dal_k)
+    bb = torch.ones_like(gt_mask) if bbox is None else (bbox != 0).float()
+    rgb = (img0 * bb[:, None]).permute(0, 2, 3, 1).double()
+    ref = 0.5 * (10.0 * (rgb - gt_rgb.double()).abs().mean(dim=(1, 2, 3)).sum()
+                 + ((ctx0.alpha.double().clamp(-0.001, 1.0) - gt_mask.double()) ** 2).mean(dim=(1, 2)).sum()).item()
+    assert abs(loss.item() - ref) <= 3e-6 * ref and abs(loss_k.item() - ref) <= 3e-6 * ref
+    # static lists + refresh (the fit loop's path): the refresh call fuses it too
+    _, _, c_build = raster_forward(*args, static_lists=True, **kw)
+    op2 = (s.opacity * 0.8).contiguous()
+    img_r, _, c_r = raster_forward(args[0], s.xyz, op2, s.scaling, s.rotation, refresh_of=c_build, fit_loss=spec, **kw)
+    assert c_r.fit is not None
+    img_p, _, c_p = raster_forward(args[0], s.xyz, op2, s.scaling, s.rotation, **kw)
+    assert torch.equal(img_r, img_p) and torch.equal(c_r.alpha, c_p.alpha)
+    lk, dk, ak = _fit_kernel(img_p, c_p.alpha, *spec)
+    assert torch.equal(c_r.fit[1], dk) and torch.equal(c_r.fit[2], ak) and abs(c_r.fit[0].item() - lk.item()) <= 4e-6 * abs(lk.item())
+    # the L1 form over a refresh, too
+    tgt = torch.rand(nv, 3, s.H, s.W, generator=torch.Generator().manual_seed(5)).to(dev)
+    kw1 = dict(H=s.H, W=s.W, colors_precomp=s.shs.squeeze(1))
+    _, _, c_b1 = raster_forward(*args, static_lists=True, **kw1)
+    img_r1, _, c_r1 = raster_forward(args[0], s.xyz, op2, s.scaling, s.rotation, refresh_of=c_b1, l1_target=tgt, **kw1)
+    assert c_r1.l1 is not None and torch.equal(img_r1, img_p)
+    inv_n = torch.tensor(1.0 / img_p.numel(), dtype=torch.float64).to(torch.float32).to(dev)
+    assert torch.equal(c_r1.l1[1], torch.sign(img_p - tgt) * inv_n)
+
+
+def test_fused_fit_loss_through_the_one_node_loss_equals_the_two_node_form(dev):
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.loss import fit_image_loss, rendered_fit_loss
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("one_hand", n_views=3, P=8000, use_rgb=True, blend=True)
+    s = sc.to(dev)
+    cams = s.cams().contiguous()
+    gt_rgb, gt_mask, bbox = _fit_inputs(sc, 3, dev, 31, True)
+    names = ("opacity", "shs", "opacity_b", "color_w", "color_b")
+    pa = {k: getattr(s, k).clone().requires_grad_(True) for k in names}
+    pb = {k: getattr(s, k).clone().requires_grad_(True) for k in names}
+    kw = lambda p: dict(H=sc.H, W=sc.W, use_rgb=True, xyz_b=s.xyz_b, opacity_b=p["opacity_b"], color_w=p["color_w"], color_b=p["color_b"])
+    img, alpha, _ = R.rasterize_views(cams, s.xyz, pa["opacity"], s.scaling, s.rotation, pa["shs"], return_alpha=True, **kw(pa))
+    la = fit_image_loss(img, alpha, gt_rgb, gt_mask, bbox, 10.0, 1.0, 0.125)
+    lb, img_b, alpha_b = rendered_fit_loss(cams, s.xyz, pb["opacity"], s.scaling, s.rotation, pb["shs"], gt_rgb, gt_mask, bbox, 10.0, 1.0, 0.125, **kw(pb))
+    assert torch.equal(img_b, img.detach()) and torch.equal(alpha_b, alpha.detach())
+    assert abs(la.item() - lb.item()) <= 4e-6 * abs(la.item())
+    (1.5 * la).backward()
+    (1.5 * lb).backward()
+    for k in names:
+        assert torch.equal(pa[k].grad, pb[k].grad), k
+
+
+def test_fused_fit_loss_of_an_invalid_call_is_nan_with_no_gradient(dev):
+    from guassianhand_amd.rasterizer import GhOverflowError, check_overflow, raster_forward
+    from guassianhand_amd.scenes import make_scene
+    s = make_scene("random1k", n_views=2).to(dev)
+    gt_rgb, gt_mask, bbox = _fit_inputs(s, 2, dev, 41, False)
+    img, _, ctx = raster_forward(s.cams().contiguous(), s.xyz, s.opacity, s.scaling, s.rotation, H=s.H, W=s.W, colors_precomp=s.shs.squeeze(1),
+                                 return_alpha=True, fit_loss=(gt_rgb, gt_mask, None, 10.0, 1.0, 1.0), max_instances=128, sync=False)
+    torch.cuda.synchronize()
+    assert torch.isnan(img).all() and torch.isnan(ctx.fit[0]) and float(ctx.fit[1].abs().max()) == 0.0 and float(ctx.fit[2].abs().max()) == 0.0
+    with pytest.raises(GhOverflowError):
+        check_overflow()
