@@ -35,6 +35,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+WARM_MS = 40.0        # minimum duration of the untimed graph-replay warm-up (see main)
+
+
 def algorithmic_bytes(P, NV, H, W, D, C=12, M=0):
     """SURVEY.md §8(d) per-stage algorithmic HBM bytes for one launch sequence over NV views, D instances."""
     T = NV * ((W + 15) // 16) * ((H + 15) // 16)
@@ -444,6 +447,7 @@ def main():
     # launch sequence is ~45 small kernels, and enqueueing them one by one leaves the result at the mercy of the host
     # (0.5 ms per step on a quiet box, several ms on a busy one). Collectives stay outside the graph.
     graph, g_loss, graph_note = None, None, None
+    warm_replays = 0
     pipe = []
     if not args.no_graph:
         try:                                             # the leaves' AccumulateGrad nodes were created on the default stream
@@ -462,8 +466,18 @@ def main():
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 g_loss = local_step(sync=False)
                 g_loss.backward(seed)
-            for _ in range(max(1, args.warmup)):         # warm-up of the replay path itself (clocks, graph upload): untimed
+            # warm-up of the replay path itself (graph upload, clocks): untimed. At least --warmup replays, and at least
+            # WARM_MS of them: the eager warm-up steps above are host-bound (the GPU idles between their kernels), and the first
+            # ~30 ms of back-to-back replays run on a clock that is still ramping (measured: a window of 20 steps behind 5
+            # replays read 0.662 ms per step where every later window read 0.640). `value` is the throughput of a loop that has
+            # been running — what a training job sees —, and the line says how many replays preceded the timed region.
+            t_w = time.perf_counter()
+            warm_replays = 0
+            while warm_replays < max(1, args.warmup) or (time.perf_counter() - t_w) * 1e3 < WARM_MS:
                 graph.replay()
+                warm_replays += 1
+                if warm_replays % 8 == 0:
+                    torch.cuda.synchronize()             # (the host would otherwise queue thousands of replays inside the time limit)
             torch.cuda.synchronize()
             pipe = []
             if args.pipeline > 1 and world == 1:
@@ -633,6 +647,9 @@ def main():
                        "split_streams": bool(V >= 2 and (R._split_policy is True or (
                            R._split_policy == "auto" and V >= 4 and H * W > R._SPLIT_AUTO_MIN_PIXELS))),
                        "pipelined_steps": args.pipeline, "fused_loss": args.fused_loss == "on",
+                       "warmup_done": {"eager_steps": max(1, args.warmup), "graph_replays": warm_replays,
+                                       "note": f"--warmup is a minimum: replays continue until {WARM_MS:.0f} ms have passed, so that the timed "
+                                               "region does not start on a ramping clock"},
                        "hip_graph": graph is not None, "timed_steps": "HIP graph replay of one captured step" if graph is not None
                        else "eager kernel-by-kernel enqueue" + (f" [{graph_note}]" if graph_note else "")},
             "roofline": roofline, "stages": stages,
