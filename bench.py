@@ -655,11 +655,12 @@ def main():
             "roofline": roofline, "stages": stages,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene_one, args.cpu_seconds, torch_reference=(args.config == "random1k"))
             if not args.pose_batch:
-                # the reference's own 2-call protocol through the drop-in, per view, beside the fused per-view cost
+                # the reference's own 2-call protocol through the drop-in, per view, beside the fused per-view cost —
+                # a HOST-bound figure, taken before the CPU baseline has 16 OpenMP threads spinning beside this one
                 out["config"]["two_call_ms_per_view"] = two_call_cost(s, (s.w2c[mine[0]], s.K[mine[0]]))
                 out["config"]["fused_ms_per_view"] = dt / args.steps * 1e3 / V
+            out["cpu_baseline"] = cpu_baseline(scene_one, args.cpu_seconds, torch_reference=(args.config == "random1k"))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
