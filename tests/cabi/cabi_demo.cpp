@@ -9,6 +9,7 @@
 //       drotations[P*4], dcolors[P*3];
 //       then the SECOND call over the same geometry (gh_forward_shared / gh_backward_shared with colour 1, the reference's
 //       mask pass, renderer_one_shot.py:372-379): float mask_image[NV*3*H*W], float dopacities_mask[P];
+//       (v0.7: a forward with the fused image loss, GhOutputs.l1_*, at the end)
 //       then (v0.5) a forward that REPORTS a per-tile occlusion bound and one that APPLIES it (GhOutputs.tile_depth_seen ->
 //       GhInputs.tile_depth_bound), with GH_FLAG_DEPTH24: float bounded_image[NV*3*H*W], uint32 D_bounded, uint32 overflow_bits
 #include <hip/hip_runtime.h>
@@ -127,6 +128,17 @@ int main(int argc, char** argv) {
   CHECK(hipStreamSynchronize(stream));
   std::printf("bounded forward: instances %u (unbounded %u), overflow bits %u\n", ctr3.num_rendered, D, ctr3.overflow);
 
+  // v0.7: the fused image loss from plain C++ — the upstream-gradient array of the input file serves as the target; the render
+  // kernel's epilogue leaves mean|image - target|, sign(image - target) / n and the image of the first call (a workspace of its own)
+  float *image4, *dl4, *loss4; void* ws4 = nullptr;
+  CHECK(hipMalloc((void**)&image4, (size_t)NV * 3 * H * W * 4)); CHECK(hipMalloc((void**)&dl4, (size_t)NV * 3 * H * W * 4));
+  CHECK(hipMalloc((void**)&loss4, 4)); CHECK(hipMalloc(&ws4, ws_bytes));
+  GhOutputs out4 = {};
+  out4.image = image4; out4.l1_target = d_dimg; out4.l1_dL_dimage = dl4; out4.l1_loss = loss4;
+  const int rc4 = gh_forward(&dims, &in, &out4, ws4, ws_bytes, stream);
+  if (rc4 != GH_OK) { std::fprintf(stderr, "gh_forward (fused loss): %d\n", rc4); return 3; }
+  CHECK(hipStreamSynchronize(stream));
+
   FILE* o = std::fopen(argv[2], "wb");
   if (!o) return 1;
   auto wr = [&](const void* d, size_t bytes) {
@@ -141,6 +153,7 @@ int main(int argc, char** argv) {
   wr(image2, (size_t)NV * 3 * H * W * 4); wr(gr2.dL_dopacities, (size_t)P * 4);
   wr(image3, (size_t)NV * 3 * H * W * 4);
   std::fwrite(&ctr3.num_rendered, 4, 1, o); std::fwrite(&ctr3.overflow, 4, 1, o);
+  wr(image4, (size_t)NV * 3 * H * W * 4); wr(dl4, (size_t)NV * 3 * H * W * 4); wr(loss4, 4);
   std::fclose(o);
   std::printf("ok\n");
   return 0;

@@ -62,7 +62,14 @@ def test_cpp_driver_matches_python_host_and_oracle(tmp_path, gh_lib_path):
     mask_dop = take(P, np.float32)
     bounded_image = take(2 * 3 * H * W, np.float32).reshape(2, 3, H, W)
     D_bounded, overflow_bits = int(take(1, np.uint32)[0]), int(take(1, np.uint32)[0])
+    fused_image = take(2 * 3 * H * W, np.float32).reshape(2, 3, H, W)
+    fused_dl = take(2 * 3 * H * W, np.float32).reshape(2, 3, H, W)
+    fused_loss = float(take(1, np.float32)[0])
     assert off == raw.size
+    # v0.7 from plain C++: the fused image loss against the demo's own first image and its input file's gradient array as target
+    inv_n = torch.tensor(1.0 / image.numel(), dtype=torch.float64).to(torch.float32)
+    ref = float((image.double() - dimg.double()).abs().mean())
+    assert torch.equal(fused_image, image) and torch.equal(fused_dl, torch.sign(image - dimg) * inv_n) and abs(fused_loss - ref) <= 3e-6 * ref
     # v0.5 from plain C++: a forward that applies the occlusion bound another forward reported, with the three-pass depth sort —
     # verified on the device (no flag set), never more instances, the same image bit for bit
     assert overflow_bits & 15 == 0 and overflow_bits & 16 and 0 < D_bounded <= D and torch.equal(bounded_image, image)   # (bit 4: information)
