@@ -308,6 +308,9 @@ def main():
     ap.add_argument("--split-streams", default="off", choices=["off", "on", "auto"],
                     help="GH_FLAG_SPLIT_STREAMS: render the step's views as two halves on two HIP streams inside the library "
                          "(bit-identical results); auto = from 4 views of more than half a megapixel per rank up")
+    ap.add_argument("--defer-loss", default="on", choices=["on", "off"],
+                    help="on (default): the fused loss's final sum runs as a spare workgroup of the render backward "
+                         "(GH_FLAG_DEFER_LOSS_SUM) instead of a one-workgroup kernel between forward and backward; off: round 5's form")
     ap.add_argument("--fused-loss", default="on", choices=["on", "off"],
                     help="on (default): mean|render - gt| and its gradient come out of the render kernel's own epilogue (GhOutputs.l1_*); "
                          "off: gh_l1_loss reads the stored image back (rounds 1-4; same gradients bit for bit)")
@@ -393,8 +396,11 @@ def main():
     params.update({k: v for k, v in blend.items() if v is not None})
     params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
 
-    def local_step(sync: bool):
-        """One pass of the hot path over this rank's views: forward, loss, backward. No collective."""
+    def local_step(sync: bool, defer_loss: bool = True):
+        """One pass of the hot path over this rank's views: forward, loss, backward. No collective.
+        defer_loss: the loss VALUE (logging / the collective; no gradient depends on it) is summed up by a spare workgroup of the
+        render backward instead of a one-workgroup kernel between forward and backward (GH_FLAG_DEFER_LOSS_SUM): it exists
+        once the step's backward has run, which is when every caller below looks at it."""
         for p in params.values():
             p.grad = None
         # render + loss as one autograd node: mean|img - gt| and dL/dimg from one fused pass (gh_l1_loss), dL/dloss applied
@@ -402,7 +408,8 @@ def main():
         loss, _img, _ = rendered_l1_loss(cams, params["xyz"], params["opacity"], params["scaling"], params["rotation"],
                                          params["shs"], gt, H=H, W=W, use_rgb=s.use_rgb, sh_degree=s.sh_degree, sync=sync,
                                          xyz_b=params.get("xyz_b"), opacity_b=params.get("opacity_b"),
-                                         color_w=params.get("color_w"), color_b=params.get("color_b"), **pv)
+                                         color_w=params.get("color_w"), color_b=params.get("color_b"),
+                                         defer_loss=defer_loss and args.defer_loss == "on", **pv)
         return loss
 
     def reduce_grads(loss):
@@ -417,9 +424,10 @@ def main():
     def step(sync: bool):
         """Eager step: kernel-by-kernel enqueue. N>1, north star protocol (views are independent, RCCL only for the loss):
         the scalar all-reduce is issued as soon as the loss exists and runs on RCCL's own stream underneath the backward."""
-        loss = local_step(sync)
+        early = world > 1 and not args.allreduce_grads       # the loss collective is issued BEFORE the backward: it needs the value now
+        loss = local_step(sync, defer_loss=not early)
         work = None
-        if world > 1 and not args.allreduce_grads:
+        if early:
             loss_sum = loss.detach().clone()
             work = tdist.all_reduce(loss_sum, op=tdist.ReduceOp.SUM, async_op=True)
         loss.backward(seed)
@@ -646,7 +654,7 @@ def main():
                        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
                        "split_streams": bool(V >= 2 and (R._split_policy is True or (
                            R._split_policy == "auto" and V >= 4 and H * W > R._SPLIT_AUTO_MIN_PIXELS))),
-                       "pipelined_steps": args.pipeline, "fused_loss": args.fused_loss == "on",
+                       "pipelined_steps": args.pipeline, "fused_loss": args.fused_loss == "on", "deferred_loss_sum": args.defer_loss == "on",
                        "warmup_done": {"eager_steps": max(1, args.warmup), "graph_replays": warm_replays,
                                        "note": f"--warmup is a minimum: replays continue until {WARM_MS:.0f} ms have passed, so that the timed "
                                                "region does not start on a ramping clock"},

@@ -11,6 +11,9 @@ GH_FLAG_PER_VIEW_GAUSSIANS = 4
 GH_FLAG_SPLIT_STREAMS = 8
 GH_FLAG_STATIC_LISTS = 16
 GH_FLAG_DEPTH24 = 32
+GH_FLAG_DEFER_LOSS_SUM = 64
+GH_VERSION_MAJOR, GH_VERSION_MINOR = 0, 8        # the header this mirror was written against (checked against gh_version() on load)
+GH_ABI_TAG = 0x47480000 | (GH_VERSION_MAJOR << 8) | GH_VERSION_MINOR
 GH_COUNTER_ERROR_MASK = 15     # GhCounters.overflow bits 0-3: errors
 GH_COUNTER_DEPTH24_OK = 16     # bit 4: information (the depth keys' top byte did not vary)
 
@@ -19,16 +22,22 @@ GH_ERR_INVALID_ARG = -1
 GH_ERR_WORKSPACE_SMALL = -2
 GH_ERR_LAUNCH = -3
 GH_ERR_UNSUPPORTED = -4
+GH_ERR_ABI = -5
 _STATUS = {0: "GH_OK", -1: "GH_ERR_INVALID_ARG", -2: "GH_ERR_WORKSPACE_SMALL", -3: "GH_ERR_LAUNCH",
-           -4: "GH_ERR_UNSUPPORTED"}
+           -4: "GH_ERR_UNSUPPORTED", -5: "GH_ERR_ABI"}
 
 fp = C.POINTER(C.c_float)
 
 
 class GhDims(C.Structure):
-    _fields_ = [("P", C.c_int32), ("n_views", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+    """GhDims(P, n_views, H, W, sh_degree, M, scale_modifier, flags, max_instances): the ABI tag (first field of the C struct) is
+    filled in here, so that every struct this mirror builds carries the version this mirror was written against."""
+    _fields_ = [("abi", C.c_uint32), ("P", C.c_int32), ("n_views", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("sh_degree", C.c_int32), ("M", C.c_int32), ("scale_modifier", C.c_float),
                 ("flags", C.c_uint32), ("max_instances", C.c_int64)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(GH_ABI_TAG, *args, **kw)
 
 
 class GhInputs(C.Structure):
@@ -58,7 +67,7 @@ class GhGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "dL_dimage", "dL_dalpha", "dL_dmeans3D", "dL_dmeans2D", "dL_dopacities", "dL_dscales", "dL_drotations",
         "dL_dshs", "dL_dcolors", "dL_dblend_xyz_b", "dL_dblend_opacity_b", "dL_dblend_color_w",
-        "dL_dblend_color_b", "upstream_scale", "dL_dcov3D")]
+        "dL_dblend_color_b", "upstream_scale", "dL_dcov3D", "deferred_loss")]
 
 
 class GhAdamTensor(C.Structure):

@@ -78,6 +78,13 @@ def lib() -> C.CDLL:
         except OSError as e:  # pragma: no cover
             raise GhLibraryError(f"cannot load {path}: {e}") from e
         _abi.declare(L)
+        # the structs of the C-ABI grow between 0.x minor versions: a library built from another header (GH_RASTER_LIB pointing at
+        # a build of another commit, a stale .so) would read this mirror's structs with the wrong layout
+        want = (_abi.GH_VERSION_MAJOR << 16) | _abi.GH_VERSION_MINOR
+        have = int(L.gh_version())
+        if have != want:
+            raise GhLibraryError(f"{path} is C-ABI v{have >> 16}.{have & 0xFFFF}, this package speaks v{want >> 16}.{want & 0xFFFF}: "
+                                 "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         _lib = L
     return _lib
 

@@ -8,6 +8,7 @@ static inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a
 
 static int check_dims(const GhDims* d) {
   if (!d) return GH_ERR_INVALID_ARG;
+  if (d->abi != GH_ABI_TAG) return GH_ERR_ABI;          // a host built against another header: its structs may be shorter than ours
   if (d->P < 0 || d->n_views < 1 || d->H < 1 || d->W < 1 || d->max_instances < 0) return GH_ERR_INVALID_ARG;
   if (d->sh_degree < 0 || d->sh_degree > 3) return GH_ERR_UNSUPPORTED;
   if (d->M != 0 && d->M != 1 && d->M != 4 && d->M != 9 && d->M != 16) return GH_ERR_UNSUPPORTED;
@@ -113,7 +114,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->tile_bound = take((size_t)g.NV * g.tiles * 4);
   L->block_tiles = take((gh_proj_blocks(g) + 4) * 4);     // (two halves: + 1 block of rounding + 1 spare word each)
   L->render_guard = take(512);                            // one word (+ a second, 256 bytes on, for the other half of a split call)
-  L->loss_partials = take((size_t)g.NV * g.tiles * 4 * 4);
+  L->loss_partials = take((size_t)g.NV * g.tiles * 4 * 4 + 16);   // (+ the factor of the final sum, behind the last partial)
   L->total_bytes = off;
   return GH_OK;
 }
@@ -243,6 +244,11 @@ __global__ void gh_merge_counters_kernel(const GhCounters* __restrict__ a, const
   out->reserved[1] = 0u;
 }
 
+static inline bool gh_ranges_overlap(const void* a, size_t na, const void* b, size_t nb) {
+  const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+  return x < y + nb && y < x + na;
+}
+
 // GhOutputs.l1_* / fit_loss: the image loss from the render kernel's epilogue
 static int check_fused_loss(const GhDims* d, const GhInputs* in, const GhOutputs* out) {
   if (!out->l1_target && !out->fit_loss) return GH_OK;
@@ -252,8 +258,10 @@ static int check_fused_loss(const GhDims* d, const GhInputs* in, const GhOutputs
   if (out->tile_depth_seen || in->tile_depth_bound || gh_split_on(d)) return GH_ERR_UNSUPPORTED;
   if (out->l1_target) {
     if (!out->l1_dL_dimage || !out->l1_loss) return GH_ERR_INVALID_ARG;
-    // the gradient is stored while other waves still read the target and store the image
-    if (out->l1_dL_dimage == out->image || (const float*)out->l1_dL_dimage == out->l1_target || (const float*)out->image == out->l1_target)
+    // the gradient is stored while other waves still read the target and store the image: three arrays whose byte ranges are disjoint
+    const size_t nb = (size_t)d->n_views * 3 * (size_t)d->H * (size_t)d->W * 4;
+    if (gh_ranges_overlap(out->l1_dL_dimage, nb, out->image, nb) || gh_ranges_overlap(out->l1_dL_dimage, nb, out->l1_target, nb) ||
+        gh_ranges_overlap(out->image, nb, out->l1_target, nb))
       return GH_ERR_INVALID_ARG;
     if (out->alpha) return GH_ERR_UNSUPPORTED;             // (the L1 form has no mask channel)
     return GH_OK;
@@ -261,7 +269,15 @@ static int check_fused_loss(const GhDims* d, const GhInputs* in, const GhOutputs
   const GhFitLoss* f = out->fit_loss;
   if (!f->gt_rgb || !f->gt_mask || !f->dL_dimage || !f->dL_dalpha || !f->loss) return GH_ERR_INVALID_ARG;
   if (!out->alpha) return GH_ERR_INVALID_ARG;              // the mask term reads the fused mask channel
-  if (f->dL_dimage == out->image || f->dL_dalpha == out->alpha || f->dL_dalpha == f->dL_dimage) return GH_ERR_INVALID_ARG;
+  {
+    const size_t nb3 = (size_t)d->n_views * 3 * (size_t)d->H * (size_t)d->W * 4, nb1 = nb3 / 3;
+    const void* arr[6] = {out->image, out->alpha, f->dL_dimage, f->dL_dalpha, f->gt_rgb, f->gt_mask};
+    const size_t len[6] = {nb3, nb1, nb3, nb1, nb3, nb1};
+    for (int a = 2; a < 4; ++a)                              // each gradient array against every other array of the call
+      for (int b = 0; b < 6; ++b)
+        if (a != b && gh_ranges_overlap(arr[a], len[a], arr[b], len[b])) return GH_ERR_INVALID_ARG;
+    if (f->bbox && (gh_ranges_overlap(f->bbox, nb1, f->dL_dimage, nb3) || gh_ranges_overlap(f->bbox, nb1, f->dL_dalpha, nb1))) return GH_ERR_INVALID_ARG;
+  }
   return GH_OK;
 }
 
@@ -344,6 +360,7 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
   if (!gr || !gr->dL_dimage || !workspace) return GH_ERR_INVALID_ARG;
   // 48-wide gradient rows are written as float4s
   if ((((uintptr_t)gr->dL_dblend_color_b | (uintptr_t)gr->dL_dblend_color_w) & 15) != 0) return GH_ERR_INVALID_ARG;
+  if (gr->deferred_loss && gh_split_on(d)) return GH_ERR_UNSUPPORTED;      // (a split forward fuses no loss)
   GhLayout L;
   gh_workspace_layout(d, &L);
   if (ws_bytes < L.total_bytes) return GH_ERR_WORKSPACE_SMALL;
@@ -374,7 +391,9 @@ extern "C" int gh_backward_stages(const GhDims* d, const GhInputs* in, const GhG
       gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s, GH_PBWD_CHAIN, hv[1].v0, (size_t)hv[0].d.max_instances);
     return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
   }
-  if (stages & GH_BWD_RENDER) gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, ws, L, s, gh_records_need_geometry(in, gr));
+  if (stages & GH_BWD_RENDER)
+    gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, ws, ws, L, s, gh_records_need_geometry(in, gr),
+                         gr->deferred_loss);
   if (stages & GH_BWD_PREPROCESS) gh_launch_preprocess_bwd(d, g, in, gr, ws, ws, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
@@ -412,6 +431,7 @@ extern "C" int gh_backward_shared(const GhDims* d, const GhInputs* in, const GhG
   int rc = check_shared(d, in);
   if (rc != GH_OK) return rc;
   if (!gr || !gr->dL_dimage || !workspace || !geometry_ws || geometry_ws == workspace) return GH_ERR_INVALID_ARG;
+  if (gr->deferred_loss) return GH_ERR_UNSUPPORTED;                       // (gh_forward_shared fuses no loss)
   if ((((uintptr_t)gr->dL_dblend_color_b | (uintptr_t)gr->dL_dblend_color_w) & 15) != 0) return GH_ERR_INVALID_ARG;
   GhLayout L;
   gh_workspace_layout(d, &L);
@@ -473,7 +493,7 @@ extern "C" int gh_backward_refresh(const GhDims* d, const GhInputs* in, const Gh
   GhGrid g = gh_make_grid(d);
   (void)hipGetLastError();
   gh_launch_render_bwd(d, g, in, gr->dL_dimage, gr->dL_dalpha, gr->upstream_scale, (const char*)geometry_ws, (char*)workspace, L, s,
-                       gh_records_need_geometry(in, gr));
+                       gh_records_need_geometry(in, gr), gr->deferred_loss);
   gh_launch_preprocess_bwd(d, g, in, gr, (const char*)geometry_ws, (char*)workspace, L, s);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }

@@ -424,8 +424,16 @@ size_t gh_radix_table_words(size_t per_segment, int segs) {
 }
 
 size_t gh_radix_table_words(size_t cap) {
-  const size_t tile = (size_t)GH_BLOCK * gh_radix_items(cap, 1, false);
-  return (size_t)1024 * ((cap + tile - 1) / tile) + 1024;
+  // (monotone in cap: the keys per thread double at 2^21 and 2^25 elements, which would halve the table just above a threshold —
+  //  a capacity a little larger must never ask for a smaller workspace)
+  size_t words = 0;
+  const size_t steps[3] = {cap < ((size_t)1 << 21) ? cap : ((size_t)1 << 21), cap < ((size_t)1 << 25) ? cap : ((size_t)1 << 25), cap};
+  for (int k = 0; k < 3; ++k) {
+    const size_t tile = (size_t)GH_BLOCK * gh_radix_items(steps[k], 1, false);
+    const size_t w = (size_t)1024 * ((steps[k] + tile - 1) / tile) + 1024;
+    if (w > words) words = w;
+  }
+  return words;
 }
 
 // Passes gh_radix_sort runs for `nbits` key bits on one segment of capacity `cap` (callers pick the start buffer by its parity).

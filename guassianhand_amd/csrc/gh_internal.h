@@ -61,11 +61,12 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                           const char* wg, char* ws, const GhLayout& L, hipStream_t s, float* seen = nullptr, float seen_scale = 1.0f,
                           uint32_t seen_slack = 0u, const GhOutputs* fused = nullptr);   // fused: GhOutputs.l1_* (full forwards only)
 // out[0] = scale * (fixed-order sum of n floats, n a multiple of 4, 16-byte aligned): one workgroup (gh_loss.hip)
-void gh_launch_partials_sum(const float* partials, size_t n, float scale, float* out, hipStream_t s);
+// scale_behind: the factor is the float the forward left behind the last partial (times `scale`)
+void gh_launch_partials_sum(const float* partials, size_t n, float scale, float* out, hipStream_t s, bool scale_behind = false);
 // geom: gh_records_need_geometry(in, gr) — false: the sub-records carry the colour / opacity moments only
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s,
-                          bool geom);
+                          bool geom, float* deferred_loss = nullptr);     // deferred_loss: GhGrads.deferred_loss
 // Is a gradient that flows through the projection wanted (means, scales, rotations, means2D, xyz_b)?
 static inline bool gh_wants_geometry(const GhInputs* in, const GhGrads* gr) {
   return gr->dL_dmeans3D || gr->dL_dmeans2D || gr->dL_dscales || gr->dL_drotations || gr->dL_dcov3D ||

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_partials_sum_kernel(const float* 
 // The fused image loss's partials (GhLayout.loss_partials: 4 per tile, 21.5 k at 8 views of 512x334): one workgroup of 1024 threads,
 // 16-byte loads, every thread a fixed stride of the array, then the fixed-order block sum.
 __global__ __launch_bounds__(1024) void gh_partials_sum_wide_kernel(const float4* __restrict__ partials, size_t n4, float scale,
-                                                                      float* __restrict__ out) {
+                                                                      float* __restrict__ out, bool scale_behind) {
   __shared__ float s_w[16];
   float a = 0.0f, b = 0.0f, c = 0.0f, d = 0.0f;
   for (size_t i = threadIdx.x; i < n4; i += 1024) { const float4 v = partials[i]; a += v.x; b += v.y; c += v.z; d += v.w; }
@@ -56,12 +56,12 @@ __global__ __launch_bounds__(1024) void gh_partials_sum_wide_kernel(const float4
     float t = 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) t += s_w[k];
-    out[0] = scale * t;
+    out[0] = (scale_behind ? scale * ((const float*)partials)[n4 * 4] : scale) * t;
   }
 }
 
-void gh_launch_partials_sum(const float* partials, size_t n, float scale, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(gh_partials_sum_wide_kernel, dim3(1), dim3(1024), 0, s, (const float4*)partials, n / 4, scale, out);
+void gh_launch_partials_sum(const float* partials, size_t n, float scale, float* out, hipStream_t s, bool scale_behind) {
+  hipLaunchKernelGGL(gh_partials_sum_wide_kernel, dim3(1), dim3(1024), 0, s, (const float4*)partials, n / 4, scale, out, scale_behind);
 }
 
 extern "C" int gh_l1_loss(const float* image, const float* target, size_t n, float* loss_out, float* dL_dimage, float* partials,

@@ -291,6 +291,7 @@ struct GhFusedLoss {
   const float* bbox;         // LOSS 2: (n_views,H,W) or NULL
   float* dalpha;             // LOSS 2: (n_views,H,W)
   float k_l1, k_m;           // LOSS 2: scale * lambda_l1 / (3 HW), scale * lambda_mask / HW
+  float sum_scale;           // factor of the final sum over the partials (LOSS 1: inv_n, LOSS 2: 1); left behind the partials
 };
 
 template <bool ALPHA, bool SEEN, int LOSS>
@@ -307,13 +308,19 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   __shared__ float s_l1[GH_BLOCK / GH_WAVE];
   __shared__ uint32_t s_l1_n;
   if (LOSS) {
-    if (threadIdx.x == 0) s_l1_n = 0u;
+    if (threadIdx.x == 0) {
+      s_l1_n = 0u;
+      // the final sum's factor, behind the last partial: a deferred sum (GhGrads.deferred_loss) finds it there
+      if (blockIdx.x == 0) l1.part[(size_t)gridDim.x] = l1.sum_scale;
+    }
     __syncthreads();
   }
   int v, tx, ty;
   uint32_t item_idx, quad_u;
   gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);
-  const int tile = (int)tile_order[item_idx];             // heaviest tiles are launched first
+  // (wave-uniform values are moved to scalar registers by hand: the compiler keeps what comes out of a global load in vector
+  //  registers, and with it the tile coordinates, the list range and the three 64-bit record pointers — per lane, through the walk)
+  const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[item_idx]);             // heaviest tiles are launched first
   const int quad = (int)quad_u;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -322,8 +329,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
   const bool inside = x < W && y < H;
   const float pxf = (float)x, pyf = (float)y;
+  // Addressing of everything per pixel: a wave-uniform base (the view's plane: scalar registers) + ONE 32-bit offset per lane. With
+  // 64-bit per-lane addresses the epilogue's nine stores held eighteen address registers at once — the kernel's register peak,
+  // which cost the fused-loss variant a wave per SIMD (71 VGPRs).
+  const size_t hw = (size_t)H * W;
+  const uint32_t poff = (uint32_t)y * (uint32_t)W + (uint32_t)x;
   const int blk = ((quad >> 1) * 2 + (wid >> 1)) * 4 + (quad & 1) * 2 + (wid & 1);      // this wave's bit in the block masks
-  const uint2 range = ranges[tile];
+  const uint2 range_v = ranges[tile];
+  const uint2 range = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.y));
   const int total = (int)(range.y - range.x);
   r0 += range.x; r1 += range.x; r2 += range.x;
   // state checkpoints for the segmented backward: slot of (tile, position m*GH_SEGMENT) = range.x/GH_SEGMENT + tile + m - 1
@@ -337,14 +350,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   float tg0 = 0.0f, tg1 = 0.0f, tg2 = 0.0f, tgm = 0.0f;
   bool in_box = true;
   if (LOSS == 1 && inside && slot == 0) {
-    const size_t o = (size_t)v * 3 * H * W + (size_t)y * W + x, hw = (size_t)H * W;
-    tg0 = l1.target[o]; tg1 = l1.target[o + hw]; tg2 = l1.target[o + 2 * hw];
+    const float* tg = l1.target + (size_t)v * 3 * hw;
+    tg0 = tg[poff]; tg1 = (tg + hw)[poff]; tg2 = (tg + 2 * hw)[poff];
   }
   if (LOSS == 2 && inside && slot == 0) {
-    const size_t pix = ((size_t)v * H + y) * W + x;
-    tg0 = l1.target[pix * 3]; tg1 = l1.target[pix * 3 + 1]; tg2 = l1.target[pix * 3 + 2];     // channel-last, as the reference holds it
-    tgm = l1.gt_mask[pix];
-    if (l1.bbox) in_box = l1.bbox[pix] != 0.0f;
+    const float* tg = l1.target + (size_t)v * 3 * hw;
+    tg0 = tg[3 * poff]; tg1 = tg[3 * poff + 1]; tg2 = tg[3 * poff + 2];     // channel-last, as the reference holds it
+    tgm = (l1.gt_mask + (size_t)v * hw)[poff];
+    if (l1.bbox) in_box = (l1.bbox + (size_t)v * hw)[poff] != 0.0f;
   }
   GhPixelFwd p;
   p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.stopq = 0; p.done = inside ? 0 : 1;
@@ -392,27 +405,27 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     if (inside && slot == 0) {
       const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
       const float poison = (*render_guard & guard_mask) ? __uint_as_float(0x7FC00000u) : 0.0f;
-      const size_t o = (size_t)v * 3 * H * W + (size_t)y * W + x, hw = (size_t)H * W;
+      float* dl = l1.dL + (size_t)v * 3 * hw;
       const float c0 = fmaf(p.T, bg[0], p.C0) + poison, c1 = fmaf(p.T, bg[1], p.C1) + poison, c2 = fmaf(p.T, bg[2], p.C2) + poison;
       if (LOSS == 1) {
         const float d0 = c0 - tg0, d1 = c1 - tg1, d2 = c2 - tg2;
         labs = (fabsf(d0) + fabsf(d1)) + fabsf(d2);
         // torch.sign: sign(0) = 0; a NaN pixel (poisoned call) leaves no gradient, as gh_l1_loss's guard
-        l1.dL[o] = d0 > 0.0f ? l1.inv_n : (d0 < 0.0f ? -l1.inv_n : 0.0f);
-        l1.dL[o + hw] = d1 > 0.0f ? l1.inv_n : (d1 < 0.0f ? -l1.inv_n : 0.0f);
-        l1.dL[o + 2 * hw] = d2 > 0.0f ? l1.inv_n : (d2 < 0.0f ? -l1.inv_n : 0.0f);
+        dl[poff] = d0 > 0.0f ? l1.inv_n : (d0 < 0.0f ? -l1.inv_n : 0.0f);
+        (dl + hw)[poff] = d1 > 0.0f ? l1.inv_n : (d1 < 0.0f ? -l1.inv_n : 0.0f);
+        (dl + 2 * hw)[poff] = d2 > 0.0f ? l1.inv_n : (d2 < 0.0f ? -l1.inv_n : 0.0f);
       } else {
         // gh_fit_loss_kernel's expressions: colour zeroed outside the box, clip(alpha, -0.001, 1) passes the gradient on [min, max]
         const float d0 = (in_box ? c0 : 0.0f) - tg0, d1 = (in_box ? c1 : 0.0f) - tg1, d2 = (in_box ? c2 : 0.0f) - tg2;
         labs = l1.k_l1 * fabsf(d0); labs += l1.k_l1 * fabsf(d1); labs += l1.k_l1 * fabsf(d2);
-        l1.dL[o] = in_box ? (d0 > 0.0f ? l1.k_l1 : (d0 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
-        l1.dL[o + hw] = in_box ? (d1 > 0.0f ? l1.k_l1 : (d1 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
-        l1.dL[o + 2 * hw] = in_box ? (d2 > 0.0f ? l1.k_l1 : (d2 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
+        dl[poff] = in_box ? (d0 > 0.0f ? l1.k_l1 : (d0 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
+        (dl + hw)[poff] = in_box ? (d1 > 0.0f ? l1.k_l1 : (d1 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
+        (dl + 2 * hw)[poff] = in_box ? (d2 > 0.0f ? l1.k_l1 : (d2 < 0.0f ? -l1.k_l1 : 0.0f)) : 0.0f;
         const float a = fmaf(p.T, 0.0f, p.A) + poison;                 // the mask channel as it is stored below
         const float ac = fminf(fmaxf(a, -0.001f), 1.0f);
         const float e = ac - tgm;
         labs += l1.k_m * e * e;
-        l1.dalpha[((size_t)v * H + y) * W + x] = (a >= -0.001f && a <= 1.0f) ? 2.0f * l1.k_m * e : 0.0f;
+        (l1.dalpha + (size_t)v * hw)[poff] = (a >= -0.001f && a <= 1.0f) ? 2.0f * l1.k_m * e : 0.0f;
       }
     }
     const float wsum = gh_wave_sum_to63(labs);
@@ -478,11 +491,12 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   }
   if (inside && slot == 0) {
     const float* bg = cams + (size_t)v * GH_CAM_FLOATS + 37;
-    const size_t pix = ((size_t)v * H + y) * W + x;
-    final_T[pix] = p.T;
-    n_contrib[pix] = p.last;
-    final_C[pix] = make_float4(p.C0, p.C1, p.C2, 0.0f);
-    float* img = image + (size_t)v * 3 * H * W + (size_t)y * W + x;
+    (final_T + (size_t)v * hw)[poff] = p.T;
+    (n_contrib + (size_t)v * hw)[poff] = p.last;
+    // the backward reads final_C only for a pixel that blends entries BEHIND a segment cut (last > seg_hi >= GH_SEGMENT,
+    // gh_render_bwd_kernel): most pixels — the background, every pixel of a short list — never get there
+    if (p.last > (uint32_t)GH_SEGMENT) (final_C + (size_t)v * hw)[poff] = make_float4(p.C0, p.C1, p.C2, 0.0f);
+    float* img = image + (size_t)v * 3 * hw;
     // Device-side overflow guard: with D > max_instances the lists are truncated, so a sync-free caller must never see a
     // plausible image — it gets NaN (and GhCounters.overflow for the host to read whenever it chooses).
     // (a depth-bound miss elsewhere — bit 2 — does not touch this pixel: tiles are independent; this pixel's own miss does)
@@ -493,10 +507,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     // guard_mask: bits 0, 1, 3 (the whole call is invalid); a second call over shared lists also takes bit 2 of the call that
     // built them — it has no bound of its own to verify, and lists a miss truncated are not its lists either.
     const float poison = ((*render_guard & guard_mask) || pixel_miss) ? __uint_as_float(0x7FC00000u) : 0.0f;
-    img[0] = fmaf(p.T, bg[0], p.C0) + poison;
-    img[(size_t)H * W] = fmaf(p.T, bg[1], p.C1) + poison;
-    img[(size_t)2 * H * W] = fmaf(p.T, bg[2], p.C2) + poison;
-    if (ALPHA) alpha_img[pix] = fmaf(p.T, 0.0f, p.A) + poison;
+    img[poff] = fmaf(p.T, bg[0], p.C0) + poison;
+    (img + hw)[poff] = fmaf(p.T, bg[1], p.C1) + poison;
+    (img + 2 * hw)[poff] = fmaf(p.T, bg[2], p.C2) + poison;
+    if (ALPHA) (alpha_img + (size_t)v * hw)[poff] = fmaf(p.T, 0.0f, p.A) + poison;
   }
 }
 
@@ -521,12 +535,14 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
     loss_kind = 1;
     l1.target = fused->l1_target; l1.dL = fused->l1_dL_dimage;
     l1.inv_n = (float)(1.0 / ((double)g.NV * 3.0 * (double)g.H * (double)g.W));
+    l1.sum_scale = l1.inv_n;
   } else if (fused && fused->fit_loss) {             // GhOutputs.fit_loss: the fit's image loss (needs the mask channel)
     const GhFitLoss* f = fused->fit_loss;
     loss_kind = 2;
     l1.target = f->gt_rgb; l1.gt_mask = f->gt_mask; l1.bbox = f->bbox; l1.dL = f->dL_dimage; l1.dalpha = f->dL_dalpha;
     const float HW = (float)(g.H * g.W);
     l1.k_l1 = f->scale * f->lambda_l1 / (3.0f * HW); l1.k_m = f->scale * f->lambda_mask / HW;     // as gh_fit_loss
+    l1.sum_scale = 1.0f;
   }
   l1.part = (float*)(ws + L.loss_partials);
   auto launch = [&](auto kern) {
@@ -536,12 +552,13 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   };
   if (loss_kind == 1) {                              // (the entry point has ruled out alpha / seen / a bound)
     launch(gh_render_fwd_kernel<false, false, 1>);
-    gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, l1.inv_n, fused->l1_loss, s);
+    // GH_FLAG_DEFER_LOSS_SUM: the sum is a spare workgroup of the backward's render kernel (GhGrads.deferred_loss)
+    if (!(d->flags & GH_FLAG_DEFER_LOSS_SUM)) gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, l1.inv_n, fused->l1_loss, s);
     return;
   }
   if (loss_kind == 2) {                              // (... seen / a bound, and required alpha)
     launch(gh_render_fwd_kernel<true, false, 2>);
-    gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, 1.0f, fused->fit_loss->loss, s);
+    if (!(d->flags & GH_FLAG_DEFER_LOSS_SUM)) gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, 1.0f, fused->fit_loss->loss, s);
     return;
   }
   // SEEN (GhOutputs.tile_depth_seen wanted): the variant that walks on virtually behind the stop; the plain kernels are untouched
@@ -701,7 +718,32 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
     int H, int W, int gx, int tiles, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float4* __restrict__ ckpt_rgb, const float4* __restrict__ final_C,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, const float* __restrict__ upstream_scale,
-    float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag) {
+    float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag,
+    const float4* __restrict__ loss_part, uint32_t loss_n4, float* __restrict__ loss_out) {
+  // GhGrads.deferred_loss: the fused image loss's final sum (GH_FLAG_DEFER_LOSS_SUM left the forward without its one-workgroup sum
+  // kernel) by workgroup 0 of this launch — dispatched first, done long before the kernel's tail; every other workgroup's
+  // index moves down by one. Fixed order: bitwise reproducible.
+  uint32_t bid = blockIdx.x, nblk_items = gridDim.x;
+  if (loss_out) {
+    if (bid == 0u) {
+      __shared__ float s_ls[NW];
+      float a = 0.0f, b = 0.0f, c = 0.0f, e = 0.0f;
+      for (uint32_t i = threadIdx.x; i < loss_n4; i += NW * GH_WAVE) { const float4 v = loss_part[i]; a += v.x; b += v.y; c += v.z; e += v.w; }
+      const float sw = gh_wave_sum_to63((a + b) + (c + e));
+      const float scale = ((const float*)loss_part)[(size_t)loss_n4 * 4];          // left by the forward behind the partials
+      if (NW == 1) { if (threadIdx.x == 63) loss_out[0] = scale * sw; }
+      else {
+        if ((threadIdx.x & 63) == 63) s_ls[threadIdx.x >> 6] = sw;
+        __syncthreads();
+        if (threadIdx.x == 0) { float t = 0.0f;
+#pragma unroll
+          for (int k = 0; k < NW; ++k) t += s_ls[k];
+          loss_out[0] = scale * t; }
+      }
+      return;
+    }
+    bid -= 1u; nblk_items -= 1u;
+  }
   __shared__ float s_acc_all[NW][GH_BWD_ACC * GH_REC];    // per wave: [compact quadrant entry][9]
   __shared__ float4 s_pix[2 * (GH_WAVE + 1)];             // per pixel (T, B, d0, d1), (d2, last, px, py); last record = dummy
   __shared__ uint16_t s_q_all[NW][GH_SEGMENT];            // per wave: compacted entry list of the block being walked: raw | compact << 8
@@ -712,10 +754,11 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
   uint8_t* s_f = s_f_all[wv];
   const uint32_t n_items = ctr->reserved[1];             // written by the forward; the grid is sized for the list's capacity
   uint32_t item_idx, quad_u;
-  gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);       // the four quadrants of an item share an XCD (L2)
+  gh_item_quad(bid, nblk_items >> 2, item_idx, quad_u);       // the four quadrants of an item share an XCD (L2)
   if (item_idx >= n_items) return;
-  const uint2 item = items[n_items - 1u - item_idx];     // (tile, depth segment): the tiles the forward finished last go first
-  const int tile = (int)item.x, quad = (int)quad_u;
+  const uint2 item_v = items[n_items - 1u - item_idx];     // (tile, depth segment): the tiles the forward finished last go first
+  const uint2 item = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)item_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v.y));
+  const int tile = (int)item.x, quad = (int)quad_u;       // (wave-uniform values in scalar registers by hand: see the forward)
   const int seg_lo = (int)item.y * GH_SEGMENT, seg_hi = seg_lo + GH_SEGMENT;
   int v, tx, ty;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
@@ -724,7 +767,8 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
   const int lb = lane >> 4, lp = lane & 15;
   const int x = tx * GH_TILE + (quad & 1) * 8 + (lb & 1) * 4 + (lp & 3), y = ty * GH_TILE + (quad >> 1) * 8 + (lb >> 1) * 4 + (lp >> 2);
   const bool inside = x < W && y < H;
-  const uint2 range = ranges[tile];
+  const uint2 range_v = ranges[tile];
+  const uint2 range = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.y));
   if (range.y == range.x) return;
   r0 += range.x; r1 += range.x; r2 += range.x;
   const uint32_t* slots = sorted_slot + range.x;
@@ -913,12 +957,16 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
 
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s,
-                          bool geom) {
-  if (g.cap == 0) return;
+                          bool geom, float* deferred_loss) {
+  const size_t n_part = (size_t)g.NV * g.tiles * 4;
+  if (g.cap == 0) {                                       // nothing was listed: no render backward; a deferred sum still has to run
+    if (deferred_loss) gh_launch_partials_sum((const float*)(ws + L.loss_partials), n_part, 1.0f, deferred_loss, s, true);
+    return;
+  }
   // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (they depend on the forward's
   // n_contrib only). The work list (tile, depth segment) was written by the forward's last wave of every tile.
   const bool small = g.total_tiles <= GH_FINE_TILES;    // few tiles: four waves per quadrant (one per 4x4 block)
-  const dim3 grid(4 * (unsigned)g.n_items), block(small ? 4 * GH_WAVE : GH_WAVE);   // capacity of the work list x 4 quadrants; surplus workgroups exit at once
+  const dim3 grid(4 * (unsigned)g.n_items + (deferred_loss ? 1u : 0u)), block(small ? 4 * GH_WAVE : GH_WAVE);   // capacity of the work list x 4 quadrants; surplus workgroups exit at once
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(wg + L.ranges), (const uint2*)(ws + L.bwd_items),
                        (const GhCounters*)(ws + L.counters),
@@ -926,7 +974,7 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                        (const float2*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
                        (const uint32_t*)(ws + L.n_contrib), (const float4*)(ws + L.ckpt_rgb),
                        (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, upstream_scale, (float*)(ws + L.inst_grad),
-                       (uint8_t*)(ws + L.inst_flag));
+                       (uint8_t*)(ws + L.inst_flag), (const float4*)(ws + L.loss_partials), (uint32_t)(n_part / 4), deferred_loss);
   };
   // geom = false (precomputed colours and no geometry gradient wanted): colour / opacity moments only, see the kernel
   if (small) {

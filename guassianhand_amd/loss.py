@@ -109,7 +109,7 @@ class _RenderedLoss(torch.autograd.Function):
     its pixels, so the autograd product `dL/dimage * dL/dloss` costs no pass over the images."""
 
     @staticmethod
-    def forward(ctx, spec, cache, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, per_view, xyz, opacity,
+    def forward(ctx, spec, cache, cams, H, W, sh_degree, scale_modifier, use_rgb, sync, max_instances, per_view, defer_loss, xyz, opacity,
                 scaling, rotation, shs, xyz_b, opacity_b, color_w, color_b):
         from . import rasterizer as R
         kind = spec[0]
@@ -127,7 +127,7 @@ class _RenderedLoss(torch.autograd.Function):
                                                      color_w=color_w, color_b=color_b, sync=sync, max_instances=max_instances,
                                                      return_alpha=(kind == "fit"), per_view_gaussians=per_view,
                                                      l1_target=spec[1] if kind == "l1" else None,
-                                                     fit_loss=spec[1:] if kind == "fit" else None, **kw)
+                                                     fit_loss=spec[1:] if kind == "fit" else None, defer_loss=defer_loss, **kw)
         guard = rctx.ws[:16]                          # device-side overflow guard: an overflowed render yields loss NaN, zero gradients
         if kind == "l1":
             # the render kernel's epilogue has produced both (GhOutputs.l1_*) wherever the library fuses them; else one pass over the image
@@ -151,31 +151,34 @@ class _RenderedLoss(torch.autograd.Function):
         from . import rasterizer as R
         ctx.saved_tensors
         g = R.raster_backward(ctx.rctx, ctx.dimg, want_means2D=False, dL_dalpha=ctx.dal, grad_scale=g_loss,
-                              want=R._wanted(ctx.needs_input_grad[11:20], ctx.use_rgb))
+                              want=R._wanted(ctx.needs_input_grad[12:21], ctx.use_rgb))
         ctx.rctx = None
         s = ctx.shapes
         col = g.get("colors_precomp" if ctx.use_rgb else "shs")
         opt = lambda k, i: g[k].reshape(s[i]) if (s[i] is not None and k in g) else None
-        return (None,) * 11 + (opt("means3D", 0), opt("opacities", 1), opt("scales", 2), opt("rotations", 3),
+        return (None,) * 12 + (opt("means3D", 0), opt("opacities", 1), opt("scales", 2), opt("rotations", 3),
                               None if col is None else col.reshape(s[4]), opt("xyz_b", 5), opt("opacity_b", 6),
                               opt("color_w", 7), opt("color_b", 8))
 
 
 def _rendered_loss(spec, cams, xyz, opacity, scaling, rotation, shs, *, H, W, use_rgb, sh_degree=3, scale_modifier=1.0, xyz_b=None,
                    opacity_b=None, color_w=None, color_b=None, sync=True, max_instances=None, per_view_gaussians=False,
-                   geometry_cache=None, depth_bound=None):
+                   geometry_cache=None, depth_bound=None, defer_loss=False):
     if depth_bound is not None:                        # rasterizer.DepthBoundCache: moving geometry (see rasterize_views)
         if geometry_cache is not None:
             raise ValueError("geometry_cache (static geometry) or depth_bound (moving geometry), not both")
         geometry_cache = depth_bound
     return _RenderedLoss.apply(spec, geometry_cache, cams, int(H), int(W), int(sh_degree if not use_rgb else 0), float(scale_modifier), bool(use_rgb),
-                               bool(sync), max_instances, bool(per_view_gaussians), xyz, opacity, scaling, rotation, shs, xyz_b,
+                               bool(sync), max_instances, bool(per_view_gaussians), bool(defer_loss), xyz, opacity, scaling, rotation, shs, xyz_b,
                                opacity_b, color_w, color_b)
 
 
 def rendered_l1_loss(cams, xyz, opacity, scaling, rotation, shs, target, **kw):
     """mean|render - target| with the render (rasterizer.rasterize_views arguments) and the loss in one autograd node.
-    Returns (loss, image (Nv,3,H,W) detached, radii). Same values as l1_mean_loss(rasterize_views(...)[0], target)."""
+    Returns (loss, image (Nv,3,H,W) detached, radii). Same values as l1_mean_loss(rasterize_views(...)[0], target).
+    defer_loss=True (GH_FLAG_DEFER_LOSS_SUM): where the loss comes from the render kernel's epilogue its final one-workgroup sum
+    moves into the BACKWARD (a spare workgroup of the render backward): the returned loss tensor holds its value only once
+    loss.backward() has been enqueued — for loops that look at the loss after the step (bench.py, the fit's log)."""
     loss, image, _alpha, radii = _rendered_loss(("l1", target), cams, xyz, opacity, scaling, rotation, shs, **kw)
     return loss, image, radii
 

@@ -510,7 +510,7 @@ def _prep(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 class _Ctx:
     __slots__ = ("dims", "inp", "tensors", "ws", "layout", "H", "W", "P", "NV", "M", "wpg", "b_rgb", "rows", "stream", "alpha",
-                 "parent", "radii", "pending", "verdict", "refresh", "l1", "fit", "__weakref__")
+                 "parent", "radii", "pending", "verdict", "refresh", "l1", "fit", "defer_loss", "__weakref__")
 
     def __del__(self):
         try:
@@ -590,13 +590,15 @@ def _inputs_struct(c: _Call, with_shs: bool = True, bound=None):
                          _ptr(t["color_w"]), _ptr(t["color_b"]), _ptr(bound), _ptr(t["cov3D"]))
 
 
-def _make_ctx(c: _Call, dims, inp, ws, stream, alpha, parent, radii, pending, verdict, refresh, l1=None, fit=None) -> _Ctx:
+def _make_ctx(c: _Call, dims, inp, ws, stream, alpha, parent, radii, pending, verdict, refresh, l1=None, fit=None, defer=False) -> _Ctx:
     ctx = _Ctx()
     ctx.dims, ctx.inp, ctx.tensors, ctx.ws, ctx.H, ctx.W, ctx.P, ctx.NV, ctx.M, ctx.wpg = dims, inp, c.t, ws, c.H, c.W, c.P, c.NV, c.M, c.wpg
     ctx.b_rgb, ctx.rows, ctx.alpha, ctx.parent, ctx.radii, ctx.stream = c.b_rgb, c.rows, alpha, parent, radii, stream
     ctx.pending, ctx.verdict, ctx.refresh = pending, verdict, refresh
     ctx.l1 = l1                                    # (loss, dL/dimage) of a fused image loss (GhOutputs.l1_*), else None
     ctx.fit = fit                                  # (loss, dL/dimage, dL/dalpha) of a fused fit loss (GhOutputs.fit_loss), else None
+    # GH_FLAG_DEFER_LOSS_SUM: the fused loss's final sum is the backward's to write (GhGrads.deferred_loss)
+    ctx.defer_loss = bool(defer) and (l1 is not None or fit is not None)
     return ctx
 
 
@@ -661,13 +663,15 @@ def _forward_shared(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool):
     return image, g0.radii, ctx
 
 
-def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, expect_backward: bool, l1_target=None, fit_loss=None):
+def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, expect_backward: bool, l1_target=None, fit_loss=None,
+                     defer_loss=False):
     """gh_forward_refresh: this call's opacities / colours over the static lists of `g0`."""
     if not (g0.dims.flags & _abi.GH_FLAG_STATIC_LISTS) or (g0.P, g0.NV, g0.H, g0.W, g0.rows) != (c.P, c.NV, c.H, c.W, c.rows) or \
             (g0.dims.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) != (c.flags & _abi.GH_FLAG_PER_VIEW_GAUSSIANS) or g0.parent is not None:
         raise ValueError("refresh_of: needs the context of a static_lists forward with this call's shapes")
     cap = int(g0.dims.max_instances)
-    dims = _abi.GhDims(c.P, c.NV, c.H, c.W, c.sh_degree, c.M, c.scale_modifier, c.flags, cap)
+    defer = bool(defer_loss) and _policy.fused_loss and ((l1_target is not None and not return_alpha) or (fit_loss is not None and return_alpha))
+    dims = _abi.GhDims(c.P, c.NV, c.H, c.W, c.sh_degree, c.M, c.scale_modifier, c.flags | (_abi.GH_FLAG_DEFER_LOSS_SUM if defer else 0), cap)
     nbytes = L.gh_workspace_bytes(C.byref(dims))
     # the library applies THIS call's layout to the owner's workspace, and the arrays a refresh reads of it (cull_bound,
     # inst_c) lie behind the ones sized by the colour mode (sh_rgb, dmean_sh, sh_scratch: M != 0): the two calls must agree
@@ -713,12 +717,12 @@ def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, e
         pc = _queue_readback(st, counters, cap, gkey, learn24=False)      # (no depth sort in a refresh: nothing to learn about it)
         if auto:
             pending = pc
-    ctx = _make_ctx(c, dims, inp, ws, stream, alpha, g0, g0.radii, pending, None, True, l1, fit)
+    ctx = _make_ctx(c, dims, inp, ws, stream, alpha, g0, g0.radii, pending, None, True, l1, fit, defer)
     return image, g0.radii, ctx
 
 
 def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backward: bool, max_instances, static_lists: bool,
-                  depth_bound, l1_target=None, fit_loss=None):
+                  depth_bound, l1_target=None, fit_loss=None, defer_loss=False):
     """gh_forward: projection, both sorts, lists, render — with the capacity / GH_FLAG_DEPTH24 / occlusion-bound policies around it
     (a synced call that the device flags is re-run with what it learned; a sync-free call is recorded for check_overflow)."""
     P, NV, H, W = c.P, c.NV, c.H, c.W
@@ -726,6 +730,10 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
     if depth_bound is not None and (static_lists or _policy.graph_mode or P == 0 or NV * H * W < depth_bound.min_pixels):
         depth_bound = None                       # lists that outlive the call / a captured call / a small call: no per-call speculation
     base_flags = c.flags | (_abi.GH_FLAG_STATIC_LISTS if static_lists else 0)
+    # the final sum of a fused image loss inside the backward (only where a loss IS fused: see _fused_loss below)
+    if defer_loss and _policy.fused_loss and depth_bound is None and not c.split and \
+            ((l1_target is not None and not return_alpha) or (fit_loss is not None and return_alpha)):
+        base_flags |= _abi.GH_FLAG_DEFER_LOSS_SUM
     while True:
         cap = int(max_instances) if max_instances is not None else st.capacity.get(key, _initial_capacity(P, NV))
         # three depth-sort passes only for a shape a read-back has shown them to suffice for (_DeviceState.depth24)
@@ -807,7 +815,8 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
                 pending = pc
         break
     # verdict: the counter read-back of a sync-free call, whoever is to ask for it
-    ctx = _make_ctx(c._replace(flags=flags), dims, inp, ws, stream, alpha, None, radii, pending, verdict, False, l1, fit)
+    ctx = _make_ctx(c._replace(flags=flags), dims, inp, ws, stream, alpha, None, radii, pending, verdict, False, l1, fit,
+                    bool(flags & _abi.GH_FLAG_DEFER_LOSS_SUM))
     return image, radii, ctx
 
 
@@ -817,7 +826,7 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
                    per_view_gaussians: bool = False, geometry_of: Optional["_Ctx"] = None,
                    split_streams: Optional[bool] = None, expect_backward: bool = False, static_lists: bool = False,
                    refresh_of: Optional["_Ctx"] = None, depth_bound: Optional[DepthBoundCache] = None, cov3D_precomp=None,
-                   l1_target: Optional[torch.Tensor] = None, fit_loss=None):
+                   l1_target: Optional[torch.Tensor] = None, fit_loss=None, defer_loss: bool = False):
     """Low-level forward through the C-ABI. Returns (image (NV,3,H,W), radii (NV,P) int32, ctx);
     cov3D_precomp (P,6): the published module's precomputed 3-D covariance (xx xy xz yy yz zz, used as given: scale_modifier is
     not applied) in place of scales + rotations (pass None for both); its gradient comes back as "cov3D_precomp".
@@ -844,6 +853,8 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
     fit_loss (gt_rgb (n_views,H,W,3), gt_mask (n_views,H,W), bbox (n_views,H,W) or None, lambda_l1, lambda_mask, scale), with
     return_alpha: the fit's image loss the same way — ctx.fit = (loss, dL/dimage, dL/dalpha) (GhOutputs.fit_loss), None where
     it is not fused (loss.py then runs gh_fit_loss).
+    defer_loss (GH_FLAG_DEFER_LOSS_SUM, with a fused loss only): the loss tensor of ctx.l1 / ctx.fit is written by this context's
+    raster_backward (GhGrads.deferred_loss) instead of a one-workgroup sum kernel behind the forward; ctx.defer_loss says so.
     sync: True = read D back (and re-run with a larger capacity if needed); False = never block (check_overflow() is the
     caller's job); None = auto: read D back for the first call of a shape and for calls whose backward will not come
     (expect_backward False), otherwise sync-free with the check at the start of raster_backward.
@@ -862,9 +873,9 @@ def raster_forward(cams, means3D, opacities, scales, rotations, *, H: int, W: in
             return _forward_shared(st, L, dev, c, geometry_of, return_alpha)
         if refresh_of is not None:
             return _forward_refresh(st, L, dev, c._replace(flags=c.flags | _abi.GH_FLAG_STATIC_LISTS), refresh_of, return_alpha, sync,
-                                    expect_backward, l1_target, fit_loss)
+                                    expect_backward, l1_target, fit_loss, defer_loss)
         return _forward_full(st, L, dev, c, return_alpha, sync, expect_backward, max_instances, static_lists, depth_bound, l1_target,
-                             fit_loss)
+                             fit_loss, defer_loss)
 
 
 def cached_raster_forward(cache: Optional[GeometryCache], cams, means3D, opacities, scales, rotations, **kw):
@@ -962,7 +973,8 @@ def raster_backward(ctx: _Ctx, dL_dimage: Optional[torch.Tensor], want_means2D: 
                       dL_dopacities=_ptr(o["opacities"]), dL_dscales=_ptr(o["scales"]), dL_drotations=_ptr(o["rotations"]),
                       dL_dshs=_ptr(o["shs"]), dL_dcolors=_ptr(o["colors_precomp"]), dL_dblend_xyz_b=_ptr(o["xyz_b"]),
                       dL_dblend_opacity_b=_ptr(o["opacity_b"]), dL_dblend_color_w=_ptr(o["color_w"]),
-                      dL_dblend_color_b=_ptr(o["color_b"]), upstream_scale=_ptr(gs), dL_dcov3D=_ptr(o["cov3D_precomp"]))
+                      dL_dblend_color_b=_ptr(o["color_b"]), upstream_scale=_ptr(gs), dL_dcov3D=_ptr(o["cov3D_precomp"]),
+                      deferred_loss=_ptr((ctx.l1 or ctx.fit)[0]) if getattr(ctx, "defer_loss", False) else None)
     stream = _raw_stream(dev)
     ctx.stream = stream                            # the workspace goes back to the pool of the stream that used it last
     with _OnDevice(dev):

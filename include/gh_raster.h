@@ -40,7 +40,7 @@ extern "C" {
 #endif
 
 #define GH_VERSION_MAJOR 0
-#define GH_VERSION_MINOR 7
+#define GH_VERSION_MINOR 8
 
 #define GH_TILE 16           /* tile edge in pixels (binning granularity; fixes which Gaussians a pixel sees) */
 #define GH_CAM_FLOATS 40     /* floats per camera record, see GhCamera */
@@ -51,8 +51,16 @@ typedef enum GhStatus {
   GH_ERR_INVALID_ARG = -1,     /* NULL / inconsistent pointers, bad dims */
   GH_ERR_WORKSPACE_SMALL = -2, /* ws_bytes < gh_workspace_bytes(dims) */
   GH_ERR_LAUNCH = -3,          /* hipGetLastError() != hipSuccess after a launch */
-  GH_ERR_UNSUPPORTED = -4      /* e.g. image wider than 255 tiles, sh_degree > 3 */
+  GH_ERR_UNSUPPORTED = -4,     /* e.g. image wider than 255 tiles, sh_degree > 3 */
+  GH_ERR_ABI = -5              /* GhDims.abi != GH_ABI_TAG: the caller was built against another version of this header */
 } GhStatus;
+
+/* ABI handshake (v0.8). The structs below grow between 0.x minor versions (0.5 -> 0.7 added fields to GhInputs, GhOutputs and
+   GhGrads), and a host compiled against an older header would hand the library structs that are too short. Every entry point
+   that takes a GhDims therefore checks its FIRST field against the tag of the header the library was built from and returns
+   GH_ERR_ABI before it reads anything else; a host built against a header older than 0.8 has `P` in that place, which never
+   equals the tag. 0.x minor bumps require a recompile of the host. */
+#define GH_ABI_TAG (0x47480000u | ((uint32_t)GH_VERSION_MAJOR << 8) | (uint32_t)GH_VERSION_MINOR)   /* 'G' 'H' major minor */
 
 /* Flags for GhDims.flags */
 #define GH_FLAG_NONE 0u
@@ -74,6 +82,13 @@ typedef enum GhStatus {
                                            three 8-bit passes instead of four (the fourth would be a copy: two launches less per
                                            forward). Verified on the device before the sort; if the top byte does vary the call sets
                                            GhCounters.overflow bit 3 and returns a NaN image: re-run without the flag. */
+#define GH_FLAG_DEFER_LOSS_SUM 64u      /* with a fused image loss (GhOutputs.l1_* / fit_loss): the forward leaves the per-quadrant
+                                           partial sums in the workspace and launches NO sum kernel; *l1_loss / *fit_loss->loss is
+                                           written by the matching backward instead (GhGrads.deferred_loss, a spare workgroup of its
+                                           render kernel: the one-workgroup sum leaves the step's critical path, -4.7 us per step at
+                                           512x334). Until that backward has run the loss value is undefined; the gradients
+                                           l1_dL_dimage / fit_loss->dL_* are complete after the forward as always. Ignored without a
+                                           fused loss. */
 #define GH_FLAG_SPLIT_STREAMS 8u        /* n_views >= 2: the views are rendered as two independent halves (views [0, n/2) and
                                            [n/2, n)), the second on a HIP stream of the library's own, forked from and joined
                                            back into the caller's stream inside every call (graph-capturable): the drain of one
@@ -93,6 +108,7 @@ typedef enum GhStatus {
  *   [37..39] bg           (renderer_one_shot.py:286)
  */
 typedef struct GhDims {
+  uint32_t abi;           /* GH_ABI_TAG of the header the caller was compiled against (see above); checked first by every call */
   int32_t P;              /* Gaussians */
   int32_t n_views;        /* cameras rendered by this call (grid.z); the reference loops views in Python (:494) */
   int32_t H, W;           /* image size */
@@ -167,7 +183,7 @@ typedef struct GhOutputs {
      transmittance ended just below the 1e-4 stop needs a few more entries as soon as anything moves — possibly from the next
      surface centimetres behind; the slack entries are what it then finds. */
   uint32_t tile_depth_seen_slack;
-  /* Fused image loss (v0.7; gh_forward / gh_forward_stages only; NULL = none): the L1 term of utils.py:282-294 as bench.py and the
+  /* Fused image loss (v0.7; gh_forward / gh_forward_stages / gh_forward_refresh; NULL = none): the L1 term of utils.py:282-294 as bench.py and the
      fit loop consume the render — l1_loss[0] = mean|image - l1_target| over all n_views*3*H*W values and l1_dL_dimage =
      sign(image - l1_target) / (n_views*3*H*W) (sign(0) = 0, as torch.abs' backward), both (n_views,3,H,W) like `image` —
      produced by the render kernel's own epilogue while the pixel is still in registers: the same values gh_l1_loss computes from
@@ -175,7 +191,7 @@ typedef struct GhOutputs {
      images. Bitwise reproducible. A call the device flags as invalid (GhCounters.overflow bits 0, 1, 3) yields l1_loss = NaN and
      l1_dL_dimage = 0, like gh_l1_loss under its guard. Not available together with `alpha`, `tile_depth_seen`,
      GhInputs.tile_depth_bound or GH_FLAG_SPLIT_STREAMS (GH_ERR_UNSUPPORTED). All three pointers or none; image, l1_target and
-     l1_dL_dimage are three different arrays (GH_ERR_INVALID_ARG). */
+     l1_dL_dimage are three arrays whose byte ranges do not overlap (GH_ERR_INVALID_ARG). */
   const float* l1_target;
   float* l1_dL_dimage;
   float* l1_loss;
@@ -225,6 +241,12 @@ typedef struct GhGrads {
   const float* upstream_scale;
   float* dL_dcov3D;           /* (P,6) with GhInputs.cov3D_precomp: d(loss)/d(xx, xy, xz, yy, yz, zz) of the symmetric storage (an
                                  off-diagonal entry carries both of its matrix positions), summed over views */
+  /* v0.8, NULL = none: where the backward writes the fused image loss whose final sum the forward deferred (GH_FLAG_DEFER_LOSS_SUM
+     in that forward's GhDims.flags; the value GhOutputs.l1_loss / fit_loss->loss would have received, up to the order of the
+     fixed-order float32 sum — bitwise reproducible). Written by the render stage (gh_backward, gh_backward_refresh,
+     gh_backward_stages with GH_BWD_RENDER); not with GH_FLAG_SPLIT_STREAMS or gh_backward_shared (GH_ERR_UNSUPPORTED: those
+     forwards fuse no loss). */
+  float* deferred_loss;
 } GhGrads;
 
 /* Byte offsets of the internal arrays inside the workspace (public so tests can inspect every stage). */
@@ -289,8 +311,9 @@ typedef struct GhLayout {
   size_t render_guard;   /* uint32: the error bits of GhCounters.overflow as they stood BEFORE the render kernel of this call — written by
                             the kernel in front of it, read by every render wave through the scalar cache (the counters' own line
                             takes the render kernel's atomics) */
-  size_t loss_partials;  /* float[n_views*tiles][4]: the fused image loss's sums of |image - target| per 8x8-pixel quadrant
-                            (GhOutputs.l1_target), added up in index order by a one-workgroup kernel behind the render */
+  size_t loss_partials;  /* float[n_views*tiles][4] + 1: the fused image loss's sums of |image - target| per 8x8-pixel quadrant
+                            (GhOutputs.l1_target), added up in index order by a one-workgroup kernel behind the render (or by the
+                            backward: GH_FLAG_DEFER_LOSS_SUM); the last float is the factor of the final sum */
 } GhLayout;
 
 /* Library version: major<<16 | minor. */

@@ -284,6 +284,7 @@ static inline int f2i(float x) {
 /* ------------------------------------------------------------------------------------------- */
 int gho_forward(const GhDims* d, const GhInputs* in, const GhOutputs* out, GhoCtx** ctx_out, GhoDebug* dbg) {
   if (!d || !in || !out || !ctx_out) return GH_ERR_INVALID_ARG;
+  if (d->abi != GH_ABI_TAG) return GH_ERR_ABI;           /* (built from another version of the header than its caller) */
   if (d->P != 0 && (in->shs != NULL) == (in->colors_precomp != NULL)) return GH_ERR_INVALID_ARG;   /* (P = 0: nothing is read, the background only) */
   /* exactly one of {scales AND rotations, cov3D_precomp} (the published wrapper's second validation, App. A.0) */
   if (d->P != 0 && (((in->scales != NULL) != (in->rotations != NULL)) || ((in->scales != NULL) == (in->cov3D_precomp != NULL)))) return GH_ERR_INVALID_ARG;

@@ -27,7 +27,8 @@ class GhoDebug(C.Structure):
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "gh_oracle.c")
-    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    hdr = os.path.join(_HERE, "..", "include", "gh_raster.h")       # the oracle works on the C-ABI's own structs
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-B", "libgh_oracle.so"], check=True, capture_output=True)
     return _LIB_PATH

@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
 
   hipStream_t stream;
   CHECK(hipStreamCreate(&stream));
-  GhDims dims = {P, NV, H, W, 0, 0, 1.0f, 0u, (int64_t)4 * P * NV + 1024};
+  GhDims dims = {GH_ABI_TAG, P, NV, H, W, 0, 0, 1.0f, 0u, (int64_t)4 * P * NV + 1024};   // (v0.8: the header's tag first)
   void* ws = nullptr;
   uint32_t D = 0;
   bool fits = false;

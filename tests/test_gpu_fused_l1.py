@@ -202,3 +202,76 @@ def test_fused_fit_loss_of_an_invalid_call_is_nan_with_no_gradient(dev):
     assert torch.isnan(img).all() and torch.isnan(ctx.fit[0]) and float(ctx.fit[1].abs().max()) == 0.0 and float(ctx.fit[2].abs().max()) == 0.0
     with pytest.raises(GhOverflowError):
         check_overflow()
+
+
+# ---- the final sum inside the backward (GH_FLAG_DEFER_LOSS_SUM / GhGrads.deferred_loss, v0.8) ---------------------------------------
+@pytest.mark.parametrize("scene,nv,P", [("random1k", 1, 1000), ("one_hand", 2, 6000), ("two_hands", 8, None)])
+def test_deferred_loss_sum_is_the_forward_sum(dev, scene, nv, P):
+    """The loss value a spare workgroup of the render backward writes == the one the forward's own sum kernel writes (up to the order
+    of two fixed-order float32 sums), the gradients are untouched, and the value is bitwise reproducible. One view runs the
+    four-wave backward (the sum by 256 threads), eight views the one-wave form (64 threads)."""
+    from guassianhand_amd.rasterizer import raster_backward
+    from guassianhand_amd.scenes import make_scene
+    kw = {} if P is None else dict(P=P)
+    sc = make_scene(scene, n_views=nv, use_rgb=True, **kw)
+    s = sc.to(dev)
+    target = torch.rand(nv, 3, sc.H, sc.W, generator=torch.Generator().manual_seed(21)).to(dev)
+    img0, _, c0 = _fwd(s, target)
+    g0 = raster_backward(c0, c0.l1[1])
+    assert not c0.defer_loss
+    vals = []
+    for _ in range(2):
+        img1, _, c1 = _fwd(s, target, defer_loss=True)
+        assert c1.defer_loss and (c1.dims.flags & 64)
+        c1.l1[0].fill_(float("nan"))                     # whatever is there before the backward is not the loss
+        g1 = raster_backward(c1, c1.l1[1])
+        assert torch.equal(img1, img0) and torch.equal(c1.l1[1], c0.l1[1])
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+        vals.append(c1.l1[0].clone())
+    ref = (img0.double() - target.double()).abs().mean().item()
+    assert abs(vals[0].item() - ref) <= 2e-6 * ref and abs(vals[0].item() - c0.l1[0].item()) <= 2e-6 * ref
+    assert torch.equal(vals[0], vals[1])
+
+
+def test_deferred_loss_sum_through_the_one_node_losses(dev):
+    """rendered_l1_loss / rendered_fit_loss(defer_loss=True): same gradients as without, the loss tensor holds its value after
+    backward(); over static lists (gh_backward_refresh) too; an empty scene (no render backward at all) still gets its sum."""
+    from guassianhand_amd import rasterizer as R
+    from guassianhand_amd.loss import rendered_fit_loss, rendered_l1_loss
+    from guassianhand_amd.scenes import make_scene
+    sc = make_scene("one_hand", n_views=3, P=8000, use_rgb=True, blend=True)
+    s = sc.to(dev)
+    cams = s.cams().contiguous()
+    names = ("xyz", "opacity", "scaling", "rotation", "shs", "opacity_b", "color_w", "color_b")
+    target = torch.rand(3, 3, sc.H, sc.W, generator=torch.Generator().manual_seed(5)).to(dev)
+    gt_rgb, gt_mask, bbox = _fit_inputs(sc, 3, dev, 32, True)
+    kw = lambda p: dict(H=sc.H, W=sc.W, use_rgb=True, xyz_b=s.xyz_b, opacity_b=p["opacity_b"], color_w=p["color_w"], color_b=p["color_b"])
+    for form in ("l1", "fit", "l1_static", "fit_static"):
+        res = []
+        for defer in (False, True):
+            p = {k: getattr(s, k).clone().requires_grad_(True) for k in names}
+            cache = R.GeometryCache() if form.endswith("static") else None
+            for _step in range(2 if cache is not None else 1):        # static: build, then a refresh (the second step is the one compared)
+                for t in p.values():
+                    t.grad = None
+                args = (cams, p["xyz"], p["opacity"], p["scaling"], p["rotation"], p["shs"])
+                if form.startswith("l1"):
+                    loss = rendered_l1_loss(*args, target, geometry_cache=cache, defer_loss=defer, **kw(p))[0]
+                else:
+                    loss = rendered_fit_loss(*args, gt_rgb, gt_mask, bbox, 10.0, 1.0, 0.5, geometry_cache=cache, defer_loss=defer, **kw(p))[0]
+                (1.5 * loss).backward()
+            if cache is not None:
+                assert cache.hits == 1
+            res.append((loss.detach().clone(), {k: p[k].grad.clone() for k in names}))
+        (l0, g0), (l1_, g1) = res
+        assert abs(l0.item() - l1_.item()) <= 4e-6 * abs(l0.item()), form
+        for k in names:
+            assert torch.equal(g0[k], g1[k]), (form, k)
+    # nothing to draw: gh_backward launches no render kernel, the sum runs on its own
+    e = lambda *shape: torch.empty(*shape, device=dev, requires_grad=True)
+    tgt = torch.rand(3, 3, sc.H, sc.W, generator=torch.Generator().manual_seed(6)).to(dev)
+    loss, img, _ = rendered_l1_loss(cams, e(0, 3), e(0, 1), e(0, 3), e(0, 4), e(0, 1, 3), tgt, H=sc.H, W=sc.W, use_rgb=True, defer_loss=True)
+    loss.backward()
+    ref = (img.double() - tgt.double()).abs().mean().item()
+    assert abs(loss.item() - ref) <= 2e-6 * ref
