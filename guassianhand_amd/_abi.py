@@ -76,7 +76,7 @@ class GhAdamTensor(C.Structure):
                 ("step_state", C.c_void_p)]
 
 
-LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "depth", "rect", "clamped",
+LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "clamped",
                  "tiles_touched", "slot_begin", "depth_keys_a", "depth_keys_b", "depth_vals_a", "depth_vals_b",
                  "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "sorted_slot", "inst_r0", "inst_r1", "inst_r2",
                  "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "cull_bound", "inst_c", "attr", "half_counters", "key_bits", "tile_bound", "block_tiles", "render_guard", "loss_partials")

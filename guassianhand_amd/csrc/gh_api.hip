@@ -60,8 +60,6 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes); return o; };
   L->counters = take(sizeof(GhCounters));
   L->geom = take(N * 64);
-  L->depth = take(N * 4);
-  L->rect = take(N * 4);
   L->clamped = take(N);
   L->tiles_touched = take(N * 4);
   L->slot_begin = take(N * 4);
@@ -164,7 +162,7 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     GhLayout& o = H.L;
     o = L;
     o.counters = L.half_counters + (size_t)h * 256;
-    o.geom += n0 * 64; o.depth += n0 * 4; o.rect += n0 * 4; o.clamped += n0; o.tiles_touched += n0 * 4; o.slot_begin += n0 * 4;
+    o.geom += n0 * 64; o.clamped += n0; o.tiles_touched += n0 * 4; o.slot_begin += n0 * 4;
     o.depth_keys_a += n0 * 4; o.depth_keys_b += n0 * 4; o.depth_vals_a += n0 * 4; o.depth_vals_b += n0 * 4;
     o.block_sums += h ? (blk_a + 1) * 4 : 0;
     o.keys_a += cap0 * 4; o.keys_b += cap0 * 4; o.vals_a += cap0 * 4; o.vals_b += cap0 * 4; o.sorted_slot += cap0 * 4;

@@ -518,21 +518,25 @@ __device__ __forceinline__ uint32_t gh_kth_set_bit(uint32_t lo, uint32_t hi, uin
   return pos + ((k >= (w & 1u)) ? 1u : 0u);
 }
 
+#define GH_EMIT_MARKS 128                                // 32-bit words of run-end marks per wave: runs of up to 4,096 slots
 __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_sums, float4* __restrict__ geom,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP, uint32_t flags,
-    const float* __restrict__ tile_depth_bound, const float* __restrict__ depth) {
+    const float* __restrict__ tile_depth_bound) {
   constexpr int NW = GH_BLOCK / GH_WAVE;
   __shared__ uint32_t s_w[NW], s_p[NW];
   __shared__ uint32_t s_end[NW][GH_WAVE];               // per wave: inclusive prefix of the lanes' instance counts
   __shared__ uint4 s_g[NW][GH_WAVE];                    // (rect, hit mask lo, hi, n); rect = 0: not written by the wave
   __shared__ uint32_t s_vb[NW][GH_WAVE];                // first global tile id of the Gaussian's view
+  __shared__ __attribute__((aligned(8))) uint32_t s_marks[NW][GH_EMIT_MARKS];   // per wave: bit p = a lane's run ends at slot p of the wave's run
+  __shared__ uint2 s_own[NW][GH_WAVE];                  // by rank among the lanes that own slots: (first slot of the run, view's first tile id)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = blockIdx.x * GH_BLOCK + tid;
   const uint32_t n = i < N ? perm[i] : 0u;
   float4* grec = geom + (size_t)n * 4;
-  const uint32_t cnt = i < N ? __float_as_uint(grec[3].x) : 0u;   // instance count, rect + tile hit mask: one 64-byte line
+  const float4 g3 = grec[3];                            // (instance count, view-space depth, ..)
+  const uint32_t cnt = i < N ? __float_as_uint(g3.x) : 0u;   // instance count, rect + tile hit mask: one 64-byte line
   const float4 g2 = grec[2];
   // first emit slot of this block = sum of the per-block instance counts of all blocks before it (gh_count_sorted_kernel):
   // every block adds them up itself (a few thousand coalesced L2 reads) instead of waiting for a one-block scan kernel
@@ -551,10 +555,29 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   const uint32_t r = __float_as_uint(g2.y);
   const int minx = r & 255, miny = (r >> 8) & 255, maxx = (r >> 16) & 255, maxy = r >> 24;
   const bool small = (maxx - minx) * (maxy - miny) <= 64;               // the projection kernel kept the hit mask
-  s_end[wid][lane] = x;
-  s_g[wid][lane] = make_uint4(small && cnt ? r : 0u, __float_as_uint(g2.z), __float_as_uint(g2.w), n);
   const uint32_t vbase = (rP > 0.0f ? gh_div_small(n, (uint32_t)P, rP) : n / (uint32_t)P) * (uint32_t)tiles;   // per Gaussian, not per instance
-  s_vb[wid][lane] = vbase;
+  const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+  const bool marks = wave_total <= (uint32_t)(GH_EMIT_MARKS * 32);         // wave-uniform: which owner search the trips below use
+  if (marks) {
+    // Owner of a slot = the number of runs that END in front of it. The lanes that own slots mark the last slot of their run in a
+    // bit array over the wave's run (one LDS atomic each) and leave their record at their RANK among those lanes; a trip then reads
+    // the 64 marks of its window with one broadcast load, and a lane's owner is a running count + a popcount — where a binary
+    // search over the lanes' prefix sums took six DEPENDENT LDS reads per trip (round 5; measured -0.8 us of 23.8, not the -4 costed).
+    const bool owns = cnt != 0u;
+    const uint32_t rank = (uint32_t)__popcll(gh_ballot(owns) & ((1ull << lane) - 1ull));
+    s_marks[wid][lane] = 0u; s_marks[wid][lane + GH_WAVE] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (owns) {
+      s_g[wid][rank] = make_uint4(small ? r : 0u, __float_as_uint(g2.z), __float_as_uint(g2.w), n);
+      s_own[wid][rank] = make_uint2(x - cnt, vbase);                 // first slot of the run inside the wave's run, view's first tile id
+      atomicOr(&s_marks[wid][(x - 1u) >> 5], 1u << ((x - 1u) & 31u));
+    }
+  } else {
+    // (a wave that holds a rect of thousands of tiles: its run does not fit the mark array — a binary search over the prefix sums)
+    s_end[wid][lane] = x;
+    s_g[wid][lane] = make_uint4(small && cnt ? r : 0u, __float_as_uint(g2.z), __float_as_uint(g2.w), n);
+    s_vb[wid][lane] = vbase;
+  }
   if (lane == 63) s_w[wid] = x;
   if (lane == 0) s_p[wid] = part;
   __syncthreads();
@@ -567,24 +590,48 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     // (the projection kernel cleared the word; bits 3 / 4 may already be set; a BINNING-only re-run clears a stale bit 0)
     if (total > cap) atomicOr(&ctr->overflow, 1u); else atomicAnd(&ctr->overflow, ~1u);
   }
-  const uint32_t wave_base = blk_off + woff, wave_total = s_w[wid];
+  const uint32_t wave_base = blk_off + woff;
   // the wave's run of slots, 64 per trip
-  for (uint32_t j = 0; j < wave_total; j += GH_WAVE) {
-    const uint32_t sl = j + (uint32_t)lane;
-    if (sl >= wave_total) break;                        // (only the last trip is partial)
-    uint32_t o = 0;                                     // owner = number of lanes whose run ends at or before sl
+  if (marks) {
+    uint32_t done = 0;                                    // runs that end in front of this trip's window
+    for (uint32_t j = 0; j < wave_total; j += GH_WAVE) {
+      const uint2 w2 = *(const uint2*)&s_marks[wid][j >> 5];          // wave-uniform address: one broadcast read
+      const uint64_t wm = ((uint64_t)w2.y << 32) | w2.x;
+      const uint32_t o = done + (uint32_t)__popcll(wm & ((1ull << lane) - 1ull));
+      done += (uint32_t)__popcll(wm);
+      const uint32_t sl = j + (uint32_t)lane;
+      if (sl >= wave_total) break;                        // (only the last trip is partial)
+      const uint4 g = s_g[wid][o];
+      const uint2 ow = s_own[wid][o];
+      if (g.x == 0u) continue;                            // a large rect: written by the wave below
+      const uint32_t k = sl - ow.x;
+      const uint32_t bit = gh_kth_set_bit(g.y, g.z, k);
+      const uint32_t mnx = g.x & 255u, mny = (g.x >> 8) & 255u, wdt = ((g.x >> 16) & 255u) - mnx;
+      const uint32_t dy = (uint32_t)(((float)bit + 0.5f) * __frcp_rn((float)wdt)), dx = bit - dy * wdt;
+      const uint32_t slot = wave_base + sl;
+      if (slot < cap) {
+        keys[slot] = ow.y + (mny + dy) * (uint32_t)gx + (mnx + dx);
+        vals[slot] = g.w;                                  // the emit slot is recomputed from (n, tile) after the sort
+      }
+    }
+  } else {
+    for (uint32_t j = 0; j < wave_total; j += GH_WAVE) {
+      const uint32_t sl = j + (uint32_t)lane;
+      if (sl >= wave_total) break;
+      uint32_t o = 0;                                     // owner = number of lanes whose run ends at or before sl
 #pragma unroll
-    for (int step = 32; step >= 1; step >>= 1) if (s_end[wid][o + step - 1] <= sl) o += step;
-    const uint4 g = s_g[wid][o];
-    if (g.x == 0u) continue;                            // a large rect: written by its own lane below
-    const uint32_t k = sl - (o ? s_end[wid][o - 1] : 0u);
-    const uint32_t bit = gh_kth_set_bit(g.y, g.z, k);
-    const uint32_t mnx = g.x & 255u, mny = (g.x >> 8) & 255u, wdt = ((g.x >> 16) & 255u) - mnx;
-    const uint32_t dy = (uint32_t)(((float)bit + 0.5f) * __frcp_rn((float)wdt)), dx = bit - dy * wdt;
-    const uint32_t slot = wave_base + sl;
-    if (slot < cap) {
-      keys[slot] = s_vb[wid][o] + (mny + dy) * (uint32_t)gx + (mnx + dx);
-      vals[slot] = g.w;                                  // the emit slot is recomputed from (n, tile) after the sort
+      for (int step = 32; step >= 1; step >>= 1) if (s_end[wid][o + step - 1] <= sl) o += step;
+      const uint4 g = s_g[wid][o];
+      if (g.x == 0u) continue;
+      const uint32_t k = sl - (o ? s_end[wid][o - 1] : 0u);
+      const uint32_t bit = gh_kth_set_bit(g.y, g.z, k);
+      const uint32_t mnx = g.x & 255u, mny = (g.x >> 8) & 255u, wdt = ((g.x >> 16) & 255u) - mnx;
+      const uint32_t dy = (uint32_t)(((float)bit + 0.5f) * __frcp_rn((float)wdt)), dx = bit - dy * wdt;
+      const uint32_t slot = wave_base + sl;
+      if (slot < cap) {
+        keys[slot] = s_vb[wid][o] + (mny + dy) * (uint32_t)gx + (mnx + dx);
+        vals[slot] = g.w;
+      }
     }
   }
   // Rects larger than the hit mask: the culling test again, by the WAVE for one such Gaussian at a time (64 tiles per trip,
@@ -603,7 +650,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     const uint32_t sn_id = (uint32_t)__builtin_amdgcn_readlane((int)n, src), svb = (uint32_t)__builtin_amdgcn_readlane((int)vbase, src);
     uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)(wave_base + x - cnt), src);
     // (the speculative occlusion bound, exactly as the projection kernel applied it when it counted this Gaussian's tiles)
-    const float stz = tile_depth_bound ? bf(depth[n]) : 0.0f;
+    const float stz = bf(g3.y);
     for (uint32_t base = 0; base < sn; base += GH_WAVE) {
       const uint32_t k = base + (uint32_t)lane;
       bool h = false;
@@ -638,7 +685,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
                                                               uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin,
                                                               float rtiles, float rgx, uint32_t flags, float* __restrict__ inst_c,
-                                                              const float* __restrict__ tile_depth_bound, const float* __restrict__ depth) {
+                                                              const float* __restrict__ tile_depth_bound) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
   // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
@@ -694,7 +741,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
         const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)r, src), sbit = (uint32_t)__builtin_amdgcn_readlane((int)bit, src);
         const uint32_t sminx = sr & 255u, sminy = (sr >> 8) & 255u, sw = ((sr >> 16) & 255u) - sminx;
         // (speculative occlusion bound: the same `depth > bound` the projection and emit kernels applied)
-        const float stz = tile_depth_bound ? bf(depth[gid]) : 0.0f;
+        const float stz = tile_depth_bound ? bf(grec[3].y) : 0.0f;            // (view-space depth: the line's last float4)
         const uint32_t svb = (uint32_t)__builtin_amdgcn_readlane((int)(t - tl), src);      // first global tile id of the view
         uint32_t cnt = 0;
         for (uint32_t base = 0; base < sbit; base += GH_WAVE) {
@@ -712,7 +759,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
     } else if (!small) {                                // (the last, partial wave: lane by lane)
       uint32_t k = 0;
       const float4 bc = make_float4(b.x, (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(b.y) : b.y, 0.0f, 0.0f);   // as culled
-      const float tzl = tile_depth_bound ? depth[gid] : 0.0f;
+      const float tzl = tile_depth_bound ? grec[3].y : 0.0f;
       for (uint32_t yy = miny; yy < maxy && k < bit; ++yy)
         for (uint32_t xx = minx; xx < maxx && k < bit; ++xx, ++k) {
           bool h = gh_block_hit(a, bc, (float)(xx * GH_TILE), (float)(yy * GH_TILE), (float)(GH_TILE - 1));
@@ -805,7 +852,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
   hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
                      (const uint32_t*)(ws + L.block_sums), (float4*)(ws + L.geom), k_in, v_in, ctr,
-                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags, tile_depth_bound, (const float*)(ws + L.depth));
+                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags, tile_depth_bound);
   if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }    // the emit kernel has written D (it stores nothing past cap)
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
@@ -816,6 +863,6 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
                      (const uint32_t*)(ws + L.slot_begin),
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,   // gh_div_small's range
-                     d->flags, (float*)(ws + L.inst_c), tile_depth_bound, (const float*)(ws + L.depth));
+                     d->flags, (float*)(ws + L.inst_c), tile_depth_bound);
   gh_launch_tile_order(g, ws, L, s);
 }

@@ -29,8 +29,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_tile_bound_kernel(const float2* _
 template <bool COV>
 __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     GhInputs in, int P, int NV, int N, int H, int W, int gx, int gy, int sh_degree, int M, float mod, uint32_t flags,
-    const float4* __restrict__ sh_rgb, float4* __restrict__ geom, float* __restrict__ depth,
-    uint32_t* __restrict__ rect, uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
+    const float4* __restrict__ sh_rgb, float4* __restrict__ geom,
+    uint8_t* __restrict__ clamped, uint32_t* __restrict__ tiles_touched,
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk,
     uint2* __restrict__ key_bits, float rdiv, float* __restrict__ cull_bound_out, const float* __restrict__ tile_bound,
@@ -152,16 +152,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
       grec[1] = make_float4(g1.x, op, rgb[0], rgb[1]);
       // .y = packed tile rect, .zw = tile hit mask: the post-sort gather reads one line
       grec[2] = make_float4(rgb[2], __uint_as_float(rect_bits), __uint_as_float((unsigned)hitmask), __uint_as_float((unsigned)(hitmask >> 32)));
-      depth[n] = tz;
       dkey = __float_as_uint(tz);                     // tz > 0.2: positive floats order like their bit patterns
-      clamped[n] = (uint8_t)cl;
+      if (!in.colors_precomp) clamped[n] = (uint8_t)cl;   // (SH mode only: with precomputed colours nothing is clamped, nothing reads it)
     }
-    // .x = instance count: the emit kernel, which walks the Gaussians in depth order, finds it in the line it reads anyway
-    // (written for every Gaussian: a culled one keeps a stale line from an earlier call apart from this float4)
-    geom[(size_t)n * 4 + 3] = make_float4(__uint_as_float(tiles), 0.0f, 0.0f, 0.0f);
-    cull_bound_out[n] = cull_bound;                    // the opacity its tiles were culled with (guard of gh_forward_refresh)
+    // .x = instance count: the emit kernel, which walks the Gaussians in depth order, finds it in the line it reads anyway;
+    // .y = view-space depth, .z = the 3-sigma tile rect (0 = none) of EVERY projected Gaussian, listed or not
+    // (written for every Gaussian: a culled one keeps a stale line from an earlier call apart from this float4).
+    // Round 6: this kernel's nine 4-byte stores per thread at view-major addresses (a wave = 8 Gaussians x 8 views: eight 32-byte
+    // pieces per store) cost 0.85 us EACH at 8 views — depth and rect moved into this float4, the clamp flags are written in SH mode
+    // only and the culling opacity for lists that a refresh will re-use only: 37.9 -> 34.5 us (same-box A/B).
+    geom[(size_t)n * 4 + 3] = make_float4(__uint_as_float(tiles), tz, __uint_as_float(rect_bits), 0.0f);
+    if (flags & GH_FLAG_STATIC_LISTS) cull_bound_out[n] = cull_bound;   // the opacity its tiles were culled with (guard of gh_forward_refresh)
     tiles_touched[n] = tiles;
-    rect[n] = rect_bits;                               // 3-sigma tile rect of every projected Gaussian (0 = none)
     depth_key[n] = dkey;
     depth_val[n] = (uint32_t)n;
     if (radii) radii[n] = radius;
@@ -200,8 +202,7 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   auto kern = in->cov3D_precomp ? gh_preprocess_fwd_kernel<true> : gh_preprocess_fwd_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.NV, g.N, g.H, g.W, g.gx, g.gy,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (const float4*)(ws + L.sh_rgb), (float4*)(ws + L.geom),
-                     (float*)(ws + L.depth),
-                     (uint32_t*)(ws + L.rect), (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
+                     (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii,
                      T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk), (uint2*)(ws + L.key_bits),
                      g.N < (1 << 24) ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f,

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
     float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const uint32_t* __restrict__ render_guard,
     uint32_t guard_mask, const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
-    const uint32_t* __restrict__ sorted_gid, const float* __restrict__ depth, const GhFusedLoss l1) {
+    const uint32_t* __restrict__ sorted_gid, const float4* __restrict__ geom, const GhFusedLoss l1) {
   // LOSS: the quadrant's four wave sums meet in LDS (the last wave to arrive adds them up in block order); the arrival counter is
   // cleared behind the one barrier of the kernel, which the four waves reach as they start — before any load is in flight
   __shared__ float s_l1[GH_BLOCK / GH_WAVE];
@@ -479,9 +479,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
           const uint32_t want = sp + seen_slack;
           float seen = __uint_as_float(0x7F800000u);
           if (!unsat) {
-            if (want <= (uint32_t)total) seen = depth[sorted_gid[range.x + want - 1u]] * seen_scale;
+            if (want <= (uint32_t)total) seen = geom[(size_t)sorted_gid[range.x + want - 1u] * 4 + 3].y * seen_scale;       // (view-space depth of the Gaussian: the line's last float4)
             else if (bounded) seen = tile_depth_bound[tile] * seen_scale;     // this list was cut short itself: widen its bound
-            else seen = depth[sorted_gid[range.x + (uint32_t)total - 1u]] * seen_scale;
+            else seen = geom[(size_t)sorted_gid[range.x + (uint32_t)total - 1u] * 4 + 3].y * seen_scale;
           }
           tile_depth_seen[2 * tile] = seen;
           tile_depth_seen[2 * tile + 1] = __uint_as_float(sat_mask);
@@ -528,7 +528,7 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   // (and with nothing to project the bound kernel never ran: there is no bound to read)
   const float* bound = (wg == ws && in->tile_depth_bound && g.N > 0) ? (const float*)(ws + L.tile_bound) : nullptr;
   if (wg != ws) seen = nullptr;
-  const uint32_t* gid = (const uint32_t*)(wg + L.vals_a); const float* depth = (const float*)(wg + L.depth);
+  const uint32_t* gid = (const uint32_t*)(wg + L.vals_a); const float4* geom = (const float4*)(wg + L.geom);
   GhFusedLoss l1 = {};
   int loss_kind = 0;
   if (fused && fused->l1_target) {                   // GhOutputs.l1_*: the image loss from the kernel's own epilogue
@@ -548,7 +548,7 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
                        g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const uint32_t*)(ws + L.render_guard),
-                       wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, depth, l1);
+                       wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, geom, l1);
   };
   if (loss_kind == 1) {                              // (the entry point has ruled out alpha / seen / a bound)
     launch(gh_render_fwd_kernel<false, false, 1>);

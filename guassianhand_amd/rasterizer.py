@@ -1024,7 +1024,8 @@ def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
 
     geom = v(lay.geom, N * 64, torch.float32, N, 16)
     return dict(counters=v(lay.counters, 16, torch.int32, 4), g0=geom[:, 0:4], g1=geom[:, 4:8], gb=geom[:, 8],
-                depth=v(lay.depth, N * 4, torch.float32, N), rect=v(lay.rect, N * 4, torch.int32, N),
+                # (view-space depth and 3-sigma tile rect of every projected Gaussian: the geometry line's last float4, v0.8)
+                depth=geom[:, 13], rect=geom[:, 14].contiguous().view(torch.int32),
                 tiles_touched=v(lay.tiles_touched, N * 4, torch.int32, N), slot_begin=v(lay.slot_begin, N * 4, torch.int32, N),
                 depth_order=v(lay.depth_vals_b if (ctx.dims.flags & _abi.GH_FLAG_DEPTH24) else lay.depth_vals_a, N * 4, torch.int32, N),
                 sorted_tile=v(lay.keys_a, cap * 4, torch.int32, cap), sorted_slot=v(lay.sorted_slot, cap * 4, torch.int32, cap),

@@ -48,7 +48,7 @@ def test_workspace_layout(gh_lib_path):
     offs = [getattr(lay, f) for f in _abi.LAYOUT_FIELDS[1:]]
     assert offs == sorted(offs) and all(o % 256 == 0 for o in offs)
     assert lay.total_bytes == L.gh_workspace_bytes(C.byref(d))
-    assert lay.keys_b - lay.keys_a >= 4 * 5_000_000 and lay.depth - lay.geom >= 64 * 8 * 98562 and lay.depth_keys_b - lay.depth_keys_a >= 4 * 8 * 98562
+    assert lay.keys_b - lay.keys_a >= 4 * 5_000_000 and lay.clamped - lay.geom >= 64 * 8 * 98562 and lay.depth_keys_b - lay.depth_keys_a >= 4 * 8 * 98562
     assert lay.inst_grad + 4 * 36 * 5_000_000 <= lay.inst_flag      # 4 quadrant sub-records of 9 floats per instance
     # monotone in capacity
     d2 = _abi.GhDims(98562, 8, 512, 334, 0, 0, 1.0, 0, 6_000_000)
