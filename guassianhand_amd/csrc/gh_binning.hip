@@ -772,7 +772,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   const uint32_t rslot = slot0 + before;
   gh_stream(&sorted_slot[i], rslot < cap ? rslot : cap - 1u);           // (streamed: see gh_stream)
   const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
-  gh_stream(&r0[i], a); gh_stream(&r1[i], b); gh_stream(&r2[i], make_float2(cb, __uint_as_float(m)));
+  // the render kernels' records carry -A/2 and -C/2: their power = (A' dx dx + C' dy dy) - B dx dy is App. A.3's expression bit for
+  // bit (a scaling by a power of two commutes with every rounding) and one multiply per (entry, pixel) cheaper, forward and backward
+  gh_stream(&r0[i], make_float4(a.x, a.y, -0.5f * a.z, a.w)); gh_stream(&r1[i], make_float4(-0.5f * b.x, b.y, b.z, b.w));
+  gh_stream(&r2[i], make_float2(cb, __uint_as_float(m)));
   if (flags & GH_FLAG_STATIC_LISTS) gh_stream(&inst_c[i], b.x);   // the conic's C again, compact: what gh_forward_refresh reads of r1
 }
 

@@ -169,7 +169,7 @@ __device__ __forceinline__ void gh_pop4_high(uint64_t& mask, int& j0, int& j1, i
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
 template <bool ALPHA, bool SEEN>
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, int blk,
-                                               float pxf, float pyf, GhPixelFwd& p, float4* __restrict__ s_col) {
+                                               float& pxf, float pyf, GhPixelFwd& p, float4* __restrict__ s_col) {
   const uint32_t slot8 = (uint32_t)slot * 8u;
   // the batch's colours and opacities go through wave-private LDS memory (one 16-byte store per lane and batch, one
   // broadcast 16-byte load per trip) instead of four crossbar fetches per trip: they are needed after the exponential,
@@ -195,11 +195,15 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
     const float4 col = *(const float4*)((const char*)s_col + 4 * src);   // s_col[src >> 2]: src is 4 * lane, one shift-add
     const float r = col.x, g = col.y, bl = col.z, op = col.w;
     const float dx = gpx - pxf, dy = gpy - pyf;
-    const float power = -0.5f * (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
+    // cA, cC: the conic's A and C times -0.5, scaled once per instance by gh_ranges_kernel. Scaling by a power of two commutes with
+    // every rounding, so this IS -0.5 (A dx dx + C dy dy) - B dx dy of App. A.3 bit for bit, one multiply per (entry, pixel) cheaper.
+    const float power = (cA * dx * dx + cC * dy * dy) - cB * dx * dy;
     const float alpha = fminf(0.99f, op * gh_exp(power));          // (power > 0: rejected below, whatever this evaluates to)
+    // A finished pixel (and one outside the image) has NaN coordinates: its power is NaN, `power <= 0` fails — no test of `done`
+    // in the common path (the select below keeps the NaN out of every accumulator).
     const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
     // The recurrence collapses to DPP-fused prefix products / sums over the quad, in exact list order.
-    const bool valid = (p.done == 0) && ok;
+    const bool valid = SEEN ? (p.done == 0) && ok : ok;     // (SEEN: a stopped pixel walks on virtually with its real coordinates)
     // alpha of the entries that count, 0 for the others: ONE select serves the transmittance factor (1 - 0 == 1 exactly:
     // skipped entries leave T bit-identical) and the blend weight (0 * T == +0, C + c * 0 == C exactly)
     const float ae = valid ? alpha : 0.0f;
@@ -235,7 +239,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
           if (stopc && (qb & ((1u << slot) - 1u)) == 0u) p.stopq = (uint32_t)(4 * (base + 1)) + (uint32_t)src;
         }
       }
-      if (qb) p.done = 1;
+      if (qb) { p.done = 1; if (!SEEN) pxf = __uint_as_float(0x7FC00000u); }
       if (__all((SEEN ? p.vdone : p.done) != 0)) { finished = true; mask = 0; }   // every pixel of the block is saturated: last trip
     } else if (SEEN) {
       // pixels between their stop and their virtual stop (wave-uniform test; a few trips per pixel)
@@ -328,7 +332,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (wid & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (wid >> 1) * 4;
   const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
   const bool inside = x < W && y < H;
-  const float pxf = (float)x, pyf = (float)y;
+  float pxf = inside ? (float)x : __uint_as_float(0x7FC00000u);      // NaN = the pixel takes nothing (any more): see gh_fwd_consume
+  const float pyf = (float)y;
   // Addressing of everything per pixel: a wave-uniform base (the view's plane: scalar registers) + ONE 32-bit offset per lane. With
   // 64-bit per-lane addresses the epilogue's nine stores held eighteen address registers at once — the kernel's register peak,
   // which cost the fused-loss variant a wave per SIMD (71 VGPRs).
@@ -669,7 +674,7 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     const uint32_t pcur = pidx;
     // alpha exactly as the forward evaluated it (same expression, same gh_exp): the same entries count as blended
     const float dx = e.a.x - p1.z, dy = e.a.y - p1.w;
-    const float power = -0.5f * (e.a.z * dx * dx + e.b.x * dy * dy) - e.a.w * dx * dy;
+    const float power = (e.a.z * dx * dx + e.b.x * dy * dy) - e.a.w * dx * dy;      // (A, C carry their -0.5: see the forward)
     const float G = gh_exp(power);                              // (power > 0: `contrib` is false, G is never used)
     const float alpha = fminf(0.99f, e.b.y * G);
     const bool contrib = valid && (e.pos < __float_as_int(p1.y)) && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);
@@ -1088,9 +1093,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_instance_kernel(uint32_t 
   if (rtiles > 0.0f) { tl = t - gh_div_small(t, (uint32_t)tiles, rtiles) * (uint32_t)tiles; ty = gh_div_small(tl, (uint32_t)gx, rgx); }
   else { tl = t % (uint32_t)tiles; ty = tl / (uint32_t)gx; }
   const uint32_t tx = tl - ty * (uint32_t)gx;
+  // (inst_r0 holds -A/2 for the render kernels' power; the mask test takes the conic itself: * -2 is exact)
+  const float4 a_t = make_float4(a.x, a.y, -2.0f * a.z, a.w);
   const float4 b = make_float4(cC, at.x, at.y, at.z);
-  const uint32_t m = gh_block_mask16(a, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
-  r1[i] = b;
+  const uint32_t m = gh_block_mask16(a_t, b, (float)(tx * GH_TILE), (float)(ty * GH_TILE));
+  r1[i] = make_float4(-0.5f * cC, at.x, at.y, at.z);
   r2[i] = make_float2(at.w, __uint_as_float(m));
 }
 

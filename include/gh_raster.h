@@ -272,8 +272,9 @@ typedef struct GhLayout {
   size_t vals_a, vals_b; /* uint32[max_instances] payload view*P + gaussian; sorted result in vals_a */
   size_t sorted_slot;    /* uint32[max_instances] sorted position -> record slot (where the backward puts its sub-records): a permutation
                             of 0 .. D-1 */
-  size_t inst_r0;        /* float4[max_instances] sorted per-instance render record (px, py, conicA, conicB) */
-  size_t inst_r1;        /* float4[max_instances]                                   (conicC, opacity, r, g)  */
+  size_t inst_r0;        /* float4[max_instances] sorted per-instance render record (px, py, -conicA/2, conicB) */
+  size_t inst_r1;        /* float4[max_instances]                                   (-conicC/2, opacity, r, g): the render kernels'
+                            power is (A' dx dx + C' dy dy) - B dx dy — App. A.3's value bit for bit, one multiply cheaper (v0.8) */
   size_t inst_r2;        /* float2[max_instances]                                   (b, bits: 4x4-block mask of the tile) */
   size_t sort_tables;    /* uint32[...]        per-pass digit tables */
   size_t ranges;         /* uint2 [n_views*tiles] [start,end) into the sorted list */
