@@ -63,7 +63,7 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
                     sh_degree: int = 0, scale_modifier: float = 1.0, pixel_chunk: int = 2048,
                     return_aux: bool = False, pixel_window=None, checkpoint_chunks: bool = False,
                     ambiguity_eps: Optional[float] = None, per_gaussian_only: bool = False,
-                    cov3D_precomp: Optional[torch.Tensor] = None):
+                    cov3D_precomp: Optional[torch.Tensor] = None, per_gaussian_graph: bool = False):
     """Returns (image (3,H,W), radii (P,) int32[, aux dict]).
     pixel_window = (x0, y0, x1, y1): evaluate only the pixels x0 <= x < x1, y0 <= y < y1 of the H x W image (the image
     returned is (3, y1-y0, x1-x0)); everything else — projection, tile rects, tile membership of a pixel — is that of the
@@ -76,7 +76,10 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
     another precision may legitimately decide differently: returns (image, radii, ambiguous).
     per_gaussian_only: stop after the per-Gaussian stage (App. A.1) — O(P), no pixel is evaluated — and return (None, radii, aux)
     with the projected centre, depth, conic, colour, validity, tile rect and the quantities the discrete decisions are taken on
-    (3 sqrt(lambda_max) before the ceil, the rect bounds before the truncation, the SH colour before the clamp)."""
+    (3 sqrt(lambda_max) before the ceil, the rect bounds before the truncation, the SH colour before the clamp).
+    per_gaussian_graph (with per_gaussian_only): aux["diff"] additionally holds the stage's continuous outputs WITH their autograd
+    graph — px, py, conic (P,3) = (A, B, C), opacity, rgb — so that a caller can push an upstream gradient w.r.t. them back to
+    the inputs: the chain rule of App. A.5 as a float64 VJP, O(P), no pixel evaluated (tests/test_gpu_oracle_a_stage.py)."""
     if (shs is None) == (colors_precomp is None):
         raise ValueError("provide exactly one of shs / colors_precomp")
     dt, dev = means3D.dtype, means3D.device
@@ -155,6 +158,8 @@ def rasterize_dense(means3D, opacities, scales, rotations, *, viewmatrix, projma
                        cov=torch.stack([a, b, c], -1).detach(), rgb=rgb.detach(), rgb_raw=None if rgb_raw is None else rgb_raw.detach(),
                        valid=valid, rect=torch.stack([minx, miny, maxx, maxy], -1), radius_f=r_f, rect_edges=edges,
                        opacity=opacities.reshape(-1).to(dt).detach())
+        if per_gaussian_graph:
+            aux["diff"] = dict(px=px, py=py, conic=torch.stack([cA, cB, cC], -1), opacity=opacities.reshape(-1).to(dt), rgb=rgb)
         return None, radii, aux
 
     # depth order, stable, ties by index (App. A.2); invalid Gaussians pushed to the end
