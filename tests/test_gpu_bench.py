@@ -89,6 +89,26 @@ def test_bench_two_ranks_equal_the_single_process_run():
 
 
 @pytest.mark.timeout(900)
+def test_bench_four_ranks_of_one_view_each_equal_the_single_process_run():
+    """configs[3]'s shape on its way to 8 GPUs — ONE view per rank: the four-wave render backward, the one-view
+    binning classes (1024-digit tile partition, 4 keys per thread) and an all-reduce of the gradient block over more than two ranks,
+    equal to the single-process run over the same cameras. Four ranks, not eight: a GPU box admits at most six processes on its
+    card (this pytest process is one of them), so the 8 x 1-view split cannot run on one GPU; 4 x 1 exercises every code path
+    that 8 x 1 does — the day an 8-GPU node exists the only new thing is RCCL itself."""
+    one = _run_bench(1, "--views-per-step", "4")
+    L1, G1 = one["config"]["final_loss"], one["config"]["grad_l1"]
+    strong = _run_bench(4, "--views-per-step", "4", "--scaling", "strong", "--allreduce-grads")
+    c = strong["config"]
+    assert strong["n_gpus"] == 4 and strong["scaling"] == "strong" and c["views_per_step_per_gpu"] == 1 and c["views_per_step_total"] == 4
+    assert c["ranks"]["world_size"] == 4 and c["ranks"]["answered_all_reduce"] == 4 and c["collective"] == "all-reduce(loss + gradient block)"
+    # every rank's loss is the mean over its one view: their sum is four times the 4-view mean; likewise the summed gradients
+    assert c["final_loss"] == pytest.approx(4 * L1, rel=1e-5)
+    assert c["grad_l1"] == pytest.approx(4 * G1, rel=1e-4)
+    weak = _run_bench(4, "--views-per-step", "1")
+    assert weak["config"]["views_per_step_total"] == 4 and weak["config"]["final_loss"] == pytest.approx(4 * L1, rel=1e-5)
+
+
+@pytest.mark.timeout(900)
 def test_bench_two_gpus_over_rccl():
     """the driver's N > 1 launch line with the real backend ("nccl" = RCCL over xGMI), one rank per GPU —
     runs wherever the box has two GPUs, so the first multi-GPU lease exercises RCCL in the test suite; skipped on one GPU."""
