@@ -208,19 +208,26 @@ def cpu_baseline(scene, seconds: float, torch_reference: bool = False):
                       "value = renders per second of library time; serial_fraction = library time on one thread / library time"}
 
 
-def two_call_cost(s, cams_w2c_K, n_iter: int = 30):
-    """per-view cost of the REFERENCE's protocol through the drop-in — blend in torch, then the RGB call and the
-    mask call of renderer_one_shot.py:338-346 / :372-379 through GaussianRasterizer (autograd, L1 + mask loss), forward +
-    backward — as a maintainer who changes nothing gets it. Milliseconds per view; host-bound."""
+def two_call_cost(s, view_ids, n_iter: int = 30):
+    """per-view cost of the REFERENCE's protocol through the drop-in, as a maintainer who changes nothing gets it — per view
+    the attribute blend in torch (renderer_one_shot.py:298-334), then the RGB call and the mask call of :338-346 / :372-379 through
+    GaussianRasterizer; ONE loss over the step's views (L1 + mask MSE) and ONE backward, gradients w.r.t. every Gaussian attribute
+    and blend parameter (forward_single_batch loops the views of a batch item, :494-503; the loss and its backward come once per
+    step). Returns milliseconds per view of a step over `view_ids`; host-bound.
+    ONE harness for every caller (this file's JSON line, tools/two_call_cost.py): rounds 3-5 had two — the bench's ran a backward of
+    its own after every view over nine leaves, the tool's one backward per eight views over a single leaf — and their figures for
+    "the same protocol" lay 56 % apart (profiles/r6_two_call_cost.txt)."""
     import math
     from guassianhand_amd.camera import Camera
     from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
-    w2c, K = cams_w2c_K
-    cam = Camera.from_w2c(w2c, K, s.H, s.W)
-    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
-    mk = lambda bg, deg: GaussianRasterizationSettings(
-        image_height=s.H, image_width=s.W, tanfovx=tfx, tanfovy=tfy, bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
-        projmatrix=cam.full_proj_transform.float(), sh_degree=deg, campos=cam.camera_center, prefiltered=False, debug=False)
+    settings = []
+    for v in view_ids:
+        cam = Camera.from_w2c(s.w2c[v], s.K[v], s.H, s.W)
+        tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        mk = lambda bg, deg, cam=cam, tfx=tfx, tfy=tfy: GaussianRasterizationSettings(
+            image_height=s.H, image_width=s.W, tanfovx=tfx, tanfovy=tfy, bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform.float(), sh_degree=deg, campos=cam.camera_center, prefiltered=False, debug=False)
+        settings.append(mk)
     leaves = {k: getattr(s, k).clone().requires_grad_(True) for k in ("xyz", "opacity", "scaling", "rotation", "shs", "color_w", "color_b", "opacity_b")
               if getattr(s, k) is not None}
     zero = torch.zeros(3, device=s.xyz.device)
@@ -229,27 +236,30 @@ def two_call_cost(s, cams_w2c_K, n_iter: int = 30):
     def one():
         for p in leaves.values():
             p.grad = None
-        means, op = leaves["xyz"], leaves["opacity"]
-        if "opacity_b" in leaves:
-            op = op + leaves["opacity_b"].view(-1, 1)
-        sp = torch.zeros_like(means, requires_grad=True) + 0
-        if s.use_rgb:
-            col, shs = leaves["shs"].squeeze(1), None
-            if "color_w" in leaves:
-                w = leaves["color_w"].view(-1, 16, 3)
-                col = col * w[:, 0, :] + w[:, 1, :] - 1
-            if "color_b" in leaves:
-                col = col + leaves["color_b"].view(-1, 16, 3)[:, 0, :]
-        else:
-            col, shs = None, leaves["shs"]
-            if "color_w" in leaves:
-                shs = shs * leaves["color_w"].view(-1, 16, 3)
-            if "color_b" in leaves:
-                shs = shs * leaves["color_w"].view(-1, 16, 3) + leaves["color_b"].view(-1, 16, 3)
-        kw = dict(means3D=means, means2D=sp, opacities=op, scales=leaves["scaling"], rotations=leaves["rotation"], cov3D_precomp=None)
-        img, _ = GaussianRasterizer(mk(s.bg, s.sh_degree))(shs=shs, colors_precomp=col, **kw)
-        msk, _ = GaussianRasterizer(mk(zero, 0))(colors_precomp=torch.ones_like(means), **kw)
-        ((img - gt).abs().mean() + ((msk.mean(0) - gt[0]) ** 2).mean()).backward()
+        loss = 0
+        for mk in settings:
+            means, op = leaves["xyz"], leaves["opacity"]
+            if "opacity_b" in leaves:
+                op = op + leaves["opacity_b"].view(-1, 1)
+            sp = torch.zeros_like(means, requires_grad=True) + 0
+            if s.use_rgb:
+                col, shs = leaves["shs"].squeeze(1), None
+                if "color_w" in leaves:
+                    w = leaves["color_w"].view(-1, 16, 3)
+                    col = col * w[:, 0, :] + w[:, 1, :] - 1
+                if "color_b" in leaves:
+                    col = col + leaves["color_b"].view(-1, 16, 3)[:, 0, :]
+            else:
+                col, shs = None, leaves["shs"]
+                if "color_w" in leaves:
+                    shs = shs * leaves["color_w"].view(-1, 16, 3)
+                if "color_b" in leaves:
+                    shs = shs * leaves["color_w"].view(-1, 16, 3) + leaves["color_b"].view(-1, 16, 3)
+            kw = dict(means3D=means, means2D=sp, opacities=op, scales=leaves["scaling"], rotations=leaves["rotation"], cov3D_precomp=None)
+            img, _ = GaussianRasterizer(mk(s.bg, s.sh_degree))(shs=shs, colors_precomp=col, **kw)
+            msk, _ = GaussianRasterizer(mk(zero, 0))(colors_precomp=torch.ones_like(means), **kw)
+            loss = loss + (img - gt).abs().mean() + ((msk.mean(0) - gt[0]) ** 2).mean()
+        loss.backward()
 
     import gc
     for _ in range(5):
@@ -261,7 +271,7 @@ def two_call_cost(s, cams_w2c_K, n_iter: int = 30):
     for _ in range(n_iter):
         one()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n_iter * 1e3
+    return (time.perf_counter() - t0) / n_iter * 1e3 / len(settings)
 
 
 def self_launch(n: int) -> int:
@@ -666,7 +676,8 @@ def main():
             if not args.pose_batch:
                 # the reference's own 2-call protocol through the drop-in, per view, beside the fused per-view cost —
                 # a HOST-bound figure, taken before the CPU baseline has 16 OpenMP threads spinning beside this one
-                out["config"]["two_call_ms_per_view"] = two_call_cost(s, (s.w2c[mine[0]], s.K[mine[0]]))
+                out["config"]["two_call_ms_per_view"] = two_call_cost(s, list(mine), n_iter=max(4, 30 // len(mine)))   # this step's views, one backward
+                out["config"]["two_call_ms_per_view_one_view_steps"] = two_call_cost(s, [mine[0]])      # B = 1, one view per step, a backward each
                 out["config"]["fused_ms_per_view"] = dt / args.steps * 1e3 / V
             out["cpu_baseline"] = cpu_baseline(scene_one, args.cpu_seconds, torch_reference=(args.config == "random1k"))
         else:

@@ -7,6 +7,9 @@ include/gh_raster.h describes.
 """
 from __future__ import annotations
 
+import os
+import threading
+from collections import OrderedDict
 from typing import Sequence
 
 import torch
@@ -54,29 +57,41 @@ class Camera:
         return Camera(w2c, intrinsic, FoVx, FoVy, height, width, znear, zfar)
 
 
-_pack_cache = None      # (viewmatrix, projmatrix, campos, their versions, tanfovx, tanfovy) -> 37-float prefix; strong refs, `is` compare
+_PACK_ON = os.environ.get("GH_PACK_CACHE", "1") != "0"     # (measurement A/B only)
+_PACK_MAX = 64          # records kept (a step of the reference protocol cycles through 2 x its views: RGB call + mask call each)
+_pack_lock = threading.Lock()
+_pack_cache: "OrderedDict" = OrderedDict()      # key (tensor ids, versions, tan) -> (the four tensors: strong refs keep the ids valid, record)
 
 
 def pack_camera(viewmatrix, projmatrix, campos, tanfovx, tanfovy, bg) -> torch.Tensor:
     """One GH_CAM_FLOATS record from the 12-field settings of the reference call (:281-294), built on the device without a
-    host->device copy (a pageable copy would synchronise). The reference's RGB and mask call of a view hand over the same
-    camera tensors with a different bg (:281-296, :355-370): the 37-float prefix of the previous call is reused when the
-    very same tensor objects arrive unmodified."""
-    global _pack_cache
+    host->device copy (a pageable copy would synchronise). A loop that hands over the very same, unmodified tensor objects again
+    (the same settings objects step after step; the reference's RGB and mask call of a view: same camera tensors, another bg,
+    :281-296, :355-370) gets the record it got before: a small bounded cache keyed by tensor identity + version, behind a lock
+    (round 6: it was a lock-less single entry that the alternating bg of the two calls evicted every time)."""
     dev = viewmatrix.device
     tx, ty = float(tanfovx), float(tanfovy)
-    c = _pack_cache
-    if c is not None and c[0] is viewmatrix and c[1] is projmatrix and c[2] is campos and c[3] == (viewmatrix._version, projmatrix._version, campos._version, tx, ty):
-        prefix = c[4]
-    else:
-        tf = torch.empty(2, dtype=torch.float32, device=dev)
-        tf[0].fill_(tx)
-        tf[1].fill_(ty)
-        prefix = torch.cat([viewmatrix.reshape(16).float(), projmatrix.reshape(16).float(), campos.reshape(3).float(), tf])
-        _pack_cache = (viewmatrix, projmatrix, campos, (viewmatrix._version, projmatrix._version, campos._version, tx, ty), prefix)
-    if bg.dtype is not torch.float32 or bg.device != dev or bg.dim() != 1:
-        bg = bg.reshape(3).float().to(dev)
-    return torch.cat((prefix, bg)).reshape(1, GH_CAM_FLOATS)
+    key = (id(viewmatrix), id(projmatrix), id(campos), id(bg), viewmatrix._version, projmatrix._version, campos._version, bg._version, tx, ty)
+    with _pack_lock:
+        hit = _pack_cache.get(key) if _PACK_ON else None
+        if hit is not None and hit[0] is viewmatrix and hit[1] is projmatrix and hit[2] is campos and hit[3] is bg:
+            _pack_cache.move_to_end(key)
+            return hit[4]
+    tf = torch.empty(2, dtype=torch.float32, device=dev)
+    tf[0].fill_(tx)
+    tf[1].fill_(ty)
+    b3 = bg if (bg.dtype is torch.float32 and bg.device == dev and bg.dim() == 1) else bg.reshape(3).float().to(dev)
+    rec = torch.cat([viewmatrix.reshape(16).float(), projmatrix.reshape(16).float(), campos.reshape(3).float(), tf, b3]).reshape(1, GH_CAM_FLOATS)
+    with _pack_lock:
+        _pack_cache[key] = (viewmatrix, projmatrix, campos, bg, rec)
+        while len(_pack_cache) > _PACK_MAX:
+            _pack_cache.popitem(last=False)
+    return rec
+
+
+def clear_pack_cache() -> None:
+    with _pack_lock:
+        _pack_cache.clear()
 
 
 def pack_cameras_from_w2c(w2cs: torch.Tensor, Ks: torch.Tensor, H: int, W: int, bg: torch.Tensor) -> torch.Tensor:
