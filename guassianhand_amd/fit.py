@@ -212,6 +212,10 @@ class OneShotFit(nn.Module):
                               color_b=blend["color_b"], opacity_b=blend["opacity_b"], use_rgb=self.use_rgb,
                               sh_degree=self.sh_degree, sync=sync, **kw)
 
+    def _is_depth_bound_cache(self) -> bool:
+        from . import rasterizer as R
+        return isinstance(self._geom_cache, R.DepthBoundCache)
+
     # -- one optimisation step over all cameras (sharded over ranks) ------------------------------------
     def step(self, w2cs, Ks, H: int, W: int, bg, gt_rgb, gt_mask, bbox_mask=None, sync: bool = True) -> torch.Tensor:
         """w2cs/Ks/gt_* hold ALL Nv cameras on every rank; each rank renders views v % world == rank."""
@@ -222,7 +226,7 @@ class OneShotFit(nn.Module):
         if not self.active:
             self.opt.zero_grad(set_to_none=True)
 
-        if not sync and self._geom_cache is not None and not hasattr(self._geom_cache, "ctx") and self.color_w.is_cuda:
+        if not sync and self.color_w.is_cuda and self._is_depth_bound_cache():
             # Moving geometry through a DepthBoundCache, sync-free: a miss of the speculative bound is an EXPECTED event
             # there — the device-side guard turned that step into a no-op (NaN loss, untouched parameters) and the cache dropped the
             # bound. Look at the read-backs that have arrived, count the skipped step instead of leaving it unseen until somebody
@@ -435,11 +439,11 @@ class CapturedFitStep:
     def check(self) -> None:
         """Host read-back of the captured render's counters: raises rasterizer.GhOverflowError if a replay overflowed."""
         from . import rasterizer as R
-        for counters, cap, key in self.counters:
+        for counters, cap, key, full in self.counters:
             c4 = counters.tolist()
             # stale static lists (an opacity above their bound) / GH_FLAG_DEPTH24 not holding / an instance overflow: the rasteriser
             # learns what the word says (capacity, verdicts, caches cleared) and raises the matching error
             R.report_counter_word(key, c4[1], c4[0] & 0xFFFFFFFF, cap, c4[2] & 0xFFFFFFFF, dev=counters.device,
                                   where=(" [inside the captured fit step: the next replay() rebuilds and re-captures]" if (c4[1] & 2) else
                                          " [inside the captured fit step: construct a new CapturedFitStep]" if (c4[1] & 8) else
-                                         " inside the captured fit step"))
+                                         " inside the captured fit step"), learn24=full)

@@ -218,10 +218,15 @@ def _state(dev=None) -> _DeviceState:
     return st
 
 
-def _learn_depth24(st: _DeviceState, key, flags_word: int) -> None:
-    """Update the GH_FLAG_DEPTH24 verdict of a call shape from a counter word that has been read back."""
+def _learn_depth24(st: _DeviceState, key, flags_word: int, d: int = 1) -> None:
+    """Update the GH_FLAG_DEPTH24 verdict of a call shape from a counter word that has been read back — the word of a FULL forward
+    whose depth sort ran (callers pass nothing else: a refresh, a shared call or a call with nothing to project sorted nothing, and
+    a word that says nothing must not decide anything). d: the call's instance count; with d = 0 no key took part in
+    the (OR, AND) of the key bits, so "the top byte did not vary" is vacuous and "bit 4 absent" impossible: unknown stays unknown."""
     if flags_word & 8:
         st.depth24[key] = False
+    elif d == 0:
+        return
     elif flags_word & _abi.GH_COUNTER_DEPTH24_OK:
         st.depth24.setdefault(key, True)
     elif not (flags_word & 1):             # a complete call whose depths' top byte varies (truncated lists prove nothing)
@@ -260,7 +265,7 @@ class _Pending:
                 self.miss = (c[1] & 4) != 0
                 self.wide = (c[1] & 8) != 0                    # GH_FLAG_DEPTH24 did not hold: four passes for this shape from now on
                 if self.learn24:
-                    _learn_depth24(st, self.key, c[1])
+                    _learn_depth24(st, self.key, c[1], self.d)
                 if self.miss and self.dbound is not None:      # the speculation failed: the re-run of the step renders without a bound
                     self.dbound.clear()
                     self.dbound.misses += 1
@@ -392,13 +397,15 @@ def _initial_capacity(P: int, NV: int) -> int:
     return max(1 << 16, 8 * P * NV)
 
 
-def report_counter_word(key, flags_word: int, d: int, cap: int, reserved0: int = 0, dev=None, where: str = "") -> None:
+def report_counter_word(key, flags_word: int, d: int, cap: int, reserved0: int = 0, dev=None, where: str = "", learn24: bool = True) -> None:
     """Act on a GhCounters.overflow word read back from a workspace the caller holds itself (a captured graph's, see
-    fit.CapturedFitStep.check): learn what it says (capacity, GH_FLAG_DEPTH24 verdict, stale caches) and raise the matching error."""
+    fit.CapturedFitStep.check): learn what it says (capacity, GH_FLAG_DEPTH24 verdict, stale caches) and raise the matching error.
+    learn24: the word is a FULL forward's (its depth sort ran); a refresh over static lists passes False."""
     st = _state(dev)
     with st.lock:
         st.last_D = d
-        _learn_depth24(st, key, flags_word)
+        if learn24 or (flags_word & 8):
+            _learn_depth24(st, key, flags_word, d)
         if flags_word & 2:                                  # a static-geometry replay met an opacity above its lists' bound
             GeometryCache.clear_all()
             raise GhStaleGeometryError(_STALE_MSG + where)
@@ -418,25 +425,31 @@ def check_overflow(block: bool = True, keep_recent: int = 0, dev=None) -> None:
     calls are waited for regardless (they finished long ago), which bounds how late an overflow can surface."""
     st = _state(dev)
     with st.lock:
-        for counters, cap, key in list(st.graph_counters.values()):   # graph mode: workspaces are static, read them directly
+        for counters, cap, key, full in list(st.graph_counters.values()):   # graph mode: workspaces are static, read them directly
             c4 = counters.tolist()
             report_counter_word(key, c4[1], c4[0] & 0xFFFFFFFF, cap, c4[2] & 0xFFFFFFFF, dev=st.index,
-                                where=" [inside a captured graph: capture again]" if (c4[1] & 10) else "")
-        keep, bad = [], None
+                                where=" [inside a captured graph: capture again]" if (c4[1] & 10) else "", learn24=full)
+        keep, bad = [], []
         n_old = len(st.pending) - keep_recent if keep_recent > 0 else 0
         for i, pc in enumerate(st.pending):
             if pc.done:
                 if pc.over and not pc.told:                    # resolved by somebody who did not report it (the geometry-reuse check)
-                    bad = pc
+                    bad.append(pc)
                 continue
             if not block and i >= n_old and not pc.ev.query():
                 keep.append(pc)
                 continue
             if pc.resolve():
-                bad = pc
+                bad.append(pc)
+        if bad:
+            # ONE error per call, the most severe first (ADVICE r5): stale lists / a capacity overflow ask for a rebuild or a larger
+            # workspace, an occlusion-bound miss or a depth-key verdict only for the step again; the records not reported now stay
+            # in the list (done, untold) and surface at the next check instead of being dropped.
+            sev = lambda p: 3 if p.stale else (2 if (p.over and p.d > p.cap) else (1 if p.wide and not p.miss else 0))
+            worst = max(bad, key=sev)
+            st.pending = [p for p in bad if p is not worst] + keep
+            raise worst.error()
         st.pending = keep
-        if bad is not None:
-            raise bad.error()
 
 
 # Workspace pool: a forward takes its workspace from here and the context gives it back when it dies (after its backward,
@@ -707,7 +720,7 @@ def _forward_refresh(st, L, dev, c: _Call, g0: _Ctx, return_alpha: bool, sync, e
             GeometryCache.clear_all()
             raise GhOverflowError("the static tile lists were built by a call that overflowed its capacity; caches cleared")
     elif _policy.graph_mode:
-        st.graph_counters[ws.data_ptr()] = (counters, cap, gkey)
+        st.graph_counters[ws.data_ptr()] = (counters, cap, gkey, False)       # (a refresh: no depth sort ran, nothing to learn about it)
     else:
         # a refresh whose opacity guard fired (or whose lists an overflow truncated) poisons every later step too: look at
         # the read-backs that have arrived, so that a stale loop surfaces within two calls instead of _PENDING_MAX
@@ -780,7 +793,7 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
             c4 = counters.tolist()                        # the one host read-back, as in the reference wrapper
             d = c4[0] & 0xFFFFFFFF
             st.last_D = d
-            _learn_depth24(st, key, c4[1])
+            _learn_depth24(st, key, c4[1], d)
             if c4[1] & 8:                                      # the three-pass depth sort does not cover this call's depths
                 if depth_bound is not None:
                     depth_bound.clear()
@@ -803,7 +816,7 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
         elif _policy.graph_mode:
             # every captured workspace is registered (keyed by its address, so a workspace re-used by later captures is
             # listed once); check_overflow() reads each of them
-            st.graph_counters[ws.data_ptr()] = (counters, cap, key)
+            st.graph_counters[ws.data_ptr()] = (counters, cap, key, True)
         else:
             if len(st.pending) >= _PENDING_MAX:
                 check_overflow(block=False, dev=st.index)

@@ -80,3 +80,72 @@ def test_report_counter_word_learns_and_raises():
     with pytest.raises(R.GhOverflowError, match="24 key bits"):
         R.report_counter_word(key, 8, 100, 1000, dev=97)
     assert st.depth24[key] is False
+
+
+def test_depth24_is_not_learned_from_words_that_say_nothing():
+    """a counter word without bit 4 marked a shape False for good even when no depth sort had run (a refresh over static
+    lists, a call with nothing to project: counters memset to 0). Only a full forward with D > 0 decides."""
+    st = R._DeviceState(97)
+    key = (10, 1, 16, 16, False)
+    R._learn_depth24(st, key, 0, 0)                     # nothing was listed: no key took part in the (OR, AND)
+    assert key not in st.depth24
+    R._learn_depth24(st, key, _abi.GH_COUNTER_DEPTH24_OK, 0)      # "the top byte did not vary" over zero keys is vacuous
+    assert key not in st.depth24
+    R._learn_depth24(st, key, 0, 5)
+    assert st.depth24[key] is False
+    # a graph-mode refresh registers its counters with learn24 = False: its word (no depth sort: bit 4 absent) leaves the shape alone
+    st2 = R._state(0)
+    key2 = (123456, 1, 16, 16, False)
+    st2.depth24.pop(key2, None)
+    R.report_counter_word(key2, 0, 7, 100, dev=0, learn24=False)
+    assert key2 not in st2.depth24
+    R.report_counter_word(key2, _abi.GH_COUNTER_DEPTH24_OK, 7, 100, dev=0)
+    assert st2.depth24.pop(key2) is True
+
+
+def test_check_overflow_reports_the_most_severe_record_and_keeps_the_others():
+    """with several bad records pending, check_overflow raised the LAST one and dropped the rest — a capacity overflow
+    behind a bound miss was never reported. Now: one error per call, the most severe first, the others stay for the next check."""
+    st = R._DeviceState(96)
+
+    def done(**kw):
+        pc = R._Pending(st, None, None, 100, (1, 1, 16, 16, False))
+        pc.done, pc.over = True, True
+        for k, v in kw.items():
+            setattr(pc, k, v)
+        return pc
+
+    miss, cap, stale = done(miss=True, d=10), done(d=500), done(stale=True, d=10)
+    st.pending = [cap, miss, stale]
+    R._states[96] = st
+    try:
+        with pytest.raises(R.GhStaleGeometryError):
+            R.check_overflow(dev=96)
+        assert len(st.pending) == 2
+        with pytest.raises(R.GhOverflowError) as e:
+            R.check_overflow(dev=96)
+        assert not isinstance(e.value, (R.GhDepthBoundMiss, R.GhStaleGeometryError)) and "D=500" in str(e.value)
+        with pytest.raises(R.GhDepthBoundMiss):
+            R.check_overflow(dev=96)
+        assert st.pending == []
+        R.check_overflow(dev=96)                           # nothing left
+    finally:
+        R._states.pop(96, None)
+
+
+def test_camera_record_cache_is_keyed_by_identity_and_version():
+    import torch
+    from guassianhand_amd import camera as Cm
+    Cm.clear_pack_cache()
+    V, Pm, cp, bg0, bg1 = torch.eye(4), torch.eye(4) * 2, torch.zeros(3), torch.zeros(3), torch.ones(3)
+    a = Cm.pack_camera(V, Pm, cp, 0.1, 0.2, bg0)
+    b = Cm.pack_camera(V, Pm, cp, 0.1, 0.2, bg1)            # the mask call's other bg: a second entry, not an eviction
+    assert Cm.pack_camera(V, Pm, cp, 0.1, 0.2, bg0) is a and Cm.pack_camera(V, Pm, cp, 0.1, 0.2, bg1) is b
+    assert a.shape == (1, _abi.GH_CAM_FLOATS) and torch.equal(a[0, 37:], bg0) and torch.equal(b[0, 37:], bg1) and float(a[0, 35]) == pytest.approx(0.1)
+    bg0.add_(0.5)                                           # an in-place update moves the version: a new record
+    c = Cm.pack_camera(V, Pm, cp, 0.1, 0.2, bg0)
+    assert c is not a and torch.equal(c[0, 37:], bg0)
+    assert Cm.pack_camera(V.clone(), Pm, cp, 0.1, 0.2, bg0) is not c      # another object, same values: identity decides
+    for k in range(2 * Cm._PACK_MAX):                       # bounded
+        Cm.pack_camera(V, Pm, cp, 0.1 + k, 0.2, bg1)
+    assert len(Cm._pack_cache) <= Cm._PACK_MAX
