@@ -215,6 +215,109 @@ def forward_single_batch(self, gs_hidden_features: torch.Tensor, query_points: t
             "comp_mask": out["comp_mask"], "3dgs": gs}
 
 
+# ---- forward_single_batch of the EDIT renderer (renderer_one_shot_edit.py:440-520), composed ---------------------------------------
+_EDIT_MAP_W, _EDIT_MAP_H = 2048, 1024           # the size of the colour-weight map the reference builds per call (:483)
+
+
+def edit_color_w_rows(vert_uv: torch.Tensor, color_w: torch.Tensor, duplication: bool = False) -> torch.Tensor:
+    """The per-Gaussian colour weights of the edit renderer, (N,48), without the map. The reference (renderer_one_shot_edit.py:483-493)
+    fills a 16 x 3 x 1024 x 2048 tensor of ones ON THE HOST in every call — 403 MB — writes `color_w.view(-1,16,3)[0, k]` into the left
+    half (k = 0, 1: the scale and shift of one hand) and the right half (k = 2, 3: the other hand) of its first two coefficient planes,
+    copies it to the device and samples it bilinearly at the Gaussians' UVs (query_triplane_texture: grid_sample, align_corners=True,
+    zeros outside). The map is constant inside a half, so the sample is a function of the UV alone: the four bilinear weights times
+    the left / right constant of the corner's column (and 0 for a corner outside the map) — evaluated here per Gaussian with
+    grid_sample's own arithmetic (unnormalise, floor, corner weights (x1 - x)(y1 - y).., products summed nw, ne, sw, se), O(N) on
+    the device. render_edit['duplication'] copies the right half's constants onto the left half (:491-493).
+    vert_uv: (1,N,2) in [-1, 1] (radius_texture = 1 is assumed like everywhere in the reference's configs)."""
+    uv = vert_uv.reshape(-1, 2).float()
+    w = color_w.reshape(-1, 16, 3)[0].float()                       # (16,3): rows 0..3 are used
+    left = torch.stack([w[0], w[1]], 0)                             # (2 planes, 3): coefficient planes 0 and 1, columns < 1024
+    right = torch.stack([w[2], w[3]], 0)
+    if duplication:
+        left = right
+    W, H = _EDIT_MAP_W, _EDIT_MAP_H
+    ix = ((uv[:, 0] + 1) / 2) * (W - 1)
+    iy = ((uv[:, 1] + 1) / 2) * (H - 1)
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    x1, y1 = x0 + 1, y0 + 1
+    wnw, wne, wsw, wse = (x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)
+    inx0, inx1 = (x0 >= 0) & (x0 <= W - 1), (x1 >= 0) & (x1 <= W - 1)
+    iny0, iny1 = (y0 >= 0) & (y0 <= H - 1), (y1 >= 0) & (y1 <= H - 1)
+    half = W // 2
+
+    def corner(xc, inx, iny, wt):                                   # value of a corner x its weight, (N, planes, 3); ones elsewhere are handled below
+        val = torch.where((xc < half)[:, None, None], left[None], right[None])
+        return torch.where((inx & iny)[:, None, None], val * wt[:, None, None], torch.zeros_like(val))
+
+    two = corner(x0, inx0, iny0, wnw) + corner(x1, inx1, iny0, wne) + corner(x0, inx0, iny1, wsw) + corner(x1, inx1, iny1, wse)
+    # the other 14 coefficient planes hold ones everywhere: the sample is the sum of the in-bounds corner weights
+    ones = (torch.where(inx0 & iny0, wnw, torch.zeros_like(wnw)) + torch.where(inx1 & iny0, wne, torch.zeros_like(wne)) +
+            torch.where(inx0 & iny1, wsw, torch.zeros_like(wsw)) + torch.where(inx1 & iny1, wse, torch.zeros_like(wse)))
+    out = ones[:, None, None].expand(-1, 16, 3).clone()
+    out[:, 0:2, :] = two
+    return out.reshape(-1, 48)
+
+
+def forward_single_batch_edit(self, gs_hidden_features: torch.Tensor, query_points: torch.Tensor, w2cs: torch.Tensor,
+                              intrinsics: torch.Tensor, height: int, width: int, znear, zfar,
+                              background_color: Optional[torch.Tensor], color_w=None, xyz_b=None, color_b=None, opacity_b=None,
+                              vert3d_uv=None, face_uv=None, face_uv_xy=None, render_edit=None):
+    """GS3DRenderer.forward_single_batch of the EDIT / avatar-drive renderer (renderer_one_shot_edit.py:440-520; bound by
+    config_one_shot_edit.yaml:179, config_one_shot_avatar_drive.yaml:179, config_one_shot_edit_drive.yaml:180) with the reference's
+    signature over the reference's own sub-modules, as forward_single_batch above. What differs from the one-shot renderer:
+
+        colour weights are PER GAUSSIAN: the two hands carry their own (scale, shift) pair, looked up by UV   edit_color_w_rows (:483-500)
+            -> the rasteriser's (P,48) form, GH_FLAG_BLEND_W_PER_GAUSSIAN (the reference builds and uploads a 403 MB map per call)
+        render_edit['duplication']     the right half's weights / colour biases serve both halves              (:491-493, :501-502)
+        render_edit['edit_left_only']  the colour-bias map's left half is zeroed IN PLACE, as the reference does (:499-500)
+
+    Everything else is forward_single_batch: selection, cat order, forward_gs, get_uvd, map lookups, one batched launch sequence."""
+    if color_w is None:
+        raise ValueError("the edit renderer's forward_single_batch needs color_w (renderer_one_shot_edit.py:484 reads it unconditionally)")
+    if_gs_valid = self.gs_valid(gs_hidden_features, query_points)
+    pts_valid, feat_valid, pts_copied, feat_copied = select_gaussians(if_gs_valid.squeeze(1), query_points, gs_hidden_features,
+                                                                      self.threshold_low, self.threshold_high)
+    pts_copied = self.vert_pos_refinement(feat_copied, pts_copied)
+    pts = torch.cat([pts_valid, pts_copied], dim=-2)
+    feats = torch.cat([feat_valid, feat_copied], dim=-2)
+    gs = self.forward_gs(feats, pts)
+
+    get_uvd = getattr(self, "get_uvd", None)
+    if get_uvd is None:
+        from livehand.input_encoder import get_uvd          # the reference's own dependency (renderer_one_shot_edit.py:19)
+    vert_uv, _vert_d, _ = get_uvd(pts, vert3d_uv[0], face_uv, face_uv_xy)
+    vert_uv = vert_uv.unsqueeze(0)
+    vert_uv[..., 0] = 2.0 * (vert_uv[..., 0] / 1) - 1.0
+    vert_uv[..., 1] = 2.0 * (vert_uv[..., 1] / 0.5) - 1.0
+    dup = bool(render_edit is not None and render_edit["duplication"])
+    color_w_rows = edit_color_w_rows(vert_uv, color_w, dup)
+    if color_b is not None:
+        if render_edit is not None:
+            if render_edit["edit_left_only"]:
+                color_b[..., :1024] = 0                       # (in place on the caller's map: the reference's own side effect, :500)
+            if render_edit["duplication"]:
+                color_b = torch.cat([color_b[..., 1024:], color_b[..., 1024:]], dim=-1)
+        color_b = _lookup_uv_map(self, vert_uv, color_b)
+    if opacity_b is not None:
+        opacity_b = _lookup_uv_map(self, vert_uv, opacity_b)
+
+    nv = w2cs.shape[0]
+    bg = background_color if background_color is not None else torch.zeros(3, dtype=torch.float32, device=pts.device)
+    out = render_views(GaussianModel(gs.xyz, gs.opacity, gs.rotation, gs.scaling, gs.shs), w2cs, intrinsics, int(height), int(width), bg,
+                       ret_mask=True, color_w=color_w_rows, xyz_b=xyz_b, color_b=color_b, opacity_b=opacity_b,
+                       use_rgb=bool(self.gs_net.cfg.use_rgb), sh_degree=int(self.cfg.sh_degree),
+                       scaling_modifier=float(self.cfg.scaling_modifier))
+    return {"comp_rgb": out["comp_rgb"], "comp_rgb_bg": bg.unsqueeze(0).expand(nv, -1) if nv else bg.new_zeros(0, 3),
+            "comp_mask": out["comp_mask"], "3dgs": gs}
+
+
+def fused_renderer_cls_edit(base):
+    """fused_renderer_cls for tgs.models.renderer_one_shot_edit.GS3DRenderer (three of the reference's four YAML configs bind it):
+    a subclass whose forward_single_batch is forward_single_batch_edit; `guassianhand_amd.tgs_renderer.GS3DRendererEdit`."""
+    return type(base.__name__, (base,), {"forward_single_batch": forward_single_batch_edit, "__module__": __name__,
+                                         "__doc__": f"{base.__module__}.{base.__name__} with the MI355X forward_single_batch"})
+
+
 def fused_renderer_cls(base):
     """The reference's plugin seam (`renderer_cls`, config/config_one_shot.yaml:175, resolved by tgs.find,
     tgs/__init__.py:4-9): a subclass of the given `GS3DRenderer` whose forward_single_batch is the composed MI355X path

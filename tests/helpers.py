@@ -226,3 +226,15 @@ def batch_inputs(N=400, n_views=2, H=64, W=48, map_hw=(16, 32), seed=5):
     return dict(feat=feat, pts=pts, w2cs=w2c, Ks=K, H=H, W=W, bg=torch.tensor([0.1, 0.2, 0.3]),
                 color_w=1 + 0.05 * torch.randn(48, generator=g), xyz_b=0.004 * torch.randn(3, generator=g),
                 color_b=0.05 * torch.randn(48, *map_hw, generator=g), opacity_b=0.05 * torch.randn(1, *map_hw, generator=g))
+
+
+def edit_batch_inputs(N=400, n_views=2, seed=9):
+    """batch_inputs for the EDIT renderer's forward_single_batch (renderer_one_shot_edit.py:440-520): maps 2048 texels wide (render_edit
+    slices them at column 1024), and a handful of points whose U lands between the map's columns 1023 and 1024 — the seam of the
+    two hands' colour weights, where the bilinear lookup mixes the left and the right constants."""
+    d = batch_inputs(N=N, n_views=n_views, map_hw=(8, 2048), seed=seed)
+    fr = torch.tensor([0.0, 0.125, 0.25, 0.5, 0.75, 0.999, 1.0, -0.3])
+    u = (1023.0 + fr) / 2047.0                                   # BatchStandIns.get_uvd: u = sigmoid(25 x)
+    d["pts"][:fr.numel(), 0] = torch.log(u / (1 - u)) / 25.0
+    d["feat"][:fr.numel(), 0] = 0.5                                # kept (> threshold_low), not duplicated
+    return d

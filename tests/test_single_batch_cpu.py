@@ -87,3 +87,75 @@ def test_forward_single_batch_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match="ROCm device"):
         forward_single_batch(st.namespace("cpu"), inp["feat"], inp["pts"], inp["w2cs"], inp["Ks"], inp["H"], inp["W"], 0.71, 1.42, inp["bg"],
                              vert3d_uv=[None])
+
+
+# ---- the edit / avatar-drive renderer (renderer_one_shot_edit.py:440-520) ------------------------------------------------------------
+@pytest.fixture(scope="module")
+def efx(golden_dir):
+    return np.load(os.path.join(golden_dir, "edit_batch_fixture.npz"), allow_pickle=False)
+
+
+def test_edit_colour_weight_rows_equal_the_reference_lookup(efx):
+    """renderer.edit_color_w_rows — the per-Gaussian colour weights without the 403 MB map — against what the reference's own
+    query_triplane_texture returned for the map it built (captured by tests/golden/make_edit_batch_fixture.py), incl. the eight points
+    placed on the seam between the two hands' halves (columns 1023 / 1024), with and without render_edit['duplication']."""
+    from helpers import edit_batch_inputs
+    from guassianhand_amd.renderer import edit_color_w_rows
+    assert list(efx["seam_ok"]) == [1, 1]
+    for vtag, dup, nv in (("plain", False, 2), ("dup", True, 1), ("left", False, 1)):
+        st, inp = BatchStandIns("cpu", use_rgb=True), edit_batch_inputs(n_views=nv)
+        s = inp["feat"][:, 0]
+        pts = torch.cat([inp["pts"][s > 0.1], st.vert_pos_refinement(inp["feat"][s > 0.9], inp["pts"][s > 0.9])])
+        uv, _, _ = st.get_uvd(pts, None, None, None)
+        uv = uv.unsqueeze(0).clone()
+        uv[..., 0] = 2.0 * (uv[..., 0] / 1) - 1.0
+        uv[..., 1] = 2.0 * (uv[..., 1] / 0.5) - 1.0
+        rows = edit_color_w_rows(uv, inp["color_w"], dup)
+        want = torch.tensor(efx[f"rgb_{vtag}_color_w_rows"])
+        assert rows.shape == want.shape == (pts.shape[0], 48)
+        assert float((rows - want).abs().max()) <= 3e-7, (vtag, float((rows - want).abs().max()))
+        w = inp["color_w"].view(16, 3)
+        # inside a half the weights are that hand's constants; on the seam a mix; the other 14 planes are ones
+        ix = (uv[0, :, 0] + 1) / 2 * 2047
+        left, right, seam = ix < 1023, ix >= 1024, (ix >= 1023) & (ix < 1024)
+        assert int(seam.sum()) >= 5 and int(left.sum()) > 50 and int(right.sum()) > 50
+        lw = w[2:4] if dup else w[0:2]
+        assert float((rows[left].view(-1, 16, 3)[:, 0:2] - lw).abs().max()) <= 3e-7
+        assert float((rows[right].view(-1, 16, 3)[:, 0:2] - w[2:4]).abs().max()) <= 3e-7
+        assert float((rows.view(-1, 16, 3)[:, 2:] - 1).abs().max()) <= 3e-7
+        if not dup:
+            mixed = rows[seam].view(-1, 16, 3)[:, 0, 0]
+            lo, hi = min(float(w[0, 0]), float(w[2, 0])), max(float(w[0, 0]), float(w[2, 0]))
+            assert bool(((mixed >= lo - 1e-6) & (mixed <= hi + 1e-6)).all()) and float(mixed.max() - mixed.min()) > 1e-4
+    # the gradient reaches the (48,) parameter: d rows / d color_w through the twelve entries the map holds
+    cw = edit_batch_inputs()["color_w"].clone().requires_grad_(True)
+    edit_color_w_rows(uv, cw, False).sum().backward()
+    g = cw.grad.view(16, 3)
+    assert float(g[:4].abs().min()) > 0 and float(g[4:].abs().max()) == 0.0
+
+
+def test_fused_renderer_cls_edit_overrides_only_forward_single_batch(monkeypatch):
+    import importlib
+    from guassianhand_amd.renderer import forward_single_batch_edit, fused_renderer_cls_edit
+
+    class GS3DRenderer:                                  # the attribute names of tgs.models.renderer_one_shot_edit.GS3DRenderer
+        def forward(self): return "ref forward"
+        def forward_single_batch(self, gs_hidden_features, query_points, w2cs, intrinsics, height, width, znear, zfar, background_color,
+                                 color_w=None, xyz_b=None, color_b=None, opacity_b=None, vert3d_uv=None, face_uv=None, face_uv_xy=None,
+                                 render_edit=None):
+            return "ref batch"
+
+    cls = fused_renderer_cls_edit(GS3DRenderer)
+    assert issubclass(cls, GS3DRenderer) and cls.forward_single_batch is forward_single_batch_edit and cls.forward is GS3DRenderer.forward
+    assert list(inspect.signature(forward_single_batch_edit).parameters) == list(inspect.signature(GS3DRenderer.forward_single_batch).parameters)
+    # the renderer_cls string of the three edit configs resolves like tgs.find does
+    pkg, models, mod = types.ModuleType("tgs"), types.ModuleType("tgs.models"), types.ModuleType("tgs.models.renderer_one_shot_edit")
+    mod.GS3DRenderer = GS3DRenderer
+    for name, m in (("tgs", pkg), ("tgs.models", models), ("tgs.models.renderer_one_shot_edit", mod)):
+        monkeypatch.setitem(sys.modules, name, m)
+    import guassianhand_amd.tgs_renderer as tr
+    monkeypatch.setattr(tr, "_cache", {})
+    cls_string = "guassianhand_amd.tgs_renderer.GS3DRendererEdit"
+    module = importlib.import_module(".".join(cls_string.split(".")[:-1]), package=None)
+    got = getattr(module, cls_string.split(".")[-1])
+    assert issubclass(got, GS3DRenderer) and got.forward_single_batch is forward_single_batch_edit
