@@ -624,18 +624,22 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
   }
   __syncthreads();
   if (threadIdx.x < 64 && (red_w || red_x))
-    scratch[(size_t)blockIdx.x * 64 + threadIdx.x] =
+    scratch[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
         s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
 }
 
 // Second stage of the blend-parameter reduction: one block per slot, fixed-order sum over the per-block
-// partials (strided per thread, DPP per wave, 4 waves in order) => bitwise reproducible.
+// partials (strided per thread, DPP per wave, 4 waves in order) => bitwise reproducible. scratch: [64 slots][nblk] (the writers'
+// grid size = nblk).
 __global__ __launch_bounds__(GH_BLOCK) void gh_blend_reduce_kernel(const float* __restrict__ scratch, int nblk,
                                                                     float* __restrict__ d_w, float* __restrict__ d_xyz) {
   __shared__ float s_w[GH_BLOCK / GH_WAVE];
   const int t = blockIdx.x;      // slot 0..50
   float s = 0.0f;
-  for (int b = threadIdx.x; b < nblk; b += GH_BLOCK) s += scratch[(size_t)b * 64 + t];
+  // (slot-major partials, scratch[slot][block]: this block's row is contiguous — with the block-major layout of rounds 1-5 every
+  //  load of the wave touched 64 different lines, 20 MB of line traffic for 0.6 MB of partials; the per-thread order of the sum is
+  //  unchanged, so the result is the same bit for bit)
+  for (int b = threadIdx.x; b < nblk; b += GH_BLOCK) s += scratch[(size_t)t * nblk + b];
   s = gh_wave_sum_to63(s);
   if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = s;
   __syncthreads();

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd_kernel(
     if (threadIdx.x < 64) {
       float s = 0.0f;
       if (threadIdx.x < 48) for (int r = 0; r < GH_BLOCK / 16; ++r) s += s_cw[r][threadIdx.x];
-      scratch[(size_t)blockIdx.x * 64 + threadIdx.x] = s;
+      scratch[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = s;
     }
   }
 }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_sh_colour_bwd2_kernel(
     if (tid < 64) {
       float sum = 0.0f;
       if (tid < 48) for (int r = 0; r < GH_BLOCK / 16; ++r) sum += s_cw[r][tid];
-      scratch[(size_t)blockIdx.x * 64 + tid] = sum;
+      scratch[(size_t)tid * gridDim.x + blockIdx.x] = sum;
     }
   }
 }
