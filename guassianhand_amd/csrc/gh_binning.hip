@@ -459,21 +459,34 @@ void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*
 
 // ------------------------------------------------------------------------------------------------
 // Level 2: walk the Gaussians in depth order.
-// Per-block sums of tiles-touched in depth-sorted order (the emit kernel's slot scan) — and, in the same launch, the RECORD slots:
-// thread i here is thread i of the projection kernel (same block size), whose blocks left their instance counts in block_tiles;
-// every block adds up the counts of the blocks before it (coalesced L2 reads) and scans its own 256 counts, so slot_begin[n]
-// = number of instances of all (view, Gaussian) pairs in front of n in the projection kernel's thread order. The backward's
-// sub-records live there: the chain-rule kernel walks the pairs in that order and reads one contiguous stretch per wave.
-__global__ __launch_bounds__(GH_BLOCK) void gh_count_sorted_kernel(int N, int P, int NV, float rdiv, const uint32_t* __restrict__ perm,
+// Per-block sums of tiles-touched in depth-sorted order (the emit kernel's slot scan).
+__global__ __launch_bounds__(GH_BLOCK) void gh_count_sorted_kernel(int N, const uint32_t* __restrict__ perm,
                                                                     const uint32_t* __restrict__ tiles_touched,
-                                                                    uint32_t* __restrict__ block_sums,
-                                                                    const uint32_t* __restrict__ block_tiles,
-                                                                    uint32_t* __restrict__ slot_begin) {
+                                                                    uint32_t* __restrict__ block_sums) {
   __shared__ unsigned s_wsum[GH_BLOCK / GH_WAVE];
-  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE], s_p[GH_BLOCK / GH_WAVE];
   const int tid = threadIdx.x;
   const int i = blockIdx.x * GH_BLOCK + tid;
   const unsigned c = i < N ? tiles_touched[perm[i]] : 0u;
+  const unsigned ws = gh_wave_sum_u32(c);
+  if ((tid & 63) == 0) s_wsum[tid >> 6] = ws;
+  __syncthreads();
+  if (tid == 0) block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+}
+
+// The RECORD slots (where the backward puts its sub-records): thread i here is thread i of the projection kernel (same block
+// size), whose blocks left their instance counts in block_tiles; every block adds up the counts of the blocks before it (coalesced
+// L2 reads) and scans its own 256 counts, so slot_begin[n] = number of instances of all (view, Gaussian) pairs in front of n in the
+// projection kernel's thread order: the chain-rule kernel walks the pairs in that order and reads one contiguous stretch per wave.
+// Runs as SPARE workgroups of gh_emit_kernel (round 6): nothing on the way to the emit reads the slots — their first reader is
+// gh_ranges_kernel, four launches on — so the numbering costs gh_count_sorted_kernel's critical path nothing (10.6 -> 6.x us) and
+// rides in the emit kernel's latency gaps. (Folding the scan into the projection kernel instead cost that kernel 3 us and
+// gh_ranges_kernel 1.4-3.3 us for the extra gather: measured, App. R6.)
+__device__ __forceinline__ void gh_number_record_slots(uint32_t blk, int N, int P, int NV, float rdiv,
+                                                       const uint32_t* __restrict__ tiles_touched,
+                                                       const uint32_t* __restrict__ block_tiles, uint32_t* __restrict__ slot_begin) {
+  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE], s_p[GH_BLOCK / GH_WAVE];
+  const int tid = threadIdx.x;
+  const int i = (int)blk * GH_BLOCK + tid;
   // (view, Gaussian) of projection thread i: Gaussian-major, views adjacent (NV == 0: row-major, the pose batch)
   uint32_t n = 0u;
   if (i < N) {
@@ -482,7 +495,6 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_count_sorted_kernel(int N, int P,
   }
   const uint32_t ct = i < N ? tiles_touched[n] : 0u;
   uint32_t part = 0;
-  const uint32_t blk = blockIdx.x;
   for (uint32_t b = tid; b < blk; b += 4 * GH_BLOCK) {
     const uint32_t b1 = b + GH_BLOCK, b2 = b + 2 * GH_BLOCK, b3 = b + 3 * GH_BLOCK;    // four loads in flight per trip
     const uint32_t v0 = block_tiles[b], v1 = b1 < blk ? block_tiles[b1] : 0u, v2 = b2 < blk ? block_tiles[b2] : 0u,
@@ -490,11 +502,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_count_sorted_kernel(int N, int P,
     part += (v0 + v1) + (v2 + v3);
   }
   part = gh_wave_sum_u32(part);
-  const unsigned ws = gh_wave_sum_u32(c);
-  if ((tid & 63) == 0) { s_wsum[tid >> 6] = ws; s_p[tid >> 6] = part; }
+  if ((tid & 63) == 0) s_p[tid >> 6] = part;
   uint32_t total;
-  const uint32_t excl = gh_block_excl_scan(ct, s_w, &total);        // (two barriers: s_wsum / s_p are visible behind them)
-  if (tid == 0) block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+  const uint32_t excl = gh_block_excl_scan(ct, s_w, &total);        // (two barriers: s_p is visible behind them)
   if (i < N) slot_begin[n] = ((s_p[0] + s_p[1]) + (s_p[2] + s_p[3])) + excl;
 }
 
@@ -523,8 +533,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     int N, int P, int gx, int tiles, uint32_t cap, const uint32_t* __restrict__ perm, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_sums, float4* __restrict__ geom,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP, uint32_t flags,
-    const float* __restrict__ tile_depth_bound) {
+    const float* __restrict__ tile_depth_bound, int n_emit_blocks, int NVs, float rdiv, const uint32_t* __restrict__ block_tiles,
+    uint32_t* __restrict__ slot_begin) {
   constexpr int NW = GH_BLOCK / GH_WAVE;
+  if ((int)blockIdx.x >= n_emit_blocks) {               // the spare workgroups: the record-slot numbering (see gh_number_record_slots)
+    gh_number_record_slots(blockIdx.x - (uint32_t)n_emit_blocks, N, P, NVs, rdiv, tiles_touched, block_tiles, slot_begin);
+    return;
+  }
   __shared__ uint32_t s_w[NW], s_p[NW];
   __shared__ uint32_t s_end[NW][GH_WAVE];               // per wave: inclusive prefix of the lanes' instance counts
   __shared__ uint4 s_g[NW][GH_WAVE];                    // (rect, hit mask lo, hi, n); rect = 0: not written by the wave
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   uint32_t woff = 0, blk_off = 0, blk_sum = 0;
 #pragma unroll
   for (int w = 0; w < NW; ++w) { if (w < wid) woff += s_w[w]; blk_sum += s_w[w]; blk_off += s_p[w]; }
-  if (blockIdx.x == gridDim.x - 1 && tid == 0) {        // the last block knows the instance total D
+  if ((int)blockIdx.x == n_emit_blocks - 1 && tid == 0) {        // the last emit block knows the instance total D
     const uint32_t total = blk_off + blk_sum;
     ctr->num_rendered = total;
     // (the projection kernel cleared the word; bits 3 / 4 may already be set; a BINNING-only re-run clears a stale bit 0)
@@ -843,9 +858,8 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   // level 2: emit in depth order
   const uint32_t* tiles_touched = (const uint32_t*)(ws + L.tiles_touched);
   const bool per_view = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
-  hipLaunchKernelGGL(gh_count_sorted_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, per_view ? 0 : g.NV,
-                     g.N < (1 << 24) && !per_view ? 1.0f / (float)g.NV : 0.0f, perm, tiles_touched,
-                     (uint32_t*)(ws + L.block_sums), (const uint32_t*)(ws + L.block_tiles), (uint32_t*)(ws + L.slot_begin));
+  hipLaunchKernelGGL(gh_count_sorted_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, perm, tiles_touched,
+                     (uint32_t*)(ws + L.block_sums));
   // level 3: stable partition by tile id; an odd number of passes starts in the b buffers so the result is in *_a
   const int tile_passes = gh_radix_passes((size_t)g.cap, g.tile_bits);
   uint32_t* ka = (uint32_t*)(ws + L.keys_a); uint32_t* kb = (uint32_t*)(ws + L.keys_b);
@@ -853,9 +867,12 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   const bool start_b = (tile_passes & 1) != 0;
   uint32_t* k_in = start_b ? kb : ka; uint32_t* k_out = start_b ? ka : kb;
   uint32_t* v_in = start_b ? vb : va; uint32_t* v_out = start_b ? va : vb;
-  hipLaunchKernelGGL(gh_emit_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
+  // (grid: the emit blocks, then as many spare blocks that number the record slots in the projection kernel's thread order)
+  hipLaunchKernelGGL(gh_emit_kernel, dim3(2 * nblk_pre), dim3(GH_BLOCK), 0, s, g.N, g.P, g.gx, g.tiles, cap, perm, tiles_touched,
                      (const uint32_t*)(ws + L.block_sums), (float4*)(ws + L.geom), k_in, v_in, ctr,
-                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags, tile_depth_bound);
+                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags, tile_depth_bound, nblk_pre, per_view ? 0 : g.NV,
+                     g.N < (1 << 24) && !per_view ? 1.0f / (float)g.NV : 0.0f, (const uint32_t*)(ws + L.block_tiles),
+                     (uint32_t*)(ws + L.slot_begin));
   if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }    // the emit kernel has written D (it stores nothing past cap)
   gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
