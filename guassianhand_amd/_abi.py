@@ -79,7 +79,7 @@ class GhAdamTensor(C.Structure):
 LAYOUT_FIELDS = ("total_bytes", "counters", "geom", "clamped",
                  "tiles_touched", "slot_begin", "depth_keys_a", "depth_keys_b", "depth_vals_a", "depth_vals_b",
                  "block_sums", "keys_a", "keys_b", "vals_a", "vals_b", "sorted_slot", "inst_r0", "inst_r1", "inst_r2",
-                 "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "cull_bound", "inst_c", "attr", "half_counters", "key_bits", "tile_bound", "block_tiles", "render_guard", "loss_partials")
+                 "sort_tables", "ranges", "tile_walk", "tile_order", "bwd_items", "ckpt_rgb", "final_C", "final_T", "n_contrib", "inst_grad", "inst_flag", "sh_rgb", "dmean_sh", "sh_scratch", "grad_sums", "bwd_scratch", "cull_bound", "inst_c", "attr", "half_counters", "key_bits", "tile_bound", "block_tiles", "render_guard", "loss_partials", "view_start")
 
 
 class GhLayout(C.Structure):
@@ -98,6 +98,8 @@ def declare(lib: C.CDLL) -> None:
     lib.gh_workspace_layout.argtypes = [C.POINTER(GhDims), C.POINTER(GhLayout)]
     lib.gh_workspace_bytes.restype = C.c_size_t
     lib.gh_workspace_bytes.argtypes = [C.POINTER(GhDims)]
+    lib.gh_partition_is_per_view.restype = C.c_int
+    lib.gh_partition_is_per_view.argtypes = [C.POINTER(GhDims)]
     lib.gh_forward.restype = C.c_int
     lib.gh_forward.argtypes = [C.POINTER(GhDims), C.POINTER(GhInputs), C.POINTER(GhOutputs),
                                C.c_void_p, C.c_size_t, C.c_void_p]
@@ -167,7 +169,7 @@ def declare(lib: C.CDLL) -> None:
 GH_FWD_PREPROCESS, GH_FWD_BINNING, GH_FWD_RENDER, GH_FWD_ALL = 1, 2, 4, 7
 GH_BWD_RENDER, GH_BWD_PREPROCESS, GH_BWD_ALL = 1, 2, 3
 
-EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_forward", "gh_backward",
+EXPORTED_SYMBOLS = ("gh_version", "gh_workspace_layout", "gh_workspace_bytes", "gh_partition_is_per_view", "gh_forward", "gh_backward",
                     "gh_forward_stages", "gh_backward_stages", "gh_forward_shared", "gh_backward_shared", "gh_forward_refresh", "gh_backward_refresh", "gh_uv_sample_forward", "gh_uv_sample_backward",
                     "gh_uv_gather_forward", "gh_uv_gather_backward", "gh_uv_scatter_sorted", "gh_adam_reg_step", "gh_reg_total", "gh_adam_reg_step_group", "gh_uv_gather_forward2", "gh_uv_scatter_sorted2",
                     "gh_knn_workspace_bytes", "gh_knn_indices", "gh_knn_mismatch_mask", "gh_l1_loss", "gh_fit_loss",

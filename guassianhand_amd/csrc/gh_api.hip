@@ -41,7 +41,7 @@ static GhDims gh_half_dims(const GhDims* d, int h, int* v0, size_t* cap0) {
 
 static size_t gh_sort_table_words(const GhGrid& g) {
   const size_t tab_n = gh_radix_table_words((size_t)g.P, g.NV);          // per-view depth sort: NV segments of P keys
-  const size_t tab_d = gh_radix_table_words((size_t)g.cap);
+  const size_t tab_d = gh_radix_table_words((size_t)g.cap) + 512 * (size_t)g.NV;      // (+ the per-view partition's extra blocks and totals)
   return tab_n > tab_d ? tab_n : tab_d;
 }
 
@@ -113,6 +113,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->block_tiles = take((gh_proj_blocks(g) + 4) * 4);     // (two halves: + 1 block of rounding + 1 spare word each)
   L->render_guard = take(512);                            // one word (+ a second, 256 bytes on, for the other half of a split call)
   L->loss_partials = take((size_t)g.NV * g.tiles * 4 * 4 + 16);   // (+ the factor of the final sum, behind the last partial)
+  L->view_start = take(((size_t)g.NV + 2) * 4);           // (a split call: each half's n_views + 1 bounds, the second half's behind the first's)
   L->total_bytes = off;
   return GH_OK;
 }
@@ -121,6 +122,17 @@ extern "C" size_t gh_workspace_bytes(const GhDims* d) {
   GhLayout L;
   if (gh_workspace_layout(d, &L) != GH_OK) return 0;
   return L.total_bytes;
+}
+
+extern "C" int gh_partition_is_per_view(const GhDims* d) {
+  const int rc = check_dims(d);
+  if (rc != GH_OK) return rc;
+  if (gh_split_on(d)) {                                  // the halves decide for themselves; a caller that inspects them asks per half
+    int v0; size_t c0;
+    const GhDims da = gh_half_dims(d, 0, &v0, &c0);
+    return gh_partition_per_view(gh_make_grid(&da)) ? 1 : 0;
+  }
+  return gh_partition_per_view(gh_make_grid(d)) ? 1 : 0;
 }
 
 static int check_inputs(const GhDims* d, const GhInputs* in) {
@@ -178,6 +190,7 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     o.key_bits += h ? (proj_a + 1) * 8 : 0;
     o.block_tiles += h ? (proj_a + 1) * 4 : 0;
     o.render_guard += (size_t)h * 256;
+    o.view_start += h ? ((size_t)hv[0].d.n_views + 1) * 4 : 0;
     o.tile_bound += t0 * 4;
     if (h == 0) {
       blk_a = ((size_t)H.g.N + GH_BLOCK - 1) / GH_BLOCK; items_a = (size_t)H.g.n_items; tab_a = gh_sort_table_words(H.g);

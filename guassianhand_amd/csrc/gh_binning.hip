@@ -31,6 +31,33 @@ __device__ __forceinline__ uint32_t gh_seg_count(const uint32_t* n_ptr, uint32_t
   return seg_len ? seg_len : gh_clamp_n(n_ptr, cap);
 }
 
+// Third shape (round 6): `nseg` segments of VARIABLE length whose bounds live in device memory — vstart[0 .. nseg], ascending,
+// clamped to cap here — the per-view tile partition: view v's instances are emit slots [vstart[v], vstart[v+1]). The grid is one
+// row of ceil(cap / tile) + nseg blocks; block b finds its segment by walking the bounds (wave-uniform scalar loads, nseg <= a few
+// dozen); the digit tables are indexed by the GLOBAL block number b, the per-digit totals by (segment, digit).
+struct GhVarSeg { uint32_t seg, lb, n, s0, gb0, nb; };   // segment, block inside it, its element count / first element / first global block / blocks
+__device__ __forceinline__ bool gh_var_seg_of_block(const uint32_t* __restrict__ vstart, int nseg, uint32_t cap, uint32_t tile,
+                                                    uint32_t b, GhVarSeg& o) {
+  uint32_t acc = 0, a = vstart[0] < cap ? vstart[0] : cap;
+  for (int v = 0; v < nseg; ++v) {
+    uint32_t e = vstart[v + 1]; e = e < cap ? e : cap; e = e < a ? a : e;
+    const uint32_t nb = (e - a + tile - 1u) / tile;
+    if (b < acc + nb) { o.seg = (uint32_t)v; o.lb = b - acc; o.n = e - a; o.s0 = a; o.gb0 = acc; o.nb = nb; return true; }
+    acc += nb; a = e;
+  }
+  return false;
+}
+__device__ __forceinline__ void gh_var_seg_of_index(const uint32_t* __restrict__ vstart, int nseg, uint32_t cap, uint32_t tile,
+                                                    uint32_t seg, GhVarSeg& o) {
+  uint32_t acc = 0, a = vstart[0] < cap ? vstart[0] : cap;
+  for (int v = 0; v <= (int)seg; ++v) {
+    uint32_t e = vstart[v + 1]; e = e < cap ? e : cap; e = e < a ? a : e;
+    const uint32_t nb = (e - a + tile - 1u) / tile;
+    if (v == (int)seg) { o.seg = seg; o.lb = 0; o.n = e - a; o.s0 = a; o.gb0 = acc; o.nb = nb; return; }
+    acc += nb; a = e;
+  }
+}
+
 // Exclusive scan of one value per thread over the block (thread order); returns the prefix, *total = block sum.
 // s_w: GH_BLOCK / GH_WAVE words of LDS. Contains two barriers.
 __device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
@@ -82,13 +109,20 @@ template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
                                                                   uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
                                                                   uint32_t* __restrict__ table, const uint2* __restrict__ key_bits,
-                                                                  int n_bits, uint32_t* __restrict__ wide_flag, int total_bits) {
+                                                                  int n_bits, uint32_t* __restrict__ wide_flag, int total_bits,
+                                                                  const uint32_t* __restrict__ vstart, int nseg) {
   __shared__ uint32_t s_hist[MAXD];
   if (key_bits && shift == 0 && blockIdx.x == 0 && blockIdx.y == 0) gh_store_varying_bits((uint2*)key_bits, n_bits, wide_flag, total_bits <= 24);
   if (!gh_digit_varies(key_bits, n_bits, shift, dmask)) return;       // the scatter of this pass is a plain copy
-  const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
-  const uint32_t seg = blockIdx.y, nblk = gridDim.x, ndig = dmask + 1u;
-  const uint32_t base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
+  uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
+  uint32_t seg = blockIdx.y;
+  const uint32_t nblk = gridDim.x, ndig = dmask + 1u;
+  uint32_t base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
+  if (vstart) {                                          // variable segments: this block's segment; tables by global block number
+    GhVarSeg vs;
+    if (!gh_var_seg_of_block(vstart, nseg, cap, (uint32_t)(GH_BLOCK * ITEMS), blockIdx.x, vs)) return;
+    n = vs.n; base = vs.lb * (uint32_t)(GH_BLOCK * ITEMS); keys += vs.s0; seg = 0u;
+  }
   if (base >= n) return;
   keys += (size_t)seg * seg_len;
   uint32_t k[ITEMS];                                       // loads in flight while the counters are cleared
@@ -124,14 +158,20 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_hist_kernel(const uint32_t*
 template <int ITEMS>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scan_kernel(uint32_t* __restrict__ table, uint32_t* __restrict__ tot,
                                                                   const uint32_t* __restrict__ n_ptr, uint32_t cap, uint32_t seg_len,
-                                                                  int nblk_cap) {
+                                                                  int nblk_cap, const uint32_t* __restrict__ vstart, int nseg) {
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   __shared__ uint32_t s_carry;
   const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
-  const int nblk = (int)((n + (GH_BLOCK * ITEMS) - 1) / (GH_BLOCK * ITEMS));
+  int nblk = (int)((n + (GH_BLOCK * ITEMS) - 1) / (GH_BLOCK * ITEMS));
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const size_t rowi = (size_t)blockIdx.y * gridDim.x + blockIdx.x;       // seg * ndig + digit
   uint32_t* row = table + rowi * nblk_cap;
+  if (vstart) {                                          // variable segments: the digit's row over the segment's own blocks
+    GhVarSeg vs;
+    gh_var_seg_of_index(vstart, nseg, cap, (uint32_t)(GH_BLOCK * ITEMS), blockIdx.y, vs);
+    row = table + (size_t)blockIdx.x * nblk_cap + vs.gb0;
+    nblk = (int)vs.nb;
+  }
   if (tid == 0) s_carry = 0;
   __syncthreads();
   for (int base = 0; base < nblk; base += 4 * GH_BLOCK) {
@@ -172,7 +212,8 @@ template <int ITEMS, int MAXD, bool SELF>
 __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
     uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ n_ptr, uint32_t cap, uint32_t seg_len, int shift, uint32_t dmask,
-    int nbit, const uint32_t* __restrict__ table, const uint32_t* __restrict__ tot, const uint2* __restrict__ key_bits, int n_bits) {
+    int nbit, const uint32_t* __restrict__ table, const uint32_t* __restrict__ tot, const uint2* __restrict__ key_bits, int n_bits,
+    const uint32_t* __restrict__ vstart, int nseg) {
   constexpr int DPT = MAXD / GH_BLOCK;
   constexpr int NW = GH_BLOCK / GH_WAVE;
   __shared__ uint32_t s_base[MAXD];                        // global base of (digit, this block)
@@ -180,12 +221,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
   __shared__ uint32_t s_w[NW];
   __shared__ uint32_t s_lbase[MAXD];                       // first position of each digit in the locally sorted tile
   __shared__ uint32_t s_key[(GH_BLOCK * ITEMS)], s_val[(GH_BLOCK * ITEMS)];
-  const uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
-  const uint32_t seg = blockIdx.y, nblk = gridDim.x, ndig = dmask + 1u;
-  const uint32_t blk_base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
+  uint32_t n = gh_seg_count(n_ptr, cap, seg_len);
+  uint32_t seg = blockIdx.y, tseg = blockIdx.y;            // segment of the per-digit totals / of the table rows
+  const uint32_t nblk = gridDim.x, ndig = dmask + 1u;
+  uint32_t blk_base = blockIdx.x * (uint32_t)(GH_BLOCK * ITEMS);
+  size_t seg_off = (size_t)seg * seg_len;
+  if (!SELF && vstart) {                                 // variable segments (see gh_var_seg_of_block)
+    GhVarSeg vs;
+    if (!gh_var_seg_of_block(vstart, nseg, cap, (uint32_t)(GH_BLOCK * ITEMS), blockIdx.x, vs)) return;
+    n = vs.n; blk_base = vs.lb * (uint32_t)(GH_BLOCK * ITEMS); seg_off = vs.s0; seg = vs.seg; tseg = 0u;
+  }
   const bool varies = gh_digit_varies(key_bits, n_bits, shift, dmask);
   if (blk_base >= n) return;
-  const size_t seg_off = (size_t)seg * seg_len;
   keys_in += seg_off; vals_in += seg_off; keys_out += seg_off; vals_out += seg_off;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (!varies) {                                   // every key carries the same digit: the stable scatter is the identity
@@ -266,7 +313,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_radix_scatter_kernel(
     for (int k = 0; k < DPT; ++k) {
       const uint32_t d = (uint32_t)(tid * DPT + k);
       v[k] = d < ndig ? tot[(size_t)seg * ndig + d] : 0u;
-      pre[k] = d < ndig ? table[((size_t)seg * ndig + d) * nblk + blockIdx.x] : 0u;
+      pre[k] = d < ndig ? table[((size_t)tseg * ndig + d) * nblk + blockIdx.x] : 0u;
       sum += v[k];
 #pragma unroll
       for (int w = 0; w < NW; ++w) s_cnt[w][d] = 0;
@@ -375,10 +422,10 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
     const uint32_t dmask = (1u << nbits) - 1u, ndig = dmask + 1u;
     uint32_t* tot = table + (size_t)ndig * nblk;
     const dim3 gb(nblk, 1), gs(ndig, 1), blk(GH_BLOCK);
-    hipLaunchKernelGGL((gh_radix_hist_kernel<4, 1024, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, 0, dmask, table, key_bits, n_bits, wide_flag, nbits);
-    hipLaunchKernelGGL(gh_radix_scan_kernel<4>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
+    hipLaunchKernelGGL((gh_radix_hist_kernel<4, 1024, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, 0, dmask, table, key_bits, n_bits, wide_flag, nbits, nullptr, 0);
+    hipLaunchKernelGGL(gh_radix_scan_kernel<4>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk, nullptr, 0);
     hipLaunchKernelGGL((gh_radix_scatter_kernel<4, 1024, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
-                       0, dmask, nbits, table, tot, key_bits, n_bits);
+                       0, dmask, nbits, table, tot, key_bits, n_bits, nullptr, 0);
     uint32_t* t = k_in; k_in = k_out; k_out = t;
     t = v_in; v_in = v_out; v_out = t;
     return;
@@ -392,14 +439,14 @@ static void gh_radix_sort_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, 
     uint32_t* tot = table + (size_t)segs * ndig * nblk;
     const dim3 gb(nblk, segs), gs(ndig, segs), blk(GH_BLOCK);
     if (nblk <= 128) {                                   // short segments: no scan kernel (see gh_radix_scatter_kernel)
-      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag, nbits);
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag, nbits, nullptr, 0);
       hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, true>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
-                         lo, dmask, hi - lo, table, tot, key_bits, n_bits);
+                         lo, dmask, hi - lo, table, tot, key_bits, n_bits, nullptr, 0);
     } else {
-      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag, nbits);
-      hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk);
+      hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, n_ptr, cap, seg_len, lo, dmask, table, key_bits, n_bits, wide_flag, nbits, nullptr, 0);
+      hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, n_ptr, cap, seg_len, nblk, nullptr, 0);
       hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, n_ptr, cap, seg_len,
-                         lo, dmask, hi - lo, table, tot, key_bits, n_bits);
+                         lo, dmask, hi - lo, table, tot, key_bits, n_bits, nullptr, 0);
     }
     uint32_t* t = k_in; k_in = k_out; k_out = t;
     t = v_in; v_in = v_out; v_out = t;
@@ -450,6 +497,36 @@ void gh_radix_sort_ex(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32
   if (items == 4) gh_radix_sort_t<4>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits, wide_flag);
   else if (items == 8) gh_radix_sort_t<8>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits, wide_flag);
   else gh_radix_sort_t<16>(k_in, v_in, k_out, v_out, n_ptr, cap, nbits, seg_len, segs, table, s, key_bits, n_bits, wide_flag);
+}
+
+// Variable-length segments (gh_var_seg_of_block): nseg segments [vstart[v], vstart[v+1]) of one array of capacity cap, each sorted
+// stably on bits [0, nbits) among its own elements, in place in its range: ceil(nbits / 8) passes of (histogram, row scan, scatter).
+template <int ITEMS>
+static void gh_radix_sort_var_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* vstart, int nseg,
+                                uint32_t cap, int nbits, uint32_t* table, hipStream_t s) {
+  const int nblk = (int)(((size_t)cap + GH_BLOCK * ITEMS - 1) / (GH_BLOCK * ITEMS)) + nseg;
+  const int passes = (nbits + 7) / 8;
+  for (int p = 0; p < passes; ++p) {
+    const int lo = (nbits * p) / passes, hi = (nbits * (p + 1)) / passes;
+    const uint32_t dmask = (1u << (hi - lo)) - 1u, ndig = dmask + 1u;
+    uint32_t* tot = table + (size_t)ndig * nblk;
+    const dim3 gb(nblk, 1), gs(ndig, nseg), blk(GH_BLOCK);
+    hipLaunchKernelGGL((gh_radix_hist_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, vstart, cap, 0u, lo, dmask, table, (const uint2*)nullptr, 0,
+                       (uint32_t*)nullptr, nbits, vstart, nseg);
+    hipLaunchKernelGGL(gh_radix_scan_kernel<ITEMS>, gs, blk, 0, s, table, tot, vstart, cap, 0u, nblk, vstart, nseg);
+    hipLaunchKernelGGL((gh_radix_scatter_kernel<ITEMS, 256, false>), gb, blk, 0, s, k_in, v_in, k_out, v_out, vstart, cap, 0u, lo, dmask, hi - lo,
+                       table, tot, (const uint2*)nullptr, 0, vstart, nseg);
+    uint32_t* t = k_in; k_in = k_out; k_out = t;
+    t = v_in; v_in = v_out; v_out = t;
+  }
+}
+
+void gh_radix_sort_var(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* vstart, int nseg,
+                       uint32_t cap, int nbits, uint32_t* table, hipStream_t s) {
+  const int items = gh_radix_items((size_t)cap, 1, false);
+  if (items == 4) gh_radix_sort_var_t<4>(k_in, v_in, k_out, v_out, vstart, nseg, cap, nbits, table, s);
+  else if (items == 8) gh_radix_sort_var_t<8>(k_in, v_in, k_out, v_out, vstart, nseg, cap, nbits, table, s);
+  else gh_radix_sort_var_t<16>(k_in, v_in, k_out, v_out, vstart, nseg, cap, nbits, table, s);
 }
 
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,
@@ -534,7 +611,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     const uint32_t* __restrict__ block_sums, float4* __restrict__ geom,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP, uint32_t flags,
     const float* __restrict__ tile_depth_bound, int n_emit_blocks, int NVs, float rdiv, const uint32_t* __restrict__ block_tiles,
-    uint32_t* __restrict__ slot_begin) {
+    uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ view_start, int n_views) {
   constexpr int NW = GH_BLOCK / GH_WAVE;
   if ((int)blockIdx.x >= n_emit_blocks) {               // the spare workgroups: the record-slot numbering (see gh_number_record_slots)
     gh_number_record_slots(blockIdx.x - (uint32_t)n_emit_blocks, N, P, NVs, rdiv, tiles_touched, block_tiles, slot_begin);
@@ -570,7 +647,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   const uint32_t r = __float_as_uint(g2.y);
   const int minx = r & 255, miny = (r >> 8) & 255, maxx = (r >> 16) & 255, maxy = r >> 24;
   const bool small = (maxx - minx) * (maxy - miny) <= 64;               // the projection kernel kept the hit mask
-  const uint32_t vbase = (rP > 0.0f ? gh_div_small(n, (uint32_t)P, rP) : n / (uint32_t)P) * (uint32_t)tiles;   // per Gaussian, not per instance
+  const uint32_t vtile0 = (rP > 0.0f ? gh_div_small(n, (uint32_t)P, rP) : n / (uint32_t)P) * (uint32_t)tiles;   // first global tile id of the view
+  // keys: global tile ids, or (view_start given: the per-view partition) tile ids inside the view — the views are segments of the
+  // emit order already, so the partition only has to order each view's instances by their ceil(log2 tiles) local bits
+  const uint32_t vbase = view_start ? 0u : vtile0;
   const uint32_t wave_total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
   const bool marks = wave_total <= (uint32_t)(GH_EMIT_MARKS * 32);         // wave-uniform: which owner search the trips below use
   if (marks) {
@@ -602,10 +682,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
   if ((int)blockIdx.x == n_emit_blocks - 1 && tid == 0) {        // the last emit block knows the instance total D
     const uint32_t total = blk_off + blk_sum;
     ctr->num_rendered = total;
+    if (view_start) view_start[n_views] = total;
     // (the projection kernel cleared the word; bits 3 / 4 may already be set; a BINNING-only re-run clears a stale bit 0)
     if (total > cap) atomicOr(&ctr->overflow, 1u); else atomicAnd(&ctr->overflow, ~1u);
   }
   const uint32_t wave_base = blk_off + woff;
+  // first emit slot of every view = that of the first Gaussian of its segment of the depth order (position v * P)
+  if (view_start && i < N) {
+    const uint32_t iv = rP > 0.0f ? gh_div_small((uint32_t)i, (uint32_t)P, rP) : (uint32_t)i / (uint32_t)P;
+    if ((uint32_t)i == iv * (uint32_t)P) view_start[iv] = wave_base + x - cnt;
+  }
   // the wave's run of slots, 64 per trip
   if (marks) {
     uint32_t done = 0;                                    // runs that end in front of this trip's window
@@ -662,7 +748,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     const float4 s1 = make_float4(bf(g1v.x), (flags & GH_FLAG_STATIC_LISTS) ? gh_static_cull_opacity(sop) : sop, 0.0f, 0.0f);
     const uint32_t sr = (uint32_t)__builtin_amdgcn_readlane((int)r, src);
     const uint32_t sminx = sr & 255u, sminy = (sr >> 8) & 255u, sw = ((sr >> 16) & 255u) - sminx, sn = sw * ((sr >> 24) - sminy);
-    const uint32_t sn_id = (uint32_t)__builtin_amdgcn_readlane((int)n, src), svb = (uint32_t)__builtin_amdgcn_readlane((int)vbase, src);
+    const uint32_t sn_id = (uint32_t)__builtin_amdgcn_readlane((int)n, src), svb = (uint32_t)__builtin_amdgcn_readlane((int)vtile0, src);
+    const uint32_t svk = (uint32_t)__builtin_amdgcn_readlane((int)vbase, src);      // base of the keys (0 with the per-view partition)
     uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)(wave_base + x - cnt), src);
     // (the speculative occlusion bound, exactly as the projection kernel applied it when it counted this Gaussian's tiles)
     const float stz = bf(g3.y);
@@ -680,7 +767,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
       if (h) {
         const uint32_t slot = off + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
         if (slot < cap) {
-          keys[slot] = svb + ty * (uint32_t)gx + tx;
+          keys[slot] = svk + ty * (uint32_t)gx + tx;
           vals[slot] = sn_id;
         }
       }
@@ -700,7 +787,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
                                                               uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin,
                                                               float rtiles, float rgx, uint32_t flags, float* __restrict__ inst_c,
-                                                              const float* __restrict__ tile_depth_bound) {
+                                                              const float* __restrict__ tile_depth_bound, uint32_t P_local, float rP) {
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
   // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
@@ -712,14 +799,18 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
   const uint32_t i = ((blockIdx.x & 7u) * chunk + (blockIdx.x >> 3)) * GH_BLOCK + threadIdx.x;
   if (i >= n) return;
   gh_stream(&inst_flag[i], 0u);                        // quadrant flags of the backward's sub-records (emit slots 0 .. D-1)
-  const uint32_t t = keys[i];
+  const uint32_t gid = vals[i];
+  uint32_t t = keys[i];
+  // P_local != 0: the per-view partition left tile ids INSIDE the view in the keys; the view is the payload's (view * P + row)
+  auto view_tiles = [&](uint32_t g_) { return (rP > 0.0f ? gh_div_small(g_, P_local, rP) : g_ / P_local) * (uint32_t)tiles; };
+  if (P_local) t += view_tiles(gid);
   if (i == 0) ranges[t].x = 0;
   else {
-    const uint32_t tp = keys[i - 1];
+    uint32_t tp = keys[i - 1];
+    if (P_local) tp += view_tiles(vals[i - 1]);
     if (tp != t) { ranges[tp].y = i; ranges[t].x = i; }
   }
   if (i == n - 1) ranges[t].y = n;
-  const uint32_t gid = vals[i];
   const float4* grec = geom + (size_t)gid * 4;       // one 64-byte line: record, tile rect, tile hit mask
   const float4 a = grec[0], b = grec[1], c = grec[2];
   const uint32_t slot0 = slot_begin[gid];            // first record slot (4-byte gather from an L2-sized array)
@@ -860,8 +951,14 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
   const bool per_view = (d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   hipLaunchKernelGGL(gh_count_sorted_kernel, dim3(nblk_pre), dim3(GH_BLOCK), 0, s, g.N, perm, tiles_touched,
                      (uint32_t*)(ws + L.block_sums));
-  // level 3: stable partition by tile id; an odd number of passes starts in the b buffers so the result is in *_a
-  const int tile_passes = gh_radix_passes((size_t)g.cap, g.tile_bits);
+  // level 3: stable partition by tile id; an odd number of passes starts in the b buffers so the result is in *_a.
+  // Two or more views: PER VIEW (round 6) — the views are contiguous segments of the emit order, so each is partitioned by the
+  // ceil(log2 tiles) bits of the tile id INSIDE the view (8 views of 512x334: 2 passes of 5 bits instead of 6 + 7; 32 poses of
+  // 1024x1024: 2 passes instead of 3); the segments' bounds (GhLayout.view_start) come from the emit kernel.
+  const bool per_view_part = gh_partition_per_view(g);
+  int vbits = 1; while ((1 << vbits) < g.tiles) ++vbits;
+  const int tile_passes = per_view_part ? (vbits + 7) / 8 : gh_radix_passes((size_t)g.cap, g.tile_bits);
+  uint32_t* view_start = per_view_part ? (uint32_t*)(ws + L.view_start) : nullptr;
   uint32_t* ka = (uint32_t*)(ws + L.keys_a); uint32_t* kb = (uint32_t*)(ws + L.keys_b);
   uint32_t* va = (uint32_t*)(ws + L.vals_a); uint32_t* vb = (uint32_t*)(ws + L.vals_b);
   const bool start_b = (tile_passes & 1) != 0;
@@ -872,9 +969,10 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (const uint32_t*)(ws + L.block_sums), (float4*)(ws + L.geom), k_in, v_in, ctr,
                      g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f, d->flags, tile_depth_bound, nblk_pre, per_view ? 0 : g.NV,
                      g.N < (1 << 24) && !per_view ? 1.0f / (float)g.NV : 0.0f, (const uint32_t*)(ws + L.block_tiles),
-                     (uint32_t*)(ws + L.slot_begin));
+                     (uint32_t*)(ws + L.slot_begin), view_start, g.NV);
   if (cap == 0) { gh_launch_tile_order(g, ws, L, s); return; }    // the emit kernel has written D (it stores nothing past cap)
-  gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
+  if (per_view_part) gh_radix_sort_var(k_in, v_in, k_out, v_out, view_start, g.NV, cap, vbits, table, s);
+  else gh_radix_sort(k_in, v_in, k_out, v_out, &ctr->num_rendered, cap, g.tile_bits, table, s);
 
   const int nblk_d = (int)((g.cap + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_ranges_kernel, dim3((nblk_d + 7) & ~7), dim3(GH_BLOCK), 0, s, ka, va, ctr, cap, g.gx, g.tiles,
@@ -883,6 +981,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
                      (const uint32_t*)(ws + L.slot_begin),
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,   // gh_div_small's range
-                     d->flags, (float*)(ws + L.inst_c), tile_depth_bound);
+                     d->flags, (float*)(ws + L.inst_c), tile_depth_bound, per_view_part ? (uint32_t)g.P : 0u,
+                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f);
   gh_launch_tile_order(g, ws, L, s);
 }

@@ -86,6 +86,20 @@ void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*
                    int nbits, uint32_t* table, hipStream_t s);
 size_t gh_radix_table_words(size_t cap);
 int gh_radix_passes(size_t cap, int nbits);
+// Variable-length segments [vstart[v], vstart[v+1]) (device memory) of one array, each sorted among itself (gh_binning.hip)
+void gh_radix_sort_var(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* vstart, int nseg,
+                       uint32_t cap, int nbits, uint32_t* table, hipStream_t s);
+// Is the tile partition of this launch done per view (tile ids inside the view as keys)? From two views on, when that takes no
+// more launches than the partition by global tile id (small launches sort in two launches per pass, the per-view form in three).
+static inline bool gh_partition_per_view(const GhGrid& g) {
+  if (g.NV < 2 || g.cap == 0) return false;
+  int vbits = 1; while ((1 << vbits) < g.tiles) ++vbits;
+  const int items = (size_t)g.cap <= ((size_t)1 << 21) ? 4 : ((size_t)g.cap <= ((size_t)1 << 25) ? 8 : 16);
+  const size_t nblk = ((size_t)g.cap + (size_t)GH_BLOCK * items - 1) / ((size_t)GH_BLOCK * items);
+  const int per_pass_global = nblk <= 128 ? 2 : 3;
+  const int launches_global = gh_radix_passes((size_t)g.cap, g.tile_bits) * per_pass_global, launches_var = ((vbits + 7) / 8) * 3;
+  return launches_var <= launches_global;
+}
 // General form: `segs` independent segments of exactly seg_len elements each (seg_len = 0: one segment, count from *n_ptr).
 // table: gh_radix_table_words(per-segment capacity, segs).
 // key_bits / n_bits: optional per-producer-block (OR, AND) of the key bits: a pass whose digit no two keys differ in is a copy.

@@ -1077,7 +1077,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_instance_kernel(uint32_t 
                                                                         const float4* __restrict__ g_r0, const float* __restrict__ g_c,
                                                                         const float4* __restrict__ attr, float4* __restrict__ r1,
                                                                         float2* __restrict__ r2, uint32_t* __restrict__ inst_flag,
-                                                                        const GhCounters* __restrict__ ctr, uint32_t* __restrict__ render_guard) {
+                                                                        const GhCounters* __restrict__ ctr, uint32_t* __restrict__ render_guard,
+                                                                        int local_keys) {
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   // the kernel in front of the render (gh_refresh_attr_kernel, complete by now, may have raised bit 1): the error bits in their own word
   if (i == 0) *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK;
@@ -1088,9 +1089,10 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_instance_kernel(uint32_t 
   const float4 at = attr[vals[i]];                      // (opacity, r, g, b) of the instance's (view, Gaussian)
   const float4 a = g_r0[i];
   const float cC = g_c[i];
-  const uint32_t t = keys[i];
+  const uint32_t t = keys[i];                            // global tile id, or (per-view partition: local_keys) the tile id inside the view
   uint32_t tl, ty;
-  if (rtiles > 0.0f) { tl = t - gh_div_small(t, (uint32_t)tiles, rtiles) * (uint32_t)tiles; ty = gh_div_small(tl, (uint32_t)gx, rgx); }
+  if (local_keys) { tl = t; ty = gh_div_small(tl, (uint32_t)gx, rgx); }
+  else if (rtiles > 0.0f) { tl = t - gh_div_small(t, (uint32_t)tiles, rtiles) * (uint32_t)tiles; ty = gh_div_small(tl, (uint32_t)gx, rgx); }
   else { tl = t % (uint32_t)tiles; ty = tl / (uint32_t)gx; }
   const uint32_t tx = tl - ty * (uint32_t)gx;
   // (inst_r0 holds -A/2 for the render kernels' power; the mask test takes the conic itself: * -2 is exact)
@@ -1114,5 +1116,5 @@ void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, con
                      (const GhCounters*)(wg + L.counters), (const uint32_t*)(wg + L.keys_a), (const uint32_t*)(wg + L.vals_a),
                      (const float4*)(wg + L.inst_r0), (const float*)(wg + L.inst_c), (const float4*)(ws + L.attr),
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
-                     (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard));
+                     (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard), gh_partition_per_view(g) ? 1 : 0);
 }

@@ -1036,12 +1036,15 @@ def workspace_views(ctx: _Ctx) -> Dict[str, torch.Tensor]:
         return ws[off:off + nbytes].view(dtype).reshape(*shape)
 
     geom = v(lay.geom, N * 64, torch.float32, N, 16)
+    sorted_tile = v(lay.keys_a, cap * 4, torch.int32, cap)
+    if L.gh_partition_is_per_view(C.byref(ctx.dims)) == 1:      # the keys hold tile ids inside the view: the global id through the payload's view
+        sorted_tile = sorted_tile + (v(lay.vals_a, cap * 4, torch.int32, cap).clamp(0, max(N - 1, 0)) // max(ctx.P, 1)) * (gx * gy)
     return dict(counters=v(lay.counters, 16, torch.int32, 4), g0=geom[:, 0:4], g1=geom[:, 4:8], gb=geom[:, 8],
                 # (view-space depth and 3-sigma tile rect of every projected Gaussian: the geometry line's last float4, v0.8)
                 depth=geom[:, 13], rect=geom[:, 14].contiguous().view(torch.int32),
                 tiles_touched=v(lay.tiles_touched, N * 4, torch.int32, N), slot_begin=v(lay.slot_begin, N * 4, torch.int32, N),
                 depth_order=v(lay.depth_vals_b if (ctx.dims.flags & _abi.GH_FLAG_DEPTH24) else lay.depth_vals_a, N * 4, torch.int32, N),
-                sorted_tile=v(lay.keys_a, cap * 4, torch.int32, cap), sorted_slot=v(lay.sorted_slot, cap * 4, torch.int32, cap),
+                sorted_tile=sorted_tile, sorted_slot=v(lay.sorted_slot, cap * 4, torch.int32, cap),
                 sorted_gid=v(lay.vals_a, cap * 4, torch.int32, cap),
                 inst_r2=v(lay.inst_r2, cap * 8, torch.int32, cap, 2),
                 ranges=v(lay.ranges, ctx.NV * gx * gy * 8, torch.int32, ctx.NV * gx * gy, 2),

@@ -268,7 +268,8 @@ typedef struct GhLayout {
   size_t depth_keys_a, depth_keys_b; /* uint32[n_views*P] level-1 sort: depth bits (0xFFFFFFFF when culled); result in _a */
   size_t depth_vals_a, depth_vals_b; /* uint32[n_views*P] level-1 payload: view*P + gaussian; depth order in _a */
   size_t block_sums;     /* uint32[...]        scan scratch */
-  size_t keys_a, keys_b; /* uint32[max_instances] level-3 sort: global tile id; sorted result in keys_a */
+  size_t keys_a, keys_b; /* uint32[max_instances] level-3 sort: global tile id (one view) or tile id inside the view (two or more views: the
+                            partition runs per view); sorted result in keys_a */
   size_t vals_a, vals_b; /* uint32[max_instances] payload view*P + gaussian; sorted result in vals_a */
   size_t sorted_slot;    /* uint32[max_instances] sorted position -> record slot (where the backward puts its sub-records): a permutation
                             of 0 .. D-1 */
@@ -316,6 +317,8 @@ typedef struct GhLayout {
   size_t loss_partials;  /* float[n_views*tiles][4] + 1: the fused image loss's sums of |image - target| per 8x8-pixel quadrant
                             (GhOutputs.l1_target), added up in index order by a one-workgroup kernel behind the render (or by the
                             backward: GH_FLAG_DEFER_LOSS_SUM); the last float is the factor of the final sum */
+  size_t view_start;     /* uint32[n_views + 1] first emit slot of every view (and D): the segments of the per-view tile partition (v0.8;
+                            from two views on keys_a / keys_b hold tile ids INSIDE the view, see gh_partition_per_view) */
 } GhLayout;
 
 /* Library version: major<<16 | minor. */
@@ -326,6 +329,11 @@ int gh_workspace_layout(const GhDims* dims, GhLayout* out);
 
 /* Convenience: total workspace bytes (0 on invalid dims). */
 size_t gh_workspace_bytes(const GhDims* dims);
+
+/* 1 when a forward with these dims partitions its tile instances PER VIEW (GhLayout.keys_a then holds tile ids inside the view and
+   GhLayout.view_start the views' first slots), 0 when by global tile id, negative GhStatus on invalid dims. For callers that
+   inspect the binning arrays (tests, tools); nothing on the render path needs it. */
+int gh_partition_is_per_view(const GhDims* dims);
 
 /*
  * Forward: blend -> project -> conic -> bin -> sort -> composite. Replaces
