@@ -41,7 +41,8 @@ static GhDims gh_half_dims(const GhDims* d, int h, int* v0, size_t* cap0) {
 
 static size_t gh_sort_table_words(const GhGrid& g) {
   const size_t tab_n = gh_radix_table_words((size_t)g.P, g.NV);          // per-view depth sort: NV segments of P keys
-  const size_t tab_d = gh_radix_table_words((size_t)g.cap) + 512 * (size_t)g.NV;      // (+ the per-view partition's extra blocks and totals)
+  const size_t tab_d = gh_radix_table_words((size_t)g.cap) + 2048 * (size_t)g.NV;     // (+ the per-view partition's extra blocks and totals: up to
+                                                                                       //  1024 digits x (one more block + one row of totals) per view)
   return tab_n > tab_d ? tab_n : tab_d;
 }
 

@@ -505,6 +505,8 @@ template <int ITEMS>
 static void gh_radix_sort_var_t(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* vstart, int nseg,
                                 uint32_t cap, int nbits, uint32_t* table, hipStream_t s) {
   const int nblk = (int)(((size_t)cap + GH_BLOCK * ITEMS - 1) / (GH_BLOCK * ITEMS)) + nseg;
+  // (ONE pass of 1024 digits per view instead of two of 32 — measured at 8 views: histogram 18.2 + scan 13.6 + scatter 31.0 = 63 us against
+  //  51 for the two narrow passes, as round 1 found for the single-segment form: the 6 MB digit table costs more than the second pass)
   const int passes = (nbits + 7) / 8;
   for (int p = 0; p < passes; ++p) {
     const int lo = (nbits * p) / passes, hi = (nbits * (p + 1)) / passes;
