@@ -67,7 +67,7 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-PROFILE_TAG = "r5"        # profiles/<tag>_pmc_*.json: the committed counter passes this build's bench lines quote
+PROFILE_TAG = "r6"        # profiles/<tag>_pmc_*.json: the committed counter passes this build's bench lines quote
 
 
 def workload_key(args, V: int):
@@ -216,7 +216,7 @@ def two_call_cost(s, view_ids, n_iter: int = 30):
     step). Returns milliseconds per view of a step over `view_ids`; host-bound.
     ONE harness for every caller (this file's JSON line, tools/two_call_cost.py): rounds 3-5 had two — the bench's ran a backward of
     its own after every view over nine leaves, the tool's one backward per eight views over a single leaf — and their figures for
-    "the same protocol" lay 56 % apart (profiles/r6_two_call_cost.txt)."""
+    "the same protocol" lay 56 % apart (profiles/r6_two_call_reconcile.txt)."""
     import math
     from guassianhand_amd.camera import Camera
     from guassianhand_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer

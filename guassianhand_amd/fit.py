@@ -255,7 +255,9 @@ class OneShotFit(nn.Module):
                                                    self.gs.shs, gt_rgb, gt_mask, None if bbox_mask is None else bbox_mask.float(),
                                                    scale=1.0 / n_total, H=H, W=W, use_rgb=self.use_rgb, sh_degree=self.sh_degree,
                                                    xyz_b=leaves["xyz_b"], opacity_b=leaves["opacity_b"], color_w=leaves["color_w"],
-                                                   color_b=leaves["color_b"], sync=sync, geometry_cache=self._geom_cache)
+                                                   color_b=leaves["color_b"], sync=sync, geometry_cache=self._geom_cache,
+                                                   defer_loss=True)      # (the value is looked at behind the backward only: its final sum
+                                                                         #  rides in the render backward, GH_FLAG_DEFER_LOSS_SUM)
             else:
                 if allv:
                     w_sel, k_sel = w2cs, Ks

@@ -18,11 +18,11 @@ def test_design_numbers_are_the_profiles():
 
 
 def test_profiles_share_one_source_hash():
-    tr = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")))
-    sq = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_sq.json")))
-    head = open(os.path.join(ROOT, "profiles", "r5_kernel_stats_bench_8views.csv")).readline()
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r6_pmc_traffic.json")))
+    sq = json.load(open(os.path.join(ROOT, "profiles", "r6_pmc_sq.json")))
+    head = open(os.path.join(ROOT, "profiles", "r6_kernel_stats_bench_8views.csv")).readline()
     assert tr["source_hash"] == sq["source_hash"] and tr["source_hash"] in head
-    b = json.load(open(os.path.join(ROOT, "profiles", "r5_bench_default.json")))
+    b = json.load(open(os.path.join(ROOT, "profiles", "r6_bench_default.json")))
     # the committed bench line quotes counters of its own build (null + the reason otherwise)
     assert b["roofline"]["traffic"] is not None and tr["source_hash"] in b["roofline"]["traffic_source"]
 
@@ -32,5 +32,5 @@ def test_profiles_were_measured_on_the_committed_sources():
     `traffic: null` and why): the committed profiles must carry the hash of the committed HIP sources + C header."""
     sys.path.insert(0, ROOT)
     import bench
-    tr = json.load(open(os.path.join(ROOT, "profiles", "r5_pmc_traffic.json")))
-    assert tr["source_hash"] == bench.source_hash(), "sources changed since profiles/ were refreshed: bash tools/refresh_profiles.sh r5"
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r6_pmc_traffic.json")))
+    assert tr["source_hash"] == bench.source_hash(), "sources changed since profiles/ were refreshed: bash tools/refresh_profiles.sh r6"

@@ -4,7 +4,7 @@
 tests/test_docs.py asserts DESIGN.md holds exactly this block for the committed profiles."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r5"
+TAG = "r6"
 BEGIN, END = "<!-- BEGIN GENERATED: tools/design_table.py -->", "<!-- END GENERATED -->"
 
 
@@ -68,27 +68,27 @@ def numbers() -> str:
             m = re.match(r"fit step, (\d+) views, .*static_geometry=(\w+): eager ([\d.]+) ms, captured graph ([\d.]+) ms", l)
             if m:
                 fit[(int(m.group(1)), m.group(2) == "True")] = float(m.group(4))
-    two = re.search(r"= ([\d.]+) ms per view", open(os.path.join(ROOT, "profiles", f"{TAG}_two_call_cost.txt")).readline()).group(1)
+    two8, two1 = (re.search(r": ([\d.]+) ms per view", l).group(1) for l in open(os.path.join(ROOT, "profiles", f"{TAG}_two_call_cost.txt")).readlines()[:2])
     st = lambda x: " / ".join(f"{x['stages'][k]['ms']:.3f}" for k in ("preprocess_fwd", "binning", "render_fwd", "render_bwd", "preprocess_bwd"))
     L = [BEGIN7,
-         f"Round-5 numbers (MI355X, 1 GPU; `profiles/{TAG}_*`; window 1 of the bench line, per-step median in brackets):", "",
-         "| configuration | renders/s | ms/step | round 4 |", "|---|---|---|---|",
-         f"| two hands, 8 views/step (default, BASELINE configs[2]/[3] shape), graph replay | **{d['value']:,.0f}** | {d['ms_per_step']:.3f} ({med(d):.3f}; p10 / p90 {d['config']['step_ms']['p10']:.3f} / {d['config']['step_ms']['p90']:.3f}) | 12,001 / 0.667 |",
-         f"| same with `--split-streams on` (two halves of the views on two streams, bit-identical) | {sp['value']:,.0f} | {sp['ms_per_step']:.3f} ({med(sp):.3f}) | 11,803 / 0.678 |",
-         f"| two hands, 1 view/step (the reference's own batch shape) | {v1['value']:,.0f} | {v1['ms_per_step']:.3f} | 4,557 / 0.219 |",
-         f"| two hands, 2 / 4 / 16 views/step | {v2['value']:,.0f} / {v4['value']:,.0f} / {v16['value']:,.0f} | {v2['ms_per_step']:.3f} / {v4['ms_per_step']:.3f} / {v16['ms_per_step']:.3f} | 6,482 / 8,992 / 13,228 |",
-         f"| two hands 1024², SH degree 3 (configs[4] shape), 8 views/step; dominant kernel `{hd['roofline']['kernel']}` {hd['roofline']['frac']:.3f} of 8 TB/s, counter traffic {hd['roofline']['traffic'] / 1e6:.0f} MB | {hd['value']:,.0f} | {hd['ms_per_step']:.2f} | 5,278 / 1.52 |",
-         f"| same with `--split-streams on` (bit-identical) | {B('hd_sh3_split')['value']:,.0f} | {B('hd_sh3_split')['ms_per_step']:.2f} | 5,491 / 1.46 |",
-         f"| same, **32 different poses per step** (configs[4]'s batch: `--pose-batch --views-per-step 32`); dominant kernel `{pb['roofline']['kernel']}` {pb['roofline']['frac']:.3f} of 8 TB/s, counter traffic {pb['roofline']['traffic'] / 1e9:.2f} GB | {pb['value']:,.0f} | {pb['ms_per_step']:.2f} | 4,637 / 6.90 |",
-         f"| same with `--split-streams on` (bit-identical) | {B('hd_sh3_pose32_split')['value']:,.0f} | {B('hd_sh3_pose32_split')['ms_per_step']:.2f} | 4,803 / 6.66 |",
-         f"| 1k random Gaussians, 128², 1 view (configs[0]) | {rk['value']:,.0f} | {rk['ms_per_step']:.3f} | 10,838 / 0.092 |",
-         f"| reference protocol through the drop-in (2 rasteriser calls per view), per view fwd+bwd (`tools/two_call_cost.py`; the bench line's own harness: {d['config']['two_call_ms_per_view']:.2f}) | — | {two} (host-bound) | 0.741 (0.68–1.03 by box) |",
-         f"| full-size one-shot fit step, 8 views (fused α, 1024×2048 maps, active texels, static geometry, captured graph; `profiles/{TAG}_fit_step_profile.txt`) | — | **{fit[(8, True)]:.2f}** (full path {fit[(8, False)]:.2f}) | 0.51 (full path 0.68) |",
-         f"| same, 4 / 2 / 1 view(s) (configs[3] on 2 / 4 / 8 GPUs; `profiles/{TAG}_fit_step_views.txt`) | — | {fit[(4, True)]:.2f} / {fit[(2, True)]:.2f} / **{fit[(1, True)]:.2f}** | 0.35 / 0.26 / 0.18 (full path 0.47 / 0.35 / 0.25); this round's full path: {fit[(4, False)]:.2f} / {fit[(2, False)]:.2f} / {fit[(1, False)]:.2f} |",
-         f"| CPU oracle in its all-core baseline mode, {d['cpu_baseline']['threads']} threads ({d['cpu_baseline']['cpu_model']}), serial fraction {d['cpu_baseline']['serial_fraction']:.4f}, configs[2] | {d['cpu_baseline']['value']:.1f} | — | 11.4 |",
+         f"Round-6 numbers (MI355X, 1 GPU; `profiles/{TAG}_*`; window 1 of the bench line, per-step median in brackets):", "",
+         "| configuration | renders/s | ms/step | round 5 |", "|---|---|---|---|",
+         f"| two hands, 8 views/step (default, BASELINE configs[2]/[3] shape), graph replay | **{d['value']:,.0f}** | {d['ms_per_step']:.3f} ({med(d):.3f}; p10 / p90 {d['config']['step_ms']['p10']:.3f} / {d['config']['step_ms']['p90']:.3f}) | 12,523 / 0.639 |",
+         f"| same with `--split-streams on` (two halves of the views on two streams, bit-identical) | {sp['value']:,.0f} | {sp['ms_per_step']:.3f} ({med(sp):.3f}) | 12,206 / 0.655 |",
+         f"| two hands, 1 view/step (the reference's own batch shape) | {v1['value']:,.0f} | {v1['ms_per_step']:.3f} | 4,694 / 0.213 |",
+         f"| two hands, 2 / 4 / 16 views/step | {v2['value']:,.0f} / {v4['value']:,.0f} / {v16['value']:,.0f} | {v2['ms_per_step']:.3f} / {v4['ms_per_step']:.3f} / {v16['ms_per_step']:.3f} | 6,725 / 9,387 / 13,876 |",
+         f"| two hands 1024², SH degree 3 (configs[4] shape), 8 views/step; dominant kernel `{hd['roofline']['kernel']}` {hd['roofline']['frac']:.3f} of 8 TB/s, counter traffic {hd['roofline']['traffic'] / 1e6:.0f} MB | {hd['value']:,.0f} | {hd['ms_per_step']:.2f} | 5,226 / 1.53 |",
+         f"| same with `--split-streams on` (bit-identical) | {B('hd_sh3_split')['value']:,.0f} | {B('hd_sh3_split')['ms_per_step']:.2f} | 5,714 / 1.40 |",
+         f"| same, **32 different poses per step** (configs[4]'s batch: `--pose-batch --views-per-step 32`); dominant kernel `{pb['roofline']['kernel']}` {pb['roofline']['frac']:.3f} of 8 TB/s, counter traffic {pb['roofline']['traffic'] / 1e9:.2f} GB | {pb['value']:,.0f} | {pb['ms_per_step']:.2f} | 4,553 / 7.03 |",
+         f"| same with `--split-streams on` (bit-identical) | {B('hd_sh3_pose32_split')['value']:,.0f} | {B('hd_sh3_pose32_split')['ms_per_step']:.2f} | 4,764 / 6.72 |",
+         f"| 1k random Gaussians, 128², 1 view (configs[0]) | {rk['value']:,.0f} | {rk['ms_per_step']:.3f} | 10,960 / 0.091 |",
+         f"| reference protocol through the drop-in (2 rasteriser calls per view, one loss and one backward per step, every leaf), per view fwd+bwd: 8 views per step / 1 view per step (`tools/two_call_cost.py` = `bench.two_call_cost`, the bench line's own figures: {d['config']['two_call_ms_per_view']:.2f} / {d['config']['two_call_ms_per_view_one_view_steps']:.2f}; `profiles/{TAG}_two_call_reconcile.txt`) | — | {two8} / {two1} (host-bound) | two harnesses, two protocols: 0.714 / 1.11 |",
+         f"| full-size one-shot fit step, 8 views (fused α, 1024×2048 maps, active texels, static geometry, captured graph; `profiles/{TAG}_fit_step_profile.txt`) | — | **{fit[(8, True)]:.2f}** (full path {fit[(8, False)]:.2f}) | 0.51 (full path 0.67) |",
+         f"| same, 4 / 2 / 1 view(s) (configs[3] on 2 / 4 / 8 GPUs; `profiles/{TAG}_fit_step_views.txt`) | — | {fit[(4, True)]:.2f} / {fit[(2, True)]:.2f} / **{fit[(1, True)]:.2f}** | 0.34 / 0.25 / 0.18 (full path 0.46 / 0.34 / 0.25); this round's full path: {fit[(4, False)]:.2f} / {fit[(2, False)]:.2f} / {fit[(1, False)]:.2f} |",
+         f"| CPU oracle in its all-core baseline mode, {d['cpu_baseline']['threads']} threads ({d['cpu_baseline']['cpu_model']}), serial fraction {d['cpu_baseline']['serial_fraction']:.4f}, configs[2] | {d['cpu_baseline']['value']:.1f} | — | 11.2 |",
          f"| PyTorch CPU autograd (dense `oracle_torch`, {rk['cpu_baseline']['cores']} threads), configs[0] | {rk['cpu_baseline']['value']:.3f} | — | — |", "",
          f"Stage times (ms; projection / binning / render forward / render backward / per-Gaussian backward) at 8 views: {st(d)}; at 1 view: {st(v1)} — the forward",
-         "render is bound by its longest tile (sequential per pixel block by the bit-exactness contract), binning by the latency of 18 small",
+         "render is as long as its longest wave at the lone-wave rate (profiles/r6_forward_one_view_waves.txt), binning is the latency of 13 small",
          f"kernels; at 1024² SH3 × 8 views: {st(hd)}; 32 poses: {st(pb)}.",
          END7]
     return "\n".join(L)

@@ -1,6 +1,6 @@
 # One GPU call that regenerates everything under profiles/ for the current build (usage: bash tools/refresh_profiles.sh <tag>)
 # Per workload: the bench line, rocprofv3 kernel stats, HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and the SQ passes.
-TAG=${1:-r5}
+TAG=${1:-r6}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG

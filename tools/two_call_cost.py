@@ -1,7 +1,7 @@
 """Per-view cost of the reference's own protocol — per view the attribute blend in torch, the RGB pass and the mask pass
 through the drop-in GaussianRasterizer, one loss and one backward per step — against the fused batched form. The protocol's harness
 is bench.two_call_cost (ONE harness for the bench line and for this tool: rounds 3-5 had two that measured different protocols,
-see profiles/r6_two_call_cost.txt); this tool adds the step shapes side by side and the fused form."""
+see profiles/r6_two_call_reconcile.txt); this tool adds the step shapes side by side and the fused form."""
 import os
 import sys
 import time
