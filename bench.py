@@ -676,7 +676,7 @@ def main():
             if not args.pose_batch:
                 # the reference's own 2-call protocol through the drop-in, per view, beside the fused per-view cost —
                 # a HOST-bound figure, taken before the CPU baseline has 16 OpenMP threads spinning beside this one
-                out["config"]["two_call_ms_per_view"] = two_call_cost(s, list(mine), n_iter=max(4, 30 // len(mine)))   # this step's views, one backward
+                out["config"]["two_call_ms_per_view"] = two_call_cost(s, list(mine), n_iter=max(8, 30 // len(mine)))   # this step's views, one backward
                 out["config"]["two_call_ms_per_view_one_view_steps"] = two_call_cost(s, [mine[0]])      # B = 1, one view per step, a backward each
                 out["config"]["fused_ms_per_view"] = dt / args.steps * 1e3 / V
             out["cpu_baseline"] = cpu_baseline(scene_one, args.cpu_seconds, torch_reference=(args.config == "random1k"))

@@ -1,6 +1,8 @@
-# One GPU call that regenerates everything under profiles/ for the current build (usage: bash tools/refresh_profiles.sh <tag>)
+# Regenerates everything under profiles/ for the current build (usage: bash tools/refresh_profiles.sh <tag> [a|b|all]; a = the three
+# profiled workloads + micro benchmarks + timelines, b = the host-side figures and every bench line: two GPU calls of <= 20 minutes each)
 # Per workload: the bench line, rocprofv3 kernel stats, HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes) and the SQ passes.
 TAG=${1:-r6}
+PART=${2:-all}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$TAG
@@ -28,6 +30,7 @@ profile_workload() {   # <name> <bench args...>
     rm -rf $D/pmc_$tag
   done
 }
+if [ $PART != b ]; then
 profile_workload default || exit 1
 profile_workload hd_sh3 --config two_hands_hd || exit 1
 profile_workload hd_sh3_pose32 --config two_hands_hd --pose-batch --views-per-step 32 || exit 1
@@ -39,13 +42,16 @@ bash tools/micro/kernel_floor.sh $O > /dev/null 2>&1
 bash tools/micro/fetch_calib.sh $O > /dev/null 2>&1
 bash tools/kernel_timeline.sh > $O/timeline_8view.txt 2>&1
 bash tools/kernel_timeline.sh --views-per-step 1 > $O/timeline_1view.txt 2>&1
+fi
+if [ $PART = a ]; then echo "part a done"; exit 0; fi
 echo "== two-call protocol, host breakdown of the drop-in, fit step"
 timeout 300 python3 tools/two_call_cost.py > $O/two_call_cost.txt 2> $O/two_call_cost.err
 timeout 300 python3 tools/dropin_time.py 2> /dev/null | grep -v amdgpu.ids > $O/dropin_host_breakdown.txt
 (timeout 300 python3 tools/fit_static_time.py 2> /dev/null | grep -v amdgpu.ids; bash tools/fit_kstats.sh 1 2> /dev/null | head -24) > $O/fit_step_profile.txt
 # the bench lines last: they quote the counter summaries of THIS build (profiles/<tag>_pmc_*.json, written here on the box by the
 # assemble step; run tools/assemble_profiles.py again at home to pick up the bench lines themselves)
-python3 tools/assemble_profiles.py $TAG > /dev/null || exit 1
+# (run in two parts, the counter summaries of part a were assembled at home and travel with the tree: nothing to assemble on this box)
+if [ -d $O/default ]; then python3 tools/assemble_profiles.py $TAG > /dev/null || exit 1; fi
 for V in 2 4 16; do
   echo "== bench $V views" && timeout 300 python3 bench.py --views-per-step $V --no-cpu-baseline --no-stage-timing > $O/bench_${V}view.json 2> $O/bench_${V}view.err || exit 1
 done
