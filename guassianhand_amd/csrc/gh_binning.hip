@@ -14,6 +14,7 @@
 // The instance count D never leaves the device: kernels read their element count from device memory and grids
 // are sized from the caller's capacity (max_instances), so the whole stage is sync-free / graph-capturable.
 #include "gh_internal.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // LSD radix sort engine: 32-bit keys + 32-bit payload, digits of up to 8 bits (MAXD = 256 digit slots).
@@ -895,21 +896,34 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
 // inside a bucket is arbitrary. (The backward's order comes from the forward itself: gh_render_fwd_kernel.)
 __global__ __launch_bounds__(GH_BLOCK) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int tiles, int NV,
                                                                   uint32_t* __restrict__ order, const GhCounters* __restrict__ ctr,
-                                                                  uint32_t* __restrict__ render_guard) {
+                                                                  uint32_t* __restrict__ render_guard, uint32_t* __restrict__ heavy) {
   __shared__ uint32_t s_cnt[256];
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   const int tid = threadIdx.x, v = blockIdx.x;
   // the last kernel in front of the render: the error bits as they stand now, in a word of their own (the render kernel's waves
   // read it through the scalar cache; its own atomics go to the counters' line)
-  if (v == 0 && tid == 0) *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK;
+  if (v == 0 && tid == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; render_guard[1] = 0u; }   // ([1]: items in the work list's end region)
   ranges += (size_t)v * tiles;
+  if (heavy) heavy += (size_t)v * tiles;
+  // bucket 0 = heaviest. The key is the list length — or, in launches small enough for the fine-grained forward, what the previous
+  // forward over this workspace measured: the most entries any 4x4 block of the tile let through (its longest wave's work; a list of
+  // 544 entries can keep a wave busier than one of 1,265). A hint: stale values (another scene, the first call) only cost time.
+  auto bucket_of = [&](int t) {
+    const uint2 r = ranges[t];
+    uint32_t b = (r.y - r.x + 15u) >> 4;
+    if (heavy) { const uint32_t h = heavy[t]; if (h != 0u && r.y != r.x) b = 128u + ((h + 7u) >> 3); else b = b > 127u ? 127u : b; }
+    return b > 255u ? 255u : b;
+  };
+  // (a thread's first four tiles keep their bucket in registers between the two passes: every launch the heaviness key applies to)
+  uint32_t bk[4];
   s_cnt[tid] = 0;
   __syncthreads();
-  for (int t = tid; t < tiles; t += GH_BLOCK) {
-    const uint2 r = ranges[t];
-    uint32_t b = (r.y - r.x + 15u) >> 4; b = b > 255u ? 255u : b;
-    atomicAdd(&s_cnt[255u - b], 1u);                 // bucket 0 = longest lists
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = tid + j * GH_BLOCK;
+    if (t < tiles) { bk[j] = bucket_of(t); atomicAdd(&s_cnt[255u - bk[j]], 1u); }
   }
+  for (int t = tid + 4 * GH_BLOCK; t < tiles; t += GH_BLOCK) atomicAdd(&s_cnt[255u - bucket_of(t)], 1u);
   __syncthreads();
   uint32_t total;
   const uint32_t c = s_cnt[tid];
@@ -917,17 +931,27 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_tile_order_kernel(const uint2* __
   __syncthreads();
   s_cnt[tid] = pre;
   __syncthreads();
-  for (int t = tid; t < tiles; t += GH_BLOCK) {
-    const uint2 r = ranges[t];
-    uint32_t b = (r.y - r.x + 15u) >> 4; b = b > 255u ? 255u : b;
-    const uint32_t rank = atomicAdd(&s_cnt[255u - b], 1u);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = tid + j * GH_BLOCK;
+    if (t < tiles) {
+      const uint32_t rank = atomicAdd(&s_cnt[255u - bk[j]], 1u);
+      order[(size_t)rank * NV + v] = (uint32_t)(v * tiles + t);
+      if (heavy) heavy[t] = 0u;                        // the forward of THIS call fills it again
+    }
+  }
+  for (int t = tid + 4 * GH_BLOCK; t < tiles; t += GH_BLOCK) {
+    const uint32_t rank = atomicAdd(&s_cnt[255u - bucket_of(t)], 1u);
     order[(size_t)rank * NV + v] = (uint32_t)(v * tiles + t);
+    if (heavy) heavy[t] = 0u;
   }
 }
 
 static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
+  static const bool by_hits = !(getenv("GH_FWD_HEAVY_ORDER") && atoi(getenv("GH_FWD_HEAVY_ORDER")) == 0);   // (A/B switch)
+  uint32_t* heavy = gh_fwd_fine_launch(g) && by_hits ? (uint32_t*)(ws + L.tile_walk) + 3 * (size_t)g.NV * g.tiles : nullptr;
   hipLaunchKernelGGL(gh_tile_order_kernel, dim3(g.NV), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges), g.tiles, g.NV,
-                     (uint32_t*)(ws + L.tile_order), (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard));
+                     (uint32_t*)(ws + L.tile_order), (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard), heavy);
 }
 
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s, const float* tile_depth_bound) {

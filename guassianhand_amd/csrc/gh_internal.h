@@ -11,6 +11,18 @@
 #define GH_REC 9                     // LDS stride (floats) of a partial gradient record: 18 KB per block keeps 8 blocks per CU
 #define GH_REC_G 9                   // floats per (instance, quadrant) sub-record in HBM: packed, three 12-byte accesses
 #define GH_FINE_TILES 2048           // launches of at most this many tiles run the backward with one wave per 4x4 block
+// Small launches of the forward (gh_render_fwd_kernel<.., FINE>: at most GH_FWD_FINE_TILES tiles, up to four views of 512x334 — there the
+// kernel is as long as its heaviest waves): (1) the launch order goes by what the PREVIOUS forward over the workspace measured
+// per tile (the most list entries one 4x4-pixel block let through = its longest wave's work) instead of the list length; (2) the
+// GH_FWD_FINE_K tiles at the head of that order whose list holds at least GH_FWD_FINE_MIN entries are walked by 64 waves of 2x2 pixels x
+// 16 depth slots instead of 16 waves of 4x4 pixels x 4 slots — the same arithmetic in the same order per pixel, a quarter of the trips
+// per wave at 2.4x the instructions per tile; (3) the backward's work list keeps the first quarter of the launch order in a region of
+// its own, taken first. Measured optimum K = 24..48 at one, two and four views alike; from six views up all three cost more than they buy.
+#ifndef GH_FWD_FINE_TILES
+#define GH_FWD_FINE_TILES 3072
+#endif
+#define GH_FWD_FINE_K 32
+#define GH_FWD_FINE_MIN 256
 
 struct GhF3 { float x, y, z; };      // 12-byte access (global_load/store_dwordx3)
 
@@ -46,6 +58,13 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
   g.n_items = (int)((size_t)g.NV * g.tiles + (size_t)g.cap / GH_SEGMENT + 2);
   g.total_tiles = (int64_t)g.NV * g.tiles;
   return g;
+}
+
+// Floats of the fused image loss's partial sums (GhLayout.loss_partials): one per 8x8-pixel quadrant; a launch that may run tiles in
+// the fine-grained form keeps four per quadrant (one per workgroup of a fine tile; a coarse tile's workgroup zeroes the other three).
+static inline bool gh_fwd_fine_launch(const GhGrid& g) { return g.total_tiles <= GH_FWD_FINE_TILES; }
+static inline size_t gh_loss_partial_count(const GhGrid& g) {
+  return (size_t)g.NV * g.tiles * (gh_fwd_fine_launch(g) ? 16 : 4);
 }
 
 // ---- launchers (each enqueues on `s`, never synchronises) --------------------------------------

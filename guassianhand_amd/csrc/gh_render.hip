@@ -21,6 +21,7 @@
 // on average, the barrier made the kernel 58 us slower for 25 us saved in the record sum —
 // tools/experiments/r3_bwd_coupled_quadrants.patch, profiles/r3_bwd_coupled_ab.txt.)
 #include "gh_internal.h"
+#include <stdlib.h>
 
 // blockIdx -> (work item, quadrant) with the four quadrant workgroups of an item on ONE XCD: workgroups are dealt
 // round-robin over the 8 XCDs (b and b + 8 share one), so inside every run of 32 workgroups item = r & 7, quadrant = r >> 3.
@@ -169,7 +170,7 @@ __device__ __forceinline__ void gh_pop4_high(uint64_t& mask, int& j0, int& j1, i
 // Consume one staged batch front to back, four entries per trip. Returns true when all 16 pixels are finished.
 template <bool ALPHA, bool SEEN>
 __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int total, int lane, int slot, int blk,
-                                               float& pxf, float pyf, GhPixelFwd& p, float4* __restrict__ s_col) {
+                                               float& pxf, float pyf, GhPixelFwd& p, float4* __restrict__ s_col, int& hits) {
   const uint32_t slot8 = (uint32_t)slot * 8u;
   // the batch's colours and opacities go through wave-private LDS memory (one 16-byte store per lane and batch, one
   // broadcast 16-byte load per trip) instead of four crossbar fetches per trip: they are needed after the exponential,
@@ -177,6 +178,7 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
   s_col[lane] = make_float4(t.b.z, t.b.w, t.cb, t.b.y);            // (r, g, b, opacity)
   const bool hit = (base + lane < total) && ((t.blocks >> blk) & 1u);
   uint64_t mask = gh_ballot(hit);
+  hits += __builtin_popcountll(mask);                                // (FINE launches: how heavy this wave's walk was, for the next launch order)
   bool finished = false;                                             // set (and the mask cleared) inside the rare stop branch, so
   while (mask) {                                                     // the common path's loop control is one scalar compare
     // next four set bits, ascending (wave-uniform scalar work)
@@ -278,6 +280,100 @@ __device__ __forceinline__ bool gh_fwd_consume(const GhBatch& t, int base, int t
   return finished;
 }
 
+// ---- forward, fine-grained form: wave = 2x2 pixels x 16 depth slots -----------------------------------------------
+// lane = 16 * pixel + slot: a pixel's slots are one DPP row. Per trip the wave takes the next (up to) SIXTEEN surviving entries of the
+// batch — a quarter of the trips of the 4-slot form for the same 4x4-pixel block, split over four waves. The entry lanes come from a
+// wave-private byte table (hit lanes store their lane number at their rank among the hits; slot s of trip t reads byte 16 t + s),
+// not from scalar picks. The recurrence stays the sequential one of App. A.3, as FIXED-POINT iterations along the row:
+//     I_s <- I_{s-1} * f_s   (v_mul_f32_dpp row_shr:1, in place; lane 0 of the row has no source lane and keeps T * f_0)
+// applied 15 times leaves ((T f_0) f_1) ... f_s in lane s — after step k lanes 0..k hold their final value and every later step
+// recomputes exactly the same product from the same operands. The colour sums run the same way with v_add_f32_dpp. State between
+// trips (T, C) is the value in the row's LAST lane: the next trip's lane 0 takes it with row_ror:1 (fused into its first operation).
+__device__ __forceinline__ float gh_row_ror1(float v) {       // lane s of a row takes lane s - 1, lane 0 takes lane 15
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));
+}
+#define GH_ROW_STEP(OP, R, X) "s_nop 1\n\t" OP " " R ", " R ", " X " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define GH_X5(a) a a a a a
+#define GH_X15(a) GH_X5(a) GH_X5(a) GH_X5(a)
+
+template <bool ALPHA>
+__device__ __forceinline__ bool gh_fwd_consume_fine(const GhBatch& t, int base, int total, int lane, int slot, int blk,
+                                                    float& pxf, float pyf, GhPixelFwd& p, float4* __restrict__ s_col,
+                                                    uint8_t* __restrict__ s_idx, int& hits) {
+  s_col[lane] = make_float4(t.b.z, t.b.w, t.cb, t.b.y);            // (r, g, b, opacity), as gh_fwd_consume
+  const bool hit = (base + lane < total) && ((t.blocks >> blk) & 1u);
+  const uint64_t mask = gh_ballot(hit);
+  const int nh = __builtin_popcountll(mask);
+  hits += nh;
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  if (hit) s_idx[rank] = (uint8_t)(lane * 4);                      // 4 * entry lane = ds_bpermute address
+  bool finished = false;
+  for (int t0 = 0; t0 < nh; t0 += 16) {
+    const bool have = t0 + slot < nh;
+    // (bytes past the batch's hits are stale: & 0xFC keeps them a valid 4 * lane — the records behind it are finite, their
+    //  weight is zero)
+    const int src = (int)s_idx[t0 + slot] & 0xFC;
+    const float gpx = gh_lane_fetch(t.a.x, src), gpy = gh_lane_fetch(t.a.y, src), cA = gh_lane_fetch(t.a.z, src);
+    const float cB = gh_lane_fetch(t.a.w, src), cC = gh_lane_fetch(t.b.x, src);
+    const float4 col = *(const float4*)((const char*)s_col + 4 * src);
+    const float dx = gpx - pxf, dy = gpy - pyf;
+    const float power = (cA * dx * dx + cC * dy * dy) - cB * dx * dy;      // the same expression as gh_fwd_consume, bit for bit
+    const float alpha = fminf(0.99f, col.w * gh_exp(power));
+    const bool ok = have && (power <= 0.0f) && (alpha >= 1.0f / 255.0f);   // (a finished pixel has NaN coordinates: never ok)
+    const float ae = ok ? alpha : 0.0f;
+    const float f = 1.0f - ae;
+    // T right behind every slot's entry, in list order along the row
+    const float Tin = gh_row_ror1(p.T);                                    // lane 0: T in front of the trip
+    float I = Tin * f, Pm = Tin;
+    asm(GH_X15(GH_ROW_STEP("v_mul_f32_dpp", "%0", "%2"))
+        "s_nop 1\n\tv_mov_b32_dpp %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(I), "+v"(Pm) : "v"(f));                                      // Pm: T seen by this lane's entry (lane 0 keeps Tin)
+    // Early stop (App. A.3): the FIRST entry of a pixel with T (1 - alpha) < 1e-4 is not blended and ends the pixel; up to and
+    // including that entry the products above are the sequential ones (see gh_fwd_consume).
+    bool blend = ok;
+    float w = ae * Pm;
+    const bool stopc = ok && I < 0.0001f;
+    const uint64_t sm = gh_ballot(stopc);
+    if (sm) {                                                              // wave-uniform, rare
+      const uint32_t qb = (uint32_t)(sm >> (lane & 48)) & 0xFFFFu;         // stop flags of this pixel's sixteen slots
+      if (qb) {
+        const int fs = __builtin_ctz(qb);
+        blend = ok && slot < fs;                                           // no stop at or before this slot
+        w = blend ? w : 0.0f;
+        p.done = 1; pxf = __uint_as_float(0x7FC00000u);
+      }
+      // T right before the stop = what the stopping entry saw (rows without a stop fetch their own lane: unchanged)
+      const float Tstop = gh_lane_fetch(Pm, ((lane & 48) + (qb ? __builtin_ctz(qb) : 0)) * 4);
+      I = qb ? Tstop : I;
+      if (__all(p.done != 0)) finished = true;                             // every pixel of the block is saturated: last trip
+    }
+    // C = (((C + m[slot 0]) + m[slot 1]) + ...) + m[slot 15] with m = colour * w, in list order; the mask channel's m is w
+    {
+      float m0, m1, m2;
+      if (ALPHA)
+        asm("v_mul_f32 %4, %7, %10\n\tv_mul_f32 %5, %8, %10\n\tv_mul_f32 %6, %9, %10\n\t"
+            "v_add_f32_dpp %0, %0, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %5 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %2, %2, %6 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %10 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            GH_X15("v_add_f32_dpp %0, %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %10 row_shr:1 row_mask:0xf bank_mask:0xf\n\t")
+            : "+v"(p.C0), "+v"(p.C1), "+v"(p.C2), "+v"(p.A), "=&v"(m0), "=&v"(m1), "=&v"(m2)
+            : "v"(col.x), "v"(col.y), "v"(col.z), "v"(w));
+      else
+        asm("v_mul_f32 %3, %6, %9\n\tv_mul_f32 %4, %7, %9\n\tv_mul_f32 %5, %8, %9\n\t"
+            "v_add_f32_dpp %0, %0, %3 row_ror:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %4 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %2, %2, %5 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            GH_X15("v_add_f32_dpp %0, %0, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_add_f32_dpp %2, %2, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\t")
+            : "+v"(p.C0), "+v"(p.C1), "+v"(p.C2), "=&v"(m0), "=&v"(m1), "=&v"(m2)
+            : "v"(col.x), "v"(col.y), "v"(col.z), "v"(w));
+    }
+    p.T = I;                                                               // (the row's last lane: T behind the trip)
+    p.last = blend ? (uint32_t)(4 * (base + 1)) + (uint32_t)src : p.last;
+    if (finished) break;
+  }
+  return finished;
+}
+
 // grid = 4 blocks per tile (one per 8x8 quadrant), 4 waves per block (one per 4x4 pixel block); no LDS, no barriers.
 // ALPHA: also accumulate the mask channel (colour 1, bg 0) — SURVEY §8 f-2.
 // LOSS: fused image loss. 1 = GhOutputs.l1_target: every wave leaves the gradient sign(img - gt) / n of its 16 pixels, every workgroup
@@ -298,7 +394,11 @@ struct GhFusedLoss {
   float sum_scale;           // factor of the final sum over the partials (LOSS 1: inv_n, LOSS 2: 1); left behind the partials
 };
 
-template <bool ALPHA, bool SEEN, int LOSS>
+// FINE (launches of at most GH_FWD_FINE_TILES tiles, never with SEEN): the grid carries 12 extra workgroups for each of the first
+// `fine_k` tiles of the launch order; such a tile, if its list holds at least `fine_min` entries, is walked by 16 workgroups — one per
+// 4x4-pixel block, its four waves 2x2 pixels x 16 slots each (gh_fwd_consume_fine) — instead of four; the others run as ever and
+// their extra workgroups exit at once. Results are the same bit for bit: only which wave owns a pixel changes.
+template <bool ALPHA, bool SEEN, int LOSS, bool FINE = false>
 __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order, const float4* __restrict__ r0,
     const float4* __restrict__ r1, const float2* __restrict__ r2, const float* __restrict__ cams, int H, int W, int gx,
@@ -306,7 +406,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_walk, float4* __restrict__ ckpt_rgb,
     float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const uint32_t* __restrict__ render_guard,
     uint32_t guard_mask, const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
-    const uint32_t* __restrict__ sorted_gid, const float4* __restrict__ geom, const GhFusedLoss l1) {
+    const uint32_t* __restrict__ sorted_gid, const float4* __restrict__ geom, const GhFusedLoss l1,
+    uint32_t n_tiles_call, uint32_t fine_k, uint32_t fine_min, uint32_t n_items_cap, uint32_t* __restrict__ back_count, uint32_t back_k) {
   // LOSS: the quadrant's four wave sums meet in LDS (the last wave to arrive adds them up in block order); the arrival counter is
   // cleared behind the one barrier of the kernel, which the four waves reach as they start — before any load is in flight
   __shared__ float s_l1[GH_BLOCK / GH_WAVE];
@@ -315,22 +416,33 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     if (threadIdx.x == 0) {
       s_l1_n = 0u;
       // the final sum's factor, behind the last partial: a deferred sum (GhGrads.deferred_loss) finds it there
-      if (blockIdx.x == 0) l1.part[(size_t)gridDim.x] = l1.sum_scale;
+      if (blockIdx.x == 0) l1.part[(size_t)n_tiles_call * (FINE ? 16 : 4)] = l1.sum_scale;
     }
     __syncthreads();
   }
   int v, tx, ty;
-  uint32_t item_idx, quad_u;
-  gh_item_quad(blockIdx.x, gridDim.x >> 2, item_idx, quad_u);
+  uint32_t item_idx, quad_u, sub = 0u;
+  // FINE: the first 16 fine_k workgroups belong to the fine_k tiles at the head of the launch order, sixteen each (one per 4x4-pixel
+  // block: they must START first — behind the other tiles' workgroups they would begin a round late); the rest as ever, four per tile
+  bool extra = false;                                                // a workgroup that only exists for the fine form of its tile
+  if (FINE && blockIdx.x < 16u * fine_k) { item_idx = blockIdx.x >> 4; quad_u = (blockIdx.x >> 2) & 3u; sub = blockIdx.x & 3u; extra = sub != 0u; }
+  else { gh_item_quad(blockIdx.x - (FINE ? 16u * fine_k : 0u), n_tiles_call - (FINE ? fine_k : 0u), item_idx, quad_u); item_idx += FINE ? fine_k : 0u; }
   // (wave-uniform values are moved to scalar registers by hand: the compiler keeps what comes out of a global load in vector
   //  registers, and with it the tile coordinates, the list range and the three 64-bit record pointers — per lane, through the walk)
   const int tile = __builtin_amdgcn_readfirstlane((int)tile_order[item_idx]);             // heaviest tiles are launched first
   const int quad = (int)quad_u;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int slot = lane & 3, pi = lane >> 2;
-  const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (wid & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (wid >> 1) * 4;
-  const int x = bx0 + (pi & 3), y = by0 + (pi >> 2);
+  const uint2 range_v = ranges[tile];
+  const uint2 range = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.y));
+  const int total = (int)(range.y - range.x);
+  // fine form: this workgroup owns the 4x4-pixel block `sub` of its quadrant, its waves the block's 2x2-pixel quarters
+  const bool fine = FINE && item_idx < fine_k && (uint32_t)total >= fine_min;
+  if (FINE && extra && !fine) return;                               // (no barrier between here and the kernel's end for this workgroup's waves)
+  const int blk4 = fine ? (int)sub : wid;                            // the 4x4 block of the quadrant this wave works in
+  const int slot = fine ? (lane & 15) : (lane & 3), pi = fine ? (lane >> 4) : (lane >> 2);
+  const int bx0 = tx * GH_TILE + (quad & 1) * 8 + (blk4 & 1) * 4, by0 = ty * GH_TILE + (quad >> 1) * 8 + (blk4 >> 1) * 4;
+  const int x = fine ? bx0 + (wid & 1) * 2 + (pi & 1) : bx0 + (pi & 3), y = fine ? by0 + (wid >> 1) * 2 + (pi >> 1) : by0 + (pi >> 2);
   const bool inside = x < W && y < H;
   float pxf = inside ? (float)x : __uint_as_float(0x7FC00000u);      // NaN = the pixel takes nothing (any more): see gh_fwd_consume
   const float pyf = (float)y;
@@ -339,10 +451,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
   // which cost the fused-loss variant a wave per SIMD (71 VGPRs).
   const size_t hw = (size_t)H * W;
   const uint32_t poff = (uint32_t)y * (uint32_t)W + (uint32_t)x;
-  const int blk = ((quad >> 1) * 2 + (wid >> 1)) * 4 + (quad & 1) * 2 + (wid & 1);      // this wave's bit in the block masks
-  const uint2 range_v = ranges[tile];
-  const uint2 range = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.y));
-  const int total = (int)(range.y - range.x);
+  const int blk = ((quad >> 1) * 2 + (blk4 >> 1)) * 4 + (quad & 1) * 2 + (blk4 & 1);    // this wave's bit in the block masks
   r0 += range.x; r1 += range.x; r2 += range.x;
   // state checkpoints for the segmented backward: slot of (tile, position m*GH_SEGMENT) = range.x/GH_SEGMENT + tile + m - 1
   // (disjoint between tiles because floor(a+b) >= floor(a) + floor(b)); pixel = row-major index inside the tile
@@ -350,6 +459,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
 
   __shared__ float4 s_col_all[GH_BLOCK / GH_WAVE][GH_WAVE];
   float4* s_col = s_col_all[wid];
+  __shared__ uint8_t s_idx_all[FINE ? GH_BLOCK / GH_WAVE : 1][80];          // fine form: entry lanes of a batch's hits, in list order
+  uint8_t* s_idx = s_idx_all[FINE ? wid : 0];
   // LOSS: the pixel's target is fetched NOW (three registers through the walk) — at the end of the wave the loads' latency would be
   // exposed time of a finished wave's slot
   float tg0 = 0.0f, tg1 = 0.0f, tg2 = 0.0f, tgm = 0.0f;
@@ -364,19 +475,48 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     tgm = (l1.gt_mask + (size_t)v * hw)[poff];
     if (l1.bbox) in_box = (l1.bbox + (size_t)v * hw)[poff] != 0.0f;
   }
+  int hits = 0;                                      // list entries this wave's block mask let through (batches it consumed)
   GhPixelFwd p;
   p.T = 1.0f; p.C0 = p.C1 = p.C2 = p.A = 0.0f; p.last = 0; p.stopq = 0; p.done = inside ? 0 : 1;
   p.vT = 1.0f; p.vdone = p.done;
+  if (FINE && fine) {
+    if (total > 0 && !__all(p.done != 0)) {
+      GhBatch A, B;
+      gh_load_batch(A, r0, r1, r2, lane, total);
+      for (int base = 0; base < total; base += 2 * GH_WAVE) {
+        gh_load_batch(B, r0, r1, r2, base + GH_WAVE + lane, total);
+        if (gh_fwd_consume_fine<ALPHA>(A, base, total, lane, slot, blk, pxf, pyf, p, s_col, s_idx, hits)) break;
+        if (base + GH_WAVE >= total) break;
+        gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
+        if (gh_fwd_consume_fine<ALPHA>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p, s_col, s_idx, hits)) break;
+        const int next = base + 2 * GH_WAVE;
+        if ((next % GH_SEGMENT) == 0 && next < total) {                 // (wave-uniform, rare; the state sits in the rows' last lanes)
+          const float cT = gh_row_ror1(p.T), c0 = gh_row_ror1(p.C0), c1 = gh_row_ror1(p.C1), c2 = gh_row_ror1(p.C2);
+          if (inside && slot == 0) ckpt_rgb[ck0 + (size_t)(next / GH_SEGMENT - 1) * 256] = make_float4(cT, c0, c1, c2);
+        }
+      }
+    }
+    // the walk's state from the rows' last lanes to their first (the epilogue's lanes); n_contrib = max over the row
+    p.T = gh_row_ror1(p.T); p.C0 = gh_row_ror1(p.C0); p.C1 = gh_row_ror1(p.C1); p.C2 = gh_row_ror1(p.C2);
+    if (ALPHA) p.A = gh_row_ror1(p.A);
+    p.last >>= 2;
+    {
+      uint32_t a = (uint32_t)__builtin_amdgcn_mov_dpp((int)p.last, 0x128, 0xF, 0xF, false); p.last = a > p.last ? a : p.last;   // row_ror:8
+      a = (uint32_t)__builtin_amdgcn_mov_dpp((int)p.last, 0x124, 0xF, 0xF, false); p.last = a > p.last ? a : p.last;            // row_ror:4
+      a = (uint32_t)__builtin_amdgcn_mov_dpp((int)p.last, 0x122, 0xF, 0xF, false); p.last = a > p.last ? a : p.last;            // row_ror:2
+      a = (uint32_t)__builtin_amdgcn_mov_dpp((int)p.last, 0x121, 0xF, 0xF, false); p.last = a > p.last ? a : p.last;            // row_ror:1
+    }
+  } else {
   if (total > 0 && !__all(p.done != 0)) {
     // two register sets in flight: while one batch is consumed the next one is already being loaded
     GhBatch A, B;
     gh_load_batch(A, r0, r1, r2, lane, total);
     for (int base = 0; base < total; base += 2 * GH_WAVE) {
       gh_load_batch(B, r0, r1, r2, base + GH_WAVE + lane, total);
-      if (gh_fwd_consume<ALPHA, SEEN>(A, base, total, lane, slot, blk, pxf, pyf, p, s_col)) break;
+      if (gh_fwd_consume<ALPHA, SEEN>(A, base, total, lane, slot, blk, pxf, pyf, p, s_col, hits)) break;
       if (base + GH_WAVE >= total) break;
       gh_load_batch(A, r0, r1, r2, base + 2 * GH_WAVE + lane, total);
-      if (gh_fwd_consume<ALPHA, SEEN>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p, s_col)) break;
+      if (gh_fwd_consume<ALPHA, SEEN>(B, base + GH_WAVE, total, lane, slot, blk, pxf, pyf, p, s_col, hits)) break;
       const int next = base + 2 * GH_WAVE;              // wave-uniform: a checkpoint every GH_SEGMENT entries (rare)
       if ((next % GH_SEGMENT) == 0 && next < total && inside && slot == 0) {
         const size_t ck = ck0 + (size_t)(next / GH_SEGMENT - 1) * 256;
@@ -390,6 +530,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     p.last = a > p.last ? a : p.last;
     const uint32_t b = (uint32_t)gh_quad_perm_i<0x4E>((int)p.last);      // quad_perm [2,3,0,1]
     p.last = b > p.last ? b : p.last;
+  }
   }
   // Speculative occlusion bound (GhInputs.tile_depth_bound): the tile's list holds nothing behind the bound. A pixel that reached
   // the early stop inside it looked at nothing further back — its result is the unbounded call's bit for bit; a pixel that ran
@@ -433,11 +574,28 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
         (l1.dalpha + (size_t)v * hw)[poff] = (a >= -0.001f && a <= 1.0f) ? 2.0f * l1.k_m * e : 0.0f;
       }
     }
+    if (FINE && fine) {
+      // FINE launches keep one partial per 4x4-pixel block, and it must not depend on the form the tile was walked in (which tiles
+      // go fine is a scheduling decision: the loss may not change with it): the block's sixteen pixel terms meet in LDS and the last
+      // wave to arrive adds them up in the lanes and the order of the coarse form's wave sum.
+      __shared__ float s_px[16];
+      if (slot == 0) s_px[(y - by0) * 4 + (x - bx0)] = labs;
+      uint32_t k = 0u;
+      if (lane == 63) k = __hip_atomic_fetch_add(&s_l1_n, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((uint32_t)__builtin_amdgcn_readlane((int)k, 63) == GH_BLOCK / GH_WAVE - 1) {
+        const float bsum = gh_wave_sum_to63((lane & 3) == 0 ? s_px[lane >> 2] : 0.0f);
+        if (lane == 63) l1.part[(size_t)tile * 16 + quad * 4 + sub] = bsum;
+      }
+    } else {
     const float wsum = gh_wave_sum_to63(labs);
     if (lane == 63) {
       s_l1[wid] = wsum;
       const uint32_t k = __hip_atomic_fetch_add(&s_l1_n, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (k == GH_BLOCK / GH_WAVE - 1) l1.part[(size_t)tile * 4 + quad] = (s_l1[0] + s_l1[1]) + (s_l1[2] + s_l1[3]);
+      if (k == GH_BLOCK / GH_WAVE - 1) {
+        if (!FINE) l1.part[(size_t)tile * 4 + quad] = (s_l1[0] + s_l1[1]) + (s_l1[2] + s_l1[3]);
+        else ((float4*)l1.part)[(size_t)tile * 4 + quad] = make_float4(s_l1[0], s_l1[1], s_l1[2], s_l1[3]);   // (wave = block)
+      }
+    }
     }
   }
   if (total > 0) {                                   // walked length of the tile = max n_contrib over its 16 waves
@@ -454,11 +612,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       // the end, so the tiles that ran longest start first; the order only affects scheduling, never results.
       // Ordering without fences (an agent-scope release would write back the whole L2): only relaxed agent-scope RMW
       // atomics carry the data; each returns its old value, so waiting for the return means it has been performed.
+      // FINE launches: the most entries any 4x4 block of the tile took = what the tile's longest wave does; the NEXT call's launch
+      // order and choice of fine tiles go by it (gh_tile_order_kernel; a scheduling hint only — stale or missing values cost time)
+      if (FINE) __hip_atomic_fetch_max(&tile_walk[3 * (size_t)n_tiles_call + tile], (uint32_t)hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t prev_max = __hip_atomic_fetch_max(&tile_walk[tile], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" :: "v"(prev_max) : "memory");
-      uint32_t* done = tile_walk + (size_t)gridDim.x / 4;          // completion counters follow the T walk entries
+      uint32_t* done = tile_walk + (size_t)n_tiles_call;          // completion counters follow the T walk entries
       if (SEEN) {                                                  // (same ordering discipline: relaxed RMWs, results awaited)
-        uint32_t* stop = done + (size_t)gridDim.x / 4;             // ... and the stop positions follow those
+        uint32_t* stop = done + (size_t)n_tiles_call;             // ... and the stop positions follow those
         const uint32_t ps = __hip_atomic_fetch_max(&stop[tile], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" :: "v"(ps) : "memory");
       }
@@ -466,17 +627,23 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       // (each wave adds its own bit once: the sum is the OR)
       const uint32_t my_bit = (SEEN && !wave_unsat) ? (0x100u << blk) : 0u;
       const uint32_t prev_done = __hip_atomic_fetch_add(&done[tile], 1u + my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((prev_done & 0xFFu) == 4u * (GH_BLOCK / GH_WAVE) - 1u) {
+      if ((prev_done & 0xFFu) == (fine ? 16u : 4u) * (GH_BLOCK / GH_WAVE) - 1u) {     // (a fine tile: 16 workgroups)
         const uint32_t w = __hip_atomic_fetch_max(&tile_walk[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // final value
         const uint32_t nseg = (w + GH_SEGMENT - 1u) / GH_SEGMENT;
         if (nseg) {
-          const uint32_t pos = __hip_atomic_fetch_add(&ctr->reserved[1], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // FINE launches (heaviest tiles launched FIRST by measured work, so the order of completion no longer says which tiles are
+          // the heavy ones): the first quarter of the launch order appends from the END of the list downwards, the rest from its
+          // start upwards; the backward takes the end region first.
+          uint32_t pos;
+          if (FINE && item_idx < back_k)
+            pos = n_items_cap - nseg - __hip_atomic_fetch_add(back_count, nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else pos = __hip_atomic_fetch_add(&ctr->reserved[1], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           for (uint32_t k = 0; k < nseg; ++k) items[pos + k] = make_uint2((uint32_t)tile, k);
         }
         if (SEEN) {
           // every pixel of the tile stopped (and passed the virtual threshold): nothing behind the last entry any of them looked at can matter next time either
           // (up to the motion margin seen_scale); otherwise no bound for this tile
-          uint32_t* stop = done + (size_t)gridDim.x / 4;
+          uint32_t* stop = done + (size_t)n_tiles_call;
           const uint32_t sp = __hip_atomic_fetch_max(&stop[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const uint32_t sat_mask = ((prev_done | my_bit) >> 8) & 0xFFFFu;
           const bool unsat = sat_mask != 0xFFFFu || sp == 0u;
@@ -521,7 +688,19 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
 
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha, const char* wg, char* ws,
                           const GhLayout& L, hipStream_t s, float* seen, float seen_scale, uint32_t seen_slack, const GhOutputs* fused) {
-  const dim3 grid(4 * g.NV * g.tiles), block(GH_BLOCK);
+  // Small launches (resident all at once: as long as their longest wave) run their heaviest tiles in the fine-grained form: see the
+  // kernel. GH_FWD_FINE_K / GH_FWD_FINE_MIN in the environment override the two thresholds (0 tiles = the coarse form only; tests
+  // walk EVERY tile of their small scenes in the fine form with K = a large number, MIN = 0).
+  static const long env_k = getenv("GH_FWD_FINE_K") ? atol(getenv("GH_FWD_FINE_K")) : -1;
+  static const long env_min = getenv("GH_FWD_FINE_MIN") ? atol(getenv("GH_FWD_FINE_MIN")) : -1;
+  const uint32_t n_tiles_call = (uint32_t)(g.NV * g.tiles);
+  const bool fine_launch = gh_fwd_fine_launch(g) && !seen;
+  uint32_t fine_k = fine_launch ? (uint32_t)(env_k >= 0 ? env_k : GH_FWD_FINE_K) : 0u;
+  if (fine_k > n_tiles_call) fine_k = n_tiles_call;
+  const uint32_t fine_min = (uint32_t)(env_min >= 0 ? env_min : GH_FWD_FINE_MIN);
+  static const long env_back = getenv("GH_FWD_BACK_DIV") ? atol(getenv("GH_FWD_BACK_DIV")) : 4;      // (A/B knob)
+  const uint32_t back_k = env_back > 0 ? n_tiles_call / (uint32_t)env_back : 0u;
+  const dim3 grid(4 * n_tiles_call + 12 * fine_k), block(GH_BLOCK);
   const uint2* ranges = (const uint2*)(wg + L.ranges);
   const uint32_t* order = (const uint32_t*)(wg + L.tile_order);
   const float4* r0 = (const float4*)(wg + L.inst_r0); const float4* r1 = (const float4*)(ws + L.inst_r1);
@@ -553,21 +732,23 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
                        g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const uint32_t*)(ws + L.render_guard),
-                       wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, geom, l1);
+                       wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, geom, l1,
+                       n_tiles_call, fine_k, fine_min, (uint32_t)g.n_items, (uint32_t*)(ws + L.render_guard) + 1, back_k);
   };
   if (loss_kind == 1) {                              // (the entry point has ruled out alpha / seen / a bound)
-    launch(gh_render_fwd_kernel<false, false, 1>);
+    if (fine_launch) launch(gh_render_fwd_kernel<false, false, 1, true>); else launch(gh_render_fwd_kernel<false, false, 1>);
     // GH_FLAG_DEFER_LOSS_SUM: the sum is a spare workgroup of the backward's render kernel (GhGrads.deferred_loss)
-    if (!(d->flags & GH_FLAG_DEFER_LOSS_SUM)) gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, l1.inv_n, fused->l1_loss, s);
+    if (!(d->flags & GH_FLAG_DEFER_LOSS_SUM)) gh_launch_partials_sum(l1.part, gh_loss_partial_count(g), l1.inv_n, fused->l1_loss, s);
     return;
   }
   if (loss_kind == 2) {                              // (... seen / a bound, and required alpha)
-    launch(gh_render_fwd_kernel<true, false, 2>);
-    if (!(d->flags & GH_FLAG_DEFER_LOSS_SUM)) gh_launch_partials_sum(l1.part, (size_t)g.NV * g.tiles * 4, 1.0f, fused->fit_loss->loss, s);
+    if (fine_launch) launch(gh_render_fwd_kernel<true, false, 2, true>); else launch(gh_render_fwd_kernel<true, false, 2>);
+    if (!(d->flags & GH_FLAG_DEFER_LOSS_SUM)) gh_launch_partials_sum(l1.part, gh_loss_partial_count(g), 1.0f, fused->fit_loss->loss, s);
     return;
   }
   // SEEN (GhOutputs.tile_depth_seen wanted): the variant that walks on virtually behind the stop; the plain kernels are untouched
   if (seen) { if (alpha) launch(gh_render_fwd_kernel<true, true, 0>); else launch(gh_render_fwd_kernel<false, true, 0>); }
+  else if (fine_launch) { if (alpha) launch(gh_render_fwd_kernel<true, false, 0, true>); else launch(gh_render_fwd_kernel<false, false, 0, true>); }
   else { if (alpha) launch(gh_render_fwd_kernel<true, false, 0>); else launch(gh_render_fwd_kernel<false, false, 0>); }
 }
 
@@ -724,7 +905,8 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
     const float4* __restrict__ ckpt_rgb, const float4* __restrict__ final_C,
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, const float* __restrict__ upstream_scale,
     float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag,
-    const float4* __restrict__ loss_part, uint32_t loss_n4, float* __restrict__ loss_out) {
+    const float4* __restrict__ loss_part, uint32_t loss_n4, float* __restrict__ loss_out,
+    const uint32_t* __restrict__ back_count, uint32_t n_items_cap) {
   // GhGrads.deferred_loss: the fused image loss's final sum (GH_FLAG_DEFER_LOSS_SUM left the forward without its one-workgroup sum
   // kernel) by workgroup 0 of this launch — dispatched first, done long before the kernel's tail; every other workgroup's
   // index moves down by one. Fixed order: bitwise reproducible.
@@ -757,11 +939,15 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
   float* s_acc = s_acc_all[wv];
   uint16_t* s_q = s_q_all[wv];
   uint8_t* s_f = s_f_all[wv];
-  const uint32_t n_items = ctr->reserved[1];             // written by the forward; the grid is sized for the list's capacity
+  // the work list, written by the forward (the grid is sized for its capacity): items appended from the start upwards in the order the
+  // tiles finished, and — launches with the fine-grained forward — the heaviest quarter of the launch order from the END downwards
+  const uint32_t n_front = ctr->reserved[1], n_back = *back_count;
+  const uint32_t n_items = n_front + n_back;
   uint32_t item_idx, quad_u;
   gh_item_quad(bid, nblk_items >> 2, item_idx, quad_u);       // the four quadrants of an item share an XCD (L2)
   if (item_idx >= n_items) return;
-  const uint2 item_v = items[n_items - 1u - item_idx];     // (tile, depth segment): the tiles the forward finished last go first
+  // (tile, depth segment): the end region first, then the tiles the forward finished last
+  const uint2 item_v = item_idx < n_back ? items[n_items_cap - n_back + item_idx] : items[n_front - 1u - (item_idx - n_back)];
   const uint2 item = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)item_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v.y));
   const int tile = (int)item.x, quad = (int)quad_u;       // (wave-uniform values in scalar registers by hand: see the forward)
   const int seg_lo = (int)item.y * GH_SEGMENT, seg_hi = seg_lo + GH_SEGMENT;
@@ -963,7 +1149,7 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
 void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, const float* dL_dimage,
                           const float* dL_dalpha, const float* upstream_scale, const char* wg, char* ws, const GhLayout& L, hipStream_t s,
                           bool geom, float* deferred_loss) {
-  const size_t n_part = (size_t)g.NV * g.tiles * 4;
+  const size_t n_part = gh_loss_partial_count(g);          // (as the forward's fused loss left them)
   if (g.cap == 0) {                                       // nothing was listed: no render backward; a deferred sum still has to run
     if (deferred_loss) gh_launch_partials_sum((const float*)(ws + L.loss_partials), n_part, 1.0f, deferred_loss, s, true);
     return;
@@ -979,7 +1165,8 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                        (const float2*)(ws + L.inst_r2), in->cams, g.H, g.W, g.gx, g.tiles, (const float*)(ws + L.final_T),
                        (const uint32_t*)(ws + L.n_contrib), (const float4*)(ws + L.ckpt_rgb),
                        (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, upstream_scale, (float*)(ws + L.inst_grad),
-                       (uint8_t*)(ws + L.inst_flag), (const float4*)(ws + L.loss_partials), (uint32_t)(n_part / 4), deferred_loss);
+                       (uint8_t*)(ws + L.inst_flag), (const float4*)(ws + L.loss_partials), (uint32_t)(n_part / 4), deferred_loss,
+                       (const uint32_t*)(ws + L.render_guard) + 1, (uint32_t)g.n_items);
   };
   // geom = false (precomputed colours and no geometry gradient wanted): colour / opacity moments only, see the kernel
   if (small) {
@@ -1007,6 +1194,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_recolour_kernel(GhInputs in, uint
   if (i == 0) {
     ctr->num_rendered = D; ctr->overflow = gctr->overflow; ctr->reserved[0] = gctr->reserved[0]; ctr->reserved[1] = 0;
     *render_guard = gctr->overflow & GH_COUNTER_ERROR_MASK;        // (this is the kernel in front of the render, see gh_render_fwd_kernel)
+    render_guard[1] = 0u;                                          // (the work list's end region: gh_render_fwd_kernel)
   }
   if (i < (uint32_t)T) { tile_walk[i] = 0u; tile_walk[T + i] = 0u; tile_walk[2 * T + i] = 0u; }
   const uint32_t n = D < cap ? D : cap;
@@ -1081,7 +1269,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_instance_kernel(uint32_t 
                                                                         int local_keys) {
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   // the kernel in front of the render (gh_refresh_attr_kernel, complete by now, may have raised bit 1): the error bits in their own word
-  if (i == 0) *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK;
+  if (i == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; render_guard[1] = 0u; }
   const uint32_t D = gctr->num_rendered;
   const uint32_t n = D < cap ? D : cap;
   if (i >= n) return;

@@ -1,0 +1,15 @@
+# Sweep of the fine-grained forward's knobs on the in-tree library: bench line + stage times.
+# usage: bash tools/fine_sweep.sh '<bench args>' 'K:MIN[:ORDER[:BACKDIV]] ...'   (GH_FWD_FINE_K tiles at the head of the launch order walked in the fine
+# form if their list holds at least GH_FWD_FINE_MIN entries; ORDER 0 = launch order by list length, 1 (default) = by the previous forward's hits; BACKDIV: the first 1/BACKDIV of the launch order
+# goes to the end region of the backward's work list, 0 = none)
+ARGS=$1; shift
+for r in 1 2; do
+for km in $@; do
+  IFS=: read K MIN ORD BACK <<< "$km"
+  export GH_FWD_FINE_K=$K GH_FWD_FINE_MIN=$MIN GH_FWD_HEAVY_ORDER=${ORD:-1} GH_FWD_BACK_DIV=${BACK:-4}
+  python3 bench.py --steps 50 --warmup 20 --repeats 3 --no-cpu-baseline $ARGS 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); c=d['config']
+print('K:MIN:ORDER $km', round(d['value']), 'renders/s', round(d['ms_per_step'],4), 'ms; median', round(c['repeats']['ms_per_step_median'],4), {k: round(v['ms'],4) for k,v in d.get('stages',{}).items()})"
+done
+done
