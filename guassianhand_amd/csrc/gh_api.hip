@@ -86,7 +86,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   }
   L->sort_tables = take(tab * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
-  L->tile_walk = take((size_t)g.NV * g.tiles * 16);      // walked entries [T] + completion counters [T] + stop positions [T] + heaviness of the previous FINE launch [T] (never cleared);
+  L->tile_walk = take((size_t)g.NV * g.tiles * (gh_fwd_fine_launch(g) ? 16 : 12));      // walked entries [T] + completion counters [T] + stop positions [T] + heaviness of the previous FINE launch [T] (never cleared);
                                                          // directly after ranges: all cleared by one memset when there is
                                                          // nothing to project
   L->tile_order = take((size_t)g.NV * g.tiles * 4);
@@ -113,11 +113,7 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   L->tile_bound = take((size_t)g.NV * g.tiles * 4);
   L->block_tiles = take((gh_proj_blocks(g) + 4) * 4);     // (two halves: + 1 block of rounding + 1 spare word each)
   L->render_guard = take(512);                            // one word (+ a second, 256 bytes on, for the other half of a split call)
-  {                                                   // (+ the factor of the final sum, behind the last partial; sized so that it
-    const size_t t = (size_t)g.NV * g.tiles;          //  grows with the tile count across the fine / coarse threshold)
-    const size_t nf = (t < (size_t)GH_FWD_FINE_TILES ? t : (size_t)GH_FWD_FINE_TILES) * 16, nc = t * 4;
-    L->loss_partials = take((nf > nc ? nf : nc) * 4 + 16);
-  }
+  L->loss_partials = take(gh_loss_partial_count(g) * 4 + 16);   // (+ the factor of the final sum, behind the last partial)
   L->view_start = take(((size_t)g.NV + 2) * 4);           // (a split call: each half's n_views + 1 bounds, the second half's behind the first's)
   L->total_bytes = off;
   return GH_OK;
@@ -185,7 +181,7 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     o.keys_a += cap0 * 4; o.keys_b += cap0 * 4; o.vals_a += cap0 * 4; o.vals_b += cap0 * 4; o.sorted_slot += cap0 * 4;
     o.inst_r0 += cap0 * 16; o.inst_r1 += cap0 * 16; o.inst_r2 += cap0 * 8;
     o.sort_tables += h ? tab_a * 4 : 0;
-    o.ranges += t0 * 8; o.tile_walk += t0 * 16; o.tile_order += t0 * 4;
+    o.ranges += t0 * 8; o.tile_walk += t0 * (gh_fwd_fine_launch(gf) ? 16 : 12); o.tile_order += t0 * 4;
     o.bwd_items += h ? items_a * 8 : 0; o.ckpt_rgb += h ? items_a * 256 * 16 : 0;
     o.final_C += p0 * 16; o.final_T += p0 * 4; o.n_contrib += p0 * 4;
     o.inst_grad += cap0 * 4 * GH_REC_G * 4; o.inst_flag += cap0 * 4;
