@@ -59,23 +59,6 @@ __device__ __forceinline__ void gh_var_seg_of_index(const uint32_t* __restrict__
   }
 }
 
-// Exclusive scan of one value per thread over the block (thread order); returns the prefix, *total = block sum.
-// s_w: GH_BLOCK / GH_WAVE words of LDS. Contains two barriers.
-__device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  uint32_t x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-  __syncthreads();                                     // s_w may still be read by a previous scan
-  if (lane == 63) s_w[wid] = x;
-  __syncthreads();
-  uint32_t woff = 0, tot = 0;
-#pragma unroll
-  for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { const uint32_t t = s_w[w]; if (w < wid) woff += t; tot += t; }
-  *total = tot;
-  return woff + x - v;
-}
-
 // Bits in which at least two (relevant) keys differ, from the per-producer-block (OR, AND) of the key bits
 // (gh_preprocess_fwd_kernel; key_bits[n_bits] receives the word). Computed ONCE, by block (0, 0) of the first pass's histogram
 // kernel; every later pass reads the word: a pass whose digit has no varying bit is the identity (its histogram kernel exits,
@@ -790,7 +773,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               float4* __restrict__ r1, float2* __restrict__ r2,
                                                               uint32_t* __restrict__ inst_flag, const uint32_t* __restrict__ slot_begin,
                                                               float rtiles, float rgx, uint32_t flags, float* __restrict__ inst_c,
-                                                              const float* __restrict__ tile_depth_bound, uint32_t P_local, float rP) {
+                                                              const float* __restrict__ tile_depth_bound, uint32_t P_local, float rP,
+                                                              uint32_t* __restrict__ render_guard) {
+  // render_guard given (small launches, whose launch order was ranked inside the projection kernel): this IS the last kernel in front
+  // of the render — the error bits as they stand now (every kernel that raises one is complete), in their own word; see gh_tile_order_kernel
+  if (render_guard && blockIdx.x == 0 && threadIdx.x == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; render_guard[1] = 0u; }
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
   // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
@@ -897,59 +884,20 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
 __global__ __launch_bounds__(GH_BLOCK) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int tiles, int NV,
                                                                   uint32_t* __restrict__ order, const GhCounters* __restrict__ ctr,
                                                                   uint32_t* __restrict__ render_guard, uint32_t* __restrict__ heavy) {
-  __shared__ uint32_t s_cnt[256];
-  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
-  const int tid = threadIdx.x, v = blockIdx.x;
   // the last kernel in front of the render: the error bits as they stand now, in a word of their own (the render kernel's waves
   // read it through the scalar cache; its own atomics go to the counters' line)
-  if (v == 0 && tid == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; render_guard[1] = 0u; }   // ([1]: items in the work list's end region)
-  ranges += (size_t)v * tiles;
-  if (heavy) heavy += (size_t)v * tiles;
-  // bucket 0 = heaviest. The key is the list length — or, in launches small enough for the fine-grained forward, what the previous
-  // forward over this workspace measured: the most entries any 4x4 block of the tile let through (its longest wave's work; a list of
-  // 544 entries can keep a wave busier than one of 1,265). A hint: stale values (another scene, the first call) only cost time.
-  auto bucket_of = [&](int t) {
-    const uint2 r = ranges[t];
-    uint32_t b = (r.y - r.x + 15u) >> 4;
-    if (heavy) { const uint32_t h = heavy[t]; if (h != 0u && r.y != r.x) b = 128u + ((h + 7u) >> 3); else b = b > 127u ? 127u : b; }
-    return b > 255u ? 255u : b;
-  };
-  // (a thread's first four tiles keep their bucket in registers between the two passes: every launch the heaviness key applies to)
-  uint32_t bk[4];
-  s_cnt[tid] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int t = tid + j * GH_BLOCK;
-    if (t < tiles) { bk[j] = bucket_of(t); atomicAdd(&s_cnt[255u - bk[j]], 1u); }
-  }
-  for (int t = tid + 4 * GH_BLOCK; t < tiles; t += GH_BLOCK) atomicAdd(&s_cnt[255u - bucket_of(t)], 1u);
-  __syncthreads();
-  uint32_t total;
-  const uint32_t c = s_cnt[tid];
-  const uint32_t pre = gh_block_excl_scan(c, s_w, &total);
-  __syncthreads();
-  s_cnt[tid] = pre;
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int t = tid + j * GH_BLOCK;
-    if (t < tiles) {
-      const uint32_t rank = atomicAdd(&s_cnt[255u - bk[j]], 1u);
-      order[(size_t)rank * NV + v] = (uint32_t)(v * tiles + t);
-      if (heavy) heavy[t] = 0u;                        // the forward of THIS call fills it again
-    }
-  }
-  for (int t = tid + 4 * GH_BLOCK; t < tiles; t += GH_BLOCK) {
-    const uint32_t rank = atomicAdd(&s_cnt[255u - bucket_of(t)], 1u);
-    order[(size_t)rank * NV + v] = (uint32_t)(v * tiles + t);
-    if (heavy) heavy[t] = 0u;
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; render_guard[1] = 0u; }   // ([1]: items in the work list's end region)
+  gh_rank_tiles(ranges, tiles, NV, (int)blockIdx.x, order, heavy);
 }
 
-static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
+bool gh_heavy_order_enabled() {
   static const bool by_hits = !(getenv("GH_FWD_HEAVY_ORDER") && atoi(getenv("GH_FWD_HEAVY_ORDER")) == 0);   // (A/B switch)
-  uint32_t* heavy = gh_fwd_fine_launch(g) && by_hits ? (uint32_t*)(ws + L.tile_walk) + 3 * (size_t)g.NV * g.tiles : nullptr;
+  return by_hits;
+}
+
+// (the rare paths of a small launch — nothing projected, nothing listed — and every large launch: the order by a kernel of its own)
+static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
+  uint32_t* heavy = gh_fwd_fine_launch(g) && gh_heavy_order_enabled() ? (uint32_t*)(ws + L.tile_walk) + 3 * (size_t)g.NV * g.tiles : nullptr;
   hipLaunchKernelGGL(gh_tile_order_kernel, dim3(g.NV), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges), g.tiles, g.NV,
                      (uint32_t*)(ws + L.tile_order), (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard), heavy);
 }
@@ -1008,6 +956,7 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
                      (const uint32_t*)(ws + L.slot_begin),
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,   // gh_div_small's range
                      d->flags, (float*)(ws + L.inst_c), tile_depth_bound, per_view_part ? (uint32_t)g.P : 0u,
-                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f);
-  gh_launch_tile_order(g, ws, L, s);
+                     g.N < (1 << 24) ? 1.0f / (float)g.P : 0.0f,
+                     gh_order_in_projection(g) ? (uint32_t*)(ws + L.render_guard) : nullptr);
+  if (!gh_order_in_projection(g)) gh_launch_tile_order(g, ws, L, s);
 }

@@ -63,6 +63,10 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
 // Floats of the fused image loss's partial sums (GhLayout.loss_partials): one per 8x8-pixel quadrant; a launch that may run tiles in
 // the fine-grained form keeps four per quadrant (one per workgroup of a fine tile; a coarse tile's workgroup zeroes the other three).
 static inline bool gh_fwd_fine_launch(const GhGrid& g) { return g.total_tiles <= GH_FWD_FINE_TILES; }
+// ... and its launch order is ranked by spare workgroups of the projection kernel (from the previous call's measurements) instead of
+// gh_tile_order_kernel behind the binning — whenever there is a projection kernel (N > 0) and no A/B switch says otherwise.
+bool gh_heavy_order_enabled();                         // (GH_FWD_HEAVY_ORDER=0 in the environment: launch order by list length, gh_binning.hip)
+static inline bool gh_order_in_projection(const GhGrid& g) { return gh_fwd_fine_launch(g) && g.N > 0 && gh_heavy_order_enabled(); }
 static inline size_t gh_loss_partial_count(const GhGrid& g) {
   return (size_t)g.NV * g.tiles * (gh_fwd_fine_launch(g) ? 16 : 4);
 }
@@ -418,6 +422,78 @@ __device__ __forceinline__ float gh_wave_sum_to63(float v) {
   v += gh_dpp<0x142, 0xA>(v);    // row_bcast15 -> rows 1,3
   v += gh_dpp<0x143, 0xC>(v);    // row_bcast31 -> rows 2,3
   return v;
+}
+
+// Exclusive scan of one value per thread over the block (thread order); returns the prefix, *total = block sum.
+// s_w: GH_BLOCK / GH_WAVE words of LDS. Contains two barriers.
+__device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+  __syncthreads();                                     // s_w may still be read by a previous scan
+  if (lane == 63) s_w[wid] = x;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < GH_BLOCK / GH_WAVE; ++w) { const uint32_t t = s_w[w]; if (w < wid) woff += t; tot += t; }
+  *total = tot;
+  return woff + x - v;
+}
+
+
+// The forward's launch order of one view's tiles: order[rank * NV + v] = global tile id, heaviest first (a counting sort over 256
+// buckets by one workgroup of GH_BLOCK threads; ties in no particular order — placement only, never results).
+// The key: the list length (ranges given), or — launches small enough for the fine-grained forward — what the previous forward over
+// this workspace measured per tile (`heavy`: the most entries one 4x4-pixel block let through = its longest wave's work; a list of 544
+// entries can keep a wave busier than one of 1,265). With `heavy` and NO ranges (the ranking runs as spare workgroups of the projection
+// kernel, before this call's lists exist) the measurement alone decides: a tile never measured goes last. Stale values (another scene,
+// the first call) only cost time. `heavy` is cleared behind the read: the forward of THIS call fills it again.
+__device__ __forceinline__ void gh_rank_tiles(const uint2* __restrict__ ranges, int tiles, int NV, int v, uint32_t* __restrict__ order,
+                                              uint32_t* __restrict__ heavy) {
+  __shared__ uint32_t s_cnt[256];
+  __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
+  const int tid = threadIdx.x;
+  if (ranges) ranges += (size_t)v * tiles;
+  if (heavy) heavy += (size_t)v * tiles;
+  auto bucket_of = [&](int t) {                         // bucket 255 = heaviest
+    uint32_t b = 0u;
+    bool listed = true;
+    if (ranges) { const uint2 r = ranges[t]; b = (r.y - r.x + 15u) >> 4; listed = r.y != r.x; }
+    if (heavy) { const uint32_t h = heavy[t]; if (h != 0u && listed) b = 128u + ((h + 7u) >> 3); else b = b > 127u ? 127u : b; }
+    return b > 255u ? 255u : b;
+  };
+  // (a thread's first four tiles keep their bucket in registers between the two passes: every launch the heaviness key applies to)
+  uint32_t bk[4];
+  s_cnt[tid] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = tid + j * GH_BLOCK;
+    if (t < tiles) { bk[j] = bucket_of(t); atomicAdd(&s_cnt[255u - bk[j]], 1u); }
+  }
+  for (int t = tid + 4 * GH_BLOCK; t < tiles; t += GH_BLOCK) atomicAdd(&s_cnt[255u - bucket_of(t)], 1u);
+  __syncthreads();
+  uint32_t total;
+  const uint32_t c = s_cnt[tid];
+  const uint32_t pre = gh_block_excl_scan(c, s_w, &total);
+  __syncthreads();
+  s_cnt[tid] = pre;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = tid + j * GH_BLOCK;
+    if (t < tiles) {
+      const uint32_t rank = atomicAdd(&s_cnt[255u - bk[j]], 1u);
+      order[(size_t)rank * NV + v] = (uint32_t)(v * tiles + t);
+      if (heavy) heavy[t] = 0u;
+    }
+  }
+  for (int t = tid + 4 * GH_BLOCK; t < tiles; t += GH_BLOCK) {
+    const uint32_t rank = atomicAdd(&s_cnt[255u - bucket_of(t)], 1u);
+    order[(size_t)rank * NV + v] = (uint32_t)(v * tiles + t);
+    if (heavy) heavy[t] = 0u;
+  }
 }
 
 __device__ __forceinline__ unsigned gh_wave_sum_u32(unsigned v) {  // all lanes get the total

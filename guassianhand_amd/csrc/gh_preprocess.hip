@@ -34,7 +34,14 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     uint32_t* __restrict__ depth_key, uint32_t* __restrict__ depth_val, GhCounters* __restrict__ ctr,
     int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk,
     uint2* __restrict__ key_bits, float rdiv, float* __restrict__ cull_bound_out, const float* __restrict__ tile_bound,
-    uint32_t* __restrict__ block_tiles) {
+    uint32_t* __restrict__ block_tiles, int n_proj_blocks, uint32_t* __restrict__ tile_order, int tiles_per_view) {
+  // Small launches (gh_fwd_fine_launch): the forward's launch order comes from what the PREVIOUS forward over this workspace measured
+  // per tile (tile_walk[3]), so it does not wait for this call's lists: one spare workgroup per view ranks the tiles here, in the
+  // shadow of the projection, instead of a kernel of its own between the binning and the render (4.5 us of a one-view step).
+  if ((int)blockIdx.x >= n_proj_blocks) {
+    gh_rank_tiles(nullptr, tiles_per_view, T / tiles_per_view, (int)blockIdx.x - n_proj_blocks, tile_order, tile_walk + 3 * (size_t)T);
+    return;
+  }
   __shared__ uint2 s_bits[GH_BLOCK / GH_WAVE];
   __shared__ uint32_t s_tiles[GH_BLOCK / GH_WAVE];
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
@@ -200,13 +207,14 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
     tile_bound = (const float*)(ws + L.tile_bound);
   }
   auto kern = in->cov3D_precomp ? gh_preprocess_fwd_kernel<true> : gh_preprocess_fwd_kernel<false>;
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(GH_BLOCK), 0, s, *in, g.P, g.NV, g.N, g.H, g.W, g.gx, g.gy,
+  const int n_rank = gh_order_in_projection(g) ? g.NV : 0;        // spare workgroups: the forward's launch order (see the kernel)
+  hipLaunchKernelGGL(kern, dim3(nblk + n_rank), dim3(GH_BLOCK), 0, s, *in, g.P, g.NV, g.N, g.H, g.W, g.gx, g.gy,
                      d->sh_degree, d->M, d->scale_modifier, d->flags, (const float4*)(ws + L.sh_rgb), (float4*)(ws + L.geom),
                      (uint8_t*)(ws + L.clamped), (uint32_t*)(ws + L.tiles_touched),
                      (uint32_t*)(ws + L.depth_keys_a), (uint32_t*)(ws + L.depth_vals_a), (GhCounters*)(ws + L.counters), radii,
                      T, (uint2*)(ws + L.ranges), (uint32_t*)(ws + L.tile_walk), (uint2*)(ws + L.key_bits),
                      g.N < (1 << 24) ? 1.0f / (float)((d->flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? g.P : g.NV) : 0.0f,
-                     (float*)(ws + L.cull_bound), tile_bound, (uint32_t*)(ws + L.block_tiles));
+                     (float*)(ws + L.cull_bound), tile_bound, (uint32_t*)(ws + L.block_tiles), nblk, (uint32_t*)(ws + L.tile_order), g.tiles);
 }
 
 // ------------------------------------------------------------------------------------------------

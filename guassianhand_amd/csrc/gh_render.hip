@@ -407,7 +407,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const uint32_t* __restrict__ render_guard,
     uint32_t guard_mask, const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
     const uint32_t* __restrict__ sorted_gid, const float4* __restrict__ geom, const GhFusedLoss l1,
-    uint32_t n_tiles_call, uint32_t fine_k, uint32_t fine_min, uint32_t n_items_cap, uint32_t* __restrict__ back_count, uint32_t back_k) {
+    uint32_t n_tiles_call, uint32_t fine_k, uint32_t fine_min, uint32_t n_items_cap, uint32_t* __restrict__ back_count, uint32_t back_k, uint32_t* __restrict__ heavy_out) {
   // LOSS: the quadrant's four wave sums meet in LDS (the last wave to arrive adds them up in block order); the arrival counter is
   // cleared behind the one barrier of the kernel, which the four waves reach as they start — before any load is in flight
   __shared__ float s_l1[GH_BLOCK / GH_WAVE];
@@ -614,7 +614,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       // atomics carry the data; each returns its old value, so waiting for the return means it has been performed.
       // FINE launches: the most entries any 4x4 block of the tile took = what the tile's longest wave does; the NEXT call's launch
       // order and choice of fine tiles go by it (gh_tile_order_kernel; a scheduling hint only — stale or missing values cost time)
-      if (FINE) __hip_atomic_fetch_max(&tile_walk[3 * (size_t)n_tiles_call + tile], (uint32_t)hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (heavy_out = tile_walk[3] in every small launch, the SEEN variants included: a call that leaves nothing leaves the next one
+      //  without an order; the plain kernels of large launches never count)
+      if ((FINE || SEEN) && heavy_out) __hip_atomic_fetch_max(&heavy_out[tile], (uint32_t)hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const uint32_t prev_max = __hip_atomic_fetch_max(&tile_walk[tile], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" :: "v"(prev_max) : "memory");
       uint32_t* done = tile_walk + (size_t)n_tiles_call;          // completion counters follow the T walk entries
@@ -733,7 +735,8 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
     hipLaunchKernelGGL(kern, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
                        g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const uint32_t*)(ws + L.render_guard),
                        wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, geom, l1,
-                       n_tiles_call, fine_k, fine_min, (uint32_t)g.n_items, (uint32_t*)(ws + L.render_guard) + 1, back_k);
+                       n_tiles_call, fine_k, fine_min, (uint32_t)g.n_items, (uint32_t*)(ws + L.render_guard) + 1, back_k,
+                       gh_fwd_fine_launch(g) ? tw + 3 * (size_t)n_tiles_call : nullptr);
   };
   if (loss_kind == 1) {                              // (the entry point has ruled out alpha / seen / a bound)
     if (fine_launch) launch(gh_render_fwd_kernel<false, false, 1, true>); else launch(gh_render_fwd_kernel<false, false, 1>);
