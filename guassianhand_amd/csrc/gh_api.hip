@@ -86,12 +86,12 @@ extern "C" int gh_workspace_layout(const GhDims* d, GhLayout* L) {
   }
   L->sort_tables = take(tab * 4);
   L->ranges = take((size_t)g.NV * g.tiles * 8);
-  L->tile_walk = take((size_t)g.NV * g.tiles * (gh_fwd_fine_launch(g) ? 16 : 12));      // walked entries [T] + completion counters [T] + stop positions [T] + heaviness of the previous FINE launch [T] (never cleared);
+  L->tile_walk = take((size_t)g.NV * g.tiles * (4 + GH_BWD_COST_SLOTS) * 4);      // walked entries [T] + completion counters [T] + stop positions [T] + heaviness of the previous FINE launch [T] (never cleared);
                                                          // directly after ranges: all cleared by one memset when there is
                                                          // nothing to project
   L->tile_order = take((size_t)g.NV * g.tiles * 4);
   const size_t n_items = (size_t)g.NV * g.tiles + cap / GH_SEGMENT + 4;       // backward work items / checkpoint slots (2 + 2 spare per half)
-  L->bwd_items = take(n_items * 8);
+  L->bwd_items = take(n_items * 8 * GH_BWD_CLASSES);        // (one region of the list's full capacity per cost class)
   L->ckpt_rgb = take(n_items * 256 * 16);
   L->final_C = take(pix * 16);
   L->final_T = take(pix * 4);
@@ -181,8 +181,8 @@ static void gh_make_halves(const GhDims* d, const GhLayout& L, const GhInputs* i
     o.keys_a += cap0 * 4; o.keys_b += cap0 * 4; o.vals_a += cap0 * 4; o.vals_b += cap0 * 4; o.sorted_slot += cap0 * 4;
     o.inst_r0 += cap0 * 16; o.inst_r1 += cap0 * 16; o.inst_r2 += cap0 * 8;
     o.sort_tables += h ? tab_a * 4 : 0;
-    o.ranges += t0 * 8; o.tile_walk += t0 * (gh_fwd_fine_launch(gf) ? 16 : 12); o.tile_order += t0 * 4;
-    o.bwd_items += h ? items_a * 8 : 0; o.ckpt_rgb += h ? items_a * 256 * 16 : 0;
+    o.ranges += t0 * 8; o.tile_walk += t0 * (4 + GH_BWD_COST_SLOTS) * 4; o.tile_order += t0 * 4;
+    o.bwd_items += h ? items_a * 8 * GH_BWD_CLASSES : 0; o.ckpt_rgb += h ? items_a * 256 * 16 : 0;
     o.final_C += p0 * 16; o.final_T += p0 * 4; o.n_contrib += p0 * 4;
     o.inst_grad += cap0 * 4 * GH_REC_G * 4; o.inst_flag += cap0 * 4;
     if (sh_mode) { o.sh_rgb += n0 * 16; o.dmean_sh += n0 * 16; }

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               uint32_t* __restrict__ render_guard) {
   // render_guard given (small launches, whose launch order was ranked inside the projection kernel): this IS the last kernel in front
   // of the render — the error bits as they stand now (every kernel that raises one is complete), in their own word; see gh_tile_order_kernel
-  if (render_guard && blockIdx.x == 0 && threadIdx.x == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; render_guard[1] = 0u; }
+  if (render_guard && blockIdx.x == 0 && threadIdx.x == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; for (int c = 0; c < GH_BWD_CLASSES; ++c) render_guard[1 + c] = 0u; }
   const uint32_t n = gh_clamp_n(&ctr->num_rendered, cap);
   // Blocks b, b + 8, b + 16, .. share an XCD (round-robin dispatch): each of the 8 groups takes one CONTIGUOUS eighth of the
   // sorted instances. A Gaussian's instances sit in neighbouring tiles' lists — a list length apart for the tile to the
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_tile_order_kernel(const uint2* __
                                                                   uint32_t* __restrict__ render_guard, uint32_t* __restrict__ heavy) {
   // the last kernel in front of the render: the error bits as they stand now, in a word of their own (the render kernel's waves
   // read it through the scalar cache; its own atomics go to the counters' line)
-  if (blockIdx.x == 0 && threadIdx.x == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; render_guard[1] = 0u; }   // ([1]: items in the work list's end region)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; for (int c = 0; c < GH_BWD_CLASSES; ++c) render_guard[1 + c] = 0u; }   // ([1..]: items per class of the backward's work list)
   gh_rank_tiles(ranges, tiles, NV, (int)blockIdx.x, order, heavy);
 }
 
@@ -895,9 +895,14 @@ bool gh_heavy_order_enabled() {
   return by_hits;
 }
 
+bool gh_bwd_classes_enabled() {
+  static const bool on = !(getenv("GH_BWD_CLASSES") && atoi(getenv("GH_BWD_CLASSES")) == 0);               // (A/B switch)
+  return on;
+}
+
 // (the rare paths of a small launch — nothing projected, nothing listed — and every large launch: the order by a kernel of its own)
 static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
-  uint32_t* heavy = gh_fwd_fine_launch(g) && gh_heavy_order_enabled() ? (uint32_t*)(ws + L.tile_walk) + 3 * (size_t)g.NV * g.tiles : nullptr;
+  uint32_t* heavy = g.total_tiles <= GH_ORDER_TILES && gh_heavy_order_enabled() ? (uint32_t*)(ws + L.tile_walk) + 3 * (size_t)g.NV * g.tiles : nullptr;
   hipLaunchKernelGGL(gh_tile_order_kernel, dim3(g.NV), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges), g.tiles, g.NV,
                      (uint32_t*)(ws + L.tile_order), (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard), heavy);
 }

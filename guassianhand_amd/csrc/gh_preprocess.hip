@@ -196,7 +196,7 @@ void gh_launch_preprocess_fwd(const GhDims* d, const GhGrid& g, const GhInputs* 
   if (g.N == 0) {                                      // nothing to project: only the counters and per-tile state
     (void)hipMemsetAsync(ws + L.counters, 0, sizeof(GhCounters), s);
     (void)hipMemsetAsync(ws + L.ranges, 0, L.tile_order - L.ranges, s);
-    (void)hipMemsetAsync(ws + L.render_guard, 0, 8, s);      // (a refresh call over nothing goes straight to the render)
+    (void)hipMemsetAsync(ws + L.render_guard, 0, 4 + 4 * GH_BWD_CLASSES, s);      // (a refresh call over nothing goes straight to the render)
     return;
   }
   int nblk = ((g.N > T ? g.N : T) + GH_BLOCK - 1) / GH_BLOCK;

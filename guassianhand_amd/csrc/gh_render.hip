@@ -407,7 +407,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
     float4* __restrict__ final_C, uint2* __restrict__ items, GhCounters* __restrict__ ctr, const uint32_t* __restrict__ render_guard,
     uint32_t guard_mask, const float* __restrict__ tile_depth_bound, float* __restrict__ tile_depth_seen, float seen_scale, uint32_t seen_slack,
     const uint32_t* __restrict__ sorted_gid, const float4* __restrict__ geom, const GhFusedLoss l1,
-    uint32_t n_tiles_call, uint32_t fine_k, uint32_t fine_min, uint32_t n_items_cap, uint32_t* __restrict__ back_count, uint32_t back_k, uint32_t* __restrict__ heavy_out) {
+    uint32_t n_tiles_call, uint32_t fine_k, uint32_t fine_min, uint32_t n_items_cap, uint32_t* __restrict__ class_count, uint32_t* __restrict__ heavy_out, uint32_t heavy_hits, uint32_t use_classes) {
   // LOSS: the quadrant's four wave sums meet in LDS (the last wave to arrive adds them up in block order); the arrival counter is
   // cleared behind the one barrier of the kernel, which the four waves reach as they start — before any load is in flight
   __shared__ float s_l1[GH_BLOCK / GH_WAVE];
@@ -616,7 +616,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       // order and choice of fine tiles go by it (gh_tile_order_kernel; a scheduling hint only — stale or missing values cost time)
       // (heavy_out = tile_walk[3] in every small launch, the SEEN variants included: a call that leaves nothing leaves the next one
       //  without an order; the plain kernels of large launches never count)
-      if ((FINE || SEEN) && heavy_out) __hip_atomic_fetch_max(&heavy_out[tile], (uint32_t)hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((FINE || SEEN) && heavy_hits) __hip_atomic_fetch_max(&heavy_out[tile], (uint32_t)hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the tile's backward history (see below), fetched by EVERY wave's lane 0 under the atomics that follow: only the tile's last
+      // wave uses it, but a load behind the last of those round trips would be one more on the tail of the tile that ends the kernel
+      uint32_t* cost = tile_walk + 4 * (size_t)n_tiles_call + (size_t)tile * GH_BWD_COST_SLOTS;
+      uint4 hist_lo = make_uint4(0u, 0u, 0u, 0u), hist_hi = hist_lo;
+      if (use_classes == 1u) { hist_lo = ((const uint4*)cost)[0]; hist_hi = ((const uint4*)cost)[1]; }
+      // (use_classes == 2 — launches of at most GH_FINE_TILES tiles, whose backward runs four waves per workgroup: no history; the
+      //  first quarter of the forward's launch order, the heaviest tiles by ITS measure, goes to class 1, the rest to class 0: there
+      //  the measured classes lost to this — two views 74 -> 80 us — and won from 2,049 tiles up: four views 117 -> 96, eight 187 -> 162)
+      //  (handled where the items are appended)
       const uint32_t prev_max = __hip_atomic_fetch_max(&tile_walk[tile], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" :: "v"(prev_max) : "memory");
       uint32_t* done = tile_walk + (size_t)n_tiles_call;          // completion counters follow the T walk entries
@@ -631,16 +640,44 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       const uint32_t prev_done = __hip_atomic_fetch_add(&done[tile], 1u + my_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((prev_done & 0xFFu) == (fine ? 16u : 4u) * (GH_BLOCK / GH_WAVE) - 1u) {     // (a fine tile: 16 workgroups)
         const uint32_t w = __hip_atomic_fetch_max(&tile_walk[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // final value
+        // large launches: the NEXT call's launch order goes by the entries this tile actually walked (one plain store per tile, by
+        // its last wave; small launches keep the finer measure above) — gh_rank_tiles in the next projection kernel
+        if (!heavy_hits && heavy_out) heavy_out[tile] = (w + 1u) >> 1;
         const uint32_t nseg = (w + GH_SEGMENT - 1u) / GH_SEGMENT;
         if (nseg) {
-          // FINE launches (heaviest tiles launched FIRST by measured work, so the order of completion no longer says which tiles are
-          // the heavy ones): the first quarter of the launch order appends from the END of the list downwards, the rest from its
-          // start upwards; the backward takes the end region first.
-          uint32_t pos;
-          if (FINE && item_idx < back_k)
-            pos = n_items_cap - nseg - __hip_atomic_fetch_add(back_count, nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else pos = __hip_atomic_fetch_add(&ctr->reserved[1], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          for (uint32_t k = 0; k < nseg; ++k) items[pos + k] = make_uint2((uint32_t)tile, k);
+          // The work list is kept in GH_BWD_CLASSES regions by what the item COST the previous backward over this workspace (cycles of its
+          // slowest quadrant, left per (tile, segment) by gh_render_bwd_kernel: tile_walk[4..12)); the backward takes the regions from the
+          // most expensive class down — longest first. In completion order (rounds 2-6) the long items sat anywhere in the list and the
+          // kernel ended on a few of them with most wave slots idle (profiles/r6_bwd_order.txt). A hint only: no history = class 0 =
+          // the old order. The tile's history is cleared behind the read: this call's backward writes it again.
+          // (launches too large for the order to matter — gh_bwd_class_mode — keep ONE region, class 0, and no history)
+          const uint32_t hist[GH_BWD_COST_SLOTS] = {hist_lo.x, hist_lo.y, hist_lo.z, hist_lo.w, hist_hi.x, hist_hi.y, hist_hi.z, hist_hi.w};
+          if (use_classes != 1u) {                                 // one region, or two by the launch order: one atomic per tile
+            const uint32_t c = (use_classes == 2u && item_idx < (n_tiles_call >> 2)) ? 1u : 0u;
+            const uint32_t pos = __hip_atomic_fetch_add(&class_count[c], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t j = 0; j < nseg; ++j)
+              items[(size_t)c * n_items_cap + pos + (c ? nseg - 1u - j : j)] = make_uint2((uint32_t)tile, j);    // (class 1: segment 0 first)
+          }
+          // one atomic per RUN of segments of one class (a tile's segments get cheaper towards the back: one to three runs)
+          uint32_t k = use_classes == 1u ? 0u : nseg;
+          while (k < nseg) {
+            uint32_t c = hist[k < GH_BWD_COST_SLOTS ? k : GH_BWD_COST_SLOTS - 1u] >> GH_BWD_CLASS_SHIFT;
+            c = c < GH_BWD_CLASSES ? c : GH_BWD_CLASSES - 1u;
+            uint32_t e = k + 1u;
+            while (e < nseg) {
+              uint32_t c2 = hist[e < GH_BWD_COST_SLOTS ? e : GH_BWD_COST_SLOTS - 1u] >> GH_BWD_CLASS_SHIFT;
+              c2 = c2 < GH_BWD_CLASSES ? c2 : GH_BWD_CLASSES - 1u;
+              if (c2 != c) break;
+              ++e;
+            }
+            const uint32_t pos = __hip_atomic_fetch_add(&class_count[c], e - k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (the backward reads a region from its END: a run's segments are stored back to front, so that a tile's segment 0 — all
+            //  its pixels still live: the expensive one — goes first; the one-region form of large launches keeps rounds 2-5's order)
+            for (uint32_t j = k; j < e; ++j)
+              items[(size_t)c * n_items_cap + pos + (use_classes ? e - 1u - j : j - k)] = make_uint2((uint32_t)tile, j);
+            k = e;
+          }
+          if (use_classes == 1u) { ((uint4*)cost)[0] = make_uint4(0u, 0u, 0u, 0u); ((uint4*)cost)[1] = make_uint4(0u, 0u, 0u, 0u); }
         }
         if (SEEN) {
           // every pixel of the tile stopped (and passed the virtual threshold): nothing behind the last entry any of them looked at can matter next time either
@@ -700,8 +737,7 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   uint32_t fine_k = fine_launch ? (uint32_t)(env_k >= 0 ? env_k : GH_FWD_FINE_K) : 0u;
   if (fine_k > n_tiles_call) fine_k = n_tiles_call;
   const uint32_t fine_min = (uint32_t)(env_min >= 0 ? env_min : GH_FWD_FINE_MIN);
-  static const long env_back = getenv("GH_FWD_BACK_DIV") ? atol(getenv("GH_FWD_BACK_DIV")) : 4;      // (A/B knob)
-  const uint32_t back_k = env_back > 0 ? n_tiles_call / (uint32_t)env_back : 0u;
+
   const dim3 grid(4 * n_tiles_call + 12 * fine_k), block(GH_BLOCK);
   const uint2* ranges = (const uint2*)(wg + L.ranges);
   const uint32_t* order = (const uint32_t*)(wg + L.tile_order);
@@ -735,8 +771,8 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
     hipLaunchKernelGGL(kern, grid, block, 0, s, ranges, order, r0, r1, r2, in->cams, g.H, g.W, g.gx,
                        g.tiles, image, alpha, fT, nc, tw, ck, fC, items, ctr, (const uint32_t*)(ws + L.render_guard),
                        wg == ws ? 11u : GH_COUNTER_ERROR_MASK, bound, seen, seen_scale, seen_slack, gid, geom, l1,
-                       n_tiles_call, fine_k, fine_min, (uint32_t)g.n_items, (uint32_t*)(ws + L.render_guard) + 1, back_k,
-                       gh_fwd_fine_launch(g) ? tw + 3 * (size_t)n_tiles_call : nullptr);
+                       n_tiles_call, fine_k, fine_min, (uint32_t)g.n_items, (uint32_t*)(ws + L.render_guard) + 1,
+                       g.total_tiles <= GH_ORDER_TILES ? tw + 3 * (size_t)n_tiles_call : nullptr, gh_fwd_fine_launch(g) ? 1u : 0u, gh_bwd_class_mode(g));
   };
   if (loss_kind == 1) {                              // (the entry point has ruled out alpha / seen / a bound)
     if (fine_launch) launch(gh_render_fwd_kernel<false, false, 1, true>); else launch(gh_render_fwd_kernel<false, false, 1>);
@@ -899,6 +935,32 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
 // views leave most of the 256 CUs idle and the longest quadrant IS the kernel): the quadrant's four blocks run in four
 // waves of one workgroup, each with its own accumulator rows, and are combined in fixed wave order behind one barrier.
 // GEOM = false: sub-records carry sum h and the three colour moments only (their last 16 bytes; the rest is not written).
+// Leaves the workgroup's duration behind when it ends, wherever it returns (a destructor: the kernel has many exits).
+// (ON = the one-wave form only: launches small enough for the four-wave form never record — gh_bwd_class_mode — and the five
+//  registers this held there cost that kernel a workgroup per CU: 79 -> 84 VGPRs, one view 51 -> 55 us)
+template <bool ON>
+struct GhBwdCost {
+  uint32_t t0; uint32_t* slot;
+  __device__ ~GhBwdCost() {
+    if (ON) {
+      const uint32_t dt = ((uint32_t)__builtin_readcyclecounter() - t0) >> 8;       // (a workgroup lives far less than 2^32 cycles)
+      if (threadIdx.x == 0 && slot) __hip_atomic_fetch_max(slot, dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+};
+#ifdef GH_EXP_BWD_TIME
+// (experiment: per-workgroup cycle counters of the backward, read back by gh_exp_read_bwd_times: tools/experiments/bwd_lpt_sim.py)
+__device__ uint4 gh_exp_bwd_times[1 << 18];
+struct GhExpTimer {
+  uint64_t t0; uint32_t slot, item, tile;
+  __device__ ~GhExpTimer() {
+    const uint64_t t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && slot < (1u << 18)) gh_exp_bwd_times[slot] = make_uint4((uint32_t)(t1 - t0), item, tile, (uint32_t)t0);
+  }
+};
+extern "C" int gh_exp_read_bwd_times(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gh_exp_bwd_times), bytes); }
+extern "C" int gh_exp_clear_bwd_times() { void* p; if (hipGetSymbolAddress(&p, HIP_SYMBOL(gh_exp_bwd_times)) != hipSuccess) return -1; return (int)hipMemset(p, 0, sizeof(uint4) << 18); }
+#endif
 template <bool ALPHA, int NW, bool GEOM>
 __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ items, const GhCounters* __restrict__ ctr,
@@ -909,7 +971,7 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
     const float* __restrict__ dL_dimage, const float* __restrict__ dL_dalpha_img, const float* __restrict__ upstream_scale,
     float* __restrict__ inst_grad, uint8_t* __restrict__ inst_flag,
     const float4* __restrict__ loss_part, uint32_t loss_n4, float* __restrict__ loss_out,
-    const uint32_t* __restrict__ back_count, uint32_t n_items_cap) {
+    const uint32_t* __restrict__ class_count, uint32_t n_items_cap, uint32_t* __restrict__ cost, uint32_t use_classes) {
   // GhGrads.deferred_loss: the fused image loss's final sum (GH_FLAG_DEFER_LOSS_SUM left the forward without its one-workgroup sum
   // kernel) by workgroup 0 of this launch — dispatched first, done long before the kernel's tail; every other workgroup's
   // index moves down by one. Fixed order: bitwise reproducible.
@@ -942,17 +1004,38 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
   float* s_acc = s_acc_all[wv];
   uint16_t* s_q = s_q_all[wv];
   uint8_t* s_f = s_f_all[wv];
-  // the work list, written by the forward (the grid is sized for its capacity): items appended from the start upwards in the order the
-  // tiles finished, and — launches with the fine-grained forward — the heaviest quarter of the launch order from the END downwards
-  const uint32_t n_front = ctr->reserved[1], n_back = *back_count;
-  const uint32_t n_items = n_front + n_back;
+  // The work list, written by the forward (the grid is sized for its capacity): GH_BWD_CLASSES regions of n_items_cap entries, an item
+  // in the region of what it cost the previous backward (see gh_render_fwd_kernel); the most expensive class goes first, inside a class
+  // the tiles the forward finished last. (use_classes = 0 — large launches, or the A/B switch: the forward put everything into class 0.)
   uint32_t item_idx, quad_u;
   gh_item_quad(bid, nblk_items >> 2, item_idx, quad_u);       // the four quadrants of an item share an XCD (L2)
-  if (item_idx >= n_items) return;
-  // (tile, depth segment): the end region first, then the tiles the forward finished last
-  const uint2 item_v = item_idx < n_back ? items[n_items_cap - n_back + item_idx] : items[n_front - 1u - (item_idx - n_back)];
+  // (wave-uniform scalar work: a running total from the top class down; the item sits in the first class whose running total passes
+  //  its index, at that total - 1 - index from the region's start = the region read from its end)
+  // (written as the five scalar instructions per class it is: the compiler built 64-bit lane masks and vector adds out of the
+  //  C form — 270 instructions in front of every workgroup's first load, 2 us of a small launch)
+  static_assert(GH_BWD_CLASSES == 16, "sixteen counts, one 64-byte line");
+  uint32_t acc = 0u, before = 0u, first_end = 0xFFFFFFFFu, tmp;
+  // (s_cselect reads the compare's SCC before s_addc consumes AND overwrites it)
+#define GH_CLS_STEP(N) "s_add_u32 %2, %2, %" #N "\n\ts_cmp_le_u32 %2, %4\n\ts_cselect_b32 %3, -1, %2\n\ts_addc_u32 %0, %0, 0\n\ts_min_u32 %1, %1, %3\n\t"
+  asm(GH_CLS_STEP(20) GH_CLS_STEP(19) GH_CLS_STEP(18) GH_CLS_STEP(17) GH_CLS_STEP(16) GH_CLS_STEP(15) GH_CLS_STEP(14) GH_CLS_STEP(13)
+      GH_CLS_STEP(12) GH_CLS_STEP(11) GH_CLS_STEP(10) GH_CLS_STEP(9) GH_CLS_STEP(8) GH_CLS_STEP(7) GH_CLS_STEP(6) GH_CLS_STEP(5)
+      : "+s"(before), "+s"(first_end), "+s"(acc), "=&s"(tmp)
+      : "s"(item_idx), "s"(class_count[0]), "s"(class_count[1]), "s"(class_count[2]), "s"(class_count[3]), "s"(class_count[4]),
+        "s"(class_count[5]), "s"(class_count[6]), "s"(class_count[7]), "s"(class_count[8]), "s"(class_count[9]), "s"(class_count[10]),
+        "s"(class_count[11]), "s"(class_count[12]), "s"(class_count[13]), "s"(class_count[14]), "s"(class_count[15])
+      : "scc");
+#undef GH_CLS_STEP
+  if (before == GH_BWD_CLASSES) return;                         // past the end of the list
+  const uint32_t cls = GH_BWD_CLASSES - 1u - before;
+  const uint2 item_v = items[(size_t)cls * n_items_cap + (first_end - 1u - item_idx)];
   const uint2 item = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)item_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)item_v.y));
   const int tile = (int)item.x, quad = (int)quad_u;       // (wave-uniform values in scalar registers by hand: see the forward)
+#ifdef GH_EXP_BWD_TIME
+  GhExpTimer exp_timer = {__builtin_readcyclecounter(), bid, item_idx * 4u + quad_u, item.x | (item.y << 24)};
+#endif
+  // what this workgroup costs, for the next call's work list: cycles / 256 of the item's slowest quadrant, per (tile, segment)
+  GhBwdCost<NW == 1> cost_rec = {NW == 1 ? (uint32_t)__builtin_readcyclecounter() : 0u,
+                                 NW == 1 && use_classes ? cost + (size_t)item.x * GH_BWD_COST_SLOTS + (item.y < GH_BWD_COST_SLOTS ? item.y : GH_BWD_COST_SLOTS - 1u) : nullptr};
   const int seg_lo = (int)item.y * GH_SEGMENT, seg_hi = seg_lo + GH_SEGMENT;
   int v, tx, ty;
   gh_tile_coords(tile, gx, tiles, v, tx, ty);
@@ -1160,6 +1243,7 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
   // inst_flag was cleared by gh_ranges_kernel; repeated backwards set the same flags again (they depend on the forward's
   // n_contrib only). The work list (tile, depth segment) was written by the forward's last wave of every tile.
   const bool small = g.total_tiles <= GH_FINE_TILES;    // few tiles: four waves per quadrant (one per 4x4 block)
+
   const dim3 grid(4 * (unsigned)g.n_items + (deferred_loss ? 1u : 0u)), block(small ? 4 * GH_WAVE : GH_WAVE);   // capacity of the work list x 4 quadrants; surplus workgroups exit at once
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, block, 0, s, (const uint2*)(wg + L.ranges), (const uint2*)(ws + L.bwd_items),
@@ -1169,7 +1253,8 @@ void gh_launch_render_bwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
                        (const uint32_t*)(ws + L.n_contrib), (const float4*)(ws + L.ckpt_rgb),
                        (const float4*)(ws + L.final_C), dL_dimage, dL_dalpha, upstream_scale, (float*)(ws + L.inst_grad),
                        (uint8_t*)(ws + L.inst_flag), (const float4*)(ws + L.loss_partials), (uint32_t)(n_part / 4), deferred_loss,
-                       (const uint32_t*)(ws + L.render_guard) + 1, (uint32_t)g.n_items);
+                       (const uint32_t*)(ws + L.render_guard) + 1, (uint32_t)g.n_items,
+                       (uint32_t*)(ws + L.tile_walk) + 4 * (size_t)g.NV * g.tiles, gh_bwd_class_mode(g) == 1u ? 1u : 0u);
   };
   // geom = false (precomputed colours and no geometry gradient wanted): colour / opacity moments only, see the kernel
   if (small) {
@@ -1197,7 +1282,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_recolour_kernel(GhInputs in, uint
   if (i == 0) {
     ctr->num_rendered = D; ctr->overflow = gctr->overflow; ctr->reserved[0] = gctr->reserved[0]; ctr->reserved[1] = 0;
     *render_guard = gctr->overflow & GH_COUNTER_ERROR_MASK;        // (this is the kernel in front of the render, see gh_render_fwd_kernel)
-    render_guard[1] = 0u;                                          // (the work list's end region: gh_render_fwd_kernel)
+    for (int c = 0; c < GH_BWD_CLASSES; ++c) render_guard[1 + c] = 0u;       // (the work list's class counts: gh_render_fwd_kernel)
   }
   if (i < (uint32_t)T) { tile_walk[i] = 0u; tile_walk[T + i] = 0u; tile_walk[2 * T + i] = 0u; }
   const uint32_t n = D < cap ? D : cap;
@@ -1272,7 +1357,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_instance_kernel(uint32_t 
                                                                         int local_keys) {
   const uint32_t i = blockIdx.x * GH_BLOCK + threadIdx.x;
   // the kernel in front of the render (gh_refresh_attr_kernel, complete by now, may have raised bit 1): the error bits in their own word
-  if (i == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; render_guard[1] = 0u; }
+  if (i == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; for (int c = 0; c < GH_BWD_CLASSES; ++c) render_guard[1 + c] = 0u; }
   const uint32_t D = gctr->num_rendered;
   const uint32_t n = D < cap ? D : cap;
   if (i >= n) return;
