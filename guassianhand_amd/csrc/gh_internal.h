@@ -26,7 +26,9 @@
 // segment); GH_BWD_COST_SLOTS history words per tile (segments past the last share it), classes of 2^GH_BWD_CLASS_SHIFT x 256 cycles.
 #define GH_BWD_CLASSES 16
 #define GH_BWD_COST_SLOTS 8
+#ifndef GH_BWD_CLASS_SHIFT
 #define GH_BWD_CLASS_SHIFT 5
+#endif
 #define GH_FWD_FINE_MIN 256
 
 struct GhF3 { float x, y, z; };      // 12-byte access (global_load/store_dwordx3)
@@ -74,13 +76,18 @@ static inline bool gh_fwd_fine_launch(const GhGrid& g) { return g.total_tiles <=
 bool gh_heavy_order_enabled();                         // (GH_FWD_HEAVY_ORDER=0 in the environment: launch order by list length, gh_binning.hip)
 // Launches of at most GH_ORDER_TILES tiles: from ten rounds of workgroups up the tail a bad order leaves is short against the kernel and
 // what concurrent workgroups share in the L2 weighs more (1024^2 x 8 views: backward +25 us with the classed list, 16 views of 512x334: +-0).
+#ifndef GH_ORDER_TILES
 #define GH_ORDER_TILES 8192
+#endif
+#ifndef GH_CLASS_TILES
+#define GH_CLASS_TILES GH_ORDER_TILES
+#endif
 static inline bool gh_order_in_projection(const GhGrid& g) { return g.total_tiles <= GH_ORDER_TILES && g.N > 0 && gh_heavy_order_enabled(); }
 bool gh_bwd_classes_enabled();                         // (GH_BWD_CLASSES=0 in the environment: the work list in one piece, gh_binning.hip)
 // 0: one region (completion order, taken from the end: rounds 2-5); 1: regions by the cost the previous backward measured per (tile,
 // segment); 2: two regions by the forward's launch order (launches whose backward runs in its four-wave form)
 static inline uint32_t gh_bwd_class_mode(const GhGrid& g) {
-  if (!gh_bwd_classes_enabled() || g.total_tiles > GH_ORDER_TILES) return 0u;
+  if (!gh_bwd_classes_enabled() || g.total_tiles > GH_CLASS_TILES) return 0u;
   return g.total_tiles <= GH_FINE_TILES ? 2u : 1u;
 }
 static inline size_t gh_loss_partial_count(const GhGrid& g) {

@@ -607,25 +607,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
       const uint32_t u = __shfl_xor(sq, o); sq = u > sq ? u : sq;
     }
     if (lane == 0) {
-      // The LAST of the tile's 16 waves (4 quadrant blocks x 4) appends the tile's backward work items, one per depth
-      // segment of the walked prefix: the list is in the order the forward finished the tiles. The backward takes it from
-      // the end, so the tiles that ran longest start first; the order only affects scheduling, never results.
+      // The LAST of the tile's waves (16, or 64 of a fine tile) appends the tile's backward work items, one per depth segment of the
+      // walked prefix (the order of the list only affects scheduling, never results: see below).
       // Ordering without fences (an agent-scope release would write back the whole L2): only relaxed agent-scope RMW
       // atomics carry the data; each returns its old value, so waiting for the return means it has been performed.
-      // FINE launches: the most entries any 4x4 block of the tile took = what the tile's longest wave does; the NEXT call's launch
-      // order and choice of fine tiles go by it (gh_tile_order_kernel; a scheduling hint only — stale or missing values cost time)
-      // (heavy_out = tile_walk[3] in every small launch, the SEEN variants included: a call that leaves nothing leaves the next one
-      //  without an order; the plain kernels of large launches never count)
+      // Small launches (heavy_hits): the most entries any 4x4 block of the tile took = what the tile's longest wave does; the NEXT
+      // call's launch order and choice of fine tiles go by it (gh_rank_tiles; a scheduling hint only — stale or missing values cost
+      // time). Every variant a small launch can run leaves it, SEEN included: a call that left nothing would leave the next one
+      // without an order.
       if ((FINE || SEEN) && heavy_hits) __hip_atomic_fetch_max(&heavy_out[tile], (uint32_t)hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // the tile's backward history (see below), fetched by EVERY wave's lane 0 under the atomics that follow: only the tile's last
-      // wave uses it, but a load behind the last of those round trips would be one more on the tail of the tile that ends the kernel
-      uint32_t* cost = tile_walk + 4 * (size_t)n_tiles_call + (size_t)tile * GH_BWD_COST_SLOTS;
-      uint4 hist_lo = make_uint4(0u, 0u, 0u, 0u), hist_hi = hist_lo;
-      if (use_classes == 1u) { hist_lo = ((const uint4*)cost)[0]; hist_hi = ((const uint4*)cost)[1]; }
-      // (use_classes == 2 — launches of at most GH_FINE_TILES tiles, whose backward runs four waves per workgroup: no history; the
-      //  first quarter of the forward's launch order, the heaviest tiles by ITS measure, goes to class 1, the rest to class 0: there
-      //  the measured classes lost to this — two views 74 -> 80 us — and won from 2,049 tiles up: four views 117 -> 96, eight 187 -> 162)
-      //  (handled where the items are appended)
+      uint32_t* cost = tile_walk + 4 * (size_t)n_tiles_call + (size_t)tile * GH_BWD_COST_SLOTS;      // the tile's backward history (below)
       const uint32_t prev_max = __hip_atomic_fetch_max(&tile_walk[tile], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" :: "v"(prev_max) : "memory");
       uint32_t* done = tile_walk + (size_t)n_tiles_call;          // completion counters follow the T walk entries
@@ -645,14 +636,22 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
         if (!heavy_hits && heavy_out) heavy_out[tile] = (w + 1u) >> 1;
         const uint32_t nseg = (w + GH_SEGMENT - 1u) / GH_SEGMENT;
         if (nseg) {
-          // The work list is kept in GH_BWD_CLASSES regions by what the item COST the previous backward over this workspace (cycles of its
-          // slowest quadrant, left per (tile, segment) by gh_render_bwd_kernel: tile_walk[4..12)); the backward takes the regions from the
-          // most expensive class down — longest first. In completion order (rounds 2-6) the long items sat anywhere in the list and the
-          // kernel ended on a few of them with most wave slots idle (profiles/r6_bwd_order.txt). A hint only: no history = class 0 =
-          // the old order. The tile's history is cleared behind the read: this call's backward writes it again.
-          // (launches too large for the order to matter — gh_bwd_class_mode — keep ONE region, class 0, and no history)
+          // The work list is kept in GH_BWD_CLASSES regions, and the backward takes them from the highest class down (inside a region
+          // from its end). use_classes (gh_bwd_class_mode):
+          //  1 (2,049 .. 8,192 tiles): the class is what the item COST the previous backward over this workspace — cycles of its slowest
+          //    quadrant, left per (tile, segment) by gh_render_bwd_kernel in tile_walk[4..12) — so the longest items go first. In the order
+          //    of completion (rounds 2-5) the long items sat anywhere in the list and the kernel ended on a few of them with most wave
+          //    slots idle (profiles/r6_bwd_order.txt: 8 views 187 -> 163 us). A hint only: no history = class 0 = the old order. The
+          //    history is cleared behind the read (this call's backward writes it again) and fetched HERE, by the tile's last wave only:
+          //    every wave prefetching it under its completion atomics measured 1-2 us slower.
+          //  2 (up to 2,048 tiles, whose backward runs four waves per workgroup): no history — the first quarter of the forward's launch
+          //    order (the heaviest tiles by ITS measure) is class 1, the rest class 0; the measured classes lost to this there.
+          //  0 (larger launches): one region, the order of completion: ten rounds of workgroups leave a short tail whatever the order,
+          //    and what concurrent workgroups share in the L2 weighs more (1024^2 x 8 views: 429 -> 439 us with classes).
+          uint4 hist_lo = make_uint4(0u, 0u, 0u, 0u), hist_hi = hist_lo;
+          if (use_classes == 1u) { hist_lo = ((const uint4*)cost)[0]; hist_hi = ((const uint4*)cost)[1]; }
           const uint32_t hist[GH_BWD_COST_SLOTS] = {hist_lo.x, hist_lo.y, hist_lo.z, hist_lo.w, hist_hi.x, hist_hi.y, hist_hi.z, hist_hi.w};
-          if (use_classes != 1u) {                                 // one region, or two by the launch order: one atomic per tile
+          if (use_classes != 1u) {                                 // modes 0 and 2: one atomic per tile
             const uint32_t c = (use_classes == 2u && item_idx < (n_tiles_call >> 2)) ? 1u : 0u;
             const uint32_t pos = __hip_atomic_fetch_add(&class_count[c], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (uint32_t j = 0; j < nseg; ++j)

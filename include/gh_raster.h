@@ -279,15 +279,18 @@ typedef struct GhLayout {
   size_t inst_r2;        /* float2[max_instances]                                   (b, bits: 4x4-block mask of the tile) */
   size_t sort_tables;    /* uint32[...]        per-pass digit tables */
   size_t ranges;         /* uint2 [n_views*tiles] [start,end) into the sorted list */
-  size_t tile_walk;      /* uint32[4][n_views*tiles] list entries actually walked by the forward (max n_contrib of the tile);
-                            forward waves that have finished the tile (the last one appends the tile's backward items); stop positions
-                            (tile_depth_seen); [3]: launches of at most 1,024 tiles — the most entries one 4x4-pixel block of the tile
-                            took in the PREVIOUS forward over this workspace: a scheduling hint for the next launch order, never cleared */
+  size_t tile_walk;      /* uint32[12][n_views*tiles]: [0] list entries actually walked by the forward (max n_contrib of the tile); [1] forward
+                            waves that have finished the tile (the last one appends the tile's backward items); [2] stop positions
+                            (tile_depth_seen). SCHEDULING HINTS, never cleared by the library's entry points, never affecting results:
+                            [3] calls of at most 8,192 tiles — what the PREVIOUS forward over this workspace measured per tile (up to 3,072
+                            tiles: the most entries one 4x4-pixel block took; above: half the entries walked): the next launch order;
+                            [4..12) calls of 2,049 .. 8,192 tiles — uint32[n_views*tiles][8], cycles / 256 the previous backward's slowest
+                            workgroup spent on (tile, depth segment min(k, 7)): the order of the next backward's work list */
   size_t tile_order;     /* uint32[n_views*tiles] forward launch order of the render blocks: longest tile lists first */
-  size_t bwd_items;      /* uint2 [n_views*tiles + max_instances/GH_SEGMENT + 2] backward work items (tile, depth segment) in the order the
-                            forward finished the tiles; the backward takes them from the end (long tiles finish last). Calls of at most
-                            3,072 tiles: the first quarter of the forward's launch order (the heaviest tiles) appends from the END of the
-                            array downwards instead (count: the second word of render_guard); the backward takes that region first */
+  size_t bwd_items;      /* uint2 [16][n_views*tiles + max_instances/GH_SEGMENT + 2] backward work items (tile, depth segment): sixteen regions
+                            of the list's full capacity, counts in render_guard[1..17). The backward takes the regions from the highest
+                            down, each from its end. Calls of more than 8,192 tiles use region 0 only, filled in the order the forward
+                            finished the tiles (long tiles finish last); smaller calls: see tile_walk */
   size_t ckpt_rgb;       /* float4[slots][256] forward state (T, C0, C1, C2) of every pixel of a tile at list positions that are
                             multiples of GH_SEGMENT; slots = max_instances/GH_SEGMENT + n_views*tiles + 2 */
   size_t final_C;        /* float4[n_views*H*W] colour accumulated by the forward, without background */
@@ -317,7 +320,7 @@ typedef struct GhLayout {
   size_t block_tiles;    /* uint32[projection blocks] instances counted by each block of the projection kernel (record-slot scan) */
   size_t render_guard;   /* uint32: the error bits of GhCounters.overflow as they stood BEFORE the render kernel of this call — written by
                             the kernel in front of it, read by every render wave through the scalar cache (the counters' own line
-                            takes the render kernel's atomics); second uint32: items in the end region of bwd_items */
+                            takes the render kernel's atomics); uint32[16] behind it: items per region of bwd_items */
   size_t loss_partials;  /* float[n_views*tiles][4] + 1: the fused image loss's sums of |image - target| per 8x8-pixel quadrant
                             (GhOutputs.l1_target), added up in index order by a one-workgroup kernel behind the render (or by the
                             backward: GH_FLAG_DEFER_LOSS_SUM); the last float is the factor of the final sum. Calls of at most 3,072
