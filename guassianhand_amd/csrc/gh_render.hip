@@ -374,6 +374,42 @@ __device__ __forceinline__ bool gh_fwd_consume_fine(const GhBatch& t, int base, 
   return finished;
 }
 
+// The tile's backward work items into the work list (one lane of the tile's last wave; kept out of line: it runs once per tile and
+// the render kernel's code should stay as small as its walk) — see the call site for what the regions are.
+__device__ __attribute__((noinline)) void gh_append_items(int tile, uint32_t nseg, uint32_t item_idx, uint32_t n_tiles_call, uint32_t use_classes,
+                                                          uint32_t* __restrict__ class_count, uint2* __restrict__ items, uint32_t n_items_cap,
+                                                          uint32_t* __restrict__ cost) {
+  uint4 hist_lo = make_uint4(0u, 0u, 0u, 0u), hist_hi = hist_lo;
+  if (use_classes == 1u) { hist_lo = ((const uint4*)cost)[0]; hist_hi = ((const uint4*)cost)[1]; }
+  const uint32_t hist[GH_BWD_COST_SLOTS] = {hist_lo.x, hist_lo.y, hist_lo.z, hist_lo.w, hist_hi.x, hist_hi.y, hist_hi.z, hist_hi.w};
+  if (use_classes != 1u) {                                 // modes 0 and 2: one atomic per tile
+    const uint32_t c = (use_classes == 2u && item_idx < (n_tiles_call >> 2)) ? 1u : 0u;
+    const uint32_t pos = __hip_atomic_fetch_add(&class_count[c], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t j = 0; j < nseg; ++j)
+      items[(size_t)c * n_items_cap + pos + (c ? nseg - 1u - j : j)] = make_uint2((uint32_t)tile, j);    // (class 1: segment 0 first)
+  }
+  // one atomic per RUN of segments of one class (a tile's segments get cheaper towards the back: one to three runs)
+  uint32_t k = use_classes == 1u ? 0u : nseg;
+  while (k < nseg) {
+    uint32_t c = hist[k < GH_BWD_COST_SLOTS ? k : GH_BWD_COST_SLOTS - 1u] >> GH_BWD_CLASS_SHIFT;
+    c = c < GH_BWD_CLASSES ? c : GH_BWD_CLASSES - 1u;
+    uint32_t e = k + 1u;
+    while (e < nseg) {
+      uint32_t c2 = hist[e < GH_BWD_COST_SLOTS ? e : GH_BWD_COST_SLOTS - 1u] >> GH_BWD_CLASS_SHIFT;
+      c2 = c2 < GH_BWD_CLASSES ? c2 : GH_BWD_CLASSES - 1u;
+      if (c2 != c) break;
+      ++e;
+    }
+    const uint32_t pos = __hip_atomic_fetch_add(&class_count[c], e - k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the backward reads a region from its END: a run's segments are stored back to front, so that a tile's segment 0 — all
+    //  its pixels still live: the expensive one — goes first; the one-region form of large launches keeps rounds 2-5's order)
+    for (uint32_t j = k; j < e; ++j)
+      items[(size_t)c * n_items_cap + pos + (use_classes ? e - 1u - j : j - k)] = make_uint2((uint32_t)tile, j);
+    k = e;
+  }
+  if (use_classes == 1u) { ((uint4*)cost)[0] = make_uint4(0u, 0u, 0u, 0u); ((uint4*)cost)[1] = make_uint4(0u, 0u, 0u, 0u); }
+}
+
 // grid = 4 blocks per tile (one per 8x8 quadrant), 4 waves per block (one per 4x4 pixel block); no LDS, no barriers.
 // ALPHA: also accumulate the mask channel (colour 1, bg 0) — SURVEY §8 f-2.
 // LOSS: fused image loss. 1 = GhOutputs.l1_target: every wave leaves the gradient sign(img - gt) / n of its 16 pixels, every workgroup
@@ -633,7 +669,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
         const uint32_t w = __hip_atomic_fetch_max(&tile_walk[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // final value
         // large launches: the NEXT call's launch order goes by the entries this tile actually walked (one plain store per tile, by
         // its last wave; small launches keep the finer measure above) — gh_rank_tiles in the next projection kernel
-        if (!heavy_hits && heavy_out) heavy_out[tile] = (w + 1u) >> 1;
+        if (!heavy_hits && heavy_out) heavy_out[tile] = (w + 1u) >> 1;      // (the list LENGTH as the key instead: forward +1.4 us at 8 views)
         const uint32_t nseg = (w + GH_SEGMENT - 1u) / GH_SEGMENT;
         if (nseg) {
           // The work list is kept in GH_BWD_CLASSES regions, and the backward takes them from the highest class down (inside a region
@@ -648,35 +684,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
           //    order (the heaviest tiles by ITS measure) is class 1, the rest class 0; the measured classes lost to this there.
           //  0 (larger launches): one region, the order of completion: ten rounds of workgroups leave a short tail whatever the order,
           //    and what concurrent workgroups share in the L2 weighs more (1024^2 x 8 views: 429 -> 439 us with classes).
-          uint4 hist_lo = make_uint4(0u, 0u, 0u, 0u), hist_hi = hist_lo;
-          if (use_classes == 1u) { hist_lo = ((const uint4*)cost)[0]; hist_hi = ((const uint4*)cost)[1]; }
-          const uint32_t hist[GH_BWD_COST_SLOTS] = {hist_lo.x, hist_lo.y, hist_lo.z, hist_lo.w, hist_hi.x, hist_hi.y, hist_hi.z, hist_hi.w};
-          if (use_classes != 1u) {                                 // modes 0 and 2: one atomic per tile
-            const uint32_t c = (use_classes == 2u && item_idx < (n_tiles_call >> 2)) ? 1u : 0u;
-            const uint32_t pos = __hip_atomic_fetch_add(&class_count[c], nseg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t j = 0; j < nseg; ++j)
-              items[(size_t)c * n_items_cap + pos + (c ? nseg - 1u - j : j)] = make_uint2((uint32_t)tile, j);    // (class 1: segment 0 first)
-          }
-          // one atomic per RUN of segments of one class (a tile's segments get cheaper towards the back: one to three runs)
-          uint32_t k = use_classes == 1u ? 0u : nseg;
-          while (k < nseg) {
-            uint32_t c = hist[k < GH_BWD_COST_SLOTS ? k : GH_BWD_COST_SLOTS - 1u] >> GH_BWD_CLASS_SHIFT;
-            c = c < GH_BWD_CLASSES ? c : GH_BWD_CLASSES - 1u;
-            uint32_t e = k + 1u;
-            while (e < nseg) {
-              uint32_t c2 = hist[e < GH_BWD_COST_SLOTS ? e : GH_BWD_COST_SLOTS - 1u] >> GH_BWD_CLASS_SHIFT;
-              c2 = c2 < GH_BWD_CLASSES ? c2 : GH_BWD_CLASSES - 1u;
-              if (c2 != c) break;
-              ++e;
-            }
-            const uint32_t pos = __hip_atomic_fetch_add(&class_count[c], e - k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (the backward reads a region from its END: a run's segments are stored back to front, so that a tile's segment 0 — all
-            //  its pixels still live: the expensive one — goes first; the one-region form of large launches keeps rounds 2-5's order)
-            for (uint32_t j = k; j < e; ++j)
-              items[(size_t)c * n_items_cap + pos + (use_classes ? e - 1u - j : j - k)] = make_uint2((uint32_t)tile, j);
-            k = e;
-          }
-          if (use_classes == 1u) { ((uint4*)cost)[0] = make_uint4(0u, 0u, 0u, 0u); ((uint4*)cost)[1] = make_uint4(0u, 0u, 0u, 0u); }
+          gh_append_items(tile, nseg, item_idx, n_tiles_call, use_classes, class_count, items, n_items_cap, cost);
         }
         if (SEEN) {
           // every pixel of the tile stopped (and passed the virtual threshold): nothing behind the last entry any of them looked at can matter next time either
