@@ -87,9 +87,9 @@ def numbers() -> str:
          f"| same, 4 / 2 / 1 view(s) (configs[3] on 2 / 4 / 8 GPUs; `profiles/{TAG}_fit_step_views.txt`) | — | {fit[(4, True)]:.2f} / {fit[(2, True)]:.2f} / **{fit[(1, True)]:.2f}** | 0.34 / 0.25 / 0.18 (full path 0.46 / 0.34 / 0.25); this round's full path: {fit[(4, False)]:.2f} / {fit[(2, False)]:.2f} / {fit[(1, False)]:.2f} |",
          f"| CPU oracle in its all-core baseline mode, {d['cpu_baseline']['threads']} threads ({d['cpu_baseline']['cpu_model']}), serial fraction {d['cpu_baseline']['serial_fraction']:.4f}, configs[2] | {d['cpu_baseline']['value']:.1f} | — | 11.2 |",
          f"| PyTorch CPU autograd (dense `oracle_torch`, {rk['cpu_baseline']['cores']} threads), configs[0] | {rk['cpu_baseline']['value']:.3f} | — | — |", "",
-         f"Stage times (ms; projection / binning / render forward / render backward / per-Gaussian backward) at 8 views: {st(d)}; at 1 view: {st(v1)} — the forward",
-         "render is as long as its longest wave at the lone-wave rate (profiles/r6_forward_one_view_waves.txt), binning is the latency of 13 small",
-         f"kernels; at 1024² SH3 × 8 views: {st(hd)}; 32 poses: {st(pb)}.",
+         f"Stage times (ms; projection / binning / render forward / render backward / per-Gaussian backward) at 8 views: {st(d)}; at 1 view: {st(v1)} — the render",
+         "kernels are as long as their heaviest waves (§5: launch order by measured work, the heaviest tiles in the fine-grained form), binning is the",
+         f"latency of 12 small kernels (profiles/r6_timeline_1view.txt); at 1024² SH3 × 8 views: {st(hd)}; 32 poses: {st(pb)}.",
          END7]
     return "\n".join(L)
 
