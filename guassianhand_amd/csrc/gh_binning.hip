@@ -14,6 +14,7 @@
 // The instance count D never leaves the device: kernels read their element count from device memory and grids
 // are sized from the caller's capacity (max_instances), so the whole stage is sync-free / graph-capturable.
 #include "gh_internal.h"
+GH_WG_TIMER_TU(bin)
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_emit_kernel(
     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, GhCounters* __restrict__ ctr, float rP, uint32_t flags,
     const float* __restrict__ tile_depth_bound, int n_emit_blocks, int NVs, float rdiv, const uint32_t* __restrict__ block_tiles,
     uint32_t* __restrict__ slot_begin, uint32_t* __restrict__ view_start, int n_views) {
+  GH_WG_TIMER(4);
   constexpr int NW = GH_BLOCK / GH_WAVE;
   if ((int)blockIdx.x >= n_emit_blocks) {               // the spare workgroups: the record-slot numbering (see gh_number_record_slots)
     gh_number_record_slots(blockIdx.x - (uint32_t)n_emit_blocks, N, P, NVs, rdiv, tiles_touched, block_tiles, slot_begin);
@@ -775,6 +777,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
                                                               float rtiles, float rgx, uint32_t flags, float* __restrict__ inst_c,
                                                               const float* __restrict__ tile_depth_bound, uint32_t P_local, float rP,
                                                               uint32_t* __restrict__ render_guard) {
+  GH_WG_TIMER(5);
   // render_guard given (small launches, whose launch order was ranked inside the projection kernel): this IS the last kernel in front
   // of the render — the error bits as they stand now (every kernel that raises one is complete), in their own word; see gh_tile_order_kernel
   if (render_guard && blockIdx.x == 0 && threadIdx.x == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; for (int c = 0; c < GH_BWD_CLASSES; ++c) render_guard[1 + c] = 0u; }

@@ -524,4 +524,23 @@ __device__ __forceinline__ unsigned gh_wave_sum_u32(unsigned v) {  // all lanes 
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+#ifdef GH_EXP_WG_TIME
+// (experiment: per-workgroup cycle counters of any kernel of this translation unit, read back by gh_exp_wg_read_<TU>; kernels declare
+//  `GhWgTimer wg_timer(<id>);` as their first statement. tools/experiments/wg_lpt_sim.py)
+#define GH_WG_TIMER_TU(NAME) \
+  __device__ uint4 gh_exp_wg_buf_##NAME[1 << 19]; __device__ uint32_t gh_exp_wg_n_##NAME; \
+  struct GhWgTimer { uint32_t id; uint64_t t0; \
+    __device__ GhWgTimer(uint32_t k) : id(k), t0(__builtin_readcyclecounter()) {} \
+    __device__ ~GhWgTimer() { const uint64_t t1 = __builtin_readcyclecounter(); \
+      if (threadIdx.x == 0) { const uint32_t n = atomicAdd(&gh_exp_wg_n_##NAME, 1u); \
+        if (n < (1u << 19)) gh_exp_wg_buf_##NAME[n] = make_uint4((uint32_t)(t1 - t0), blockIdx.x, id, (uint32_t)(t0 >> 4)); } } }; \
+  extern "C" int gh_exp_wg_read_##NAME(void* dst, size_t bytes, uint32_t* n) { \
+    if (hipMemcpyFromSymbol(n, HIP_SYMBOL(gh_exp_wg_n_##NAME), 4) != hipSuccess) return -1; \
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gh_exp_wg_buf_##NAME), bytes); } \
+  extern "C" int gh_exp_wg_clear_##NAME() { uint32_t z = 0; return (int)hipMemcpyToSymbol(HIP_SYMBOL(gh_exp_wg_n_##NAME), &z, 4); }
+#define GH_WG_TIMER(ID) GhWgTimer wg_timer(ID)
+#else
+#define GH_WG_TIMER_TU(NAME)
+#define GH_WG_TIMER(ID)
+#endif
 #endif  // __HIPCC__

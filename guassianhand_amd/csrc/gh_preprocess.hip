@@ -4,6 +4,7 @@
 // HBM-streaming kernels: one thread per (view, Gaussian), outputs packed as float4 records so the
 // render kernels gather each Gaussian with two 16-byte loads + one 4-byte load.
 #include "gh_internal.h"
+GH_WG_TIMER_TU(pre)
 
 // ------------------------------------------------------------------------------------------------
 // Effective occlusion bound of this call from what the previous call reported (GhInputs.tile_depth_bound: (depth, block mask)
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
     int32_t* __restrict__ radii, int T, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_walk,
     uint2* __restrict__ key_bits, float rdiv, float* __restrict__ cull_bound_out, const float* __restrict__ tile_bound,
     uint32_t* __restrict__ block_tiles, int n_proj_blocks, uint32_t* __restrict__ tile_order, int tiles_per_view) {
+  GH_WG_TIMER(2);
   // Small launches (gh_fwd_fine_launch): the forward's launch order comes from what the PREVIOUS forward over this workspace measured
   // per tile (tile_walk[3]), so it does not wait for this call's lists: one spare workgroup per view ranks the tiles here, in the
   // shadow of the projection, instead of a kernel of its own between the binning and the render (4.5 us of a one-view step).
@@ -408,6 +410,7 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_bwd_kernel(
     const uint32_t* __restrict__ tiles_touched, const float4* __restrict__ dmean_sh, const float4* __restrict__ gsum,
     float* __restrict__ scratch, const uint32_t* __restrict__ slot_begin, const float* __restrict__ inst_grad,
     const uint32_t* __restrict__ inst_flag, int v_split, uint32_t cap_a, uint32_t cap_b) {
+  GH_WG_TIMER(3);
   __shared__ float s_part[GH_BLOCK / GH_WAVE][64];
   const bool per_view = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) != 0;
   const int G = 1 << lg;

@@ -870,7 +870,7 @@ struct GhBwdEntry {            // one list entry in the lane's registers
 // blend into the batch (bit i = pixel i of the block, wave-uniform); pix_base: LDS record index of the block's pixel 0.
 // Adds the lane's nine sums into acc[9]; returns whether some pixel blended the lane's entry.
 // GEOM = false (no gradient w.r.t. the geometry is wanted — the one-shot fit): the five position / conic moments are left out.
-template <int L, bool GEOM>
+template <int L, bool GEOM, bool UNROLL2>
 __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, uint32_t am_in, int pix_base, int lane,
                                              float4* s_pix, float (&acc)[9]) {
   constexpr int NPX = GH_WAVE / L;
@@ -895,9 +895,14 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     return NPX == 1 ? packed : ((packed >> slot8) & 0xFFu);
   };
   uint32_t pidx = pick();
-  float4 p0 = s_pix[2 * pidx], p1 = s_pix[2 * pidx + 1];        // (T, B, d0, d1), (d2, last, px, py) of this lane's pixel
+  float4 pa0 = s_pix[2 * pidx], pa1 = s_pix[2 * pidx + 1], pb0, pb1;   // (T, B, d0, d1), (d2, last, px, py) of this lane's pixel
   bool more;
-  do {
+  // One pixel of the lane's sub-list; the records of the next one are loaded into (n0, n1) half way through. UNROLL2 (the one-wave
+  // form): the loop below runs it with the two register sets swapped every other time — written as `p = next` the compiler copies
+  // five registers per pixel (72 -> 70 vector instructions per pixel). Measured nothing while the kernel ended on a few long
+  // workgroups (round 6, before its work list went longest-first); with its wave slots full 162.4 -> 161.3 us at 8 views, the step
+  // -2 us; the four-wave form of small launches lost 1.7 us to it (its longest workgroup IS the kernel there) and keeps the plain loop.
+  auto one_pixel = [&](const float4& p0, const float4& p1, float4& n0, float4& n1) {
     const uint32_t pcur = pidx;
     // alpha exactly as the forward evaluated it (same expression, same gh_exp): the same entries count as blended
     const float dx = e.a.x - p1.z, dy = e.a.y - p1.w;
@@ -921,7 +926,7 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     // the pixel records of the next iteration land while the second half of this one is computed
     more = am != 0u;
     pidx = pick();                                               // all dummy once the mask is empty
-    p0 = s_pix[2 * pidx]; p1 = s_pix[2 * pidx + 1];
+    n0 = s_pix[2 * pidx]; n1 = s_pix[2 * pidx + 1];
     const float S = gh_scan_add<L>(we) + sB;          // d . (colour blended at or behind this entry) + background / mask term
     // dL/dalpha_k = T_k (d . c_k) - (d . colour strictly behind + background / mask term) / (1 - alpha_k)
     const float dLda = Tk * ec - rm1 * (S - we);
@@ -934,7 +939,17 @@ __device__ __forceinline__ bool gh_bwd_batch(const GhBwdEntry& e, bool valid, ui
     acc[5] += h;
     // state in front of the batch: the group's last lane holds the totals (lanes past the count: factor 1, weight 0)
     if (seg_last) *(float2*)&s_pix[2 * pcur] = make_float2(Tk, S);
-  } while (more);
+  };
+  if (UNROLL2) {
+    for (;;) {
+      one_pixel(pa0, pa1, pb0, pb1);
+      if (!more) break;
+      one_pixel(pb0, pb1, pa0, pa1);
+      if (!more) break;
+    }
+  } else {
+    do { one_pixel(pa0, pa1, pb0, pb1); pa0 = pb0; pa1 = pb1; } while (more);
+  }
   return any;
 }
 
@@ -1178,9 +1193,9 @@ __global__ __launch_bounds__(NW * GH_WAVE) void gh_render_bwd_kernel(
         float acc[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         bool any = false;
         if (am) {
-          if (L == 64) any = gh_bwd_batch<64, GEOM>(e, valid, am, 16 * b, lane, s_pix, acc);
-          else if (L == 32) any = gh_bwd_batch<32, GEOM>(e, valid, am, 16 * b, lane, s_pix, acc);
-          else any = gh_bwd_batch<16, GEOM>(e, valid, am, 16 * b, lane, s_pix, acc);
+          if (L == 64) any = gh_bwd_batch<64, GEOM, NW == 1>(e, valid, am, 16 * b, lane, s_pix, acc);
+          else if (L == 32) any = gh_bwd_batch<32, GEOM, NW == 1>(e, valid, am, 16 * b, lane, s_pix, acc);
+          else any = gh_bwd_batch<16, GEOM, NW == 1>(e, valid, am, 16 * b, lane, s_pix, acc);
         }
         // The lane groups of a 32- / 16-lane batch hold partial sums of the SAME entries (different pixels): fold them into
         // group 0 (fixed order). Then plain read-modify-write of the entry's accumulator row: the wave owns the rows and the
