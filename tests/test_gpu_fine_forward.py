@@ -5,7 +5,9 @@ which the suite's small scenes rarely have. The library reads its two thresholds
 
 What must hold: images, n_contrib, final T bit-equal to the oracle in either form (the same arithmetic per pixel in the same order);
 gradients within 1e-3; the fused image loss bit-IDENTICAL whichever tiles went fine (which tiles do is a scheduling decision that
-depends on the previous call over the workspace — the loss may not depend on it)."""
+depends on the previous call over the workspace — the loss may not depend on it). The same for the other scheduling hints the
+workspace carries between calls (GH_FWD_HEAVY_ORDER: the launch order; GH_BWD_CLASSES: the backward's work list by measured cost):
+loss, image and gradients of four consecutive steps are the same bits in every mode."""
 import json
 import os
 import subprocess
@@ -49,6 +51,20 @@ for ci, sc in enumerate([sized(make_scene("two_hands", n_views=2), 2, 256, 256, 
         out["img%%d_%%d" %% (ci, rep)] = h(img)
     loss.backward()
     out["dxyz%%d" %% ci] = h(xyz.grad)
+# (3) a launch in the range of the backward's cost classes (2,049 .. 8,192 tiles: four views of 512x334): forward + backward four
+#     times over one workspace — the second step on, the launch order comes from the first step's measurements and the backward's work
+#     list from what its items cost the step before. Loss, image and gradient must be the same bits in every step and every mode.
+sc = make_scene("two_hands", n_views=4)
+s = sc.to(dev)
+cams = sc.cams().to(dev)
+gt = torch.rand(4, 3, sc.H, sc.W, generator=torch.Generator().manual_seed(4)).to(dev)
+xyz = s.xyz.clone().requires_grad_(True)
+kw = dict(H=sc.H, W=sc.W, use_rgb=sc.use_rgb, sh_degree=sc.sh_degree)
+for rep in range(4):
+    xyz.grad = None
+    loss, img, _ = rendered_l1_loss(cams, xyz, s.opacity, s.scaling, s.rotation, s.shs, gt, **kw)
+    loss.backward()
+    out["loss4_%%d" %% rep] = h(loss); out["img4_%%d" %% rep] = h(img); out["dxyz4_%%d" %% rep] = h(xyz.grad)
 print("RESULT " + json.dumps(out))
 '''
 
@@ -67,12 +83,15 @@ def test_every_tile_in_the_fine_form_equals_the_oracle_and_the_loss_does_not_dep
     fine = _run({"GH_FWD_FINE_K": "1000000", "GH_FWD_FINE_MIN": "0"})        # every tile of every small launch goes fine
     coarse = _run({"GH_FWD_FINE_K": "0"})                                      # none does
     mixed = _run({"GH_FWD_FINE_K": "7", "GH_FWD_FINE_MIN": "64"})            # a few do — which ones depends on the previous call
+    plain = _run({"GH_FWD_HEAVY_ORDER": "0", "GH_BWD_CLASSES": "0"})          # launch order by list length, the work list in one piece
     for k in fine:
-        if k.startswith(("loss", "img")):
+        assert fine[k] == plain[k], (k, fine[k], plain[k])                    # no scheduling hint changes a bit of any result
+    for k in fine:
+        if k.startswith(("loss", "img", "dxyz4")):
             base = k.rsplit("_", 1)[0]
             assert fine[k] == fine[base + "_0"] == coarse[k] == mixed[k], (k, fine[k], coarse[k], mixed[k])
-        elif not k.startswith("dxyz"):            # (instance counts; the gradient sums are reproducible per form, compared below)
+        elif not k.startswith("dxyz"):            # (instance counts; the gradient sums are compared below)
             assert fine[k] == coarse[k] == mixed[k], (k, fine[k], coarse[k], mixed[k])
     # the backward is the same kernel over the same forward state in every form: its gradients are the same bits
-    for k in (k for k in fine if k.startswith("dxyz")):
+    for k in (k for k in fine if k.startswith("dxyz") and not k.startswith("dxyz4")):
         assert fine[k] == coarse[k] == mixed[k], (k, fine[k], coarse[k], mixed[k])
