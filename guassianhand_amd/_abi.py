@@ -12,6 +12,7 @@ GH_FLAG_SPLIT_STREAMS = 8
 GH_FLAG_STATIC_LISTS = 16
 GH_FLAG_DEPTH24 = 32
 GH_FLAG_DEFER_LOSS_SUM = 64
+GH_FLAG_FRESH_ORDER = 128
 GH_VERSION_MAJOR, GH_VERSION_MINOR = 0, 8        # the header this mirror was written against (checked against gh_version() on load)
 GH_ABI_TAG = 0x47480000 | (GH_VERSION_MAJOR << 8) | GH_VERSION_MINOR
 GH_COUNTER_ERROR_MASK = 15     # GhCounters.overflow bits 0-3: errors

@@ -886,11 +886,11 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_ranges_kernel(
 // inside a bucket is arbitrary. (The backward's order comes from the forward itself: gh_render_fwd_kernel.)
 __global__ __launch_bounds__(GH_BLOCK) void gh_tile_order_kernel(const uint2* __restrict__ ranges, int tiles, int NV,
                                                                   uint32_t* __restrict__ order, const GhCounters* __restrict__ ctr,
-                                                                  uint32_t* __restrict__ render_guard, uint32_t* __restrict__ heavy) {
+                                                                  uint32_t* __restrict__ render_guard, uint32_t* __restrict__ heavy, int use_heavy) {
   // the last kernel in front of the render: the error bits as they stand now, in a word of their own (the render kernel's waves
   // read it through the scalar cache; its own atomics go to the counters' line)
   if (blockIdx.x == 0 && threadIdx.x == 0) { *render_guard = ctr->overflow & GH_COUNTER_ERROR_MASK; for (int c = 0; c < GH_BWD_CLASSES; ++c) render_guard[1 + c] = 0u; }   // ([1..]: items per class of the backward's work list)
-  gh_rank_tiles(ranges, tiles, NV, (int)blockIdx.x, order, heavy);
+  gh_rank_tiles(ranges, tiles, NV, (int)blockIdx.x, order, heavy, use_heavy != 0);
 }
 
 bool gh_heavy_order_enabled() {
@@ -907,7 +907,8 @@ bool gh_bwd_classes_enabled() {
 static void gh_launch_tile_order(const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s) {
   uint32_t* heavy = g.total_tiles <= GH_ORDER_TILES && gh_heavy_order_enabled() ? (uint32_t*)(ws + L.tile_walk) + 3 * (size_t)g.NV * g.tiles : nullptr;
   hipLaunchKernelGGL(gh_tile_order_kernel, dim3(g.NV), dim3(GH_BLOCK), 0, s, (const uint2*)(ws + L.ranges), g.tiles, g.NV,
-                     (uint32_t*)(ws + L.tile_order), (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard), heavy);
+                     (uint32_t*)(ws + L.tile_order), (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard), heavy,
+                     (g.flags & GH_FLAG_FRESH_ORDER) ? 0 : 1);
 }
 
 void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayout& L, hipStream_t s, const float* tile_depth_bound) {

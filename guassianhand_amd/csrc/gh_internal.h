@@ -50,6 +50,7 @@ struct GhGrid {
   int tile_bits, n_pass;
   int64_t cap;                        // max_instances
   int n_items;                        // capacity of the backward work list: NV*tiles + cap/GH_SEGMENT + 2
+  uint32_t flags;                     // GhDims.flags
   int64_t total_tiles;                // tiles of the whole call (a half of a GH_FLAG_SPLIT_STREAMS call keeps the full call's
                                       // kernel variants, so that its results are the unsplit call's bit for bit)
 };
@@ -64,6 +65,7 @@ static inline GhGrid gh_make_grid(const GhDims* d) {
   g.cap = d->max_instances;
   g.n_items = (int)((size_t)g.NV * g.tiles + (size_t)g.cap / GH_SEGMENT + 2);
   g.total_tiles = (int64_t)g.NV * g.tiles;
+  g.flags = d->flags;
   return g;
 }
 
@@ -82,7 +84,9 @@ bool gh_heavy_order_enabled();                         // (GH_FWD_HEAVY_ORDER=0 
 #ifndef GH_CLASS_TILES
 #define GH_CLASS_TILES GH_ORDER_TILES
 #endif
-static inline bool gh_order_in_projection(const GhGrid& g) { return g.total_tiles <= GH_ORDER_TILES && g.N > 0 && gh_heavy_order_enabled(); }
+static inline bool gh_order_in_projection(const GhGrid& g) {
+  return g.total_tiles <= GH_ORDER_TILES && g.N > 0 && !(g.flags & GH_FLAG_FRESH_ORDER) && gh_heavy_order_enabled();
+}
 bool gh_bwd_classes_enabled();                         // (GH_BWD_CLASSES=0 in the environment: the work list in one piece, gh_binning.hip)
 // 0: one region (completion order, taken from the end: rounds 2-5); 1: regions by the cost the previous backward measured per (tile,
 // segment); 2: two regions by the forward's launch order (launches whose backward runs in its four-wave form)
@@ -471,9 +475,10 @@ __device__ __forceinline__ uint32_t gh_block_excl_scan(uint32_t v, uint32_t* s_w
 // this workspace measured per tile (`heavy`: the most entries one 4x4-pixel block let through = its longest wave's work; a list of 544
 // entries can keep a wave busier than one of 1,265). With `heavy` and NO ranges (the ranking runs as spare workgroups of the projection
 // kernel, before this call's lists exist) the measurement alone decides: a tile never measured goes last. Stale values (another scene,
-// the first call) only cost time. `heavy` is cleared behind the read: the forward of THIS call fills it again.
+// the first call) only cost time. `heavy` is cleared behind the read: the forward of THIS call fills it again — also when the
+// caller has said the hint is stale (use_heavy = false, GH_FLAG_FRESH_ORDER): the list lengths decide then, as before the hints.
 __device__ __forceinline__ void gh_rank_tiles(const uint2* __restrict__ ranges, int tiles, int NV, int v, uint32_t* __restrict__ order,
-                                              uint32_t* __restrict__ heavy) {
+                                              uint32_t* __restrict__ heavy, bool use_heavy = true) {
   __shared__ uint32_t s_cnt[256];
   __shared__ uint32_t s_w[GH_BLOCK / GH_WAVE];
   const int tid = threadIdx.x;
@@ -483,7 +488,7 @@ __device__ __forceinline__ void gh_rank_tiles(const uint2* __restrict__ ranges, 
     uint32_t b = 0u;
     bool listed = true;
     if (ranges) { const uint2 r = ranges[t]; b = (r.y - r.x + 15u) >> 4; listed = r.y != r.x; }
-    if (heavy) { const uint32_t h = heavy[t]; if (h != 0u && listed) b = 128u + ((h + 7u) >> 3); else b = b > 127u ? 127u : b; }
+    if (heavy && use_heavy) { const uint32_t h = heavy[t]; if (h != 0u && listed) b = 128u + ((h + 7u) >> 3); else b = b > 127u ? 127u : b; }
     return b > 255u ? 255u : b;
   };
   // (a thread's first four tiles keep their bucket in registers between the two passes: every launch the heaviness key applies to)

@@ -757,6 +757,14 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
             raise RuntimeError("gh_workspace_bytes rejected the dimensions")
         stream = _raw_stream(dev)
         ws = _ws_acquire(st, dev, nbytes, stream)
+        # The launch-order hint in the workspace describes the cameras of the call that left it: other cameras (or a buffer
+        # fresh from the allocator) -> GH_FLAG_FRESH_ORDER, the order by this call's own list lengths. Results are the same either way.
+        # (the tensor OBJECT through a weak reference + its version counter: the address of a freed camera tensor is what the caching
+        #  allocator hands to the next one, and so is a freed object's id())
+        prev = getattr(ws, "_gh_cam_sig", None)
+        if prev is None or prev[0]() is not c.cams_obj or prev[1:] != (c.cams_obj._version, NV, H, W):
+            dims.flags |= _abi.GH_FLAG_FRESH_ORDER
+        ws._gh_cam_sig = (weakref.ref(c.cams_obj), c.cams_obj._version, NV, H, W)
         image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
         radii = torch.empty(NV, P, dtype=torch.int32, device=dev)
         alpha = torch.empty(NV, H, W, dtype=torch.float32, device=dev) if return_alpha else None

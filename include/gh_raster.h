@@ -89,6 +89,12 @@ typedef enum GhStatus {
                                            512x334). Until that backward has run the loss value is undefined; the gradients
                                            l1_dL_dimage / fit_loss->dL_* are complete after the forward as always. Ignored without a
                                            fused loss. */
+#define GH_FLAG_FRESH_ORDER 128u        /* the scheduling hints the previous forward left in this workspace (GhLayout.tile_walk[3]: the
+                                           next launch order) do not describe THIS call — other cameras, another scene: rank the
+                                           forward's tiles by this call's own list lengths (a kernel of its own behind the binning, as
+                                           before v0.8's hints) instead of inside the projection kernel. Never changes a result; with
+                                           8 views a step is ~2 % slower WITH stale hints than without, ~1 % faster with valid ones. A
+                                           host that cannot tell sets it. */
 #define GH_FLAG_SPLIT_STREAMS 8u        /* n_views >= 2: the views are rendered as two independent halves (views [0, n/2) and
                                            [n/2, n)), the second on a HIP stream of the library's own, forked from and joined
                                            back into the caller's stream inside every call (graph-capturable): the drain of one

@@ -95,3 +95,39 @@ def test_every_tile_in_the_fine_form_equals_the_oracle_and_the_loss_does_not_dep
     # the backward is the same kernel over the same forward state in every form: its gradients are the same bits
     for k in (k for k in fine if k.startswith("dxyz") and not k.startswith("dxyz4")):
         assert fine[k] == coarse[k] == mixed[k], (k, fine[k], coarse[k], mixed[k])
+
+
+def test_the_launch_order_hint_is_only_used_for_the_cameras_that_left_it():
+    """rasterizer._forward_full sets GH_FLAG_FRESH_ORDER unless the workspace it got was last used with the SAME camera tensor (object
+    and version): a recycled address or an in-place update of the cameras does not count as the same. The image is the same bits
+    either way (the flag moves the tile ranking from the projection kernel's spare workgroups back into a kernel of its own)."""
+    import torch
+    from guassianhand_amd import _abi
+    from guassianhand_amd.rasterizer import raster_forward, clear_workspace_pool
+    from guassianhand_amd.scenes import make_scene
+    from tests.helpers import scene_kwargs
+    dev = torch.device("cuda:0")
+    sc = make_scene("random1k", n_views=2, P=3000)
+    s = sc.to(dev)
+    kw, bl = scene_kwargs(s)
+    cams = sc.cams().to(dev)
+    clear_workspace_pool()
+
+    def render(c):
+        img, _, ctx = raster_forward(c, s.xyz, s.opacity, s.scaling, s.rotation, H=sc.H, W=sc.W, sync=True, **kw, **bl)
+        fresh = bool(ctx.dims.flags & _abi.GH_FLAG_FRESH_ORDER)
+        del ctx                                           # (the workspace goes back to the pool: the next call gets this buffer)
+        return img, fresh
+
+    img0, f0 = render(cams)
+    img1, f1 = render(cams)
+    assert f0 and not f1                                  # a buffer fresh from the allocator; then the same cameras again
+    cams2 = cams.clone()
+    img2, f2 = render(cams2)
+    img3, f3 = render(cams2)
+    assert f2 and not f3                                  # other tensor object (same values): stale; then valid again
+    cams2.mul_(1.0)                                       # in-place update: the version counter moves
+    img4, f4 = render(cams2)
+    assert f4
+    for im in (img1, img2, img3, img4):
+        assert torch.equal(im, img0)
