@@ -255,7 +255,7 @@ def test_workspace_layout_properties_over_random_dims(gh_lib_path):
     _abi.declare(L)
     rnd = random.Random(7)
     flag_bits = (_abi.GH_FLAG_BLEND_W_PER_GAUSSIAN, _abi.GH_FLAG_BLEND_COLOR_B_RGB, _abi.GH_FLAG_PER_VIEW_GAUSSIANS, _abi.GH_FLAG_SPLIT_STREAMS,
-                 _abi.GH_FLAG_STATIC_LISTS, _abi.GH_FLAG_DEPTH24, _abi.GH_FLAG_DEFER_LOSS_SUM)
+                 _abi.GH_FLAG_STATIC_LISTS, _abi.GH_FLAG_DEPTH24, _abi.GH_FLAG_DEFER_LOSS_SUM, _abi.GH_FLAG_FRESH_ORDER)
     ok = 0
     for _ in range(2000):
         P = rnd.choice([0, 1, 2, 255, 256, 257, 1000, 98562, rnd.randint(0, 300000)])
