@@ -761,8 +761,11 @@ def _forward_full(st, L, dev, c: _Call, return_alpha: bool, sync, expect_backwar
         # fresh from the allocator) -> GH_FLAG_FRESH_ORDER, the order by this call's own list lengths. Results are the same either way.
         # (the tensor OBJECT through a weak reference + its version counter: the address of a freed camera tensor is what the caching
         #  allocator hands to the next one, and so is a freed object's id())
+        # A step being CAPTURED into a graph is replayed over this very buffer with this very camera tensor: from its second replay on
+        # the hint is its own, and the flag would be baked into every replay — never set under capture.
         prev = getattr(ws, "_gh_cam_sig", None)
-        if prev is None or prev[0]() is not c.cams_obj or prev[1:] != (c.cams_obj._version, NV, H, W):
+        if (prev is None or prev[0]() is not c.cams_obj or prev[1:] != (c.cams_obj._version, NV, H, W)) \
+                and not torch.cuda.is_current_stream_capturing():
             dims.flags |= _abi.GH_FLAG_FRESH_ORDER
         ws._gh_cam_sig = (weakref.ref(c.cams_obj), c.cams_obj._version, NV, H, W)
         image = torch.empty(NV, 3, H, W, dtype=torch.float32, device=dev)
