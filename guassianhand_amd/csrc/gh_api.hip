@@ -487,8 +487,8 @@ extern "C" int gh_forward_refresh(const GhDims* d, const GhInputs* in, const GhO
     return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
   }
   gh_launch_sh_colour_fwd(d, g, in, (char*)workspace, L, s);           // SH mode only
-  gh_launch_refresh(d, g, in, (const char*)geometry_ws, (char*)workspace, L, s);
-  gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s, nullptr, 1.0f, 0u, out);
+  const bool own_order = gh_launch_refresh(d, g, in, (const char*)geometry_ws, (char*)workspace, L, s);
+  gh_launch_render_fwd(d, g, in, out->image, out->alpha, (const char*)geometry_ws, (char*)workspace, L, s, nullptr, 1.0f, 0u, out, own_order);
   return hipGetLastError() == hipSuccess ? GH_OK : GH_ERR_LAUNCH;
 }
 

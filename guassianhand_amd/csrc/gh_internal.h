@@ -109,7 +109,8 @@ void gh_launch_binning(const GhDims* d, const GhGrid& g, char* ws, const GhLayou
 // seen / seen_scale: GhOutputs.tile_depth_seen (optional; full forwards only)
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha,
                           const char* wg, char* ws, const GhLayout& L, hipStream_t s, float* seen = nullptr, float seen_scale = 1.0f,
-                          uint32_t seen_slack = 0u, const GhOutputs* fused = nullptr);   // fused: GhOutputs.l1_* (full forwards only)
+                          uint32_t seen_slack = 0u, const GhOutputs* fused = nullptr,     // fused: GhOutputs.l1_* (full forwards only)
+                          bool own_order = false);    // the launch order is ws's own (gh_launch_refresh re-ranked it), not wg's
 // out[0] = scale * (fixed-order sum of n floats, n a multiple of 4, 16-byte aligned): one workgroup (gh_loss.hip)
 // scale_behind: the factor is the float the forward left behind the last partial (times `scale`)
 void gh_launch_partials_sum(const float* partials, size_t n, float scale, float* out, hipStream_t s, bool scale_behind = false);
@@ -129,7 +130,9 @@ static inline bool gh_records_need_geometry(const GhInputs* in, const GhGrads* g
 }
 void gh_launch_recolour(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
 // gh_forward_refresh: per-instance records (opacity, colour, block mask) of the CURRENT opacities / colours over the lists of wg
-void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
+// returns true when it re-ranked the forward's launch order into ws's own tile_order (static lists: the order of the BUILD call is by
+// list length — no measurement existed then; every refresh has the previous step's)
+bool gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s);
 // LSD radix sort of (keys, vals) on bits [0, nbits): ceil(nbits/8) stable passes, element count read from device memory
 // (*n_ptr <= cap); pointers are swapped so that on return k_in / v_in hold the result. table: gh_radix_table_words(cap).
 void gh_radix_sort(uint32_t*& k_in, uint32_t*& v_in, uint32_t*& k_out, uint32_t*& v_out, const uint32_t* n_ptr, uint32_t cap,

@@ -733,7 +733,8 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_render_fwd_kernel(
 }
 
 void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, float* image, float* alpha, const char* wg, char* ws,
-                          const GhLayout& L, hipStream_t s, float* seen, float seen_scale, uint32_t seen_slack, const GhOutputs* fused) {
+                          const GhLayout& L, hipStream_t s, float* seen, float seen_scale, uint32_t seen_slack, const GhOutputs* fused,
+                          bool own_order) {
   // Small launches (resident all at once: as long as their longest wave) run their heaviest tiles in the fine-grained form: see the
   // kernel. GH_FWD_FINE_K / GH_FWD_FINE_MIN in the environment override the two thresholds (0 tiles = the coarse form only; tests
   // walk EVERY tile of their small scenes in the fine form with K = a large number, MIN = 0).
@@ -747,7 +748,7 @@ void gh_launch_render_fwd(const GhDims* d, const GhGrid& g, const GhInputs* in, 
 
   const dim3 grid(4 * n_tiles_call + 12 * fine_k), block(GH_BLOCK);
   const uint2* ranges = (const uint2*)(wg + L.ranges);
-  const uint32_t* order = (const uint32_t*)(wg + L.tile_order);
+  const uint32_t* order = (const uint32_t*)((own_order ? (const char*)ws : wg) + L.tile_order);
   const float4* r0 = (const float4*)(wg + L.inst_r0); const float4* r1 = (const float4*)(ws + L.inst_r1);
   const float2* r2 = (const float2*)(ws + L.inst_r2);
   float* fT = (float*)(ws + L.final_T); uint32_t* nc = (uint32_t*)(ws + L.n_contrib); uint32_t* tw = (uint32_t*)(ws + L.tile_walk);
@@ -1355,7 +1356,16 @@ __global__ void gh_refresh_init_kernel(const GhCounters* __restrict__ gctr, GhCo
 __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_attr_kernel(GhInputs in, uint32_t flags, int P, int NV, int N, int T,
                                                                     const GhCounters* __restrict__ gctr, const float* __restrict__ cull_bound,
                                                                     const float4* __restrict__ sh_rgb, float4* __restrict__ attr,
-                                                                    uint32_t* __restrict__ tile_walk, GhCounters* __restrict__ ctr) {
+                                                                    uint32_t* __restrict__ tile_walk, GhCounters* __restrict__ ctr,
+                                                                    int n_attr_blocks, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                                    int tiles_per_view) {
+  // spare workgroups (launches of at most GH_ORDER_TILES tiles): the forward's launch order, ranked anew from what the PREVIOUS step's
+  // forward measured per tile (this call's tile_walk[3]; a tile without a measurement: by its list length) into this call's own
+  // tile_order — the build call's order is by list length, and its choice of fine-grained tiles with it
+  if ((int)blockIdx.x >= n_attr_blocks) {
+    gh_rank_tiles(ranges, tiles_per_view, NV, (int)blockIdx.x - n_attr_blocks, order, tile_walk + 3 * (size_t)T);
+    return;
+  }
   const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
   if (t < T) { tile_walk[t] = 0u; tile_walk[T + t] = 0u; tile_walk[2 * T + t] = 0u; }
   if (t >= N) return;
@@ -1401,13 +1411,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_instance_kernel(uint32_t 
   r2[i] = make_float2(at.w, __uint_as_float(m));
 }
 
-void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s) {
+bool gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, const char* wg, char* ws, const GhLayout& L, hipStream_t s) {
   const int T = g.NV * g.tiles;
   const int na = g.N > T ? g.N : T;
+  const bool rank = g.total_tiles <= GH_ORDER_TILES && gh_heavy_order_enabled() && !(g.flags & GH_FLAG_FRESH_ORDER);
+  const int n_attr_blocks = (na + GH_BLOCK - 1) / GH_BLOCK;
   hipLaunchKernelGGL(gh_refresh_init_kernel, dim3(1), dim3(GH_WAVE), 0, s, (const GhCounters*)(wg + L.counters), (GhCounters*)(ws + L.counters));
-  hipLaunchKernelGGL(gh_refresh_attr_kernel, dim3((na + GH_BLOCK - 1) / GH_BLOCK), dim3(GH_BLOCK), 0, s, *in, d->flags, g.P, g.NV, g.N, T,
+  hipLaunchKernelGGL(gh_refresh_attr_kernel, dim3(n_attr_blocks + (rank ? g.NV : 0)), dim3(GH_BLOCK), 0, s, *in, d->flags, g.P, g.NV, g.N, T,
                      (const GhCounters*)(wg + L.counters), (const float*)(wg + L.cull_bound), (const float4*)(ws + L.sh_rgb),
-                     (float4*)(ws + L.attr), (uint32_t*)(ws + L.tile_walk), (GhCounters*)(ws + L.counters));
+                     (float4*)(ws + L.attr), (uint32_t*)(ws + L.tile_walk), (GhCounters*)(ws + L.counters),
+                     n_attr_blocks, (const uint2*)(wg + L.ranges), (uint32_t*)(ws + L.tile_order), g.tiles);
   const int nblk = (int)(((size_t)g.cap + GH_BLOCK - 1) / GH_BLOCK);
   hipLaunchKernelGGL(gh_refresh_instance_kernel, dim3(nblk > 0 ? nblk : 1), dim3(GH_BLOCK), 0, s, (uint32_t)g.cap, g.gx, g.tiles,
                      (long long)g.NV * g.tiles < (1ll << 24) ? 1.0f / (float)g.tiles : 0.0f, 1.0f / (float)g.gx,
@@ -1415,4 +1428,5 @@ void gh_launch_refresh(const GhDims* d, const GhGrid& g, const GhInputs* in, con
                      (const float4*)(wg + L.inst_r0), (const float*)(wg + L.inst_c), (const float4*)(ws + L.attr),
                      (float4*)(ws + L.inst_r1), (float2*)(ws + L.inst_r2), (uint32_t*)(ws + L.inst_flag),
                      (const GhCounters*)(ws + L.counters), (uint32_t*)(ws + L.render_guard), gh_partition_per_view(g) ? 1 : 0);
+  return rank;
 }
