@@ -40,13 +40,16 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
   // Small launches (gh_fwd_fine_launch): the forward's launch order comes from what the PREVIOUS forward over this workspace measured
   // per tile (tile_walk[3]), so it does not wait for this call's lists: one spare workgroup per view ranks the tiles here, in the
   // shadow of the projection, instead of a kernel of its own between the binning and the render (4.5 us of a one-view step).
-  if ((int)blockIdx.x >= n_proj_blocks) {
-    gh_rank_tiles(nullptr, tiles_per_view, T / tiles_per_view, (int)blockIdx.x - n_proj_blocks, tile_order, tile_walk + 3 * (size_t)T);
+  // (they are the FIRST workgroups of the grid: at its end they started last and their 3 us were the kernel's tail — 35.0 -> 37.5 us)
+  const int n_rank = (int)gridDim.x - n_proj_blocks;
+  if ((int)blockIdx.x < n_rank) {
+    gh_rank_tiles(nullptr, tiles_per_view, T / tiles_per_view, (int)blockIdx.x, tile_order, tile_walk + 3 * (size_t)T);
     return;
   }
+  const int bid = (int)blockIdx.x - n_rank;
   __shared__ uint2 s_bits[GH_BLOCK / GH_WAVE];
   __shared__ uint32_t s_tiles[GH_BLOCK / GH_WAVE];
-  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int t = bid * GH_BLOCK + threadIdx.x;
   unsigned tiles = 0;
   uint32_t k_or = 0u, k_and = 0xFFFFFFFFu;              // bits of this thread's depth key if its Gaussian emits instances
   if (t == 0) {                                        // counters: reserved[0] = element count of the level-1 (depth) sort
@@ -186,9 +189,9 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_preprocess_fwd_kernel(
   if ((threadIdx.x & 63) == 0) { s_bits[threadIdx.x >> 6] = make_uint2(k_or, k_and); s_tiles[threadIdx.x >> 6] = tsum; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    key_bits[blockIdx.x] = make_uint2(s_bits[0].x | s_bits[1].x | s_bits[2].x | s_bits[3].x,
+    key_bits[bid] = make_uint2(s_bits[0].x | s_bits[1].x | s_bits[2].x | s_bits[3].x,
                                       s_bits[0].y & s_bits[1].y & s_bits[2].y & s_bits[3].y);
-    block_tiles[blockIdx.x] = (s_tiles[0] + s_tiles[1]) + (s_tiles[2] + s_tiles[3]);
+    block_tiles[bid] = (s_tiles[0] + s_tiles[1]) + (s_tiles[2] + s_tiles[3]);
   }
 }
 

@@ -1362,11 +1362,13 @@ __global__ __launch_bounds__(GH_BLOCK) void gh_refresh_attr_kernel(GhInputs in, 
   // spare workgroups (launches of at most GH_ORDER_TILES tiles): the forward's launch order, ranked anew from what the PREVIOUS step's
   // forward measured per tile (this call's tile_walk[3]; a tile without a measurement: by its list length) into this call's own
   // tile_order — the build call's order is by list length, and its choice of fine-grained tiles with it
-  if ((int)blockIdx.x >= n_attr_blocks) {
-    gh_rank_tiles(ranges, tiles_per_view, NV, (int)blockIdx.x - n_attr_blocks, order, tile_walk + 3 * (size_t)T);
+  // (the grid's FIRST workgroups: they run in the shadow of the others instead of being the kernel's tail)
+  const int n_rank = (int)gridDim.x - n_attr_blocks;
+  if ((int)blockIdx.x < n_rank) {
+    gh_rank_tiles(ranges, tiles_per_view, NV, (int)blockIdx.x, order, tile_walk + 3 * (size_t)T);
     return;
   }
-  const int t = blockIdx.x * GH_BLOCK + threadIdx.x;
+  const int t = ((int)blockIdx.x - n_rank) * GH_BLOCK + threadIdx.x;
   if (t < T) { tile_walk[t] = 0u; tile_walk[T + t] = 0u; tile_walk[2 * T + t] = 0u; }
   if (t >= N) return;
   const int row = (flags & GH_FLAG_PER_VIEW_GAUSSIANS) ? t : t % P;       // n = view * P + row (view-major, as the lists' payload)
